@@ -1,0 +1,186 @@
+// Small HBM-bound kernels around the UNet call: timestep embedding, SiLU, model-input packing,
+// fused CFG + batched per-latent DDIM step, NCHW<->NHWC converters at the pipeline boundary.
+#include "common.h"
+#include "dm4d.h"
+#include "errors.h"
+
+namespace {
+
+__global__ void timestep_embedding_kernel(const float* t, u16* out, int B, int dim, int flip, float freq_shift) {
+  const int half = dim / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * half) return;
+  const int b = i / half, k = i % half;
+  // diffusers get_timestep_embedding: exponent = -ln(10000) * k / (half - shift), all in fp32
+  const float exponent = -9.210340371976184f * (float)k / ((float)half - freq_shift);
+  const float arg = t[b] * expf(exponent);
+  const float s = sinf(arg), c = cosf(arg);
+  u16* o = out + (int64_t)b * dim;
+  if (flip) {
+    o[k] = f2bf(c);
+    o[half + k] = f2bf(s);
+  } else {
+    o[k] = f2bf(s);
+    o[half + k] = f2bf(c);
+  }
+  if ((dim & 1) && k == 0) o[dim - 1] = 0;
+}
+
+__global__ void silu_kernel(const u16* X, u16* Y, int64_t n) {
+  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 8;
+  for (; i + 8 <= n; i += stride) {
+    float v[8];
+    unpack8(ldg16(X + i), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+    stg16(Y + i, pack8(v));
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (int64_t j = n & ~(int64_t)7; j < n; ++j) Y[j] = f2bf(silu_f(bf2f(X[j])));
+}
+
+// one thread per (frame, pixel): reads the 4+6+4+1 conditioning channels, writes both CFG halves
+__global__ void pack_kernel(u16* latents, const u16* pv, const u16* pl, const u16* sk, const u16* mask,
+                            const int32_t* is_cond, u16* out, int F, int HW, int cpad, int use_cfg) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)F * HW) return;
+  const int f = (int)(i / HW);
+  const bool cond = is_cond[f] != 0;
+  const u16 one = 0x3F80, mone = 0xBF80;  // +1.0, -1.0 in bf16
+  u16 lat[4];
+  if (cond) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      lat[c] = pv[i * 4 + c];
+      latents[i * 4 + c] = lat[c];  // reference aliasing side effect (pipeline_diffuman4d.py:375-379)
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lat[c] = latents[i * 4 + c];
+  }
+  const u16 m = mask[i];
+  const int nsk = sk ? 4 : 0;
+  u16* pos = out + ((use_cfg ? (int64_t)F * HW : 0) + i) * cpad;
+  int c = 0;
+  for (int k = 0; k < 4; ++k) pos[c++] = lat[k];
+  for (int k = 0; k < 6; ++k) pos[c++] = pl[i * 6 + k];
+  for (int k = 0; k < nsk; ++k) pos[c++] = sk[i * 4 + k];
+  pos[c++] = m;
+  for (; c < cpad; ++c) pos[c] = 0;
+  if (use_cfg) {
+    u16* neg = out + i * cpad;
+    c = 0;
+    for (int k = 0; k < 4; ++k) neg[c++] = cond ? one : lat[k];
+    for (int k = 0; k < 6; ++k) neg[c++] = 0;
+    for (int k = 0; k < nsk; ++k) neg[c++] = mone;
+    neg[c++] = m;
+    for (; c < cpad; ++c) neg[c] = 0;
+  }
+}
+
+// latents [F,HW,4], noise_pred [cfg*F, HW, ldn] (first 4 channels used)
+__global__ void cfg_ddim_kernel(u16* latents, const u16* np, int64_t ldn, const float* coef, const int32_t* is_cond,
+                                int F, int HW, int use_cfg, float gs, int vpred) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)F * HW) return;
+  const int f = (int)(i / HW);
+  if (is_cond[f] != 0) return;  // "only denoise target latents" (pipeline_diffuman4d.py:418-420)
+  const float sa = coef[f * 4 + 0], sb = coef[f * 4 + 1], sap = coef[f * 4 + 2], sbp = coef[f * 4 + 3];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float e;
+    if (use_cfg) {
+      const float u = bf2f(np[i * ldn + c]);
+      const float cc = bf2f(np[((int64_t)F * HW + i) * ldn + c]);
+      e = u + gs * (cc - u);
+    } else {
+      e = bf2f(np[i * ldn + c]);
+    }
+    const float x = bf2f(latents[i * 4 + c]);
+    float x0, eps;
+    if (vpred) {
+      x0 = sa * x - sb * e;
+      eps = sa * e + sb * x;
+    } else {
+      x0 = (x - sb * e) / sa;
+      eps = e;
+    }
+    latents[i * 4 + c] = f2bf(sap * x0 + sbp * eps);
+  }
+}
+
+__global__ void nchw_to_nhwc_kernel(const u16* X, u16* Y, int B, int C, int HW, int cpad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over B*HW*cpad
+  if (i >= (int64_t)B * HW * cpad) return;
+  const int c = (int)(i % cpad);
+  const int64_t bp = i / cpad;
+  const int px = (int)(bp % HW), b = (int)(bp / HW);
+  Y[i] = c < C ? X[((int64_t)b * C + c) * HW + px] : (u16)0;
+}
+
+__global__ void nhwc_to_nchw_kernel(const u16* X, u16* Y, int B, int C, int HW, int ldx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over B*C*HW
+  if (i >= (int64_t)B * C * HW) return;
+  const int px = (int)(i % HW);
+  const int64_t bc = i / HW;
+  const int c = (int)(bc % C), b = (int)(bc / C);
+  Y[i] = X[((int64_t)b * HW + px) * ldx + c];
+}
+
+inline dim3 grid1d(int64_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
+
+}  // namespace
+
+extern "C" int dm4d_timestep_embedding_bf16(void* stream, const float* t, void* out, int B, int dim, int flip,
+                                            float freq_shift) {
+  if (!t || !out || B <= 0 || dim < 2) return dm4d_set_error(DM4D_ERR_ARG, "timestep_embedding: bad arguments");
+  hipLaunchKernelGGL(timestep_embedding_kernel, grid1d((int64_t)B * (dim / 2), 256), dim3(256), 0, (hipStream_t)stream, t,
+                     (u16*)out, B, dim, flip, freq_shift);
+  return dm4d_check_launch("timestep_embedding_kernel");
+}
+
+extern "C" int dm4d_silu_bf16(void* stream, const void* X, void* Y, int64_t n) {
+  if (!X || !Y || n <= 0) return dm4d_set_error(DM4D_ERR_ARG, "silu: bad arguments");
+  int64_t blocks = (n / 8 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(silu_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const u16*)X, (u16*)Y, n);
+  return dm4d_check_launch("silu_kernel");
+}
+
+extern "C" int dm4d_pack_model_input_bf16(void* stream, void* latents, const void* pv_lat, const void* plucker,
+                                          const void* skel, const void* mask, const int32_t* is_cond, void* out, int F,
+                                          int HW, int cpad, int use_cfg) {
+  if (!latents || !pv_lat || !plucker || !mask || !is_cond || !out || F <= 0 || HW <= 0)
+    return dm4d_set_error(DM4D_ERR_ARG, "pack_model_input: null pointer or empty shape");
+  if (cpad < 11 + (skel ? 4 : 0)) return dm4d_set_error(DM4D_ERR_ARG, "pack_model_input: cpad too small");
+  hipLaunchKernelGGL(pack_kernel, grid1d((int64_t)F * HW, 256), dim3(256), 0, (hipStream_t)stream, (u16*)latents,
+                     (const u16*)pv_lat, (const u16*)plucker, (const u16*)skel, (const u16*)mask, is_cond, (u16*)out, F,
+                     HW, cpad, use_cfg);
+  return dm4d_check_launch("pack_kernel");
+}
+
+extern "C" int dm4d_cfg_ddim_step_bf16(void* stream, void* latents, const void* noise_pred, int64_t ldn,
+                                       const float* coef, const int32_t* is_cond, int F, int HW, int use_cfg,
+                                       float guidance_scale, int v_prediction) {
+  if (!latents || !noise_pred || !coef || !is_cond || F <= 0 || HW <= 0 || ldn < 4)
+    return dm4d_set_error(DM4D_ERR_ARG, "cfg_ddim_step: bad arguments");
+  hipLaunchKernelGGL(cfg_ddim_kernel, grid1d((int64_t)F * HW, 256), dim3(256), 0, (hipStream_t)stream, (u16*)latents,
+                     (const u16*)noise_pred, ldn, coef, is_cond, F, HW, use_cfg, guidance_scale, v_prediction);
+  return dm4d_check_launch("cfg_ddim_kernel");
+}
+
+extern "C" int dm4d_nchw_to_nhwc_bf16(void* stream, const void* X, void* Y, int B, int C, int HW, int cpad) {
+  if (!X || !Y || B <= 0 || C <= 0 || HW <= 0 || cpad < C) return dm4d_set_error(DM4D_ERR_ARG, "nchw_to_nhwc: bad arguments");
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid1d((int64_t)B * HW * cpad, 256), dim3(256), 0, (hipStream_t)stream,
+                     (const u16*)X, (u16*)Y, B, C, HW, cpad);
+  return dm4d_check_launch("nchw_to_nhwc_kernel");
+}
+
+extern "C" int dm4d_nhwc_to_nchw_bf16(void* stream, const void* X, void* Y, int B, int C, int HW, int ldx) {
+  if (!X || !Y || B <= 0 || C <= 0 || HW <= 0 || ldx < C) return dm4d_set_error(DM4D_ERR_ARG, "nhwc_to_nchw: bad arguments");
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid1d((int64_t)B * C * HW, 256), dim3(256), 0, (hipStream_t)stream,
+                     (const u16*)X, (u16*)Y, B, C, HW, ldx);
+  return dm4d_check_launch("nhwc_to_nchw_kernel");
+}

@@ -1,0 +1,328 @@
+// bf16 MFMA GEMM / implicit-GEMM 3x3 convolution for gfx950 (MI355X).
+//
+//   out[M,N] = epilogue( A[M,K] @ W[N,K]^T )          fp32 accumulate, bf16 in/out
+//
+// One kernel template serves the Linear layers (dense A, optionally split over two sources = the
+// up-block skip concat) and every 3x3 convolution of the UNet/VAE (A gathered on the fly from an
+// NHWC tensor: K = 9*Cin ordered (ky, kx, ci), zero padding, stride 1/2, fused nearest-x2 upsample).
+//
+// Tiling (wave64, v_mfma_f32_32x32x16_bf16): a workgroup of 4 waves owns a BM x BN output tile, each
+// wave a (BM/WM) x (BN/WN) sub-tile of 32x32 MFMA fragments.  A/B k-slabs of 32 are staged through
+// registers into a padded, double-buffered LDS image (row stride 80 B => conflict-free
+// ds_read_b128 fragment reads); global loads for slab k+1 are in flight while slab k is multiplied,
+// one barrier per slab.  The epilogue goes back through LDS (fp32) so that bias / GEGLU / rowbias
+// (time-embedding add) / residual are fused and every global store is a coalesced 16-byte row write.
+#include "common.h"
+#include "dm4d.h"
+#include "errors.h"
+
+namespace {
+
+struct GemmParams {
+  const u16* A;
+  int64_t lda;
+  const u16* A2;
+  int64_t lda2;
+  int K1;
+  // conv geometry (CONV only)
+  int H, W, Cin, Ho, Wo, stride, pad, upsample;
+  const u16* Wt;
+  int64_t ldw;
+  u16* C;
+  int64_t ldc;
+  int M, N, K;
+  const u16* bias;
+  const u16* rowbias;
+  int64_t ld_rb;
+  int rows_per_rb;
+  const u16* res;
+  int64_t ld_res;
+  unsigned flags;
+  float out_scale;
+  int tiles_n;
+};
+
+template <int BM, int BN, int WM, int WN, bool CONV>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+  constexpr int LDK = 40;  // bf16 elements per LDS row (32 + 8 pad)
+  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
+  constexpr int AI = BM / 64, BI = BN / 64;
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int SMEM_MAIN = 2 * (BM + BN) * LDK * 2;   // bytes, double-buffered A/B slabs
+  constexpr int SMEM_EPI = 4 * 32 * (TN + 4) * 4;      // bytes, per-wave fp32 staging
+  constexpr int SMEM_BYTES = SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI;
+  __shared__ __attribute__((aligned(16))) u16 smem[SMEM_BYTES / 2];
+  u16* As = smem;
+  u16* Bs = smem + 2 * BM * LDK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
+  const int m0 = tm * BM;
+  const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
+  const int n0 = tn * (geglu ? BN / 2 : BN);  // first output column of this tile
+
+  const int a_c = tid & 3, a_r = tid >> 2;
+
+  // ---- per-thread source rows -------------------------------------------------------------
+  const u16* a_base[AI];   // dense: row pointer into A ; conv: image base pointer
+  const u16* a2_base[AI];  // dense: row pointer into A2
+  int iy0[AI], ix0[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    int m = m0 + a_r + 64 * i;
+    if (m > p.M - 1) m = p.M - 1;
+    if constexpr (CONV) {
+      int ox = m % p.Wo;
+      int t = m / p.Wo;
+      int oy = t % p.Ho;
+      int b = t / p.Ho;
+      iy0[i] = oy * p.stride - p.pad;
+      ix0[i] = ox * p.stride - p.pad;
+      a_base[i] = p.A + (int64_t)b * p.H * p.W * p.Cin;
+      a2_base[i] = nullptr;
+    } else {
+      a_base[i] = p.A + (int64_t)m * p.lda;
+      a2_base[i] = p.A2 ? p.A2 + (int64_t)m * p.lda2 : nullptr;
+      iy0[i] = ix0[i] = 0;
+    }
+  }
+  const u16* w_base[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    int r = a_r + 64 * i;  // row inside the B tile
+    int n;
+    if (geglu) {
+      int wr = r / TN, rr = r % TN;
+      n = n0 + wr * (TN / 2) + (rr % (TN / 2));
+      if (n > p.N - 1) n = p.N - 1;
+      if (rr >= TN / 2) n += p.N;  // gate rows live in the second half of W
+    } else {
+      n = n0 + r;
+      if (n > p.N - 1) n = p.N - 1;
+    }
+    w_base[i] = p.Wt + (int64_t)n * p.ldw;
+  }
+
+  f32x16_t acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / 32;
+  const int Hin = p.upsample ? 2 * p.H : p.H, Win = p.upsample ? 2 * p.W : p.W;
+  int ky = 0, kx = 0, ci0 = 0;  // conv tap state for the NEXT slab to be loaded
+
+  U4 ra[AI], rb[BI];
+  auto load_slab = [&](int kt) {
+    if constexpr (CONV) {
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        int iy = iy0[i] + ky, ix = ix0[i] + kx;
+        bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+        int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
+        U4 z = {0u, 0u, 0u, 0u};
+        ra[i] = ok ? ldg16(a_base[i] + ((int64_t)sy * p.W + sx) * p.Cin + ci0 + a_c * 8) : z;
+      }
+      ci0 += 32;
+      if (ci0 >= p.Cin) {
+        ci0 = 0;
+        if (++kx == 3) {
+          kx = 0;
+          ++ky;
+        }
+      }
+    } else {
+      const int kcol = kt * 32;
+      const bool second = (p.A2 != nullptr) && (kcol >= p.K1);
+#pragma unroll
+      for (int i = 0; i < AI; ++i)
+        ra[i] = second ? ldg16(a2_base[i] + (kcol - p.K1) + a_c * 8) : ldg16(a_base[i] + kcol + a_c * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) rb[i] = ldg16(w_base[i] + kt * 32 + a_c * 8);
+  };
+  auto store_slab = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) *reinterpret_cast<U4*>(As + (buf * BM + a_r + 64 * i) * LDK + a_c * 8) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) *reinterpret_cast<U4*>(Bs + (buf * BN + a_r + 64 * i) * LDK + a_c * 8) = rb[i];
+  };
+
+  load_slab(0);
+  store_slab(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_slab(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t af[MI], bfr[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        af[i] = *reinterpret_cast<const bf16x8_t*>(As + (buf * BM + wm * TM + i * 32 + l31) * LDK + ks * 16 + lh * 8);
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8_t*>(Bs + (buf * BN + wn * TN + j * 32 + l31) * LDK + ks * 16 + lh * 8);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_slab(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------
+  // D fragment layout (32x32): lane holds column (lane & 31), rows (r&3) + 8*(r>>2) + 4*(lane>>5).
+  const int NJ = geglu ? NI / 2 : NI;
+  const int TNO = NJ * 32;            // output columns per wave
+  const int SLD = TNO + 4;            // fp32 staging row stride
+  float* stage = reinterpret_cast<float*>(smem) + wave * 32 * (TN + 4);
+  const bool do_silu = (p.flags & DM4D_EPI_SILU) != 0;
+  const int ncol0 = n0 + wn * TNO;  // first output column of this wave
+
+  float bias_h[NI], bias_g[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    bias_h[j] = 0.f;
+    bias_g[j] = 0.f;
+    int n = ncol0 + j * 32 + l31;
+    if (p.bias && j < NJ && n < p.N) {
+      bias_h[j] = bf2f(p.bias[n]);
+      if (geglu) bias_g[j] = bf2f(p.bias[p.N + n]);
+    }
+  }
+  const int chunks_per_row = TNO / 8;
+  const int tasks = 32 * chunks_per_row;
+  const bool vec_ok = ((p.ldc & 7) == 0) && ((p.N & 7) == 0) && (!p.res || (p.ld_res & 7) == 0) &&
+                      (!p.rowbias || (p.ld_rb & 7) == 0);
+
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      if (j < NJ) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          float v = acc[i][j][r] + bias_h[j];
+          if (geglu) {
+            float g = acc[i][(j + NI / 2) % NI][r] + bias_g[j];
+            v = v * gelu_erf_f(g);
+          }
+          if (do_silu) v = silu_f(v);
+          stage[row * SLD + j * 32 + l31] = v;
+        }
+      }
+    }
+    __syncthreads();
+    for (int id = lane; id < tasks; id += 64) {
+      int row = id / chunks_per_row, cc = id % chunks_per_row;
+      int m = m0 + wm * TM + i * 32 + row;
+      int n = ncol0 + cc * 8;
+      if (m >= p.M || n >= p.N) continue;
+      float v[8];
+      const float* s = stage + row * SLD + cc * 8;
+      f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(s);
+      f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(s + 4);
+      v[0] = s0[0]; v[1] = s0[1]; v[2] = s0[2]; v[3] = s0[3];
+      v[4] = s1[0]; v[5] = s1[1]; v[6] = s1[2]; v[7] = s1[3];
+      if (vec_ok) {
+        if (p.rowbias) {
+          float t[8];
+          unpack8(ldg16(p.rowbias + (int64_t)(m / p.rows_per_rb) * p.ld_rb + n), t);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += t[e];
+        }
+        if (p.res) {
+          float t[8];
+          unpack8(ldg16(p.res + (int64_t)m * p.ld_res + n), t);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += t[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+        stg16(p.C + (int64_t)m * p.ldc + n, pack8(v));
+      } else {
+        for (int e = 0; e < 8 && n + e < p.N; ++e) {
+          float x = v[e];
+          if (p.rowbias) x += bf2f(p.rowbias[(int64_t)(m / p.rows_per_rb) * p.ld_rb + n + e]);
+          if (p.res) x += bf2f(p.res[(int64_t)m * p.ld_res + n + e]);
+          p.C[(int64_t)m * p.ldc + n + e] = f2bf(x * p.out_scale);
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, bool CONV>
+int launch_cfg(hipStream_t st, GemmParams& p) {
+  const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
+  const int bn_out = geglu ? BN / 2 : BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + bn_out - 1) / bn_out;
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, CONV>), dim3(tiles_m * p.tiles_n), dim3(256), 0, st, p);
+  return dm4d_check_launch("gemm_kernel");
+}
+
+template <bool CONV>
+int launch(hipStream_t st, GemmParams& p) {
+  const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
+  const long tiles_big = (long)((p.M + 255) / 256) * ((p.N + (geglu ? 63 : 127)) / (geglu ? 64 : 128));
+  const bool n128 = geglu || (p.N % 128 == 0) || (p.N > 1024);
+  if (n128) {
+    if (tiles_big >= 384) return launch_cfg<256, 128, 2, 2, CONV>(st, p);
+    return launch_cfg<128, 128, 2, 2, CONV>(st, p);
+  }
+  const long tiles64 = (long)((p.M + 255) / 256) * ((p.N + 63) / 64);
+  if (tiles64 >= 384) return launch_cfg<256, 64, 4, 1, CONV>(st, p);
+  return launch_cfg<128, 64, 4, 1, CONV>(st, p);
+}
+
+}  // namespace
+
+extern "C" int dm4d_gemm_bf16(void* stream, const void* A, int64_t lda, const void* A2, int64_t lda2, int K1,
+                              const void* W, int64_t ldw, void* C, int64_t ldc, int M, int N, int K, const void* bias,
+                              const void* rowbias, int64_t ld_rowbias, int rows_per_rowbias, const void* residual,
+                              int64_t ld_res, unsigned flags, float out_scale) {
+  if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return dm4d_set_error(DM4D_ERR_ARG, "gemm: null pointer or empty shape");
+  if (K % 32 != 0) return dm4d_set_error(DM4D_ERR_ARG, "gemm: K must be a multiple of 32");
+  if ((lda & 7) || (ldw & 7)) return dm4d_set_error(DM4D_ERR_ARG, "gemm: lda/ldw must be multiples of 8");
+  if (A2 && ((K1 % 32) != 0 || K1 <= 0 || K1 >= K || (lda2 & 7)))
+    return dm4d_set_error(DM4D_ERR_ARG, "gemm: bad split-A arguments");
+  if (rowbias && rows_per_rowbias <= 0) return dm4d_set_error(DM4D_ERR_ARG, "gemm: rows_per_rowbias <= 0");
+  if ((flags & DM4D_EPI_GEGLU) && (N % 32 != 0)) return dm4d_set_error(DM4D_ERR_ARG, "gemm: GEGLU needs N % 32 == 0");
+  GemmParams p{};
+  p.A = (const u16*)A; p.lda = lda; p.A2 = (const u16*)A2; p.lda2 = lda2; p.K1 = K1;
+  p.Wt = (const u16*)W; p.ldw = ldw; p.C = (u16*)C; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+  p.bias = (const u16*)bias; p.rowbias = (const u16*)rowbias; p.ld_rb = ld_rowbias; p.rows_per_rb = rows_per_rowbias;
+  p.res = (const u16*)residual; p.ld_res = ld_res; p.flags = flags; p.out_scale = out_scale;
+  return launch<false>((hipStream_t)stream, p);
+}
+
+extern "C" int dm4d_conv3x3_nhwc_bf16(void* stream, const void* X, int B, int H, int W, int Cin, const void* Wt, void* Y,
+                                      int Ho, int Wo, int Cout, int stride, int pad, int upsample, const void* bias,
+                                      const void* rowbias, int64_t ld_rowbias, const void* residual, int64_t ld_res,
+                                      float out_scale) {
+  if (!X || !Wt || !Y || B <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0)
+    return dm4d_set_error(DM4D_ERR_ARG, "conv3x3: null pointer or empty shape");
+  if (Cin % 32 != 0) return dm4d_set_error(DM4D_ERR_ARG, "conv3x3: Cin must be a multiple of 32 (pad the input)");
+  if (stride != 1 && stride != 2) return dm4d_set_error(DM4D_ERR_ARG, "conv3x3: stride must be 1 or 2");
+  if (upsample && stride != 1) return dm4d_set_error(DM4D_ERR_ARG, "conv3x3: upsample needs stride 1");
+  GemmParams p{};
+  p.A = (const u16*)X; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.pad = pad;
+  p.upsample = upsample;
+  p.Wt = (const u16*)Wt; p.ldw = (int64_t)9 * Cin; p.C = (u16*)Y; p.ldc = Cout;
+  p.M = B * Ho * Wo; p.N = Cout; p.K = 9 * Cin;
+  p.bias = (const u16*)bias; p.rowbias = (const u16*)rowbias; p.ld_rb = ld_rowbias; p.rows_per_rb = Ho * Wo;
+  p.res = (const u16*)residual; p.ld_res = ld_res; p.flags = 0; p.out_scale = out_scale;
+  return launch<true>((hipStream_t)stream, p);
+}

@@ -1,0 +1,275 @@
+// HBM-bound normalisation kernels for gfx950: GroupNorm(+SiLU) over NHWC (two-source channel
+// concat fused in), LayerNorm, and a row softmax (VAE mid-block attention).  All statistics fp32,
+// all global traffic in 16-byte bf16x8 vectors.
+#include "common.h"
+#include "dm4d.h"
+#include "errors.h"
+
+namespace {
+
+constexpr int GN_THREADS = 256;
+constexpr int GN_MAXC = 4096;
+
+__host__ __device__ inline int gn_nchunk(int B, int HW) {
+  int n = (2048 + B - 1) / B;
+  int cap = (HW + 15) / 16;
+  if (n > cap) n = cap;
+  if (n < 1) n = 1;
+  return n;
+}
+
+struct GNParams {
+  const u16* X1;
+  const u16* X2;
+  int C1, C2, B, HW, groups, nchunk;
+  float eps;
+  const u16* gamma;
+  const u16* beta;
+  u16* Y;
+  int silu;
+  float* ws;  // [B][nchunk][groups][2]
+};
+
+// pass 1: per (batch, pixel chunk) partial sum / sum of squares of every group, fixed summation order
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(GNParams p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [PPB][C][2]
+  const int C = p.C1 + p.C2, CV = C / 8, CV1 = p.C1 / 8;
+  const int b = blockIdx.x / p.nchunk, chunk = blockIdx.x % p.nchunk;
+  const int per = (p.HW + p.nchunk - 1) / p.nchunk;
+  const int p0 = chunk * per, p1 = min(p0 + per, p.HW);
+  const int PPB = CV >= GN_THREADS ? 1 : GN_THREADS / CV;  // pixels processed per pass
+  const int tid = threadIdx.x;
+
+  for (int slot = tid; slot < CV * PPB; slot += GN_THREADS) {
+    const int cv = slot % CV, prow = slot / CV;
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+    const u16* src;
+    int ld, c;
+    if (cv < CV1) {
+      src = p.X1 + (int64_t)b * p.HW * p.C1;
+      ld = p.C1;
+      c = cv * 8;
+    } else {
+      src = p.X2 + (int64_t)b * p.HW * p.C2;
+      ld = p.C2;
+      c = (cv - CV1) * 8;
+    }
+    for (int px = p0 + prow; px < p1; px += PPB) {
+      float v[8];
+      unpack8(ldg16(src + (int64_t)px * ld + c), v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s[e] += v[e];
+        q[e] += v[e] * v[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sm[(prow * C + cv * 8 + e) * 2 + 0] = s[e];
+      sm[(prow * C + cv * 8 + e) * 2 + 1] = q[e];
+    }
+  }
+  __syncthreads();
+  const int gs = C / p.groups;
+  for (int g = tid; g < p.groups; g += GN_THREADS) {
+    float s = 0.f, q = 0.f;
+    for (int r = 0; r < PPB; ++r)
+      for (int c = g * gs; c < (g + 1) * gs; ++c) {
+        s += sm[(r * C + c) * 2 + 0];
+        q += sm[(r * C + c) * 2 + 1];
+      }
+    float* w = p.ws + (((int64_t)b * p.nchunk + chunk) * p.groups + g) * 2;
+    w[0] = s;
+    w[1] = q;
+  }
+}
+
+// pass 2: y = (x - mean) * rstd * gamma + beta, optional SiLU; writes the concatenated tensor
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GNParams p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // scale[C], shift[C], mean[g], rstd[g]
+  const int C = p.C1 + p.C2, CV = C / 8, CV1 = p.C1 / 8;
+  float* sc = sm;
+  float* sh = sm + C;
+  float* mean = sm + 2 * C;
+  float* rstd = mean + p.groups;
+  const int b = blockIdx.x / p.nchunk, chunk = blockIdx.x % p.nchunk;
+  const int per = (p.HW + p.nchunk - 1) / p.nchunk;
+  const int p0 = chunk * per, p1 = min(p0 + per, p.HW);
+  const int tid = threadIdx.x;
+  const int gs = C / p.groups;
+  for (int g = tid; g < p.groups; g += GN_THREADS) {
+    float s = 0.f, q = 0.f;
+    for (int k = 0; k < p.nchunk; ++k) {
+      const float* w = p.ws + (((int64_t)b * p.nchunk + k) * p.groups + g) * 2;
+      s += w[0];
+      q += w[1];
+    }
+    const float n = (float)gs * (float)p.HW;
+    const float mu = s / n;
+    float var = q / n - mu * mu;
+    var = var < 0.f ? 0.f : var;
+    mean[g] = mu;
+    rstd[g] = rsqrtf(var + p.eps);
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += GN_THREADS) {
+    const int g = c / gs;
+    const float a = bf2f(p.gamma[c]) * rstd[g];
+    sc[c] = a;
+    sh[c] = bf2f(p.beta[c]) - mean[g] * a;
+  }
+  __syncthreads();
+  const int64_t total = (int64_t)(p1 - p0) * CV;
+  for (int64_t i = tid; i < total; i += GN_THREADS) {
+    const int px = p0 + (int)(i / CV), cv = (int)(i % CV);
+    const u16* src = cv < CV1 ? p.X1 + ((int64_t)b * p.HW + px) * p.C1 + cv * 8
+                              : p.X2 + ((int64_t)b * p.HW + px) * p.C2 + (cv - CV1) * 8;
+    float v[8];
+    unpack8(ldg16(src), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float y = v[e] * sc[cv * 8 + e] + sh[cv * 8 + e];
+      v[e] = p.silu ? silu_f(y) : y;
+    }
+    stg16(p.Y + ((int64_t)b * p.HW + px) * C + cv * 8, pack8(v));
+  }
+}
+
+// LayerNorm: one wave per row, row kept in registers (two-pass mean / variance)
+template <int NV>  // 16-byte vectors per lane
+__global__ __launch_bounds__(256) void ln_kernel(const u16* X, int64_t ldx, const u16* gamma, const u16* beta, u16* Y,
+                                                 int64_t ldy, int M, int C, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= M) return;
+  const int CV = C / 8;
+  float v[NV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int cv = lane + 64 * i;
+    if (cv < CV) {
+      unpack8(ldg16(X + (int64_t)row * ldx + cv * 8), v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  const float mu = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int cv = lane + 64 * i;
+    if (cv < CV) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[i][e] - mu;
+        q += d * d;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+  const float rs = rsqrtf(q / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int cv = lane + 64 * i;
+    if (cv < CV) {
+      float g[8], bt[8], y[8];
+      unpack8(ldg16(gamma + cv * 8), g);
+      unpack8(ldg16(beta + cv * 8), bt);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = (v[i][e] - mu) * rs * g[e] + bt[e];
+      stg16(Y + (int64_t)row * ldy + cv * 8, pack8(y));
+    }
+  }
+}
+
+// row softmax over N columns: P = softmax(S * scale); one workgroup per row
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const u16* S, int64_t lds, u16* P, int64_t ldp, int N,
+                                                           float scale) {
+  __shared__ float red[8];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const u16* s = S + (int64_t)row * lds;
+  u16* o = P + (int64_t)row * ldp;
+  float mx = -1e30f;
+  for (int i = tid; i < N; i += 256) mx = fmaxf(mx, bf2f(s[i]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  const float c = scale * 1.4426950408889634f;
+  for (int i = tid; i < N; i += 256) sum += __builtin_amdgcn_exp2f((bf2f(s[i]) - mx) * c);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  sum = red[4] + red[5] + red[6] + red[7];
+  const float inv = 1.0f / sum;
+  for (int i = tid; i < N; i += 256) o[i] = f2bf(__builtin_amdgcn_exp2f((bf2f(s[i]) - mx) * c) * inv);
+}
+
+}  // namespace
+
+extern "C" size_t dm4d_groupnorm_ws_bytes(int B, int HW, int groups) {
+  return (size_t)B * gn_nchunk(B, HW) * groups * 2 * sizeof(float);
+}
+
+extern "C" int dm4d_groupnorm_nhwc_bf16(void* stream, const void* X1, int C1, const void* X2, int C2, int B, int HW,
+                                        int groups, float eps, const void* gamma, const void* beta, void* Y,
+                                        int apply_silu, void* ws) {
+  if (!X1 || !gamma || !beta || !Y || !ws || B <= 0 || HW <= 0 || groups <= 0)
+    return dm4d_set_error(DM4D_ERR_ARG, "groupnorm: null pointer or empty shape");
+  if (!X2) C2 = 0;
+  const int C = C1 + C2;
+  if ((C1 & 7) || (C2 & 7) || C % groups != 0 || C > GN_MAXC)
+    return dm4d_set_error(DM4D_ERR_ARG, "groupnorm: channels must be multiples of 8, divisible by groups, <= 4096");
+  GNParams p{(const u16*)X1, (const u16*)X2, C1, C2, B, HW, groups, gn_nchunk(B, HW), eps,
+             (const u16*)gamma, (const u16*)beta, (u16*)Y, apply_silu, (float*)ws};
+  hipStream_t st = (hipStream_t)stream;
+  const int CV = C / 8;
+  const int PPB = CV >= GN_THREADS ? 1 : GN_THREADS / CV;
+  const size_t sm1 = (size_t)PPB * C * 2 * sizeof(float);
+  const size_t sm2 = ((size_t)2 * C + 2 * groups) * sizeof(float);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(B * p.nchunk), dim3(GN_THREADS), sm1, st, p);
+  int rc = dm4d_check_launch("gn_stats_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(B * p.nchunk), dim3(GN_THREADS), sm2, st, p);
+  return dm4d_check_launch("gn_apply_kernel");
+}
+
+extern "C" int dm4d_layernorm_bf16(void* stream, const void* X, int64_t ldx, const void* gamma, const void* beta,
+                                   void* Y, int64_t ldy, int M, int C, float eps) {
+  if (!X || !gamma || !beta || !Y || M <= 0 || C <= 0)
+    return dm4d_set_error(DM4D_ERR_ARG, "layernorm: null pointer or empty shape");
+  if ((C & 7) || (ldx & 7) || (ldy & 7) || C > 64 * 8 * 8)
+    return dm4d_set_error(DM4D_ERR_ARG, "layernorm: C must be a multiple of 8 and <= 4096");
+  hipStream_t st = (hipStream_t)stream;
+  const int nv = (C / 8 + 63) / 64;
+  dim3 grid((M + 3) / 4), block(256);
+#define LN_LAUNCH(NV) \
+  hipLaunchKernelGGL((ln_kernel<NV>), grid, block, 0, st, (const u16*)X, ldx, (const u16*)gamma, (const u16*)beta, (u16*)Y, ldy, M, C, eps)
+  if (nv <= 1) LN_LAUNCH(1);
+  else if (nv <= 2) LN_LAUNCH(2);
+  else if (nv <= 3) LN_LAUNCH(3);
+  else if (nv <= 4) LN_LAUNCH(4);
+  else LN_LAUNCH(8);
+#undef LN_LAUNCH
+  return dm4d_check_launch("ln_kernel");
+}
+
+extern "C" int dm4d_softmax_rows_bf16(void* stream, const void* S, int64_t lds, void* P, int64_t ldp, int M, int N,
+                                      float scale) {
+  if (!S || !P || M <= 0 || N <= 0) return dm4d_set_error(DM4D_ERR_ARG, "softmax: null pointer or empty shape");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const u16*)S, lds, (u16*)P, ldp,
+                     N, scale);
+  return dm4d_check_launch("softmax_rows_kernel");
+}

@@ -1,0 +1,71 @@
+"""ctypes binding of libdm4d.so (C ABI declared in include/dm4d.h).
+
+The library is the product's only compute path: there is no CPU or PyTorch fallback.  Loading
+fails loudly if the shared object has not been built (``python -m diffuman4d_amd.build``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_LIB_PATH = Path(__file__).resolve().parent.parent / "libdm4d.so"
+_lib = None
+
+_vp, _i, _i64, _f, _u = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint
+
+# name -> (restype, argtypes); mirrors include/dm4d.h exactly (tests/test_abi.py checks the header)
+SIGNATURES = {
+    "dm4d_version": (_i, []),
+    "dm4d_last_error": (C.c_char_p, []),
+    "dm4d_gemm_bf16": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp, _i64, _i, _vp,
+                            _i64, _u, _f]),
+    "dm4d_conv3x3_nhwc_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i64, _vp,
+                                    _i64, _f]),
+    "dm4d_groupnorm_ws_bytes": (C.c_size_t, [_i, _i, _i]),
+    "dm4d_groupnorm_nhwc_bf16": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp]),
+    "dm4d_layernorm_bf16": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _f]),
+    "dm4d_attention_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _f]),
+    "dm4d_softmax_rows_bf16": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _f]),
+    "dm4d_timestep_embedding_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _f]),
+    "dm4d_silu_bf16": (_i, [_vp, _vp, _vp, _i64]),
+    "dm4d_pack_model_input_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    "dm4d_cfg_ddim_step_bf16": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _f, _i]),
+    "dm4d_nchw_to_nhwc_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),
+    "dm4d_nhwc_to_nchw_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),
+}
+
+EPI_GEGLU = 1
+EPI_SILU = 2
+
+
+class Dm4dError(RuntimeError):
+    pass
+
+
+def lib_path() -> Path:
+    return _LIB_PATH
+
+
+def load():
+    """Load libdm4d.so and attach prototypes.  Raises if it is missing -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise Dm4dError(
+            f"{_LIB_PATH} not found: build the HIP extension first (python -m diffuman4d_amd.build). "
+            "diffuman4d_amd has no CPU/PyTorch fallback path."
+        )
+    lib = C.CDLL(str(_LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().dm4d_last_error()
+        raise Dm4dError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,220 @@
+"""Tensor-level wrappers over the C ABI (torch is only the allocator / stream provider here).
+
+Every function requires bf16 tensors resident on a HIP device and launches on torch's current
+stream.  Nothing here computes with torch: a tensor on the CPU is an error, not a fallback.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import lib as _l
+
+BF16 = torch.bfloat16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t: torch.Tensor, name: str, dtype=BF16):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _l.Dm4dError(f"{name}: expected a tensor on a HIP device (no CPU fallback in diffuman4d_amd)")
+    if t.dtype != dtype:
+        raise _l.Dm4dError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if t.stride(-1) != 1:
+        raise _l.Dm4dError(f"{name}: last dim must be contiguous")
+    return t
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None, bias=None, rowbias=None,
+         rows_per_rowbias: int = 1, residual=None, geglu: bool = False, silu: bool = False, out_scale: float = 1.0,
+         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M,N] = epi([a | a2] @ w^T); a [M,K1], a2 [M,K-K1], w [N,K] (GEGLU: [2N,K])."""
+    lib = _l.load()
+    _req(a, "a"), _req(w, "w")
+    M, K1 = a.shape
+    K = w.shape[1]
+    N = w.shape[0] // 2 if geglu else w.shape[0]
+    if a2 is not None:
+        _req(a2, "a2")
+        assert a2.shape[0] == M and K1 + a2.shape[1] == K
+    else:
+        assert K1 == K, (K1, K)
+    for t, n in ((bias, "bias"), (rowbias, "rowbias"), (residual, "residual")):
+        if t is not None:
+            _req(t, n)
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=a.device)
+    _req(out, "out")
+    flags = (_l.EPI_GEGLU if geglu else 0) | (_l.EPI_SILU if silu else 0)
+    rc = lib.dm4d_gemm_bf16(_stream(), _p(a), a.stride(0), _p(a2), a2.stride(0) if a2 is not None else 0,
+                            K1 if a2 is not None else 0, _p(w), w.stride(0), _p(out), out.stride(0), M, N, K,
+                            _p(bias), _p(rowbias), rowbias.stride(0) if rowbias is not None else 0, rows_per_rowbias,
+                            _p(residual), residual.stride(0) if residual is not None else 0, flags, out_scale)
+    _l.check(rc, "dm4d_gemm_bf16")
+    return out
+
+
+def conv_out_hw(h: int, w: int, stride: int, pad: int, upsample: bool, pad_hi: Optional[int] = None) -> Tuple[int, int]:
+    if upsample:
+        return 2 * h, 2 * w
+    ph = pad if pad_hi is None else pad_hi
+    return (h + pad + ph - 3) // stride + 1, (w + pad + ph - 3) // stride + 1
+
+
+def conv3x3(x: torch.Tensor, wt: torch.Tensor, *, bias=None, rowbias=None, residual=None, stride: int = 1,
+            pad: int = 1, pad_hi: Optional[int] = None, upsample: bool = False, out_scale: float = 1.0) -> torch.Tensor:
+    """x [B,H,W,Cin] NHWC, wt [Cout, 9*Cin] ((ky,kx,ci) order) -> [B,Ho,Wo,Cout]."""
+    lib = _l.load()
+    _req(x, "x"), _req(wt, "wt")
+    assert x.is_contiguous() and wt.is_contiguous()
+    B, H, W, Cin = x.shape
+    Cout = wt.shape[0]
+    assert wt.shape[1] == 9 * Cin, (wt.shape, Cin)
+    Ho, Wo = conv_out_hw(H, W, stride, pad, upsample, pad_hi)
+    y = torch.empty((B, Ho, Wo, Cout), dtype=BF16, device=x.device)
+    if residual is not None:
+        _req(residual, "residual")
+        assert residual.numel() == y.numel() and residual.is_contiguous()
+    if rowbias is not None:
+        _req(rowbias, "rowbias")
+        assert rowbias.shape[0] == B
+    rc = lib.dm4d_conv3x3_nhwc_bf16(_stream(), _p(x), B, H, W, Cin, _p(wt), _p(y), Ho, Wo, Cout, stride, pad,
+                                    1 if upsample else 0, _p(bias), _p(rowbias),
+                                    rowbias.stride(0) if rowbias is not None else 0, _p(residual),
+                                    Cout if residual is not None else 0, out_scale)
+    _l.check(rc, "dm4d_conv3x3_nhwc_bf16")
+    return y
+
+
+def groupnorm(x1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, *,
+              x2: Optional[torch.Tensor] = None, silu: bool = False) -> torch.Tensor:
+    """GroupNorm(+SiLU) over the channel concat [x1 | x2]; x [B, HW, C] (any leading spatial shape)."""
+    lib = _l.load()
+    _req(x1, "x1"), _req(gamma, "gamma"), _req(beta, "beta")
+    assert x1.is_contiguous()
+    B, C1 = x1.shape[0], x1.shape[-1]
+    HW = x1.numel() // (B * C1)
+    C2 = 0
+    if x2 is not None:
+        _req(x2, "x2")
+        assert x2.is_contiguous() and x2.shape[0] == B
+        C2 = x2.shape[-1]
+    y = torch.empty(x1.shape[:-1] + (C1 + C2,), dtype=BF16, device=x1.device)
+    ws = torch.empty(lib.dm4d_groupnorm_ws_bytes(B, HW, groups) // 4, dtype=torch.float32, device=x1.device)
+    rc = lib.dm4d_groupnorm_nhwc_bf16(_stream(), _p(x1), C1, _p(x2), C2, B, HW, groups, eps, _p(gamma), _p(beta),
+                                      _p(y), 1 if silu else 0, _p(ws))
+    _l.check(rc, "dm4d_groupnorm_nhwc_bf16")
+    return y
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    lib = _l.load()
+    _req(x, "x"), _req(gamma, "gamma"), _req(beta, "beta")
+    x2 = x.reshape(-1, x.shape[-1])
+    y = torch.empty_like(x2)
+    rc = lib.dm4d_layernorm_bf16(_stream(), _p(x2), x2.stride(0), _p(gamma), _p(beta), _p(y), y.stride(0), x2.shape[0],
+                                 x2.shape[1], eps)
+    _l.check(rc, "dm4d_layernorm_bf16")
+    return y.view(x.shape)
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, heads: int, seq: int,
+              scale: Optional[float] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q/k/v: [batch*seq, >=heads*64] row-strided views (e.g. column slices of the fused QKV output)."""
+    lib = _l.load()
+    _req(q, "q"), _req(k, "k"), _req(v, "v")
+    assert q.shape[0] == batch * seq and q.shape[1] == heads * 64, (q.shape, batch, seq, heads)
+    if out is None:
+        out = torch.empty((batch * seq, heads * 64), dtype=BF16, device=q.device)
+    if scale is None:
+        scale = 0.125
+    rc = lib.dm4d_attention_bf16(_stream(), _p(q), _p(k), _p(v), _p(out), q.stride(0), k.stride(0), v.stride(0),
+                                 out.stride(0), batch, heads, seq, scale)
+    _l.check(rc, "dm4d_attention_bf16")
+    return out
+
+
+def softmax_rows(s: torch.Tensor, scale: float) -> torch.Tensor:
+    lib = _l.load()
+    _req(s, "s")
+    p = torch.empty_like(s)
+    rc = lib.dm4d_softmax_rows_bf16(_stream(), _p(s), s.stride(0), _p(p), p.stride(0), s.shape[0], s.shape[1], scale)
+    _l.check(rc, "dm4d_softmax_rows_bf16")
+    return p
+
+
+def timestep_embedding(t: torch.Tensor, dim: int, flip_sin_to_cos: bool = True, freq_shift: float = 0.0) -> torch.Tensor:
+    lib = _l.load()
+    _req(t, "t", torch.float32)
+    out = torch.empty((t.shape[0], dim), dtype=BF16, device=t.device)
+    rc = lib.dm4d_timestep_embedding_bf16(_stream(), _p(t), _p(out), t.shape[0], dim, 1 if flip_sin_to_cos else 0,
+                                          freq_shift)
+    _l.check(rc, "dm4d_timestep_embedding_bf16")
+    return out
+
+
+def silu(x: torch.Tensor) -> torch.Tensor:
+    lib = _l.load()
+    _req(x, "x")
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    _l.check(lib.dm4d_silu_bf16(_stream(), _p(x), _p(y), x.numel()), "dm4d_silu_bf16")
+    return y
+
+
+def pack_model_input(latents, pv_lat, plucker, skel, mask, is_cond, cpad: int, use_cfg: bool) -> torch.Tensor:
+    """All inputs NHWC [F, HW, c]; is_cond int32 [F].  Mutates `latents` cond rows (reference aliasing)."""
+    lib = _l.load()
+    for t, n in ((latents, "latents"), (pv_lat, "pv_lat"), (plucker, "plucker"), (mask, "mask")):
+        _req(t, n)
+        assert t.is_contiguous()
+    if skel is not None:
+        _req(skel, "skel")
+    _req(is_cond, "is_cond", torch.int32)
+    F, HW = latents.shape[0], latents.shape[1]
+    out = torch.empty(((2 if use_cfg else 1) * F, HW, cpad), dtype=BF16, device=latents.device)
+    rc = lib.dm4d_pack_model_input_bf16(_stream(), _p(latents), _p(pv_lat), _p(plucker), _p(skel), _p(mask),
+                                        _p(is_cond), _p(out), F, HW, cpad, 1 if use_cfg else 0)
+    _l.check(rc, "dm4d_pack_model_input_bf16")
+    return out
+
+
+def cfg_ddim_step(latents, noise_pred, coef, is_cond, use_cfg: bool, guidance_scale: float, v_prediction: bool):
+    """In-place DDIM update of `latents` [F,HW,4] from noise_pred [cfg*F, HW, ldn]."""
+    lib = _l.load()
+    _req(latents, "latents"), _req(noise_pred, "noise_pred"), _req(coef, "coef", torch.float32)
+    _req(is_cond, "is_cond", torch.int32)
+    F, HW = latents.shape[0], latents.shape[1]
+    rc = lib.dm4d_cfg_ddim_step_bf16(_stream(), _p(latents), _p(noise_pred), noise_pred.stride(-2), _p(coef),
+                                     _p(is_cond), F, HW, 1 if use_cfg else 0, guidance_scale, 1 if v_prediction else 0)
+    _l.check(rc, "dm4d_cfg_ddim_step_bf16")
+    return latents
+
+
+def nchw_to_nhwc(x: torch.Tensor, cpad: Optional[int] = None) -> torch.Tensor:
+    lib = _l.load()
+    _req(x, "x")
+    assert x.is_contiguous()
+    B, C, H, W = x.shape
+    cpad = cpad or C
+    y = torch.empty((B, H, W, cpad), dtype=BF16, device=x.device)
+    _l.check(lib.dm4d_nchw_to_nhwc_bf16(_stream(), _p(x), _p(y), B, C, H * W, cpad), "dm4d_nchw_to_nhwc_bf16")
+    return y
+
+
+def nhwc_to_nchw(x: torch.Tensor, C: Optional[int] = None) -> torch.Tensor:
+    lib = _l.load()
+    _req(x, "x")
+    assert x.is_contiguous()
+    B, H, W, ld = x.shape
+    C = C or ld
+    y = torch.empty((B, C, H, W), dtype=BF16, device=x.device)
+    _l.check(lib.dm4d_nhwc_to_nchw_bf16(_stream(), _p(x), _p(y), B, C, H * W, ld), "dm4d_nhwc_to_nchw_bf16")
+    return y

@@ -1,0 +1,316 @@
+"""HIP-backed UNetMultiviewConditionModel (inference only).
+
+Host-side mirror of the reference's model interface
+(``/root/reference/src/diffusers/models/unets/unet_multiview_condition.py:49-598``): same config
+fields, same ``state_dict`` key names on load, same ``forward(sample, timestep, skeletons, domains,
+num_frames)`` meaning.  All arithmetic runs in libdm4d.so (``ops``); torch only owns the buffers.
+
+Layout: activations are NHWC / token-major ``[B, H, W, C]`` bf16 end to end, so
+  * the transformer's NCHW<->[B,HW,C] permutes (transformer_multiview.py:157-160,209-216) and
+  * the 3-D attention frame folding + ``.contiguous()`` copies (attention.py:69-71,81-83)
+are no-ops, and the up-block ``torch.cat`` (unet_multiview_blocks.py:667) is fused into the
+consumers (two-source GroupNorm / split-K shortcut GEMM).
+"""
+from __future__ import annotations
+
+import json
+from dataclasses import dataclass, fields
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+
+BF16 = torch.bfloat16
+
+
+@dataclass
+class UNetConfig:
+    """Fields of ``unet/config.json`` used on this path (unet_multiview_condition.py:149-212)."""
+
+    in_channels: int = 15
+    out_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280)
+    down_block_types: Tuple[str, ...] = ("CrossAttnDownBlockMultiview", "CrossAttnDownBlockMultiview",
+                                         "CrossAttnDownBlockMultiview", "DownBlock2D")
+    up_block_types: Tuple[str, ...] = ("UpBlock2D", "CrossAttnUpBlockMultiview", "CrossAttnUpBlockMultiview",
+                                       "CrossAttnUpBlockMultiview")
+    layers_per_block: int = 2
+    attention_head_dim: Tuple[int, ...] = (5, 10, 20, 20)  # number of heads (upstream naming quirk, :222-228)
+    norm_num_groups: int = 32
+    norm_eps: float = 1e-5
+    cross_attention_dim: Optional[int] = None
+    use_linear_projection: bool = True
+    flip_sin_to_cos: bool = True
+    freq_shift: int = 0
+    num_3d_attn_blocks: int = 3
+    enable_tem_embeds: bool = False
+    enable_pose_encoder: bool = False
+    mid_block_scale_factor: float = 1.0
+    resnet_out_scale_factor: float = 1.0
+
+    @classmethod
+    def from_dict(cls, d: Dict) -> "UNetConfig":
+        names = {f.name for f in fields(cls)}
+        kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in d.items() if k in names}
+        return cls(**kw)
+
+    def heads(self, i: int) -> int:
+        a = self.attention_head_dim
+        return a if isinstance(a, int) else a[i]
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class _Weights:
+    """Converts a diffusers-style state_dict into kernel layouts on the device."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], device):
+        self.sd, self.device = sd, device
+        self.used = set()
+
+    def get(self, key: str) -> torch.Tensor:
+        if key not in self.sd:
+            raise KeyError(f"UNet checkpoint is missing '{key}'")
+        self.used.add(key)
+        return self.sd[key]
+
+    def vec(self, key: str) -> torch.Tensor:
+        return self.get(key).to(self.device, BF16).contiguous()
+
+    def linear(self, key: str) -> torch.Tensor:
+        w = self.get(key)
+        if w.ndim == 4:  # 1x1 conv used as a linear
+            w = w.reshape(w.shape[0], w.shape[1])
+        return w.to(self.device, BF16).contiguous()
+
+    def conv3(self, key: str, cin_pad: Optional[int] = None, cout_pad: Optional[int] = None) -> torch.Tensor:
+        """[Cout, Cin, 3, 3] -> [Cout, 9*Cin] with K ordered (ky, kx, ci); optional zero padding."""
+        w = self.get(key).float()
+        co, ci = w.shape[0], w.shape[1]
+        cin_pad, cout_pad = cin_pad or ci, cout_pad or co
+        wp = torch.zeros(cout_pad, 3, 3, cin_pad)
+        wp[:co, :, :, :ci] = w.permute(0, 2, 3, 1)
+        return wp.reshape(cout_pad, 9 * cin_pad).to(self.device, BF16).contiguous()
+
+
+class _Resnet:
+    def __init__(self, W: _Weights, pfx: str, groups: int, eps: float, scale: float, temb_list: List):
+        self.groups, self.eps, self.scale = groups, eps, scale
+        self.n1w, self.n1b = W.vec(pfx + "norm1.weight"), W.vec(pfx + "norm1.bias")
+        self.c1w, self.c1b = W.conv3(pfx + "conv1.weight"), W.vec(pfx + "conv1.bias")
+        self.n2w, self.n2b = W.vec(pfx + "norm2.weight"), W.vec(pfx + "norm2.bias")
+        self.c2w, self.c2b = W.conv3(pfx + "conv2.weight"), W.vec(pfx + "conv2.bias")
+        self.cout = self.c1w.shape[0]
+        self.has_sc = (pfx + "conv_shortcut.weight") in W.sd
+        if self.has_sc:
+            self.scw, self.scb = W.linear(pfx + "conv_shortcut.weight"), W.vec(pfx + "conv_shortcut.bias")
+        # time_emb_proj of every resnet is batched into one GEMM per forward (see UNet._temb)
+        self.t_off = sum(t[0].shape[0] for t in temb_list)
+        temb_list.append((W.get(pfx + "time_emb_proj.weight"), W.get(pfx + "time_emb_proj.bias")))
+
+    def __call__(self, x: torch.Tensor, tproj: torch.Tensor, skip: Optional[torch.Tensor] = None) -> torch.Tensor:
+        B, H, Wd = x.shape[:3]
+        h = ops.groupnorm(x, self.n1w, self.n1b, self.groups, self.eps, x2=skip, silu=True)
+        h = ops.conv3x3(h, self.c1w, bias=self.c1b, rowbias=tproj[:, self.t_off:self.t_off + self.cout])
+        h = ops.groupnorm(h, self.n2w, self.n2b, self.groups, self.eps, silu=True)
+        if self.has_sc:
+            M = B * H * Wd
+            sc = ops.gemm(x.view(M, -1), self.scw, a2=skip.view(M, -1) if skip is not None else None, bias=self.scb)
+            sc = sc.view(B, H, Wd, self.cout)
+        else:
+            assert skip is None
+            sc = x
+        return ops.conv3x3(h, self.c2w, bias=self.c2b, residual=sc, out_scale=1.0 / self.scale)
+
+
+class _TransformerBlock:
+    def __init__(self, W: _Weights, pfx: str, heads: int):
+        self.heads = heads
+        self.n1w, self.n1b = W.vec(pfx + "norm1.weight"), W.vec(pfx + "norm1.bias")
+        q, k, v = (W.get(pfx + f"attn1.to_{n}.weight") for n in "qkv")
+        self.qkv = torch.cat([q, k, v], dim=0).to(W.device, BF16).contiguous()  # fused [3C, C], bias-free
+        self.ow, self.ob = W.linear(pfx + "attn1.to_out.0.weight"), W.vec(pfx + "attn1.to_out.0.bias")
+        self.n3w, self.n3b = W.vec(pfx + "norm3.weight"), W.vec(pfx + "norm3.bias")
+        self.f1w, self.f1b = W.linear(pfx + "ff.net.0.proj.weight"), W.vec(pfx + "ff.net.0.proj.bias")
+        self.f2w, self.f2b = W.linear(pfx + "ff.net.2.weight"), W.vec(pfx + "ff.net.2.bias")
+        if (pfx + "attn2.to_q.weight") in W.sd:
+            raise NotImplementedError("cross-attention (attn2) checkpoints are not supported: the reference never "
+                                      "passes encoder_hidden_states (SURVEY.md section 0)")
+
+    def __call__(self, h: torch.Tensor, batch: int, seq: int) -> torch.Tensor:
+        """h [M, C] token-major; attention over `batch` sequences of `seq` tokens (attention.py:68-90)."""
+        C = h.shape[1]
+        n = ops.layernorm(h, self.n1w, self.n1b, 1e-5)
+        qkv = ops.gemm(n, self.qkv)
+        a = ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], batch, self.heads, seq,
+                          scale=(C // self.heads) ** -0.5)
+        h = ops.gemm(a, self.ow, bias=self.ob, residual=h)
+        n = ops.layernorm(h, self.n3w, self.n3b, 1e-5)
+        f = ops.gemm(n, self.f1w, bias=self.f1b, geglu=True)
+        return ops.gemm(f, self.f2w, bias=self.f2b, residual=h)
+
+
+class _Transformer:
+    """TransformerMultiviewModel (transformer_multiview.py:34-232), continuous input."""
+
+    def __init__(self, W: _Weights, pfx: str, heads: int, groups: int):
+        self.groups = groups
+        self.nw, self.nb = W.vec(pfx + "norm.weight"), W.vec(pfx + "norm.bias")
+        self.piw, self.pib = W.linear(pfx + "proj_in.weight"), W.vec(pfx + "proj_in.bias")
+        self.pow, self.pob = W.linear(pfx + "proj_out.weight"), W.vec(pfx + "proj_out.bias")
+        self.blocks = []
+        i = 0
+        while (pfx + f"transformer_blocks.{i}.norm1.weight") in W.sd:
+            self.blocks.append(_TransformerBlock(W, pfx + f"transformer_blocks.{i}.", heads))
+            i += 1
+        if (self.piw.shape[0] // heads) != 64:
+            raise NotImplementedError("the HIP attention kernel is specialised for head_dim 64")
+
+    def __call__(self, x: torch.Tensor, num_frames: int) -> torch.Tensor:
+        B, H, Wd, C = x.shape
+        M, HW = B * H * Wd, H * Wd
+        n = ops.groupnorm(x, self.nw, self.nb, self.groups, 1e-6, silu=False)  # eps 1e-6: transformer_multiview.py:43-45
+        h = ops.gemm(n.view(M, C), self.piw, bias=self.pib)
+        for blk in self.blocks:
+            h = blk(h, B // num_frames, num_frames * HW)
+        return ops.gemm(h, self.pow, bias=self.pob, residual=x.view(M, C)).view(B, H, Wd, C)
+
+
+class UNetMultiviewConditionModel:
+    """Inference-only, HIP-backed.  ``forward`` takes/returns NHWC bf16 (see ``Diffuman4DPipeline``)."""
+
+    IN_PAD = 32  # conv_in input channels are zero-padded to one 32-wide K slab
+
+    def __init__(self, config: UNetConfig, state_dict: Dict[str, torch.Tensor], device="cuda"):
+        cfg = self.config = config
+        self.device = torch.device(device)
+        if cfg.enable_pose_encoder:
+            raise NotImplementedError("enable_pose_encoder checkpoints are not supported by the HIP path yet")
+        if cfg.cross_attention_dim is not None:
+            raise NotImplementedError("cross_attention_dim must be None (SURVEY.md section 0)")
+        if cfg.in_channels > self.IN_PAD:
+            raise NotImplementedError("in_channels > 32")
+        W = _Weights(state_dict, self.device)
+        boc = cfg.block_out_channels
+        g, eps = cfg.norm_num_groups, cfg.norm_eps
+        temb_list: List = []
+        self.conv_in_w = W.conv3("conv_in.weight", cin_pad=self.IN_PAD)
+        self.conv_in_b = W.vec("conv_in.bias")
+        self.te = [W.linear("time_embedding.linear_1.weight"), W.vec("time_embedding.linear_1.bias"),
+                   W.linear("time_embedding.linear_2.weight"), W.vec("time_embedding.linear_2.bias")]
+        self.tpe = None
+        if cfg.enable_tem_embeds:
+            self.tpe = [W.linear("temporal_pos_embed.linear_1.weight"), W.vec("temporal_pos_embed.linear_1.bias"),
+                        W.linear("temporal_pos_embed.linear_2.weight"), W.vec("temporal_pos_embed.linear_2.bias")]
+        self.down = []
+        for i, t in enumerate(cfg.down_block_types):
+            p = f"down_blocks.{i}."
+            has_attn = t != "DownBlock2D"
+            res = [_Resnet(W, p + f"resnets.{j}.", g, eps, cfg.resnet_out_scale_factor if not has_attn else 1.0, temb_list)
+                   for j in range(cfg.layers_per_block)]
+            att = [_Transformer(W, p + f"attentions.{j}.", cfg.heads(i), g) for j in range(cfg.layers_per_block)] if has_attn else None
+            ds = None
+            if i != len(boc) - 1:
+                ds = (W.conv3(p + "downsamplers.0.conv.weight"), W.vec(p + "downsamplers.0.conv.bias"))
+            self.down.append((res, att, ds))
+        mp = "mid_block."
+        self.mid = ([_Resnet(W, mp + f"resnets.{j}.", g, eps, cfg.mid_block_scale_factor, temb_list) for j in range(2)],
+                    _Transformer(W, mp + "attentions.0.", cfg.heads(len(boc) - 1), g))
+        self.up = []
+        for i, t in enumerate(cfg.up_block_types):
+            p = f"up_blocks.{i}."
+            has_attn = t != "UpBlock2D"
+            n = cfg.layers_per_block + 1
+            res = [_Resnet(W, p + f"resnets.{j}.", g, eps, cfg.resnet_out_scale_factor if not has_attn else 1.0, temb_list)
+                   for j in range(n)]
+            att = [_Transformer(W, p + f"attentions.{j}.", cfg.heads(len(boc) - 1 - i), g) for j in range(n)] if has_attn else None
+            us = None
+            if i != len(boc) - 1:
+                us = (W.conv3(p + "upsamplers.0.conv.weight"), W.vec(p + "upsamplers.0.conv.bias"))
+            self.up.append((res, att, us))
+        self.no_w, self.no_b = W.vec("conv_norm_out.weight"), W.vec("conv_norm_out.bias")
+        self.conv_out_w, self.conv_out_b = W.conv3("conv_out.weight"), W.vec("conv_out.bias")
+        # one [sum(Cout), 4*C0] weight for all time_emb_proj layers
+        self.tproj_w = torch.cat([t[0] for t in temb_list], dim=0).to(self.device, BF16).contiguous()
+        self.tproj_b = torch.cat([t[1] for t in temb_list], dim=0).to(self.device, BF16).contiguous()
+        unused = [k for k in state_dict if k not in W.used and not k.startswith("time_proj")
+                  and "time_emb_proj" not in k and ".attn1.to_" not in k]
+        if unused:
+            raise KeyError(f"unexpected keys in UNet checkpoint (strict load): {unused[:8]}{'...' if len(unused) > 8 else ''}")
+
+    # -- loading --------------------------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, path, device="cuda") -> "UNetMultiviewConditionModel":
+        """``path`` = the ``unet/`` folder of a diffusers checkpoint directory."""
+        from safetensors.torch import load_file
+        path = Path(path)
+        cfg = UNetConfig.from_dict(json.loads((path / "config.json").read_text()))
+        files = sorted(path.glob("diffusion_pytorch_model*.safetensors"))
+        if not files:
+            raise FileNotFoundError(f"no diffusion_pytorch_model*.safetensors under {path}")
+        return cls(cfg, load_file(str(files[0])), device)
+
+    # -- forward --------------------------------------------------------------------------------
+    def _temb(self, timestep: torch.Tensor, domains: Sequence[str], num_frames: int) -> torch.Tensor:
+        cfg = self.config
+        c0 = cfg.block_out_channels[0]
+        t_emb = ops.timestep_embedding(timestep.to(self.device, torch.float32), c0, cfg.flip_sin_to_cos, float(cfg.freq_shift))
+        emb = ops.gemm(ops.gemm(t_emb, self.te[0], bias=self.te[1], silu=True), self.te[2], bias=self.te[3])
+        if self.tpe is not None:  # unet_multiview_condition.py:523-546
+            if len(domains) * num_frames != emb.shape[0]:
+                raise ValueError(f"num_frames: {num_frames} * len(domains): {len(domains)} != len(emb): {emb.shape[0]}")
+            idx = []
+            for d in domains:
+                if d == "spatial":
+                    idx.append(torch.zeros(num_frames))
+                elif d == "temporal":
+                    idx.append(torch.arange(num_frames // 2).repeat(2).float())
+                else:
+                    raise ValueError(f"Invalid domain for temporal embedding: {d}")
+            f_emb = ops.timestep_embedding(torch.cat(idx).to(self.device), c0, True, 0.0)
+            emb = ops.gemm(ops.gemm(f_emb, self.tpe[0], bias=self.tpe[1], silu=True), self.tpe[2], bias=self.tpe[3],
+                           residual=emb)
+        return ops.gemm(ops.silu(emb), self.tproj_w, bias=self.tproj_b)  # [B, sum Cout]
+
+    @torch.no_grad()
+    def forward(self, sample: torch.Tensor, timestep: torch.Tensor, skeletons=None, domains: Sequence[str] = ("spatial",),
+                num_frames: int = 1) -> torch.Tensor:
+        """sample [B, h, w, 32] NHWC bf16 (channels beyond in_channels zero); timestep [B]; -> [B, h, w, out_channels]."""
+        cfg = self.config
+        if sample.shape[-1] != self.IN_PAD:
+            raise ValueError(f"sample must be NHWC with {self.IN_PAD} (padded) channels")
+        if sample.shape[0] % num_frames != 0:
+            raise ValueError("batch must be a multiple of num_frames")
+        tproj = self._temb(timestep, domains, num_frames)
+        x = ops.conv3x3(sample, self.conv_in_w, bias=self.conv_in_b)
+        skips = [x]
+        nd = len(self.down)
+        for i, (res, att, ds) in enumerate(self.down):
+            nf = num_frames if (att is not None and nd - i - 1 < cfg.num_3d_attn_blocks) else 1  # :560
+            for j, r in enumerate(res):
+                x = r(x, tproj)
+                if att is not None:
+                    x = att[j](x, nf)
+                skips.append(x)
+            if ds is not None:
+                x = ops.conv3x3(x, ds[0], bias=ds[1], stride=2, pad=1)
+                skips.append(x)
+        x = self.mid[0][0](x, tproj)
+        x = self.mid[1](x, num_frames)  # :570
+        x = self.mid[0][1](x, tproj)
+        for i, (res, att, us) in enumerate(self.up):
+            nf = num_frames if (att is not None and i < cfg.num_3d_attn_blocks) else 1  # :582
+            for j, r in enumerate(res):
+                x = r(x, tproj, skip=skips.pop())
+                if att is not None:
+                    x = att[j](x, nf)
+            if us is not None:
+                x = ops.conv3x3(x, us[0], bias=us[1], upsample=True)
+        x = ops.groupnorm(x, self.no_w, self.no_b, cfg.norm_num_groups, cfg.norm_eps, silu=True)
+        return ops.conv3x3(x, self.conv_out_w, bias=self.conv_out_b)
+
+    __call__ = forward

@@ -1,0 +1,117 @@
+/*
+ * dm4d.h -- C ABI of libdm4d.so: the MI355X (gfx950) operator library underneath the
+ * Diffuman4D sliding iterative denoiser.
+ *
+ * The reference (zju3dv/Diffuman4D) has no native layer and no FFI: every device op on its hot
+ * path is an implicit torch / diffusers call.  Each entry point below
+ * therefore cites the *call site* in the reference whose arithmetic it replaces.  A reference
+ * maintainer binds these with ctypes; diffuman4d_amd/host/lib.py is that
+ * binding.
+ *
+ * Conventions
+ *   - all tensors are device pointers owned by the caller; bf16 unless noted; activations are
+ *     token-major / NHWC: [B, H*W, C] with C contiguous
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); every call is asynchronous
+ *   - return value: 0 = ok, <0 = error; dm4d_last_error() returns a thread-local message
+ *   - no entry point allocates, synchronises or touches host memory
+ */
+#ifndef DM4D_H
+#define DM4D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DM4D_OK 0
+#define DM4D_ERR_ARG -1
+#define DM4D_ERR_LAUNCH -2
+
+/* gemm / conv epilogue flags */
+#define DM4D_EPI_GEGLU 1u /* W holds [2*N, K]: out = (x W_h^T + b_h) * gelu(x W_g^T + b_g)   */
+#define DM4D_EPI_SILU 2u  /* out = silu(acc + bias ...) (time embedding MLP)                 */
+
+int dm4d_version(void);
+const char* dm4d_last_error(void);
+
+/* Linear layers: out[M,N] = epi( [A | A2][M,K] @ W[N,K]^T )
+ *   replaces nn.Linear calls of diffusers Attention.to_q/k/v/to_out, Transformer2DModel.proj_in/out,
+ *   FeedForward/GEGLU, TimestepEmbedding, ResnetBlock2D.time_emb_proj and the 1x1 conv_shortcut
+ *   (reference call sites: attention.py:73-78,90,142; transformer_multiview.py:160,209;
+ *   unet_multiview_condition.py:520; unet_multiview_blocks.py:342,518,697).
+ *   A2 != NULL: columns [K1, K) come from A2 (channel concat of the up-block skip, :667) .
+ *   epilogue: acc (+bias[n]) (GEGLU|SILU) (+rowbias[m / rows_per_rowbias, n]) (+residual[m,n]) * out_scale
+ *   K, K1 multiples of 32; lda/ldw multiples of 8.                                              */
+int dm4d_gemm_bf16(void* stream, const void* A, int64_t lda, const void* A2, int64_t lda2, int K1, const void* W,
+                   int64_t ldw, void* C, int64_t ldc, int M, int N, int K, const void* bias, const void* rowbias,
+                   int64_t ld_rowbias, int rows_per_rowbias, const void* residual, int64_t ld_res, unsigned flags,
+                   float out_scale);
+
+/* 3x3 convolution, NHWC, implicit GEMM on MFMA.
+ *   replaces nn.Conv2d(k=3) in ResnetBlock2D.conv1/conv2, Downsample2D.conv (stride 2),
+ *   Upsample2D (nearest x2 fused into the gather: upsample=1), conv_in, conv_out
+ *   (unet_multiview_condition.py:549,593; unet_multiview_blocks.py:342,381,460,518,620,697).
+ *   X [B,H,W,Cin] (Cin % 32 == 0), Wt [Cout][3][3][Cin], Y [B,Ho,Wo,Cout];
+ *   Ho = upsample ? 2H : (H + 2*pad_hi... see dm4d_conv_out_size). pad = leading pad (1 for the UNet,
+ *   0 for the VAE encoder's asymmetric (0,1,0,1) pad); trailing pad is implied by Ho/Wo.
+ *   epilogue as in dm4d_gemm_bf16 (rowbias row = batch index: the temb projection, resnet.py)   */
+int dm4d_conv3x3_nhwc_bf16(void* stream, const void* X, int B, int H, int W, int Cin, const void* Wt, void* Y, int Ho,
+                           int Wo, int Cout, int stride, int pad, int upsample, const void* bias, const void* rowbias,
+                           int64_t ld_rowbias, const void* residual, int64_t ld_res, float out_scale);
+
+/* GroupNorm (+SiLU) over [X1 | X2] (channel concat, X2 may be NULL), NHWC.
+ *   replaces nn.GroupNorm + SiLU in ResnetBlock2D.norm1/norm2, TransformerMultiviewModel.norm
+ *   (transformer_multiview.py:43-45), conv_norm_out (unet_multiview_condition.py:590-592).
+ *   ws: fp32 scratch of dm4d_groupnorm_ws_bytes(B, HW) bytes.  Statistics in fp32.              */
+size_t dm4d_groupnorm_ws_bytes(int B, int HW, int groups);
+int dm4d_groupnorm_nhwc_bf16(void* stream, const void* X1, int C1, const void* X2, int C2, int B, int HW, int groups,
+                             float eps, const void* gamma, const void* beta, void* Y, int apply_silu, void* ws);
+
+/* LayerNorm over the last dim.  replaces BasicTransformerBlock.norm1/norm3 (attention.py:49,129) */
+int dm4d_layernorm_bf16(void* stream, const void* X, int64_t ldx, const void* gamma, const void* beta, void* Y,
+                        int64_t ldy, int M, int C, float eps);
+
+/* Self-attention, head_dim 64, no mask: O = softmax(Q K^T * scale) V per (batch, head).
+ *   replaces AttnProcessor2_0 / F.scaled_dot_product_attention reached from attention.py:73-78;
+ *   the "(b t) hw c -> b (t hw) c" frame folding (attention.py:69-71,81-83) is expressed by
+ *   batch = B / num_frames, L = num_frames * HW on the SAME memory (token-major rows).
+ *   Q/K/V/O rows are tokens; element (b, t, h, d) lives at ptr[(b*L + t)*ld + h*64 + d].           */
+int dm4d_attention_bf16(void* stream, const void* Q, const void* K, const void* V, void* O, int64_t ldq, int64_t ldk,
+                        int64_t ldv, int64_t ldo, int batch, int heads, int L, float scale);
+
+/* Generic-head-dim attention pieces for the VAE mid block (single head, d = 512): row softmax.   */
+int dm4d_softmax_rows_bf16(void* stream, const void* S, int64_t lds, void* P, int64_t ldp, int M, int N, float scale);
+
+/* sinusoidal timestep embedding, diffusers get_timestep_embedding (unet_multiview_condition.py:494):
+ *   out[b, :] = [cos(t*f) | sin(t*f)] (flip_sin_to_cos) in bf16, t given as fp32                  */
+int dm4d_timestep_embedding_bf16(void* stream, const float* t, void* out, int B, int dim, int flip_sin_to_cos,
+                                 float freq_shift);
+
+int dm4d_silu_bf16(void* stream, const void* X, void* Y, int64_t n);
+
+/* Model-input assembly for one window (pipeline_diffuman4d.py:375-395, 348-357):
+ *   out [cfg*F, HW, cpad] NHWC: channels [latent 4 | plucker 6 | skeleton-latent 4 (opt) | mask 1 | 0...]
+ *   cond rows (is_cond[f] != 0) take the clean image latents (and +1.0 in the negative half);
+ *   negative half: plucker 0, skeleton -1.  Also performs the reference's aliasing side effect
+ *   (SURVEY 8a P-4 iv): latents[cond rows] <- image latents, in place.                             */
+int dm4d_pack_model_input_bf16(void* stream, void* latents, const void* pv_lat, const void* plucker, const void* skel,
+                               const void* mask, const int32_t* is_cond, void* out, int F, int HW, int cpad,
+                               int use_cfg);
+
+/* CFG combine + per-latent DDIM step (pipeline_diffuman4d.py:408-422), one launch for the window:
+ *   eps = u + s (c - u);  x <- sqrt(a_prev) x0 + sqrt(1 - a_prev) eps_hat   for non-cond rows.
+ *   noise_pred [cfg*F, HW, ldn]; coef [F,4] fp32 = {sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev)} */
+int dm4d_cfg_ddim_step_bf16(void* stream, void* latents, const void* noise_pred, int64_t ldn, const float* coef,
+                            const int32_t* is_cond, int F, int HW, int use_cfg, float guidance_scale,
+                            int v_prediction);
+
+/* layout converters at the pipeline boundary (NCHW <-> NHWC, any C) */
+int dm4d_nchw_to_nhwc_bf16(void* stream, const void* X, void* Y, int B, int C, int HW, int cpad);
+int dm4d_nhwc_to_nchw_bf16(void* stream, const void* X, void* Y, int B, int C, int HW, int ldx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DM4D_H */

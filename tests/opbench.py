@@ -1,0 +1,120 @@
+"""Per-kernel micro-benchmarks at the real UNet shapes (72x40 latents, F=16/24, CFG): prints achieved
+TFLOP/s (MFMA kernels) or GB/s (HBM-bound kernels).  Run on a GPU box: `python tests/opbench.py`."""
+from __future__ import annotations
+
+import math
+import os
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from diffuman4d_amd.host import ops  # noqa: E402
+
+BF = torch.bfloat16
+DEV = "cuda"
+
+
+def timeit(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3  # seconds
+
+
+def rnd(*shape, scale=1.0):
+    return (torch.randn(*shape, device=DEV) * scale).to(BF)
+
+
+def bench_gemm(M, N, K, geglu=False, residual=True, tag=""):
+    a, w = rnd(M, K), rnd(2 * N if geglu else N, K, scale=1 / math.sqrt(K))
+    b = rnd(2 * N if geglu else N)
+    res = rnd(M, N) if residual else None
+    t = timeit(lambda: ops.gemm(a, w, bias=b, residual=res, geglu=geglu))
+    fl = 2.0 * M * K * (2 * N if geglu else N)
+    print(f"gemm{tag:10s} M={M:6d} N={N:5d} K={K:5d} geglu={int(geglu)}  {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s", flush=True)
+
+
+def bench_conv(B, H, W, Cin, Cout, stride=1, upsample=False, tag=""):
+    x = rnd(B, H, W, Cin)
+    wt = rnd(Cout, 9 * Cin, scale=1 / math.sqrt(9 * Cin))
+    b = rnd(Cout)
+    rb = rnd(B, Cout)
+    t = timeit(lambda: ops.conv3x3(x, wt, bias=b, rowbias=rb, stride=stride, upsample=upsample))
+    Ho, Wo = ops.conv_out_hw(H, W, stride, 1, upsample)
+    fl = 2.0 * B * Ho * Wo * 9 * Cin * Cout
+    print(f"conv{tag:10s} B={B:3d} {H}x{W} {Cin:5d}->{Cout:5d} s{stride} up{int(upsample)}  {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s", flush=True)
+
+
+def bench_attn(batch, heads, L, tag=""):
+    C = heads * 64
+    qkv = rnd(batch * L, 3 * C)
+    t = timeit(lambda: ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], batch, heads, L), iters=10)
+    fl = 4.0 * batch * heads * L * L * 64
+    print(f"attn{tag:10s} b={batch:3d} h={heads:3d} L={L:6d}  {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s", flush=True)
+
+
+def bench_gn(B, HW, C, tag=""):
+    x = rnd(B, HW, C)
+    g, bt = rnd(C), rnd(C)
+    t = timeit(lambda: ops.groupnorm(x, g, bt, 32, 1e-5, silu=True))
+    by = 2.0 * B * HW * C * 2  # algorithmic: read once + write once, bf16
+    print(f"gn  {tag:10s} B={B:3d} HW={HW:6d} C={C:5d}  {t*1e6:9.1f} us  {by/t/1e9:7.1f} GB/s(alg)", flush=True)
+
+
+def bench_ln(M, C, tag=""):
+    x = rnd(M, C)
+    g, bt = rnd(C), rnd(C)
+    t = timeit(lambda: ops.layernorm(x, g, bt))
+    by = 2.0 * M * C * 2
+    print(f"ln  {tag:10s} M={M:6d} C={C:5d}  {t*1e6:9.1f} us  {by/t/1e9:7.1f} GB/s(alg)", flush=True)
+
+
+def main():
+    print("device:", torch.cuda.get_device_name(0), "attn QB env:", os.environ.get("DM4D_ATTN_QB"), flush=True)
+    B = 32  # F=16, CFG
+    # GEMMs of one transformer block per level
+    for lvl, (hw, c) in enumerate([(2880, 320), (720, 640), (180, 1280), (45, 1280)]):
+        M = B * hw
+        bench_gemm(M, 3 * c, c, residual=False, tag=f" qkv L{lvl}")
+        bench_gemm(M, c, c, tag=f" out L{lvl}")
+        bench_gemm(M, 4 * c, c, geglu=True, residual=False, tag=f" ff1 L{lvl}")
+        bench_gemm(M, c, 4 * c, tag=f" ff2 L{lvl}")
+    # convs
+    bench_conv(B, 72, 40, 320, 320, tag=" L0")
+    bench_conv(B, 72, 40, 960, 320, tag=" L0 up")
+    bench_conv(B, 72, 40, 320, 320, stride=2, tag=" L0 down")
+    bench_conv(B, 36, 20, 640, 640, tag=" L1")
+    bench_conv(B, 36, 20, 1920, 640, tag=" L1 up")
+    bench_conv(B, 18, 10, 1280, 1280, tag=" L2")
+    bench_conv(B, 18, 10, 2560, 1280, tag=" L2 up")
+    bench_conv(B, 9, 5, 1280, 1280, tag=" L3")
+    bench_conv(B, 9, 5, 2560, 1280, tag=" L3 up")
+    bench_conv(B, 18, 10, 1280, 1280, upsample=True, tag=" L2 ups")
+    bench_conv(B, 72, 40, 32, 320, tag=" conv_in")
+    bench_conv(B, 72, 40, 320, 4, tag=" conv_out")
+    # attention: 2-D L0, 3-D L1/L2/mid for F=16 and F=24
+    bench_attn(32, 5, 2880, " 2D L0")
+    bench_attn(2, 10, 11520, " 3D L1 F16")
+    bench_attn(2, 10, 17280, " 3D L1 F24")
+    bench_attn(2, 20, 2880, " 3D L2 F16")
+    bench_attn(2, 20, 4320, " 3D L2 F24")
+    bench_attn(2, 20, 720, " 3D mid")
+    bench_attn(2, 10, 65536, " 3D L1 128")
+    # norms
+    bench_gn(B, 2880, 320, " L0")
+    bench_gn(B, 720, 640, " L1")
+    bench_gn(B, 180, 1280, " L2")
+    bench_ln(B * 2880, 320, " L0")
+    bench_ln(B * 720, 640, " L1")
+
+
+if __name__ == "__main__":
+    main()

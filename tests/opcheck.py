@@ -1,0 +1,311 @@
+"""Operator-level parity checks: HIP kernels (through the C ABI) vs a plain fp32 PyTorch reference
+computed on the CPU from the same bf16-rounded inputs.
+
+Used two ways: `pytest -m gpu` (tests/test_ops_gpu.py parametrises over CASES) and
+`python tests/opcheck.py` on a GPU box, which runs every case, never stops at the first failure and
+prints one line per case (handy because GPU round-trips are expensive).
+
+Tolerance: outputs are bf16 (8 mantissa bits), accumulation fp32.  rel-L2 <= 4e-3 (about one bf16
+ulp rms) unless the case says otherwise; max-abs is reported for information.
+"""
+from __future__ import annotations
+
+import math
+import sys
+import traceback
+from pathlib import Path
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+BF = torch.bfloat16
+TOL = 4e-3
+
+
+def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def _rnd(shape, gen, scale=1.0):
+    return (torch.randn(shape, generator=gen) * scale).to(BF)
+
+
+def case_gemm(M, N, K, bias=True, rowbias=False, residual=False, geglu=False, silu=False, split=0, seed=0):
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    a = _rnd((M, K), g)
+    w = _rnd(((2 * N) if geglu else N, K), g, 1.0 / math.sqrt(K))
+    b = _rnd(((2 * N) if geglu else N,), g, 0.5) if bias else None
+    rpr = 7
+    rb = _rnd(((M + rpr - 1) // rpr, N), g) if rowbias else None
+    res = _rnd((M, N), g) if residual else None
+    ref = a.float() @ w.float().t()
+    if b is not None:
+        ref = ref + b.float()
+    if geglu:
+        h, gate = ref.chunk(2, dim=-1)
+        ref = h * F.gelu(gate)
+    if silu:
+        ref = F.silu(ref)
+    if rb is not None:
+        ref = ref + rb.float().repeat_interleave(rpr, dim=0)[:M]
+    if res is not None:
+        ref = ref + res.float()
+    d = "cuda"
+    kw = dict(bias=b.to(d) if b is not None else None, rowbias=rb.to(d) if rb is not None else None,
+              rows_per_rowbias=rpr, residual=res.to(d) if res is not None else None, geglu=geglu, silu=silu)
+    if split:
+        out = ops.gemm(a[:, :split].contiguous().to(d), w.to(d), a2=a[:, split:].contiguous().to(d), **kw)
+    else:
+        out = ops.gemm(a.to(d), w.to(d), **kw)
+    return rel_l2(out, ref), float((out.float().cpu() - ref).abs().max())
+
+
+def case_conv(B, H, W, Cin, Cout, stride=1, pad=1, pad_hi=None, upsample=False, rowbias=False, residual=False, seed=0):
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    x = _rnd((B, Cin, H, W), g)
+    w = _rnd((Cout, Cin, 3, 3), g, 1.0 / math.sqrt(9 * Cin))
+    b = _rnd((Cout,), g, 0.5)
+    xin = x.float()
+    if upsample:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    if pad_hi is not None:
+        xin = F.pad(xin, (pad, pad_hi, pad, pad_hi))
+        ref = F.conv2d(xin, w.float(), b.float(), stride=stride, padding=0)
+    else:
+        ref = F.conv2d(xin, w.float(), b.float(), stride=stride, padding=pad)
+    rb = _rnd((B, Cout), g) if rowbias else None
+    if rb is not None:
+        ref = ref + rb.float()[:, :, None, None]
+    res = _rnd(tuple(ref.shape), g) if residual else None
+    if res is not None:
+        ref = ref + res.float()
+    d = "cuda"
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().to(d)
+    wt = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().to(d)
+    out = ops.conv3x3(x_nhwc, wt, bias=b.to(d), rowbias=rb.to(d) if rb is not None else None,
+                      residual=res.permute(0, 2, 3, 1).contiguous().to(d) if res is not None else None, stride=stride,
+                      pad=pad, pad_hi=pad_hi, upsample=upsample)
+    out = out.permute(0, 3, 1, 2)
+    assert tuple(out.shape) == tuple(ref.shape), (out.shape, ref.shape)
+    return rel_l2(out, ref), float((out.float().cpu() - ref).abs().max())
+
+
+def case_attention(batch, heads, L, seed=0, spike=False):
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    C = heads * 64
+    qkv = _rnd((batch * L, 3 * C), g)
+    if spike:  # force large online-softmax rescales (one key dominates late in the sequence)
+        qkv[L - 3, C:2 * C] *= 8.0
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+
+    def heads_view(t):
+        return t.float().view(batch, L, heads, 64).transpose(1, 2)
+
+    ref = F.scaled_dot_product_attention(heads_view(q), heads_view(k), heads_view(v))
+    ref = ref.transpose(1, 2).reshape(batch * L, C)
+    dq = qkv.to("cuda")
+    out = ops.attention(dq[:, :C], dq[:, C:2 * C], dq[:, 2 * C:], batch, heads, L)
+    return rel_l2(out, ref), float((out.float().cpu() - ref).abs().max())
+
+
+def case_groupnorm(B, HW, C1, C2, groups, silu, eps=1e-5, seed=0):
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    x1 = _rnd((B, HW, C1), g) + 0.5
+    x2 = (_rnd((B, HW, C2), g) * 2.0 - 0.25) if C2 else None
+    C = C1 + C2
+    gamma, beta = _rnd((C,), g) + 1.0, _rnd((C,), g, 0.3)
+    x = torch.cat([x1, x2], dim=-1) if C2 else x1
+    ref = F.group_norm(x.float().permute(0, 2, 1), groups, gamma.float(), beta.float(), eps).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    d = "cuda"
+    out = ops.groupnorm(x1.to(d), gamma.to(d), beta.to(d), groups, eps, x2=x2.to(d) if C2 else None, silu=silu)
+    return rel_l2(out, ref), float((out.float().cpu() - ref).abs().max())
+
+
+def case_layernorm(M, C, seed=0):
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    x = _rnd((M, C), g) * 2 + 0.3
+    gamma, beta = _rnd((C,), g) + 1.0, _rnd((C,), g, 0.3)
+    ref = F.layer_norm(x.float(), (C,), gamma.float(), beta.float(), 1e-5)
+    out = ops.layernorm(x.to("cuda"), gamma.to("cuda"), beta.to("cuda"), 1e-5)
+    return rel_l2(out, ref), float((out.float().cpu() - ref).abs().max())
+
+
+def case_softmax(M, N, seed=0):
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    s = _rnd((M, N), g, 4.0)
+    ref = torch.softmax(s.float() * 0.3, dim=-1)
+    out = ops.softmax_rows(s.to("cuda"), 0.3)
+    return rel_l2(out, ref), float((out.float().cpu() - ref).abs().max())
+
+
+def case_temb(B, dim, seed=0):
+    from diffuman4d_amd.host import ops
+    from oracle.unet import timestep_embedding
+    t = torch.tensor([0, 1, 56, 111, 500, 936, 999, 3][:B], dtype=torch.float32)
+    ref = timestep_embedding(t, dim, True, 0)
+    out = ops.timestep_embedding(t.to("cuda"), dim, True, 0.0)
+    return rel_l2(out, ref), float((out.float().cpu() - ref).abs().max())
+
+
+def case_silu(n, seed=0):
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    x = _rnd((n,), g, 3.0)
+    out = ops.silu(x.to("cuda"))
+    ref = F.silu(x.float())
+    return rel_l2(out, ref), float((out.float().cpu() - ref).abs().max())
+
+
+def case_layout(B, C, H, W, cpad, seed=0):
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    x = _rnd((B, C, H, W), g)
+    y = ops.nchw_to_nhwc(x.to("cuda"), cpad).cpu()
+    ref = torch.zeros(B, H, W, cpad, dtype=BF)
+    ref[..., :C] = x.permute(0, 2, 3, 1)
+    e1 = float((y.float() - ref.float()).abs().max())
+    z = ops.nhwc_to_nchw(y.to("cuda"), C).cpu()
+    e2 = float((z.float() - x.float()).abs().max())
+    return max(e1, e2), max(e1, e2)
+
+
+def case_pack_ddim(F_, HW, use_cfg, vpred, skel=True, seed=0):
+    """pack_model_input + cfg_ddim_step vs a literal transcription of pipeline_diffuman4d.py:345-422."""
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    lat, pv = _rnd((F_, HW, 4), g), _rnd((F_, HW, 4), g)
+    pl, sk = _rnd((F_, HW, 6), g, 0.5), (_rnd((F_, HW, 4), g) if skel else None)
+    is_cond = torch.zeros(F_, dtype=torch.int32)
+    is_cond[: max(1, F_ // 4)] = 1
+    mask = (1 - is_cond).to(BF)[:, None, None].expand(F_, HW, 1).contiguous()
+    cpad = 32
+    d = "cuda"
+    lat_d = lat.to(d)
+    out = ops.pack_model_input(lat_d, pv.to(d), pl.to(d), sk.to(d) if skel else None, mask.to(d), is_cond.to(d), cpad,
+                               use_cfg).cpu()
+    c = is_cond.bool()
+    x = lat.clone()
+    x[c] = pv[c]
+    parts_pos = [x, pl] + ([sk] if skel else []) + [mask]
+    pos = torch.cat(parts_pos, dim=-1)
+    nch = pos.shape[-1]
+    ref = torch.zeros((2 if use_cfg else 1) * F_, HW, cpad, dtype=BF)
+    ref[-F_:, :, :nch] = pos
+    if use_cfg:
+        neg_x = x.clone()
+        neg_x[c] = 1.0
+        neg = torch.cat([neg_x, torch.zeros_like(pl)] + ([-torch.ones_like(sk)] if skel else []) + [mask], dim=-1)
+        ref[:F_, :, :nch] = neg
+    e_pack = float((out.float() - ref.float()).abs().max())
+    e_alias = float((lat_d.cpu().float() - x.float()).abs().max())
+    # DDIM step
+    npred = _rnd(((2 if use_cfg else 1) * F_, HW, 8), g)
+    a_t = torch.rand(F_, generator=g) * 0.9 + 0.05
+    a_p = torch.rand(F_, generator=g) * 0.9 + 0.05
+    coef = torch.stack([a_t.sqrt(), (1 - a_t).sqrt(), a_p.sqrt(), (1 - a_p).sqrt()], dim=1).float().contiguous()
+    gs = 2.0
+    e = npred[..., :4].float()
+    if use_cfg:
+        e = e[:F_] + gs * (e[F_:] - e[:F_])
+    xf = x.float()
+    sa, sb, sap, sbp = [coef[:, i][:, None, None] for i in range(4)]
+    if vpred:
+        x0, eps = sa * xf - sb * e, sa * e + sb * xf
+    else:
+        x0, eps = (xf - sb * e) / sa, e
+    new = sap * x0 + sbp * eps
+    new[c] = xf[c]
+    ops.cfg_ddim_step(lat_d, npred.to(d), coef.to(d), is_cond.to(d), use_cfg, gs, vpred)
+    e_step = rel_l2(lat_d, new)
+    ok = (e_pack == 0.0) and (e_alias == 0.0)
+    return (e_step if ok else 1.0), max(e_pack, e_alias)
+
+
+CASES = {
+    # --- GEMM: every tile config, tails, epilogues -------------------------------------------
+    "gemm_256x128_plain": (case_gemm, dict(M=1024, N=256, K=320)),
+    "gemm_big_tiles": (case_gemm, dict(M=4096 * 3, N=1280, K=640, residual=True)),
+    "gemm_n64_tiles": (case_gemm, dict(M=4096 * 6 + 40, N=320, K=320, residual=True)),
+    "gemm_small": (case_gemm, dict(M=77, N=320, K=64)),
+    "gemm_mtail_ntail": (case_gemm, dict(M=333, N=200, K=96, residual=True, rowbias=True)),
+    "gemm_n4": (case_gemm, dict(M=500, N=4, K=288, bias=True)),
+    "gemm_nobias": (case_gemm, dict(M=512, N=960, K=320, bias=False)),
+    "gemm_geglu": (case_gemm, dict(M=700, N=1280, K=320, geglu=True)),
+    "gemm_geglu_small": (case_gemm, dict(M=130, N=256, K=64, geglu=True)),
+    "gemm_silu": (case_gemm, dict(M=32, N=1280, K=320, silu=True)),
+    "gemm_split_a": (case_gemm, dict(M=300, N=640, K=1280 + 640, split=1280, residual=True)),
+    "gemm_rowbias": (case_gemm, dict(M=2880 * 2, N=320, K=320, rowbias=True)),
+    # --- conv3x3 -------------------------------------------------------------------------------
+    "conv_s1": (case_conv, dict(B=2, H=18, W=10, Cin=64, Cout=128, rowbias=True)),
+    "conv_s1_res": (case_conv, dict(B=3, H=9, W=5, Cin=128, Cout=64, residual=True)),
+    "conv_s2": (case_conv, dict(B=2, H=18, W=10, Cin=64, Cout=64, stride=2)),
+    "conv_s2_odd": (case_conv, dict(B=2, H=9, W=5, Cin=32, Cout=64, stride=2)),
+    "conv_up": (case_conv, dict(B=2, H=9, W=5, Cin=64, Cout=64, upsample=True)),
+    "conv_vae_down": (case_conv, dict(B=2, H=16, W=12, Cin=32, Cout=32, stride=2, pad=0, pad_hi=1)),
+    "conv_cin32_cout4": (case_conv, dict(B=4, H=36, W=20, Cin=32, Cout=4)),
+    "conv_big": (case_conv, dict(B=8, H=36, W=20, Cin=320, Cout=320, rowbias=True, residual=True)),
+    # --- attention -------------------------------------------------------------------------------
+    "attn_small": (case_attention, dict(batch=2, heads=2, L=128)),
+    "attn_tail45": (case_attention, dict(batch=3, heads=1, L=45)),
+    "attn_tail720": (case_attention, dict(batch=2, heads=3, L=720)),
+    "attn_2d": (case_attention, dict(batch=8, heads=5, L=2880)),
+    "attn_3d": (case_attention, dict(batch=2, heads=10, L=4320)),
+    "attn_spike": (case_attention, dict(batch=1, heads=2, L=1000, spike=True)),
+    # --- norms -----------------------------------------------------------------------------------
+    "gn_320": (case_groupnorm, dict(B=4, HW=720, C1=320, C2=0, groups=32, silu=True)),
+    "gn_concat_1920": (case_groupnorm, dict(B=3, HW=180, C1=1280, C2=640, groups=32, silu=True)),
+    "gn_concat_2560": (case_groupnorm, dict(B=2, HW=45, C1=1280, C2=1280, groups=32, silu=False, eps=1e-6)),
+    "gn_tiny64": (case_groupnorm, dict(B=5, HW=100, C1=64, C2=0, groups=32, silu=True)),
+    "gn_tiny_concat": (case_groupnorm, dict(B=2, HW=50, C1=128, C2=64, groups=32, silu=True)),
+    "ln_320": (case_layernorm, dict(M=1000, C=320)),
+    "ln_1280": (case_layernorm, dict(M=77, C=1280)),
+    "ln_64": (case_layernorm, dict(M=130, C=64)),
+    "softmax": (case_softmax, dict(M=50, N=2880)),
+    # --- small kernels ---------------------------------------------------------------------------
+    "temb": (case_temb, dict(B=8, dim=320)),
+    "silu": (case_silu, dict(n=32 * 1280 + 3)),
+    "layout": (case_layout, dict(B=3, C=4, H=9, W=5, cpad=8)),
+    "pack_ddim_cfg_eps": (case_pack_ddim, dict(F_=16, HW=45, use_cfg=True, vpred=False)),
+    "pack_ddim_nocfg_v": (case_pack_ddim, dict(F_=8, HW=30, use_cfg=False, vpred=True)),
+    "pack_ddim_noskel": (case_pack_ddim, dict(F_=8, HW=30, use_cfg=True, vpred=False, skel=False)),
+}
+
+TOLS = {"layout": 0.0, "temb": 6e-3}
+
+
+def run_case(name):
+    fn, kw = CASES[name]
+    err, mx = fn(**kw)
+    return err, mx, TOLS.get(name, TOL)
+
+
+def main():
+    torch.manual_seed(0)
+    bad = 0
+    for name in CASES:
+        try:
+            err, mx, tol = run_case(name)
+            ok = err <= tol and math.isfinite(err)
+            print(f"{'PASS' if ok else 'FAIL'} {name:24s} rel_l2={err:.3e} max_abs={mx:.3e} tol={tol:.1e}", flush=True)
+            bad += 0 if ok else 1
+        except Exception as e:  # keep going: one GPU trip should report everything
+            bad += 1
+            print(f"ERROR {name}: {type(e).__name__}: {e}", flush=True)
+            traceback.print_exc()
+    print(f"opcheck: {len(CASES) - bad}/{len(CASES)} passed", flush=True)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
