@@ -42,11 +42,14 @@ __global__ void silu_kernel(const u16* X, u16* Y, int64_t n) {
 
 // one thread per (frame, pixel): reads the 4+6+4+1 conditioning channels, writes both CFG halves
 __global__ void pack_kernel(u16* latents, const u16* pv, const u16* pl, const u16* sk, const u16* mask,
-                            const int32_t* is_cond, u16* out, int F, int HW, int cpad, int use_cfg) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)F * HW) return;
-  const int f = (int)(i / HW);
+                            const int32_t* is_cond, const int32_t* frame_idx, u16* out, int F, int HW, int cpad,
+                            int use_cfg) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // window-local (frame, pixel)
+  if (o >= (int64_t)F * HW) return;
+  const int f = (int)(o / HW);
   const bool cond = is_cond[f] != 0;
+  // i = (frame, pixel) inside the task-level tensors the window is gathered from
+  const int64_t i = frame_idx ? (int64_t)frame_idx[f] * HW + (o - (int64_t)f * HW) : o;
   const u16 one = 0x3F80, mone = 0xBF80;  // +1.0, -1.0 in bf16
   u16 lat[4];
   if (cond) {
@@ -61,7 +64,7 @@ __global__ void pack_kernel(u16* latents, const u16* pv, const u16* pl, const u1
   }
   const u16 m = mask[i];
   const int nsk = sk ? 4 : 0;
-  u16* pos = out + ((use_cfg ? (int64_t)F * HW : 0) + i) * cpad;
+  u16* pos = out + ((use_cfg ? (int64_t)F * HW : 0) + o) * cpad;
   int c = 0;
   for (int k = 0; k < 4; ++k) pos[c++] = lat[k];
   for (int k = 0; k < 6; ++k) pos[c++] = pl[i * 6 + k];
@@ -69,7 +72,7 @@ __global__ void pack_kernel(u16* latents, const u16* pv, const u16* pl, const u1
   pos[c++] = m;
   for (; c < cpad; ++c) pos[c] = 0;
   if (use_cfg) {
-    u16* neg = out + i * cpad;
+    u16* neg = out + o * cpad;
     c = 0;
     for (int k = 0; k < 4; ++k) neg[c++] = cond ? one : lat[k];
     for (int k = 0; k < 6; ++k) neg[c++] = 0;
@@ -81,21 +84,22 @@ __global__ void pack_kernel(u16* latents, const u16* pv, const u16* pl, const u1
 
 // latents [F,HW,4], noise_pred [cfg*F, HW, ldn] (first 4 channels used)
 __global__ void cfg_ddim_kernel(u16* latents, const u16* np, int64_t ldn, const float* coef, const int32_t* is_cond,
-                                int F, int HW, int use_cfg, float gs, int vpred) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)F * HW) return;
-  const int f = (int)(i / HW);
+                                const int32_t* frame_idx, int F, int HW, int use_cfg, float gs, int vpred) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // window-local (frame, pixel)
+  if (o >= (int64_t)F * HW) return;
+  const int f = (int)(o / HW);
   if (is_cond[f] != 0) return;  // "only denoise target latents" (pipeline_diffuman4d.py:418-420)
+  const int64_t i = frame_idx ? (int64_t)frame_idx[f] * HW + (o - (int64_t)f * HW) : o;
   const float sa = coef[f * 4 + 0], sb = coef[f * 4 + 1], sap = coef[f * 4 + 2], sbp = coef[f * 4 + 3];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     float e;
     if (use_cfg) {
-      const float u = bf2f(np[i * ldn + c]);
-      const float cc = bf2f(np[((int64_t)F * HW + i) * ldn + c]);
+      const float u = bf2f(np[o * ldn + c]);
+      const float cc = bf2f(np[((int64_t)F * HW + o) * ldn + c]);
       e = u + gs * (cc - u);
     } else {
-      e = bf2f(np[i * ldn + c]);
+      e = bf2f(np[o * ldn + c]);
     }
     const float x = bf2f(latents[i * 4 + c]);
     float x0, eps;
@@ -128,6 +132,71 @@ __global__ void nhwc_to_nchw_kernel(const u16* X, u16* Y, int B, int C, int HW, 
   Y[i] = X[((int64_t)b * HW + px) * ldx + c];
 }
 
+// VAE posterior sample (DiagonalGaussianDistribution.sample) * scaling_factor
+__global__ void vae_sample_kernel(const u16* mom, int64_t ldm, const u16* noise, u16* out, int64_t M, int C, float scale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * C) return;
+  const int64_t m = i / C;
+  const int c = (int)(i % C);
+  const float mean = bf2f(mom[m * ldm + c]);
+  float logvar = bf2f(mom[m * ldm + C + c]);
+  logvar = fminf(fmaxf(logvar, -30.f), 20.f);
+  out[i] = f2bf((mean + expf(0.5f * logvar) * bf2f(noise[i])) * scale);
+}
+
+__global__ void scale_pad_kernel(const u16* X, int64_t ldx, u16* Y, int cpad, int64_t M, int C, float scale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * cpad) return;
+  const int64_t m = i / cpad;
+  const int c = (int)(i % cpad);
+  Y[i] = c < C ? f2bf(bf2f(X[m * ldx + c]) * scale) : (u16)0;
+}
+
+// F.interpolate(x, size=(h,w), mode="bilinear"|"nearest") (align_corners=False, no antialias), fp32 NCHW in,
+// bf16 NHWC out -- pipeline_diffuman4d.py:90-100 computes this in fp32 and casts afterwards.
+__global__ void resize_kernel(const float* X, u16* Y, int B, int C, int H, int W, int h, int w, int bilinear) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over B*h*w*C (C fastest)
+  if (i >= (int64_t)B * h * w * C) return;
+  const int c = (int)(i % C);
+  int64_t r = i / C;
+  const int ox = (int)(r % w);
+  r /= w;
+  const int oy = (int)(r % h);
+  const int b = (int)(r / h);
+  const float* src = X + ((int64_t)b * C + c) * H * W;
+  const float sy = (float)H / (float)h, sx = (float)W / (float)w;
+  float v;
+  if (bilinear) {
+    float fy = ((float)oy + 0.5f) * sy - 0.5f, fx = ((float)ox + 0.5f) * sx - 0.5f;
+    fy = fy < 0.f ? 0.f : fy;
+    fx = fx < 0.f ? 0.f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    v = hy * (hx * src[(int64_t)y0 * W + x0] + lx * src[(int64_t)y0 * W + x1]) +
+        ly * (hx * src[(int64_t)y1 * W + x0] + lx * src[(int64_t)y1 * W + x1]);
+  } else {
+    int y0 = (int)floorf((float)oy * sy), x0 = (int)floorf((float)ox * sx);
+    y0 = y0 > H - 1 ? H - 1 : y0;
+    x0 = x0 > W - 1 ? W - 1 : x0;
+    v = src[(int64_t)y0 * W + x0];
+  }
+  Y[i] = f2bf(v);
+}
+
+// VaeImageProcessor.postprocess(denormalize): (x / 2 + 0.5).clamp(0, 1); NHWC (ld >= C) -> NCHW
+__global__ void postprocess_kernel(const u16* X, u16* Y, int B, int C, int HW, int ldx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over B*C*HW
+  if (i >= (int64_t)B * C * HW) return;
+  const int px = (int)(i % HW);
+  const int64_t bc = i / HW;
+  const int c = (int)(bc % C), b = (int)(bc / C);
+  float v = bf2f(X[((int64_t)b * HW + px) * ldx + c]) * 0.5f + 0.5f;
+  v = fminf(fmaxf(v, 0.f), 1.f);
+  Y[i] = f2bf(v);
+}
+
 inline dim3 grid1d(int64_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
 
 }  // namespace
@@ -150,24 +219,24 @@ extern "C" int dm4d_silu_bf16(void* stream, const void* X, void* Y, int64_t n) {
 }
 
 extern "C" int dm4d_pack_model_input_bf16(void* stream, void* latents, const void* pv_lat, const void* plucker,
-                                          const void* skel, const void* mask, const int32_t* is_cond, void* out, int F,
-                                          int HW, int cpad, int use_cfg) {
+                                          const void* skel, const void* mask, const int32_t* is_cond,
+                                          const int32_t* frame_idx, void* out, int F, int HW, int cpad, int use_cfg) {
   if (!latents || !pv_lat || !plucker || !mask || !is_cond || !out || F <= 0 || HW <= 0)
     return dm4d_set_error(DM4D_ERR_ARG, "pack_model_input: null pointer or empty shape");
   if (cpad < 11 + (skel ? 4 : 0)) return dm4d_set_error(DM4D_ERR_ARG, "pack_model_input: cpad too small");
   hipLaunchKernelGGL(pack_kernel, grid1d((int64_t)F * HW, 256), dim3(256), 0, (hipStream_t)stream, (u16*)latents,
-                     (const u16*)pv_lat, (const u16*)plucker, (const u16*)skel, (const u16*)mask, is_cond, (u16*)out, F,
-                     HW, cpad, use_cfg);
+                     (const u16*)pv_lat, (const u16*)plucker, (const u16*)skel, (const u16*)mask, is_cond, frame_idx,
+                     (u16*)out, F, HW, cpad, use_cfg);
   return dm4d_check_launch("pack_kernel");
 }
 
 extern "C" int dm4d_cfg_ddim_step_bf16(void* stream, void* latents, const void* noise_pred, int64_t ldn,
-                                       const float* coef, const int32_t* is_cond, int F, int HW, int use_cfg,
-                                       float guidance_scale, int v_prediction) {
+                                       const float* coef, const int32_t* is_cond, const int32_t* frame_idx, int F,
+                                       int HW, int use_cfg, float guidance_scale, int v_prediction) {
   if (!latents || !noise_pred || !coef || !is_cond || F <= 0 || HW <= 0 || ldn < 4)
     return dm4d_set_error(DM4D_ERR_ARG, "cfg_ddim_step: bad arguments");
   hipLaunchKernelGGL(cfg_ddim_kernel, grid1d((int64_t)F * HW, 256), dim3(256), 0, (hipStream_t)stream, (u16*)latents,
-                     (const u16*)noise_pred, ldn, coef, is_cond, F, HW, use_cfg, guidance_scale, v_prediction);
+                     (const u16*)noise_pred, ldn, coef, is_cond, frame_idx, F, HW, use_cfg, guidance_scale, v_prediction);
   return dm4d_check_launch("cfg_ddim_kernel");
 }
 
@@ -183,4 +252,35 @@ extern "C" int dm4d_nhwc_to_nchw_bf16(void* stream, const void* X, void* Y, int 
   hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid1d((int64_t)B * C * HW, 256), dim3(256), 0, (hipStream_t)stream,
                      (const u16*)X, (u16*)Y, B, C, HW, ldx);
   return dm4d_check_launch("nhwc_to_nchw_kernel");
+}
+
+extern "C" int dm4d_vae_sample_bf16(void* stream, const void* moments, int64_t ldm, const void* noise, void* out, int64_t M,
+                                    int C, float scale) {
+  if (!moments || !noise || !out || M <= 0 || C <= 0 || ldm < 2 * C) return dm4d_set_error(DM4D_ERR_ARG, "vae_sample: bad arguments");
+  hipLaunchKernelGGL(vae_sample_kernel, grid1d(M * C, 256), dim3(256), 0, (hipStream_t)stream, (const u16*)moments, ldm,
+                     (const u16*)noise, (u16*)out, M, C, scale);
+  return dm4d_check_launch("vae_sample_kernel");
+}
+
+extern "C" int dm4d_scale_pad_bf16(void* stream, const void* X, int64_t ldx, void* Y, int cpad, int64_t M, int C, float scale) {
+  if (!X || !Y || M <= 0 || C <= 0 || cpad < C || ldx < C) return dm4d_set_error(DM4D_ERR_ARG, "scale_pad: bad arguments");
+  hipLaunchKernelGGL(scale_pad_kernel, grid1d(M * cpad, 256), dim3(256), 0, (hipStream_t)stream, (const u16*)X, ldx,
+                     (u16*)Y, cpad, M, C, scale);
+  return dm4d_check_launch("scale_pad_kernel");
+}
+
+extern "C" int dm4d_resize_nchw_f32_to_nhwc_bf16(void* stream, const float* X, void* Y, int B, int C, int H, int W, int h,
+                                                 int w, int bilinear) {
+  if (!X || !Y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0)
+    return dm4d_set_error(DM4D_ERR_ARG, "resize: bad arguments");
+  hipLaunchKernelGGL(resize_kernel, grid1d((int64_t)B * h * w * C, 256), dim3(256), 0, (hipStream_t)stream, X, (u16*)Y, B,
+                     C, H, W, h, w, bilinear);
+  return dm4d_check_launch("resize_kernel");
+}
+
+extern "C" int dm4d_postprocess_images_bf16(void* stream, const void* X, void* Y, int B, int C, int HW, int ldx) {
+  if (!X || !Y || B <= 0 || C <= 0 || HW <= 0 || ldx < C) return dm4d_set_error(DM4D_ERR_ARG, "postprocess: bad arguments");
+  hipLaunchKernelGGL(postprocess_kernel, grid1d((int64_t)B * C * HW, 256), dim3(256), 0, (hipStream_t)stream,
+                     (const u16*)X, (u16*)Y, B, C, HW, ldx);
+  return dm4d_check_launch("postprocess_kernel");
 }

@@ -1,0 +1,40 @@
+"""``load_pipelines`` -- the Hydra ``_target_`` seam (``cfg.model``) of the reference.
+
+Mirror of ``/root/reference/src/samplers/utils/sampling_utils.py:17-51``: same keyword arguments, same
+``ValueError`` for an unsupported dtype, returns one pipeline per GPU id.  Select it with
+``model=diffuman4d_mi355x`` (configs/model/diffuman4d_mi355x.yaml).  No download is attempted when the
+checkpoint directory already exists; without network the HF download failure is logged and ignored,
+as in the reference (:37-41).
+"""
+from __future__ import annotations
+
+import logging
+import os
+from typing import List, Optional
+
+import torch
+
+log = logging.getLogger(__name__)
+
+
+def load_pipelines(repo_id: str = "krahets/Diffuman4D", model_dir: str = "./models/krahets-Diffuman4D",
+                   torch_dtype: str = "bf16", gpu_ids: Optional[List[int]] = None):
+    from .pipeline import Diffuman4DPipeline
+    if gpu_ids is None:
+        gpu_ids = list(range(torch.cuda.device_count()))
+        log.info("Found %d HIP devices.", len(gpu_ids))
+    if torch_dtype == "fp16":
+        raise ValueError("Unsupported torch_dtype: fp16 on the MI355X path (bf16 MFMA, fp32 accumulate). Use 'bf16'.")
+    if torch_dtype != "bf16":
+        raise ValueError(f"Unsupported torch_dtype: {torch_dtype}. Supported types are 'bf16' and 'fp16'.")
+    if not os.path.isdir(model_dir) or not os.listdir(model_dir):
+        try:
+            from huggingface_hub import snapshot_download
+            snapshot_download(repo_id, local_dir=model_dir, allow_patterns=["*.json", "*model.safetensors"])
+        except Exception as e:  # no network on the GPU boxes
+            log.error("Failed to download model from %s to %s: %s. Skipping download.", repo_id, model_dir, e)
+    pipelines = []
+    for gpu_id in gpu_ids:
+        pipelines.append(Diffuman4DPipeline.from_pretrained(model_dir, torch_dtype=torch.bfloat16, device=f"cuda:{gpu_id}"))
+        log.info("Loaded pipeline from %s (bf16) to cuda:%d", model_dir, gpu_id)
+    return pipelines

@@ -135,10 +135,22 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, hea
         out = torch.empty((batch * seq, heads * 64), dtype=BF16, device=q.device)
     if scale is None:
         scale = 0.125
+    prof = KERNEL_TIMER
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = lib.dm4d_attention_bf16(_stream(), _p(q), _p(k), _p(v), _p(out), q.stride(0), k.stride(0), v.stride(0),
                                  out.stride(0), batch, heads, seq, scale)
+    if prof is not None:
+        e1.record()
+        prof.append(("attn_kernel", 4.0 * batch * heads * seq * seq * 64, e0, e1))
     _l.check(rc, "dm4d_attention_bf16")
     return out
+
+
+# bench.py sets this to a list to time individual launches with HIP events on the launch stream:
+# entries are (kernel, algorithmic flops, start_event, end_event).  None = no instrumentation.
+KERNEL_TIMER = None
 
 
 def softmax_rows(s: torch.Tensor, scale: float) -> torch.Tensor:
@@ -169,8 +181,10 @@ def silu(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
-def pack_model_input(latents, pv_lat, plucker, skel, mask, is_cond, cpad: int, use_cfg: bool) -> torch.Tensor:
-    """All inputs NHWC [F, HW, c]; is_cond int32 [F].  Mutates `latents` cond rows (reference aliasing)."""
+def pack_model_input(latents, pv_lat, plucker, skel, mask, is_cond, cpad: int, use_cfg: bool,
+                     frame_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Inputs NHWC [N, HW, c] (task level); is_cond int32 [F]; frame_idx int32 [F] selects the window's frames
+    (None: F = N, identity).  Mutates the cond rows of `latents` (reference aliasing)."""
     lib = _l.load()
     for t, n in ((latents, "latents"), (pv_lat, "pv_lat"), (plucker, "plucker"), (mask, "mask")):
         _req(t, n)
@@ -178,22 +192,31 @@ def pack_model_input(latents, pv_lat, plucker, skel, mask, is_cond, cpad: int, u
     if skel is not None:
         _req(skel, "skel")
     _req(is_cond, "is_cond", torch.int32)
-    F, HW = latents.shape[0], latents.shape[1]
+    F, HW = is_cond.shape[0], latents.shape[1]
+    if frame_idx is not None:
+        _req(frame_idx, "frame_idx", torch.int32)
+        assert frame_idx.shape[0] == F
+    else:
+        assert latents.shape[0] == F
     out = torch.empty(((2 if use_cfg else 1) * F, HW, cpad), dtype=BF16, device=latents.device)
     rc = lib.dm4d_pack_model_input_bf16(_stream(), _p(latents), _p(pv_lat), _p(plucker), _p(skel), _p(mask),
-                                        _p(is_cond), _p(out), F, HW, cpad, 1 if use_cfg else 0)
+                                        _p(is_cond), _p(frame_idx), _p(out), F, HW, cpad, 1 if use_cfg else 0)
     _l.check(rc, "dm4d_pack_model_input_bf16")
     return out
 
 
-def cfg_ddim_step(latents, noise_pred, coef, is_cond, use_cfg: bool, guidance_scale: float, v_prediction: bool):
-    """In-place DDIM update of `latents` [F,HW,4] from noise_pred [cfg*F, HW, ldn]."""
+def cfg_ddim_step(latents, noise_pred, coef, is_cond, use_cfg: bool, guidance_scale: float, v_prediction: bool,
+                  frame_idx: Optional[torch.Tensor] = None):
+    """In-place DDIM update of rows frame_idx of `latents` [N,HW,4] from noise_pred [cfg*F, HW, ldn]."""
     lib = _l.load()
     _req(latents, "latents"), _req(noise_pred, "noise_pred"), _req(coef, "coef", torch.float32)
     _req(is_cond, "is_cond", torch.int32)
-    F, HW = latents.shape[0], latents.shape[1]
+    F, HW = is_cond.shape[0], latents.shape[1]
+    if frame_idx is not None:
+        _req(frame_idx, "frame_idx", torch.int32)
     rc = lib.dm4d_cfg_ddim_step_bf16(_stream(), _p(latents), _p(noise_pred), noise_pred.stride(-2), _p(coef),
-                                     _p(is_cond), F, HW, 1 if use_cfg else 0, guidance_scale, 1 if v_prediction else 0)
+                                     _p(is_cond), _p(frame_idx), F, HW, 1 if use_cfg else 0, guidance_scale,
+                                     1 if v_prediction else 0)
     _l.check(rc, "dm4d_cfg_ddim_step_bf16")
     return latents
 
@@ -217,4 +240,51 @@ def nhwc_to_nchw(x: torch.Tensor, C: Optional[int] = None) -> torch.Tensor:
     C = C or ld
     y = torch.empty((B, C, H, W), dtype=BF16, device=x.device)
     _l.check(lib.dm4d_nhwc_to_nchw_bf16(_stream(), _p(x), _p(y), B, C, H * W, ld), "dm4d_nhwc_to_nchw_bf16")
+    return y
+
+
+def vae_sample(moments: torch.Tensor, noise: torch.Tensor, channels: int, scale: float) -> torch.Tensor:
+    """moments [..., >=2C] (mean | logvar), noise [..., C] -> (mean + std * noise) * scale, [..., C]."""
+    lib = _l.load()
+    _req(moments, "moments"), _req(noise, "noise")
+    assert noise.is_contiguous() and noise.shape[-1] == channels
+    M = noise.numel() // channels
+    out = torch.empty_like(noise)
+    rc = lib.dm4d_vae_sample_bf16(_stream(), _p(moments), moments.stride(-2), _p(noise), _p(out), M, channels, scale)
+    _l.check(rc, "dm4d_vae_sample_bf16")
+    return out
+
+
+def scale_pad(x: torch.Tensor, cpad: int, scale: float) -> torch.Tensor:
+    lib = _l.load()
+    _req(x, "x")
+    C = x.shape[-1]
+    M = x.numel() // C
+    assert x.is_contiguous()
+    y = torch.empty(x.shape[:-1] + (cpad,), dtype=BF16, device=x.device)
+    _l.check(lib.dm4d_scale_pad_bf16(_stream(), _p(x), C, _p(y), cpad, M, C, scale), "dm4d_scale_pad_bf16")
+    return y
+
+
+def resize_to_nhwc(x: torch.Tensor, size: Tuple[int, int], mode: str) -> torch.Tensor:
+    """x fp32 NCHW on the device -> bf16 NHWC [B,h,w,C]; mode 'bilinear' | 'nearest' (F.interpolate semantics)."""
+    lib = _l.load()
+    _req(x, "x", torch.float32)
+    assert x.is_contiguous() and mode in ("bilinear", "nearest")
+    B, C, H, W = x.shape
+    h, w = size
+    y = torch.empty((B, h, w, C), dtype=BF16, device=x.device)
+    rc = lib.dm4d_resize_nchw_f32_to_nhwc_bf16(_stream(), _p(x), _p(y), B, C, H, W, h, w, 1 if mode == "bilinear" else 0)
+    _l.check(rc, "dm4d_resize_nchw_f32_to_nhwc_bf16")
+    return y
+
+
+def postprocess_images(x: torch.Tensor, channels: int = 3) -> torch.Tensor:
+    """NHWC [B,H,W,ld] -> NCHW [B,channels,H,W] with (x/2+0.5).clamp(0,1)."""
+    lib = _l.load()
+    _req(x, "x")
+    assert x.is_contiguous()
+    B, H, W, ld = x.shape
+    y = torch.empty((B, channels, H, W), dtype=BF16, device=x.device)
+    _l.check(lib.dm4d_postprocess_images_bf16(_stream(), _p(x), _p(y), B, channels, H * W, ld), "dm4d_postprocess_images_bf16")
     return y

@@ -1,0 +1,159 @@
+"""Diffuman4DPipeline on libdm4d.so -- drop-in for the reference's pipeline protocol.
+
+Mirrors ``/root/reference/src/diffusers/pipelines/diffuman4d/pipeline_diffuman4d.py``:
+``sliding_iterative_denoise`` (:439-559) keeps its keyword signature, its ``ValueError``s and its
+return dict; the inner ``__call__`` (:289-437) becomes ``_denoise_window`` = 3 device launches
+around the UNet (pack -> UNet -> CFG+DDIM) with no host synchronisation, because the timestep
+bookkeeping is planned on the host up front (``schedule.plan_sweep``).
+
+Differences that do not change results:
+  * everything stays on the device in NHWC; NCHW only at the boundary;
+  * the per-window ``x[window]`` gathers / ``latents[window] = ...`` scatter are index arrays
+    consumed by the pack / step kernels;
+  * random draws can be injected (``noise=``) because the reference never seeds.
+"""
+from __future__ import annotations
+
+import json
+from pathlib import Path
+from typing import Callable, Dict, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .schedule import SweepPlan, plan_sweep
+from .scheduler import DDIMScheduler
+from .unet import UNetMultiviewConditionModel
+
+BF16 = torch.bfloat16
+
+
+def _identity_tqdm(it, **kw):
+    return it
+
+
+class Diffuman4DPipeline:
+    def __init__(self, vae, unet: UNetMultiviewConditionModel, scheduler: DDIMScheduler, device="cuda"):
+        self.vae, self.unet, self.scheduler = vae, unet, scheduler
+        dev = torch.device(device)
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self._device = dev
+        self.dtype = BF16
+        self.vae_scale_factor = vae.scale_factor if vae is not None else 8
+
+    @property
+    def device(self) -> torch.device:
+        return self._device
+
+    # ------------------------------------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, model_dir, torch_dtype=BF16, device="cuda") -> "Diffuman4DPipeline":
+        """diffusers checkpoint directory (sampling_utils.py:28-46): model_index.json, unet/, vae/, scheduler/."""
+        from .vae import AutoencoderKL
+        if torch_dtype not in (BF16, "bf16"):
+            raise ValueError("the MI355X path computes in bf16 (MFMA bf16, fp32 accumulate)")
+        model_dir = Path(model_dir)
+        if (model_dir / "model_index.json").exists():
+            json.loads((model_dir / "model_index.json").read_text())  # class names only; import paths are ignored
+        unet = UNetMultiviewConditionModel.from_pretrained(model_dir / "unet", device)
+        vae = AutoencoderKL.from_pretrained(model_dir / "vae", device)
+        sched = DDIMScheduler.from_pretrained(model_dir / "scheduler")
+        return cls(vae, unet, sched, device)
+
+    def to(self, device):  # protocol compatibility (sampling_utils.py:47); weights are placed at load time
+        if torch.device(device) != self._device:
+            raise NotImplementedError("re-create the pipeline on the target device (one pipeline per GPU)")
+        return self
+
+    def set_progress_bar_config(self, **kw):
+        pass
+
+    # ------------------------------------------------------------------------------------------
+    def _to_dev_nhwc(self, x: torch.Tensor, cpad: Optional[int] = None) -> torch.Tensor:
+        """CPU/GPU NCHW (any float dtype) -> device NHWC bf16 via the layout kernel."""
+        x = x.to(device=self._device, dtype=BF16).contiguous()
+        return ops.nchw_to_nhwc(x, cpad)
+
+    def prepare_all_latents(self, pixel_values, plucker_embeds, skeletons, cond_masks, latents, noise: Optional[Dict]):
+        """pipeline_diffuman4d.py:193-263 (sliding entry).  Returns NHWC bf16 device tensors."""
+        noise = noise or {}
+        n = pixel_values.shape[0]
+        pv_lat = self.vae.encode_scaled(pixel_values, noise.get("pixel"))  # [N,h,w,4], x scaling_factor
+        h, w = pv_lat.shape[1:3]
+        pl_lat = self.vae.resize_to_nhwc(plucker_embeds, (h, w), "bilinear")
+        if self.unet.config.enable_pose_encoder:
+            raise NotImplementedError("enable_pose_encoder")
+        sk_lat = self.vae.encode_scaled(skeletons, noise.get("skeleton")) if skeletons is not None else None
+        cm_lat = self.vae.resize_to_nhwc(cond_masks, (h, w), "nearest")
+        if latents is None:
+            if "latents" in noise:
+                latents = noise["latents"]
+            else:
+                latents = torch.randn((n, 4, h, w), device=self._device, dtype=torch.float32)
+        lat = self._to_dev_nhwc(latents)  # init_noise_sigma == 1 for DDIM
+        return pv_lat, pl_lat, sk_lat, cm_lat, lat
+
+    # ------------------------------------------------------------------------------------------
+    def upload_plan(self, plan: SweepPlan, guidance_scale: float):
+        """Host plan -> device index / timestep / coefficient tables (one H2D each, no syncs later)."""
+        ts = self.scheduler.set_timesteps(plan.num_inference_steps)
+        cfg = 2 if guidance_scale > 1 else 1
+        win = np.stack(plan.windows).astype(np.int32)              # [calls, F]
+        cond = np.stack(plan.is_cond)                              # [calls, F] bool
+        t = ts[np.stack(plan.timestep_index)].astype(np.int64)     # [calls, F]
+        t[cond] = 0                                                # get_timestep :277
+        coef = self.scheduler.step_coefficients(t)                 # [calls, F, 4]
+        t_in = np.concatenate([t] * cfg, axis=1).astype(np.float32)
+        dev = self._device
+        return dict(
+            win=torch.from_numpy(win).to(dev), cond=torch.from_numpy(cond.astype(np.int32)).to(dev),
+            t=torch.from_numpy(t_in).to(dev), coef=torch.from_numpy(coef).to(dev), calls=win.shape[0], cfg=cfg,
+        )
+
+    def denoise_latents(self, pv_lat, pl_lat, sk_lat, cm_lat, lat, plan: SweepPlan, domain: str, guidance_scale: float,
+                        tqdm: Callable = _identity_tqdm, tables=None):
+        """The window sweep (:521-543) on device-resident NHWC tensors; `lat` is updated in place."""
+        tb = tables or self.upload_plan(plan, guidance_scale)
+        use_cfg = tb["cfg"] == 2
+        N, h, w, _ = lat.shape
+        HW = h * w
+        lat3, pv3, pl3, cm3 = lat.view(N, HW, 4), pv_lat.view(N, HW, 4), pl_lat.view(N, HW, 6), cm_lat.view(N, HW, 1)
+        sk3 = sk_lat.view(N, HW, 4) if sk_lat is not None else None
+        vpred = self.scheduler.config.prediction_type == "v_prediction"
+        F = tb["win"].shape[1]
+        domains = [domain] * tb["cfg"]
+        for i in tqdm(range(tb["calls"]), total=tb["calls"]):
+            widx, cond = tb["win"][i], tb["cond"][i]
+            x = ops.pack_model_input(lat3, pv3, pl3, sk3, cm3, cond, self.unet.IN_PAD, use_cfg, frame_idx=widx)
+            eps = self.unet(x.view(tb["cfg"] * F, h, w, self.unet.IN_PAD), tb["t"][i], domains=domains, num_frames=F)
+            ops.cfg_ddim_step(lat3, eps.view(tb["cfg"] * F, HW, -1), tb["coef"][i], cond, use_cfg, float(guidance_scale),
+                              vpred, frame_idx=widx)
+        return lat
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def sliding_iterative_denoise(self, pixel_values=None, plucker_embeds=None, skeletons=None, cond_masks=None,
+                                  latents=None, domain: str = "spatial", timestep_indices=None, window_size: int = 12,
+                                  sliding_stride: int = 1, sliding_shift: int = 0, bidirectional: bool = True,
+                                  num_denoising_steps: int = 1, alternation_rounds: int = 3, guidance_scale: float = 2.0,
+                                  tqdm: Callable = _identity_tqdm, noise: Optional[Dict] = None):
+        """Same contract as pipeline_diffuman4d.py:439-559 (inputs are not mutated)."""
+        if self.vae is None:
+            raise RuntimeError("this pipeline was built without a VAE; use denoise_latents()")
+        torch.cuda.set_device(self._device)  # worker threads inherit device 0 (sampling_runner.py:36)
+        cond_flags = (cond_masks[:, 0, 0, 0] == 0.0).cpu().numpy()
+        plan = plan_sweep(cond_flags, torch.as_tensor(timestep_indices).cpu().numpy(), domain, window_size,
+                          sliding_stride, sliding_shift, bidirectional, num_denoising_steps, alternation_rounds)
+        pv_lat, pl_lat, sk_lat, cm_lat, lat = self.prepare_all_latents(pixel_values, plucker_embeds, skeletons,
+                                                                       cond_masks, latents, noise)
+        self.denoise_latents(pv_lat, pl_lat, sk_lat, cm_lat, lat, plan, domain, guidance_scale, tqdm)
+        images = self.vae.decode_to_images(lat)  # [N,3,H,W] in [0,1]
+        tidx = torch.from_numpy(plan.final_timestep_indices)
+        return {
+            "images": images,
+            "latents": ops.nhwc_to_nchw(lat),
+            "timestep_indices": tidx,
+            "fully_denoised": tidx == plan.num_inference_steps,
+        }

@@ -1,0 +1,94 @@
+"""Integer bookkeeping of the sliding iterative denoiser (bit-exact with the reference).
+
+Everything here is host-side index arithmetic restating
+``pipeline_diffuman4d.py:463-472`` (step budget), ``:474-487`` (entry checks), ``:503-518`` (window
+list), ``:273-278,423,542`` (timestep-index evolution) and ``:546-551`` (exit checks).  Because the
+evolution of every latent's timestep index is data independent, the whole sweep is planned up front
+-- the device loop then runs without a single host synchronisation (the reference syncs once per
+latent per step through ``.item()``, :415).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Sequence
+
+import numpy as np
+
+
+def steps_per_alternation(window_size: int, sliding_stride: int, bidirectional: bool, num_denoising_steps: int) -> int:
+    if (window_size * num_denoising_steps) % sliding_stride != 0:
+        raise ValueError(
+            f"The window size ({window_size}) * num denoising steps ({num_denoising_steps}) "
+            f"should be divisible by the sliding stride ({sliding_stride})"
+        )
+    n = window_size * num_denoising_steps // sliding_stride
+    return n * 2 if bidirectional else n
+
+
+def build_windows(target_indices: Sequence[int], input_indices: Sequence[int], domain: str, window_size: int,
+                  sliding_stride: int, sliding_shift: int, bidirectional: bool):
+    """-> (target_windows, input_windows): lists of int64 arrays (torch.roll semantics, :508)."""
+    tgt = np.asarray(target_indices, dtype=np.int64)
+    inp = np.asarray(input_indices, dtype=np.int64)
+    tws, iws = [], []
+    for direction in ((-1, 1) if bidirectional else (-1,)):
+        for shift in range(sliding_shift, sliding_shift + len(tgt), sliding_stride):
+            tw = np.roll(tgt, shift * direction)[:window_size]
+            tws.append(tw)
+            if domain == "spatial":
+                iws.append(inp)
+            elif domain == "temporal":
+                iws.append(tw - len(inp))
+            else:
+                raise ValueError(f"unknown domain {domain!r}")
+    return tws, iws
+
+
+@dataclass
+class SweepPlan:
+    """One task's full window sweep, planned on the host."""
+
+    num_inference_steps: int
+    windows: List[np.ndarray]          # per UNet call: frame indices fed to the UNet (inputs first, then targets)
+    is_cond: List[np.ndarray]          # per call: bool [F]
+    timestep_index: List[np.ndarray]   # per call: int64 [F] index into scheduler.timesteps (cond rows 0)
+    final_timestep_indices: np.ndarray  # [N] after the sweep
+    target_indices: np.ndarray
+    input_indices: np.ndarray
+
+
+def plan_sweep(cond_flags: Sequence[bool], timestep_indices: Sequence[int], domain: str, window_size: int,
+               sliding_stride: int, sliding_shift: int, bidirectional: bool, num_denoising_steps: int,
+               alternation_rounds: int) -> SweepPlan:
+    """cond_flags[i] is True for input (conditioning) frames, i.e. cond_masks[i,0,0,0] == 0."""
+    per_alt = steps_per_alternation(window_size, sliding_stride, bidirectional, num_denoising_steps)
+    num_inference_steps = per_alt * alternation_rounds
+    cond = np.asarray(cond_flags, dtype=bool)
+    idx = np.asarray(timestep_indices, dtype=np.int64).copy()
+    target_indices = np.nonzero(~cond)[0]
+    input_indices = np.nonzero(cond)[0]
+    tt = idx[target_indices]
+    if (tt != tt[0]).any():
+        raise ValueError(f"The timestep indices should be the same for all target samples, timestep_indices = {idx}")
+    if (idx[input_indices] != 0).any():
+        raise ValueError(f"The timestep indices should be 0 for all input samples, timestep_indices = {idx}")
+    id_end = int(tt[0]) + per_alt
+    tws, iws = build_windows(target_indices, input_indices, domain, window_size, sliding_stride, sliding_shift,
+                             bidirectional)
+    windows, conds, tidx = [], [], []
+    for tw, iw in zip(tws, iws):
+        window = np.concatenate([iw, tw])
+        wc = cond[window]
+        local = idx[window].copy()
+        for _ in range(num_denoising_steps):
+            local[wc] = 0  # get_timestep, :275
+            windows.append(window)
+            conds.append(wc.copy())
+            tidx.append(local.copy())
+            local[~wc] += 1  # :423
+        idx[tw] += num_denoising_steps  # :542
+    if (idx[target_indices] != id_end).any():
+        raise ValueError(f"The denoised timesteps of target samples mismatch the config, timestep_indices = {idx}")
+    if (idx[input_indices] != 0).any():
+        raise ValueError(f"Timesteps of input samples have changed, timestep_indices = {idx}")
+    return SweepPlan(num_inference_steps, windows, conds, tidx, idx, target_indices, input_indices)

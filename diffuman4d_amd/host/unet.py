@@ -210,7 +210,7 @@ class UNetMultiviewConditionModel:
         for i, t in enumerate(cfg.down_block_types):
             p = f"down_blocks.{i}."
             has_attn = t != "DownBlock2D"
-            res = [_Resnet(W, p + f"resnets.{j}.", g, eps, cfg.resnet_out_scale_factor if not has_attn else 1.0, temb_list)
+            res = [_Resnet(W, p + f"resnets.{j}.", g, eps, 1.0, temb_list)
                    for j in range(cfg.layers_per_block)]
             att = [_Transformer(W, p + f"attentions.{j}.", cfg.heads(i), g) for j in range(cfg.layers_per_block)] if has_attn else None
             ds = None
@@ -225,7 +225,7 @@ class UNetMultiviewConditionModel:
             p = f"up_blocks.{i}."
             has_attn = t != "UpBlock2D"
             n = cfg.layers_per_block + 1
-            res = [_Resnet(W, p + f"resnets.{j}.", g, eps, cfg.resnet_out_scale_factor if not has_attn else 1.0, temb_list)
+            res = [_Resnet(W, p + f"resnets.{j}.", g, eps, 1.0, temb_list)
                    for j in range(n)]
             att = [_Transformer(W, p + f"attentions.{j}.", cfg.heads(len(boc) - 1 - i), g) for j in range(n)] if has_attn else None
             us = None

@@ -1,0 +1,240 @@
+"""HIP-backed SD AutoencoderKL (encode / decode tiles of the pipeline).
+
+Replaces the ``diffusers.AutoencoderKL`` calls of ``pipeline_diffuman4d.py:47-72`` (micro-batches of
+8 images, posterior ``sample()``, ``scaling_factor``) and the ``VaeImageProcessor`` denormalisation
+(:280-285).  Same kernels as the UNet: NHWC implicit-GEMM conv3x3, GroupNorm+SiLU, MFMA GEMM.  The
+single-head d=512 mid-block attention is expressed with the GEMM kernel (QK^T, PV) + a row softmax.
+"""
+from __future__ import annotations
+
+import json
+from dataclasses import dataclass, fields
+from pathlib import Path
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import ops
+from .unet import _Weights
+
+BF16 = torch.bfloat16
+PAD = 32
+
+
+@dataclass
+class VAEConfig:
+    in_channels: int = 3
+    out_channels: int = 3
+    latent_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (128, 256, 512, 512)
+    layers_per_block: int = 2
+    norm_num_groups: int = 32
+    scaling_factor: float = 0.18215
+
+    @classmethod
+    def from_dict(cls, d: Dict) -> "VAEConfig":
+        names = {f.name for f in fields(cls)}
+        return cls(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in d.items() if k in names})
+
+
+class _Res:
+    """ResnetBlock2D without time embedding, eps 1e-6."""
+
+    def __init__(self, W: _Weights, pfx: str, groups: int):
+        self.g = groups
+        self.n1w, self.n1b = W.vec(pfx + "norm1.weight"), W.vec(pfx + "norm1.bias")
+        self.c1w, self.c1b = W.conv3(pfx + "conv1.weight"), W.vec(pfx + "conv1.bias")
+        self.n2w, self.n2b = W.vec(pfx + "norm2.weight"), W.vec(pfx + "norm2.bias")
+        self.c2w, self.c2b = W.conv3(pfx + "conv2.weight"), W.vec(pfx + "conv2.bias")
+        self.has_sc = (pfx + "conv_shortcut.weight") in W.sd
+        if self.has_sc:
+            self.scw, self.scb = W.linear(pfx + "conv_shortcut.weight"), W.vec(pfx + "conv_shortcut.bias")
+
+    def __call__(self, x):
+        B, H, Wd, C = x.shape
+        h = ops.groupnorm(x, self.n1w, self.n1b, self.g, 1e-6, silu=True)
+        h = ops.conv3x3(h, self.c1w, bias=self.c1b)
+        h = ops.groupnorm(h, self.n2w, self.n2b, self.g, 1e-6, silu=True)
+        sc = x
+        if self.has_sc:
+            sc = ops.gemm(x.view(-1, C), self.scw, bias=self.scb).view(B, H, Wd, -1)
+        return ops.conv3x3(h, self.c2w, bias=self.c2b, residual=sc)
+
+
+class _MidAttn:
+    """Single-head attention, GroupNorm on the input, q/k/v with bias, residual connection."""
+
+    def __init__(self, W: _Weights, pfx: str, groups: int):
+        self.g = groups
+        self.nw, self.nb = W.vec(pfx + "group_norm.weight"), W.vec(pfx + "group_norm.bias")
+        ws = [W.get(pfx + f"to_{n}.weight") for n in "qkv"]
+        bs = [W.get(pfx + f"to_{n}.bias") for n in "qkv"]
+        ws = [w.reshape(w.shape[0], w.shape[1]) for w in ws]  # legacy checkpoints store 1x1 convs
+        self.qkv_w = torch.cat(ws, 0).to(W.device, BF16).contiguous()
+        self.qkv_b = torch.cat(bs, 0).to(W.device, BF16).contiguous()
+        self.ow, self.ob = W.linear(pfx + "to_out.0.weight"), W.vec(pfx + "to_out.0.bias")
+
+    def __call__(self, x):
+        B, H, Wd, C = x.shape
+        L = H * Wd
+        if L % 32 != 0:
+            raise ValueError(f"VAE mid-block attention needs H*W % 32 == 0 at latent resolution (got {H}x{Wd})")
+        n = ops.groupnorm(x, self.nw, self.nb, self.g, 1e-6, silu=False)
+        qkv = ops.gemm(n.view(B * L, C), self.qkv_w, bias=self.qkv_b)  # [B*L, 3C]
+        o = torch.empty((B * L, C), dtype=BF16, device=x.device)
+        scale = float(C) ** -0.5
+        for b in range(B):
+            rows = slice(b * L, (b + 1) * L)
+            q, k, v = qkv[rows, :C], qkv[rows, C:2 * C], qkv[rows, 2 * C:]
+            s = ops.gemm(q, k)  # [L, L] = q k^T
+            p = ops.softmax_rows(s, scale)
+            vt = _transpose(v, C)  # [C, L]
+            ops.gemm(p, vt, out=o[rows])
+        return ops.gemm(o, self.ow, bias=self.ob, residual=x.view(B * L, C)).view(B, H, Wd, C)
+
+
+def _transpose(v: torch.Tensor, C: int) -> torch.Tensor:
+    """v [L, C] row-strided view -> contiguous [C, L] via the NHWC->NCHW kernel."""
+    from . import lib as _l
+    lib = _l.load()
+    L = v.shape[0]
+    y = torch.empty((C, L), dtype=BF16, device=v.device)
+    _l.check(lib.dm4d_nhwc_to_nchw_bf16(torch.cuda.current_stream().cuda_stream, v.data_ptr(), y.data_ptr(), 1, C, L,
+                                        v.stride(0)), "dm4d_nhwc_to_nchw_bf16")
+    return y
+
+
+class AutoencoderKL:
+    def __init__(self, config: VAEConfig, state_dict: Dict[str, torch.Tensor], device="cuda"):
+        cfg = self.config = config
+        self.device = torch.device(device)
+        W = _Weights(state_dict, self.device)
+        g, boc, lc = cfg.norm_num_groups, cfg.block_out_channels, cfg.latent_channels
+        if cfg.in_channels > PAD or 2 * lc > PAD:
+            raise NotImplementedError("channel counts above 32 at the VAE boundary")
+        # ---- encoder ----
+        self.e_in_w, self.e_in_b = W.conv3("encoder.conv_in.weight", cin_pad=PAD), W.vec("encoder.conv_in.bias")
+        self.e_down = []
+        for i in range(len(boc)):
+            p = f"encoder.down_blocks.{i}."
+            res = [_Res(W, p + f"resnets.{j}.", g) for j in range(cfg.layers_per_block)]
+            ds = None
+            if i != len(boc) - 1:
+                ds = (W.conv3(p + "downsamplers.0.conv.weight"), W.vec(p + "downsamplers.0.conv.bias"))
+            self.e_down.append((res, ds))
+        self.e_mid = (_Res(W, "encoder.mid_block.resnets.0.", g), _MidAttn(W, "encoder.mid_block.attentions.0.", g),
+                      _Res(W, "encoder.mid_block.resnets.1.", g))
+        self.e_nw, self.e_nb = W.vec("encoder.conv_norm_out.weight"), W.vec("encoder.conv_norm_out.bias")
+        # conv_out writes a 32-wide row (channels >= 2*lc are zero) so quant_conv is one K=32 GEMM
+        self.e_out_w = W.conv3("encoder.conv_out.weight", cout_pad=PAD)
+        self.e_out_b = _pad_vec(W.get("encoder.conv_out.bias"), PAD, self.device)
+        self.quant_w = _pad_mat(W.get("quant_conv.weight"), 2 * lc, PAD, self.device)
+        self.quant_b = W.vec("quant_conv.bias")
+        # ---- decoder ----
+        self.pq_w = _pad_mat(W.get("post_quant_conv.weight"), PAD, PAD, self.device)  # out rows >= lc are zero
+        self.pq_b = _pad_vec(W.get("post_quant_conv.bias"), PAD, self.device)
+        self.d_in_w, self.d_in_b = W.conv3("decoder.conv_in.weight", cin_pad=PAD), W.vec("decoder.conv_in.bias")
+        self.d_mid = (_Res(W, "decoder.mid_block.resnets.0.", g), _MidAttn(W, "decoder.mid_block.attentions.0.", g),
+                      _Res(W, "decoder.mid_block.resnets.1.", g))
+        self.d_up = []
+        for i in range(len(boc)):
+            p = f"decoder.up_blocks.{i}."
+            res = [_Res(W, p + f"resnets.{j}.", g) for j in range(cfg.layers_per_block + 1)]
+            us = None
+            if i != len(boc) - 1:
+                us = (W.conv3(p + "upsamplers.0.conv.weight"), W.vec(p + "upsamplers.0.conv.bias"))
+            self.d_up.append((res, us))
+        self.d_nw, self.d_nb = W.vec("decoder.conv_norm_out.weight"), W.vec("decoder.conv_norm_out.bias")
+        self.d_out_w, self.d_out_b = W.conv3("decoder.conv_out.weight"), W.vec("decoder.conv_out.bias")
+        unused = [k for k in state_dict if k not in W.used]
+        if unused:
+            raise KeyError(f"unexpected keys in VAE checkpoint (strict load): {unused[:8]}")
+
+    @classmethod
+    def from_pretrained(cls, path, device="cuda") -> "AutoencoderKL":
+        from safetensors.torch import load_file
+        path = Path(path)
+        cfg = VAEConfig.from_dict(json.loads((path / "config.json").read_text()))
+        files = sorted(path.glob("diffusion_pytorch_model*.safetensors"))
+        if not files:
+            raise FileNotFoundError(f"no diffusion_pytorch_model*.safetensors under {path}")
+        return cls(cfg, load_file(str(files[0])), device)
+
+    @property
+    def scale_factor(self) -> int:
+        return 2 ** (len(self.config.block_out_channels) - 1)
+
+    # ---- encode --------------------------------------------------------------------------------
+    def moments(self, x_nhwc32: torch.Tensor) -> torch.Tensor:
+        """x [B,H,W,32] (3 image channels + zero pad) -> moments [B,h,w,2*lc] (mean | logvar)."""
+        x = ops.conv3x3(x_nhwc32, self.e_in_w, bias=self.e_in_b)
+        for res, ds in self.e_down:
+            for r in res:
+                x = r(x)
+            if ds is not None:
+                x = ops.conv3x3(x, ds[0], bias=ds[1], stride=2, pad=0, pad_hi=1)  # F.pad(0,1,0,1) + conv s2 p0
+        x = self.e_mid[2](self.e_mid[1](self.e_mid[0](x)))
+        x = ops.groupnorm(x, self.e_nw, self.e_nb, self.config.norm_num_groups, 1e-6, silu=True)
+        x = ops.conv3x3(x, self.e_out_w, bias=self.e_out_b)  # [B,h,w,32]
+        B, h, w, _ = x.shape
+        return ops.gemm(x.view(-1, PAD), self.quant_w, bias=self.quant_b).view(B, h, w, -1)
+
+    def encode_scaled(self, images: torch.Tensor, noise: Optional[torch.Tensor], batch_size: int = 8) -> torch.Tensor:
+        """pipeline_diffuman4d.py:47-56: images NCHW in [-1,1] (CPU or GPU) -> latents NHWC * scaling_factor.
+        `noise` NCHW [N, lc, h, w] (any device) is the posterior draw; drawn on the device if None."""
+        lc = self.config.latent_channels
+        outs = []
+        for i in range(0, images.shape[0], batch_size):
+            xb = images[i:i + batch_size].to(self.device, BF16).contiguous()
+            m = self.moments(ops.nchw_to_nhwc(xb, PAD))
+            B, h, w, _ = m.shape
+            if noise is not None:
+                nb = ops.nchw_to_nhwc(noise[i:i + batch_size].to(self.device, BF16).contiguous())
+            else:
+                nb = torch.randn((B, h, w, lc), device=self.device, dtype=torch.float32).to(BF16)
+            outs.append(ops.vae_sample(m, nb, lc, self.config.scaling_factor))
+        return torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
+
+    # ---- decode --------------------------------------------------------------------------------
+    def decode(self, z_nhwc: torch.Tensor) -> torch.Tensor:
+        """z [B,h,w,lc] (already divided by scaling_factor, padded to 32) -> image NHWC [B,H,W,3]."""
+        B, h, w, _ = z_nhwc.shape
+        x = ops.gemm(z_nhwc.view(-1, PAD), self.pq_w, bias=self.pq_b).view(B, h, w, PAD)
+        x = ops.conv3x3(x, self.d_in_w, bias=self.d_in_b)
+        x = self.d_mid[2](self.d_mid[1](self.d_mid[0](x)))
+        for res, us in self.d_up:
+            for r in res:
+                x = r(x)
+            if us is not None:
+                x = ops.conv3x3(x, us[0], bias=us[1], upsample=True)
+        x = ops.groupnorm(x, self.d_nw, self.d_nb, self.config.norm_num_groups, 1e-6, silu=True)
+        return ops.conv3x3(x, self.d_out_w, bias=self.d_out_b)
+
+    def decode_to_images(self, lat_nhwc: torch.Tensor, batch_size: int = 8) -> torch.Tensor:
+        """pipeline_diffuman4d.py:59-72,280-285: latents NHWC -> images NCHW in [0,1]."""
+        outs = []
+        for i in range(0, lat_nhwc.shape[0], batch_size):
+            z = ops.scale_pad(lat_nhwc[i:i + batch_size].contiguous(), PAD, 1.0 / self.config.scaling_factor)
+            outs.append(ops.postprocess_images(self.decode(z), self.config.out_channels))
+        return torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
+
+    # ---- conditioning resize (encode_image_resizing, :90-100) -----------------------------------
+    def resize_to_nhwc(self, images: torch.Tensor, size, mode: str, batch_size: int = 16) -> torch.Tensor:
+        outs = []
+        for i in range(0, images.shape[0], batch_size):
+            xb = images[i:i + batch_size].to(self.device, torch.float32).contiguous()
+            outs.append(ops.resize_to_nhwc(xb, size, mode))
+        return torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
+
+
+def _pad_vec(v: torch.Tensor, n: int, device) -> torch.Tensor:
+    out = torch.zeros(n)
+    out[: v.shape[0]] = v.float()
+    return out.to(device, BF16)
+
+
+def _pad_mat(w: torch.Tensor, rows: int, cols: int, device) -> torch.Tensor:
+    w = w.float().reshape(w.shape[0], w.shape[1])
+    out = torch.zeros(rows, cols)
+    out[: w.shape[0], : w.shape[1]] = w
+    return out.to(device, BF16).contiguous()

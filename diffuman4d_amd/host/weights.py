@@ -1,0 +1,171 @@
+"""Checkpoint key/shape tables (diffusers naming) and synthetic weights.
+
+There are no public weights in the build environment, so benchmarks and smoke
+tests instantiate the *architecture* with seeded random weights.  The tables double as the strict
+key contract a real ``unet/diffusion_pytorch_model.safetensors`` / ``vae/...`` must satisfy
+(state_dict key skeleton).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Tuple
+
+import torch
+
+from .unet import UNetConfig
+from .vae import VAEConfig
+
+Shapes = Dict[str, Tuple[int, ...]]
+
+
+def _resnet(s: Shapes, p: str, cin: int, cout: int, temb):
+    s[p + "norm1.weight"] = (cin,)
+    s[p + "norm1.bias"] = (cin,)
+    s[p + "conv1.weight"] = (cout, cin, 3, 3)
+    s[p + "conv1.bias"] = (cout,)
+    if temb is not None:
+        s[p + "time_emb_proj.weight"] = (cout, temb)
+        s[p + "time_emb_proj.bias"] = (cout,)
+    s[p + "norm2.weight"] = (cout,)
+    s[p + "norm2.bias"] = (cout,)
+    s[p + "conv2.weight"] = (cout, cout, 3, 3)
+    s[p + "conv2.bias"] = (cout,)
+    if cin != cout:
+        s[p + "conv_shortcut.weight"] = (cout, cin, 1, 1)
+        s[p + "conv_shortcut.bias"] = (cout,)
+
+
+def _transformer(s: Shapes, p: str, c: int, linear: bool):
+    s[p + "norm.weight"] = (c,)
+    s[p + "norm.bias"] = (c,)
+    for n in ("proj_in", "proj_out"):
+        s[p + n + ".weight"] = (c, c) if linear else (c, c, 1, 1)
+        s[p + n + ".bias"] = (c,)
+    b = p + "transformer_blocks.0."
+    for n in ("norm1", "norm3"):
+        s[b + n + ".weight"] = (c,)
+        s[b + n + ".bias"] = (c,)
+    for n in ("to_q", "to_k", "to_v"):
+        s[b + f"attn1.{n}.weight"] = (c, c)
+    s[b + "attn1.to_out.0.weight"] = (c, c)
+    s[b + "attn1.to_out.0.bias"] = (c,)
+    s[b + "ff.net.0.proj.weight"] = (8 * c, c)
+    s[b + "ff.net.0.proj.bias"] = (8 * c,)
+    s[b + "ff.net.2.weight"] = (c, 4 * c)
+    s[b + "ff.net.2.bias"] = (c,)
+
+
+def unet_param_shapes(cfg: UNetConfig) -> Shapes:
+    s: Shapes = {}
+    boc = cfg.block_out_channels
+    temb = boc[0] * 4
+    s["conv_in.weight"] = (boc[0], cfg.in_channels, 3, 3)
+    s["conv_in.bias"] = (boc[0],)
+    for n in ["time_embedding"] + (["temporal_pos_embed"] if cfg.enable_tem_embeds else []):
+        s[n + ".linear_1.weight"] = (temb, boc[0])
+        s[n + ".linear_1.bias"] = (temb,)
+        s[n + ".linear_2.weight"] = (temb, temb)
+        s[n + ".linear_2.bias"] = (temb,)
+    out_c = boc[0]
+    for i, t in enumerate(cfg.down_block_types):
+        in_c, out_c = out_c, boc[i]
+        for j in range(cfg.layers_per_block):
+            _resnet(s, f"down_blocks.{i}.resnets.{j}.", in_c if j == 0 else out_c, out_c, temb)
+            if t != "DownBlock2D":
+                _transformer(s, f"down_blocks.{i}.attentions.{j}.", out_c, cfg.use_linear_projection)
+        if i != len(boc) - 1:
+            s[f"down_blocks.{i}.downsamplers.0.conv.weight"] = (out_c, out_c, 3, 3)
+            s[f"down_blocks.{i}.downsamplers.0.conv.bias"] = (out_c,)
+    c = boc[-1]
+    _resnet(s, "mid_block.resnets.0.", c, c, temb)
+    _transformer(s, "mid_block.attentions.0.", c, cfg.use_linear_projection)
+    _resnet(s, "mid_block.resnets.1.", c, c, temb)
+    rboc = list(reversed(boc))
+    out_c = rboc[0]
+    n = cfg.layers_per_block + 1
+    for i, t in enumerate(cfg.up_block_types):
+        prev_c, out_c = out_c, rboc[i]
+        in_c = rboc[min(i + 1, len(boc) - 1)]
+        for j in range(n):
+            skip = in_c if j == n - 1 else out_c
+            rin = prev_c if j == 0 else out_c
+            _resnet(s, f"up_blocks.{i}.resnets.{j}.", rin + skip, out_c, temb)
+            if t != "UpBlock2D":
+                _transformer(s, f"up_blocks.{i}.attentions.{j}.", out_c, cfg.use_linear_projection)
+        if i != len(boc) - 1:
+            s[f"up_blocks.{i}.upsamplers.0.conv.weight"] = (out_c, out_c, 3, 3)
+            s[f"up_blocks.{i}.upsamplers.0.conv.bias"] = (out_c,)
+    s["conv_norm_out.weight"] = (boc[0],)
+    s["conv_norm_out.bias"] = (boc[0],)
+    s["conv_out.weight"] = (cfg.out_channels, boc[0], 3, 3)
+    s["conv_out.bias"] = (cfg.out_channels,)
+    return s
+
+
+def vae_param_shapes(cfg: VAEConfig) -> Shapes:
+    s: Shapes = {}
+    boc, lc = cfg.block_out_channels, cfg.latent_channels
+
+    def mid(p, c):
+        _resnet(s, p + "resnets.0.", c, c, None)
+        a = p + "attentions.0."
+        s[a + "group_norm.weight"] = (c,)
+        s[a + "group_norm.bias"] = (c,)
+        for n in ("to_q", "to_k", "to_v", "to_out.0"):
+            s[a + n + ".weight"] = (c, c)
+            s[a + n + ".bias"] = (c,)
+        _resnet(s, p + "resnets.1.", c, c, None)
+
+    s["encoder.conv_in.weight"] = (boc[0], cfg.in_channels, 3, 3)
+    s["encoder.conv_in.bias"] = (boc[0],)
+    c = boc[0]
+    for i, co in enumerate(boc):
+        for j in range(cfg.layers_per_block):
+            _resnet(s, f"encoder.down_blocks.{i}.resnets.{j}.", c if j == 0 else co, co, None)
+        if i != len(boc) - 1:
+            s[f"encoder.down_blocks.{i}.downsamplers.0.conv.weight"] = (co, co, 3, 3)
+            s[f"encoder.down_blocks.{i}.downsamplers.0.conv.bias"] = (co,)
+        c = co
+    mid("encoder.mid_block.", c)
+    s["encoder.conv_norm_out.weight"] = (c,)
+    s["encoder.conv_norm_out.bias"] = (c,)
+    s["encoder.conv_out.weight"] = (2 * lc, c, 3, 3)
+    s["encoder.conv_out.bias"] = (2 * lc,)
+    s["quant_conv.weight"] = (2 * lc, 2 * lc, 1, 1)
+    s["quant_conv.bias"] = (2 * lc,)
+    s["post_quant_conv.weight"] = (lc, lc, 1, 1)
+    s["post_quant_conv.bias"] = (lc,)
+    rboc = list(reversed(boc))
+    s["decoder.conv_in.weight"] = (rboc[0], lc, 3, 3)
+    s["decoder.conv_in.bias"] = (rboc[0],)
+    mid("decoder.mid_block.", rboc[0])
+    c = rboc[0]
+    for i, co in enumerate(rboc):
+        for j in range(cfg.layers_per_block + 1):
+            _resnet(s, f"decoder.up_blocks.{i}.resnets.{j}.", c if j == 0 else co, co, None)
+        if i != len(boc) - 1:
+            s[f"decoder.up_blocks.{i}.upsamplers.0.conv.weight"] = (co, co, 3, 3)
+            s[f"decoder.up_blocks.{i}.upsamplers.0.conv.bias"] = (co,)
+        c = co
+    s["decoder.conv_norm_out.weight"] = (c,)
+    s["decoder.conv_norm_out.bias"] = (c,)
+    s["decoder.conv_out.weight"] = (cfg.out_channels, c, 3, 3)
+    s["decoder.conv_out.bias"] = (cfg.out_channels,)
+    return s
+
+
+def random_state_dict(shapes: Shapes, seed: int = 0, device="cpu", dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:
+    """Seeded synthetic weights that keep activations O(1): N(0, 1/fan_in) matrices, norm gamma ~ 1,
+    small biases.  Generated on `device` (torch RNG is plumbing here, not compute on the hot path)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    out = {}
+    for k, shp in shapes.items():
+        if len(shp) >= 2:
+            fan_in = math.prod(shp[1:])
+            t = torch.randn(shp, generator=g, device=device, dtype=torch.float32) * (1.0 / math.sqrt(fan_in))
+        elif "norm" in k and k.endswith("weight"):
+            t = 1.0 + 0.1 * torch.randn(shp, generator=g, device=device, dtype=torch.float32)
+        else:
+            t = 0.05 * torch.randn(shp, generator=g, device=device, dtype=torch.float32)
+        out[k] = t.to(dtype)
+    return out

@@ -95,17 +95,37 @@ int dm4d_silu_bf16(void* stream, const void* X, void* Y, int64_t n);
  *   out [cfg*F, HW, cpad] NHWC: channels [latent 4 | plucker 6 | skeleton-latent 4 (opt) | mask 1 | 0...]
  *   cond rows (is_cond[f] != 0) take the clean image latents (and +1.0 in the negative half);
  *   negative half: plucker 0, skeleton -1.  Also performs the reference's aliasing side effect
- *   (SURVEY 8a P-4 iv): latents[cond rows] <- image latents, in place.                             */
+ *   (SURVEY 8a P-4 iv): latents[cond rows] <- image latents, in place.
+ *   frame_idx (int32 [F], may be NULL): window frame f reads row frame_idx[f] of the task-level
+ *   tensors latents/pv_lat/plucker/skel/mask -- the x[window] gathers of :522-531 without copies.     */
 int dm4d_pack_model_input_bf16(void* stream, void* latents, const void* pv_lat, const void* plucker, const void* skel,
-                               const void* mask, const int32_t* is_cond, void* out, int F, int HW, int cpad,
-                               int use_cfg);
+                               const void* mask, const int32_t* is_cond, const int32_t* frame_idx, void* out, int F,
+                               int HW, int cpad, int use_cfg);
 
 /* CFG combine + per-latent DDIM step (pipeline_diffuman4d.py:408-422), one launch for the window:
  *   eps = u + s (c - u);  x <- sqrt(a_prev) x0 + sqrt(1 - a_prev) eps_hat   for non-cond rows.
- *   noise_pred [cfg*F, HW, ldn]; coef [F,4] fp32 = {sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev)} */
+ *   noise_pred [cfg*F, HW, ldn]; coef [F,4] fp32 = {sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev)}
+ *   frame_idx as above: the update is scattered straight into the task-level latents (:543).         */
 int dm4d_cfg_ddim_step_bf16(void* stream, void* latents, const void* noise_pred, int64_t ldn, const float* coef,
-                            const int32_t* is_cond, int F, int HW, int use_cfg, float guidance_scale,
-                            int v_prediction);
+                            const int32_t* is_cond, const int32_t* frame_idx, int F, int HW, int use_cfg,
+                            float guidance_scale, int v_prediction);
+
+/* VAE posterior sample, DiagonalGaussianDistribution.sample() * scaling_factor
+ *   (pipeline_diffuman4d.py:52,55): out[m,c] = (mean + exp(0.5*clamp(logvar,-30,20)) * noise[m,c]) * scale
+ *   moments rows hold [mean(C) | logvar(C) | ...] with row stride ldm; noise/out are [M, C].          */
+int dm4d_vae_sample_bf16(void* stream, const void* moments, int64_t ldm, const void* noise, void* out, int64_t M, int C,
+                         float scale);
+
+/* Y[m, 0:cpad] = [X[m, 0:C] * scale | 0]   (latents / scaling_factor before post_quant_conv, :66)     */
+int dm4d_scale_pad_bf16(void* stream, const void* X, int64_t ldx, void* Y, int cpad, int64_t M, int C, float scale);
+
+/* F.interpolate(size=(h,w), mode = bilinear (1) | nearest (0)), fp32 NCHW -> bf16 NHWC
+ *   (encode_image_resizing, pipeline_diffuman4d.py:90-100: Pluecker maps and condition masks)        */
+int dm4d_resize_nchw_f32_to_nhwc_bf16(void* stream, const float* X, void* Y, int B, int C, int H, int W, int h, int w,
+                                      int bilinear);
+
+/* VaeImageProcessor.postprocess(do_denormalize): (x/2 + 0.5).clamp(0,1), NHWC(ldx) -> NCHW (:282-284)  */
+int dm4d_postprocess_images_bf16(void* stream, const void* X, void* Y, int B, int C, int HW, int ldx);
 
 /* layout converters at the pipeline boundary (NCHW <-> NHWC, any C) */
 int dm4d_nchw_to_nhwc_bf16(void* stream, const void* X, void* Y, int B, int C, int HW, int cpad);

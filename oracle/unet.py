@@ -379,8 +379,7 @@ class UNetMultiviewConditionModel(nn.Module):
             in_c, out_c = out_c, boc[i]
             heads = cfg.heads(i) if t != "DownBlock2D" else None
             self.down_blocks.append(
-                DownBlock(in_c, out_c, temb, cfg.layers_per_block, g, eps, heads, i != len(boc) - 1, lin,
-                          cfg.resnet_out_scale_factor)
+                DownBlock(in_c, out_c, temb, cfg.layers_per_block, g, eps, heads, i != len(boc) - 1, lin, 1.0)
             )
         self.mid_block = MidBlock(boc[-1], temb, g, eps, cfg.heads(len(boc) - 1), lin, cfg.mid_block_scale_factor)
         self.up_blocks = nn.ModuleList()
@@ -391,8 +390,7 @@ class UNetMultiviewConditionModel(nn.Module):
             in_c = rboc[min(i + 1, len(boc) - 1)]
             heads = cfg.heads(len(boc) - 1 - i) if t != "UpBlock2D" else None
             self.up_blocks.append(
-                UpBlock(in_c, out_c, prev_c, temb, cfg.layers_per_block + 1, g, eps, heads, i != len(boc) - 1, lin,
-                        cfg.resnet_out_scale_factor)
+                UpBlock(in_c, out_c, prev_c, temb, cfg.layers_per_block + 1, g, eps, heads, i != len(boc) - 1, lin, 1.0)
             )
         self.conv_norm_out = nn.GroupNorm(g, boc[0], eps=eps)
         self.conv_out = nn.Conv2d(boc[0], cfg.out_channels, 3, padding=1)

@@ -1,0 +1,229 @@
+"""Model-level parity checks on a GPU box: HIP UNet / VAE / pipeline (through the C ABI) vs the CPU
+oracle on identical seeded weights, inputs and injected noise.
+
+`python tests/modelcheck.py` prints one line per case; tests/test_model_gpu.py wraps the same cases.
+
+Tolerances (bf16 activations end to end, fp32 accumulation; the fp32 oracle is the ground truth):
+  * a case passes when rel-L2(HIP, oracle-fp32) <= TOL[case]; we also print the error of the ORACLE
+    run in bf16 (i.e. the reference's own arithmetic) against the same fp32 truth as a yardstick;
+  * integer bookkeeping (timestep indices, fully_denoised) must be bit-exact.
+"""
+from __future__ import annotations
+
+import math
+import sys
+import time
+import traceback
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+BF = torch.bfloat16
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def bf16_weights(model):
+    """Round parameters to bf16-representable fp32 so that oracle and HIP see identical weights."""
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(p.to(BF).float())
+    return model
+
+
+def make_unet(seed=0, **cfg_kw):
+    from oracle.unet import UNetConfig, UNetMultiviewConditionModel, init_unet_weights
+    cfg = UNetConfig.tiny(**cfg_kw)
+    m = UNetMultiviewConditionModel(cfg).eval()
+    init_unet_weights(m, seed)
+    return cfg, bf16_weights(m)
+
+
+def make_vae(seed=1):
+    from oracle.unet import init_unet_weights
+    from oracle.vae import AutoencoderKL, VAEConfig
+    cfg = VAEConfig.tiny()
+    v = AutoencoderKL(cfg).eval()
+    init_unet_weights(v, seed)
+    return cfg, bf16_weights(v)
+
+
+def hip_unet(cfg, oracle_model):
+    from dataclasses import asdict
+    from diffuman4d_amd.host.unet import UNetConfig, UNetMultiviewConditionModel
+    return UNetMultiviewConditionModel(UNetConfig.from_dict(asdict(cfg)), oracle_model.state_dict(), "cuda")
+
+
+def hip_vae(cfg, oracle_model):
+    from dataclasses import asdict
+    from diffuman4d_amd.host.vae import AutoencoderKL, VAEConfig
+    return AutoencoderKL(VAEConfig.from_dict(asdict(cfg)), oracle_model.state_dict(), "cuda")
+
+
+def case_unet(num_frames=4, cfg_batch=2, h=16, w=8, tem=False, domain="spatial", seed=0):
+    from diffuman4d_amd.host import ops
+    cfg, om = make_unet(seed, enable_tem_embeds=tem)
+    if tem:  # the temporal embedding MLP is zero-initialised in training; randomise it so it is exercised
+        g = torch.Generator().manual_seed(seed + 5)
+        with torch.no_grad():
+            for p in om.temporal_pos_embed.parameters():
+                p.copy_((torch.randn(p.shape, generator=g) * 0.05).to(BF).float())
+    hm = hip_unet(cfg, om)
+    g = torch.Generator().manual_seed(seed + 1)
+    B = num_frames * cfg_batch
+    x = (torch.randn(B, cfg.in_channels, h, w, generator=g)).to(BF)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    domains = [domain] * cfg_batch
+    with torch.no_grad():
+        ref = om(x.float(), t, domains=domains, num_frames=num_frames)
+        om_bf = om.to(BF)
+        ref_bf = om_bf(x, t, domains=domains, num_frames=num_frames).float()
+        om.float()
+    xd = ops.nchw_to_nhwc(x.cuda(), hm.IN_PAD)
+    out = hm(xd, t.float().cuda(), domains=domains, num_frames=num_frames)
+    out = ops.nhwc_to_nchw(out)
+    return rel_l2(out, ref), rel_l2(ref_bf, ref)
+
+
+def case_vae(h=64, w=64, seed=1):
+    from diffuman4d_amd.host import ops
+    cfg, ov = make_vae(seed)
+    hv = hip_vae(cfg, ov)
+    g = torch.Generator().manual_seed(seed + 1)
+    img = (torch.rand(3, 3, h, w, generator=g) * 2 - 1).to(BF)
+    noise = torch.randn(3, 4, h // 8, w // 8, generator=g).to(BF)
+    with torch.no_grad():
+        z_ref = ov.sample_posterior(ov.moments(img.float()), noise.float()) * cfg.scaling_factor
+        img_ref = (ov.decode(z_ref / cfg.scaling_factor) / 2 + 0.5).clamp(0, 1)
+        ov.to(BF)
+        z_bf = (ov.sample_posterior(ov.moments(img), noise) * cfg.scaling_factor).float()
+        ov.float()
+    z = hv.encode_scaled(img, noise)  # NHWC
+    e_enc = rel_l2(ops.nhwc_to_nchw(z), z_ref)
+    # decode the ORACLE latents so the decoder is checked in isolation
+    zin = ops.nchw_to_nhwc(z_ref.to(BF).contiguous().cuda())
+    out = hv.decode_to_images(zin)
+    e_dec = rel_l2(out, img_ref)
+    return max(e_enc, e_dec), rel_l2(z_bf, z_ref)
+
+
+def case_resize(seed=3):
+    import torch.nn.functional as F
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(2, 6, 64, 48, generator=g)
+    ref_b = F.interpolate(x, size=(8, 6), mode="bilinear").to(BF)
+    ref_n = F.interpolate(x, size=(8, 6), mode="nearest").to(BF)
+    ob = ops.resize_to_nhwc(x.cuda(), (8, 6), "bilinear").permute(0, 3, 1, 2)
+    on = ops.resize_to_nhwc(x.cuda(), (8, 6), "nearest").permute(0, 3, 1, 2)
+    e1 = float((ob.float().cpu() - ref_b.float()).abs().max())
+    e2 = float((on.float().cpu() - ref_n.float()).abs().max())
+    # odd ratio
+    x2 = torch.randn(1, 1, 50, 30, generator=g)
+    r2 = F.interpolate(x2, size=(7, 5), mode="bilinear").to(BF)
+    o2 = ops.resize_to_nhwc(x2.cuda(), (7, 5), "bilinear").permute(0, 3, 1, 2)
+    e3 = rel_l2(o2, r2)
+    r3 = F.interpolate(x2, size=(7, 5), mode="nearest").to(BF)
+    o3 = ops.resize_to_nhwc(x2.cuda(), (7, 5), "nearest").permute(0, 3, 1, 2)
+    e4 = float((o3.float().cpu() - r3.float()).abs().max())
+    return max(e1, e2, e3, e4), 0.0
+
+
+def synthetic_task(n, H, W, input_rows, seed=7):
+    """Synthetic task tensors with the value ranges of spatem_dataset.py:191-228."""
+    g = torch.Generator().manual_seed(seed)
+    pv = torch.rand(n, 3, H, W, generator=g) * 2 - 1
+    sk = -torch.ones(n, 3, H, W)
+    sk[:, :, H // 4: H // 2, W // 4: W // 2] = torch.rand(n, 3, H // 4, W // 4, generator=g) * 2 - 1
+    pl = torch.rand(n, 6, H, W, generator=g) * 2 - 1
+    cm = torch.ones(n, 1, H, W)
+    cm[input_rows] = 0.0
+    return pv, pl, sk, cm
+
+
+def case_pipeline(domain="spatial", n_cams=8, T=4, window=4, stride=2, rounds=1, steps=1, bidir=False, gs=2.0,
+                  pred="epsilon", seed=11):
+    """One full task through sliding_iterative_denoise (VAE encode -> window sweep -> VAE decode)."""
+    from diffuman4d_amd.host.pipeline import Diffuman4DPipeline
+    from diffuman4d_amd.host.scheduler import DDIMConfig as HC, DDIMScheduler as HS
+    from oracle.ddim import DDIMConfig, DDIMScheduler
+    from oracle.pipeline import OraclePipeline
+    cfg_u, ou = make_unet(seed)
+    cfg_v, ov = make_vae(seed + 1)
+    H, W = 64, 64
+    if domain == "spatial":
+        n, inputs = n_cams, [1, 5]
+    else:
+        n, inputs = 2 * T, list(range(T))
+    pv, pl, sk, cm = synthetic_task(n, H, W, inputs, seed)
+    g = torch.Generator().manual_seed(seed + 2)
+    noise = {k: torch.randn(n, 4, H // 8, W // 8, generator=g).to(BF) for k in ("pixel", "skeleton", "latents")}
+    tidx = torch.zeros(n, dtype=torch.int64)
+    kw = dict(window_size=window, sliding_stride=stride, sliding_shift=0, bidirectional=bidir,
+              num_denoising_steps=steps, alternation_rounds=rounds, guidance_scale=gs)
+    op = OraclePipeline(ov, ou, DDIMScheduler(DDIMConfig(prediction_type=pred)), torch.float32)
+    noise_f = {k: v.float() for k, v in noise.items()}
+    ref = op.sliding_iterative_denoise(pv, pl, sk, cm, None, domain, tidx, noise_f, **kw)
+    hp = Diffuman4DPipeline(hip_vae(cfg_v, ov), hip_unet(cfg_u, ou), HS(HC(prediction_type=pred)), "cuda")
+    out = hp.sliding_iterative_denoise(pixel_values=pv, plucker_embeds=pl, skeletons=sk, cond_masks=cm, latents=None,
+                                       domain=domain, timestep_indices=tidx, noise=noise, **kw)
+    exact = bool((out["timestep_indices"].cpu() == ref["timestep_indices"]).all()) and \
+        bool((out["fully_denoised"].cpu() == ref["fully_denoised"]).all())
+    e_lat = rel_l2(out["latents"], ref["latents"])
+    e_img = rel_l2(out["images"], ref["images"])
+    # yardstick: the oracle in bf16 (what the reference computes) vs the fp32 oracle
+    opb = OraclePipeline(ov, ou, DDIMScheduler(DDIMConfig(prediction_type=pred)), BF)
+    refb = opb.sliding_iterative_denoise(pv, pl, sk, cm, None, domain, tidx, noise, **kw)
+    ov.float(), ou.float()
+    yard = rel_l2(refb["images"], ref["images"])
+    print(f"    [pipeline {domain}] latents rel_l2={e_lat:.3e} images rel_l2={e_img:.3e} bookkeeping_exact={exact} "
+          f"(oracle-bf16 images rel_l2={yard:.3e})", flush=True)
+    return (max(e_lat, e_img) if exact else 1.0), yard
+
+
+CASES = {
+    "unet_spatial": (case_unet, dict(num_frames=4, cfg_batch=2)),
+    "unet_temporal_temb": (case_unet, dict(num_frames=4, cfg_batch=2, tem=True, domain="temporal")),
+    "unet_2d_only": (case_unet, dict(num_frames=1, cfg_batch=3, h=8, w=8)),
+    "vae": (case_vae, dict()),
+    "resize": (case_resize, dict()),
+    "pipeline_spatial": (case_pipeline, dict(domain="spatial")),
+    "pipeline_temporal_v": (case_pipeline, dict(domain="temporal", T=4, window=4, stride=1, pred="v_prediction")),
+    "pipeline_bidir_nocfg": (case_pipeline, dict(domain="spatial", window=3, stride=3, bidir=True, gs=1.0, steps=2)),
+}
+# multi-layer bf16 pipelines: each of ~100 ops adds ~2e-3 of rounding noise; they add in quadrature
+TOL = {"unet_spatial": 3e-2, "unet_temporal_temb": 3e-2, "unet_2d_only": 3e-2, "vae": 3e-2, "resize": 4e-3,
+       "pipeline_spatial": 6e-2, "pipeline_temporal_v": 6e-2, "pipeline_bidir_nocfg": 6e-2}
+
+
+def run_case(name):
+    fn, kw = CASES[name]
+    err, yard = fn(**kw)
+    return err, yard, TOL[name]
+
+
+def main():
+    bad = 0
+    for name in CASES:
+        t0 = time.time()
+        try:
+            err, yard, tol = run_case(name)
+            ok = err <= tol and math.isfinite(err)
+            print(f"{'PASS' if ok else 'FAIL'} {name:24s} rel_l2={err:.3e} tol={tol:.1e} oracle_bf16_vs_fp32={yard:.3e} "
+                  f"({time.time() - t0:.1f}s)", flush=True)
+            bad += 0 if ok else 1
+        except Exception as e:
+            bad += 1
+            print(f"ERROR {name}: {type(e).__name__}: {e}", flush=True)
+            traceback.print_exc()
+    print(f"modelcheck: {len(CASES) - bad}/{len(CASES)} passed", flush=True)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

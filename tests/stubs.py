@@ -1,0 +1,32 @@
+"""Test doubles (not the oracle): a deterministic stand-in for the pipeline protocol so that sampler /
+runner logic can be exercised on CPU and across processes."""
+import torch
+
+from diffuman4d_amd.host.schedule import plan_sweep
+
+
+class StubPipeline:
+    """Implements the pipeline protocol.  'Denoising' adds 1.0 to a target latent per
+    step, so the final value of a cell counts how many steps it received; cond rows carry -1."""
+
+    def __init__(self, h=2, w=2):
+        self.device = torch.device("cpu")
+        self.h, self.w = h, w
+        self.calls = []
+
+    def sliding_iterative_denoise(self, pixel_values, plucker_embeds, skeletons, cond_masks, latents, domain,
+                                  timestep_indices, window_size, sliding_stride, sliding_shift, bidirectional,
+                                  num_denoising_steps, alternation_rounds, guidance_scale, tqdm=None):
+        n = pixel_values.shape[0]
+        cond = (cond_masks[:, 0, 0, 0] == 0).tolist()
+        plan = plan_sweep(cond, timestep_indices.tolist(), domain, window_size, sliding_stride, sliding_shift,
+                          bidirectional, num_denoising_steps, alternation_rounds)
+        self.calls.append({"latents_was_none": latents is None, "domain": domain, "n": n,
+                           "cond_rows": [i for i, c in enumerate(cond) if c]})
+        lat = torch.zeros(n, 4, self.h, self.w) if latents is None else latents.clone().float()
+        for w, c in zip(plan.windows, plan.is_cond):
+            lat[w[c]] = -1.0
+            lat[w[~c]] += 1.0
+        tidx = torch.from_numpy(plan.final_timestep_indices)
+        return {"images": torch.zeros(n, 3, 8 * self.h, 8 * self.w), "latents": lat, "timestep_indices": tidx,
+                "fully_denoised": tidx == plan.num_inference_steps}
