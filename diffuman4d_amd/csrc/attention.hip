@@ -4,17 +4,22 @@
 // MultiviewTransformerBlock (reference attention.py:68-83): the fold "(b t) hw c -> b (t hw) c" is
 // free because activations are token-major, so the kernel just sees batch = B/F, L = F*HW.
 //
-// Work decomposition: grid = (q tiles, heads, batch); a workgroup = 4 waves, each wave owns QB
-// blocks of 32 query rows; K/V tiles of 64 keys are staged (register prefetch -> LDS, double
-// buffered, one barrier per tile):
+// Work decomposition: a workgroup = 8 waves (2 per SIMD, so one wave's softmax VALU work overlaps the
+// other's MFMAs); each wave owns QB blocks of 32 query rows; K/V tiles of 64 keys are staged
+// register-prefetch -> LDS, double buffered, one barrier per tile:
 //   Ks[key][d]   row-major, 144-byte rows          -> conflict-free ds_read_b128 A-fragments
 //   Vt[d][key']  TRANSPOSED, 144-byte rows, key' = key with bits 2 and 3 swapped, so that the
 //                8 keys a lane needs for one PV MFMA are one contiguous 16-byte read.
-// Math (v_mfma_f32_32x32x16_bf16):
-//   S^T = K Q^T   ("swapped" QK^T): lane (q = lane&31) holds 32 of the 64 scores of its query row,
-//                  so the row max / sum need a single cross-half exchange;
-//   O^T = V^T P^T: the P^T B-operand is exactly the packed bf16 of the S^T accumulator registers
-//                  (the k-index permutation is shared with the Vt read, so no lane shuffles).
+// Math (v_mfma_f32_32x32x16_bf16), per 32-key block:
+//   S^T = K Q^T   ("swapped" QK^T): lane (q = lane&31) holds 16 of the 32 scores of its query row,
+//                  so the row max needs a single cross-half exchange and the row sum none at all;
+//   O^T = V^T P^T: the P^T B-operand is exactly the packed bf16 (v_cvt_pk_bf16_f32) of the S^T
+//                  accumulator registers -- the k-index permutation is shared with the Vt image, so
+//                  no lane shuffles are needed between the two MFMAs.
+// The O rescale is lazy: O and l are only rescaled when some row's running max grows by more than
+// 2^8 (exact arithmetic, P stays <= 256 in bf16); on typical data that is the first tiles only.
+// The 1-D grid is remapped so that all query tiles of one (batch, head) run on one XCD and share
+// its L2 copy of K/V.
 #include "common.h"
 #include "dm4d.h"
 #include "errors.h"
@@ -26,24 +31,37 @@ struct AttnParams {
   const u16 *Q, *K, *V;
   u16* O;
   int64_t ldq, ldk, ldv, ldo;
-  int L;
+  int L, heads, nqt;
   float c;  // scale * log2(e)
 };
 
-constexpr int KV = 64;    // keys per tile
+constexpr int KV = 64;      // keys per staged tile
 constexpr int LDS_LD = 72;  // bf16 per LDS row (64 + 8 pad) = 144 B
+constexpr int NW = 8;       // waves per workgroup
+constexpr float RESCALE_THR = 8.0f;  // in log2 units
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+  f32x2_t v = {lo, hi};
+  bf16x2_t b = __builtin_convertvector(v, bf16x2_t);  // v_cvt_pk_bf16_f32
+  return *reinterpret_cast<uint32_t*>(&b);
+}
 
 template <int QB>
-__global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
+__global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) u16 smem[2 * 2 * KV * LDS_LD];
   u16* Ks = smem;                    // [2][64 keys][72]
   u16* Vt = smem + 2 * KV * LDS_LD;  // [2][64 d][72]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int head = blockIdx.y, batch = blockIdx.z;
   const int L = p.L;
-  const int q_tile0 = blockIdx.x * (4 * 32 * QB) + wave * (32 * QB);
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int qt = lid % p.nqt, bh = lid / p.nqt;
+  const int head = bh % p.heads, batch = bh / p.heads;
+  const int q_tile0 = qt * (NW * 32 * QB) + wave * (32 * QB);
 
   const u16* Qb = p.Q + (int64_t)batch * L * p.ldq + head * 64;
   const u16* Kb = p.K + (int64_t)batch * L * p.ldk + head * 64;
@@ -76,42 +94,33 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
       for (int r = 0; r < 16; ++r) o[qb][db][r] = 0.f;
   }
 
-  // staging registers: K two 16-B chunks per thread, V one key pair x one 8-wide d chunk
-  U4 rk[2], rv[2];
-  const int k_key = tid >> 3, k_c = tid & 7;  // + 32 for the second chunk
-  const int v_kp = tid & 31, v_c = tid >> 5;
+  // staging: every thread moves one 16-byte chunk of K and one of V per tile
+  U4 rk, rv;
+  const int s_key = tid >> 3, s_c = tid & 7;  // key 0..63, d-chunk 0..7
   auto load_tile = [&](int t) {
-    const int key0 = t * KV;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int key = key0 + k_key + 32 * i;
-      if (key > L - 1) key = L - 1;
-      rk[i] = ldg16(Kb + (int64_t)key * p.ldk + k_c * 8);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int key = key0 + 2 * v_kp + i;
-      if (key > L - 1) key = L - 1;
-      rv[i] = ldg16(Vb + (int64_t)key * p.ldv + v_c * 8);
-    }
+    int key = t * KV + s_key;
+    if (key > L - 1) key = L - 1;
+    rk = ldg16(Kb + (int64_t)key * p.ldk + s_c * 8);
+    rv = ldg16(Vb + (int64_t)key * p.ldv + s_c * 8);
   };
   auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      *reinterpret_cast<U4*>(Ks + (buf * KV + k_key + 32 * i) * LDS_LD + k_c * 8) = rk[i];
-    // transpose: dword {V[2kp][d], V[2kp+1][d]} -> Vt[d][perm(2kp)], perm swaps key bits 2 and 3
-    const int k2 = 2 * v_kp;
+    *reinterpret_cast<U4*>(Ks + (buf * KV + s_key) * LDS_LD + s_c * 8) = rk;
+    // V transpose.  Lane pairs (key even / key odd = lane ^ 8) exchange half of their chunk so that
+    // each writes 4 dwords {V[k][d], V[k+1][d]} into Vt[d][perm(k)]; perm swaps key bits 2 and 3.
+    const bool odd = (s_key & 1) != 0;
+    const uint32_t x0 = odd ? rv.x : rv.z, x1 = odd ? rv.y : rv.w;
+    const uint32_t r0 = __shfl_xor(x0, 8), r1 = __shfl_xor(x1, 8);
+    // even key k: owns d = 8c+0..3 -> a = (rv.x, rv.y) of key k, b = (r0, r1) of key k+1
+    // odd key k+1: owns d = 8c+4..7 -> a = (r0, r1) of key k, b = (rv.z, rv.w) of key k+1
+    const uint32_t a0 = odd ? r0 : rv.x, a1 = odd ? r1 : rv.y;
+    const uint32_t b0 = odd ? rv.z : r0, b1 = odd ? rv.w : r1;
+    const int k2 = s_key & ~1;
     const int kperm = (k2 & ~12) | ((k2 & 4) << 1) | ((k2 & 8) >> 1);
-    const uint32_t* a = reinterpret_cast<const uint32_t*>(&rv[0]);
-    const uint32_t* b = reinterpret_cast<const uint32_t*>(&rv[1]);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(Vt + (buf * 64 + v_c * 8) * LDS_LD + kperm);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      uint32_t lo = (a[e] & 0xffffu) | (b[e] << 16);          // d = 8c + 2e
-      uint32_t hi = (a[e] >> 16) | (b[e] & 0xffff0000u);      // d = 8c + 2e + 1
-      dst[(2 * e) * (LDS_LD / 2)] = lo;
-      dst[(2 * e + 1) * (LDS_LD / 2)] = hi;
-    }
+    uint32_t* dst = reinterpret_cast<uint32_t*>(Vt + (buf * 64 + s_c * 8 + (odd ? 4 : 0)) * LDS_LD + kperm);
+    dst[0 * (LDS_LD / 2)] = (a0 & 0xffffu) | (b0 << 16);
+    dst[1 * (LDS_LD / 2)] = (a0 >> 16) | (b0 & 0xffff0000u);
+    dst[2 * (LDS_LD / 2)] = (a1 & 0xffffu) | (b1 << 16);
+    dst[3 * (LDS_LD / 2)] = (a1 >> 16) | (b1 & 0xffff0000u);
   };
 
   const int nt = (L + KV - 1) / KV;
@@ -122,90 +131,79 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     if (t + 1 < nt) load_tile(t + 1);
+    const bool tail = (t == nt - 1) && (L % KV) != 0;
 
-    // ---- S^T = K Q^T -------------------------------------------------------------------
-    f32x16_t s[QB][2];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[qb][kb][r] = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
+      // ---- S^T = K Q^T for 32 keys ---------------------------------------------------------
+      f32x16_t s[QB];
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[qb][r] = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (buf * KV + kb * 32 + l31) * LDS_LD + j * 16 + lh * 8);
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) s[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][j], s[qb][kb], 0, 0, 0);
+        for (int qb = 0; qb < QB; ++qb) s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][j], s[qb], 0, 0, 0);
       }
-    }
-    // mask the key tail (only the last tile can be partial)
-    if (t == nt - 1 && (L % KV) != 0) {
-      const int key0 = t * KV;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+      if (tail) {
+        const int key0 = t * KV + kb * 32 + 4 * lh;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (key >= L) {
+          if (key0 + (r & 3) + 8 * (r >> 2) >= L) {
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb) s[qb][kb][r] = -1e30f;
+            for (int qb = 0; qb < QB; ++qb) s[qb][r] = -1e30f;
           }
         }
-    }
-
-    // ---- online softmax, P^T fragments ---------------------------------------------------
-    bf16x8_t pf[QB][2][2];
+      }
+      // ---- online softmax (lazy rescale), P^T fragments ---------------------------------------
+      bf16x8_t pf[QB][2];
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-      float mx = s[qb][0][0];
+      for (int qb = 0; qb < QB; ++qb) {
+        float mx = fmaxf(s[qb][0], s[qb][1]);
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+        for (int r = 2; r < 16; ++r) mx = fmaxf(mx, s[qb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (__any((mx - m_run[qb]) * p.c > RESCALE_THR)) {
+          const float m_new = fmaxf(m_run[qb], mx);
+          const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * p.c);
+          m_run[qb] = m_new;
+          l_run[qb] *= alpha;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qb][kb][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float m_new = fmaxf(m_run[qb], mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * p.c);
-      m_run[qb] = m_new;
-      const float mc = m_new * p.c;
-      float sum = 0.f;
+          for (int db = 0; db < 2; ++db)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+            for (int r = 0; r < 16; ++r) o[qb][db][r] *= alpha;
+        }
+        const float mc = m_run[qb] * p.c;
         float pv[16];
+        float sum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          pv[r] = __builtin_amdgcn_exp2f(s[qb][kb][r] * p.c - mc);
+          pv[r] = __builtin_amdgcn_exp2f(s[qb][r] * p.c - mc);
           sum += pv[r];
         }
+        l_run[qb] += sum;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
           U4 w;
-          w.x = pack_bf2(pv[jj * 8 + 0], pv[jj * 8 + 1]);
-          w.y = pack_bf2(pv[jj * 8 + 2], pv[jj * 8 + 3]);
-          w.z = pack_bf2(pv[jj * 8 + 4], pv[jj * 8 + 5]);
-          w.w = pack_bf2(pv[jj * 8 + 6], pv[jj * 8 + 7]);
-          pf[qb][kb][jj] = *reinterpret_cast<bf16x8_t*>(&w);
+          w.x = cvt_pk_bf16(pv[jj * 8 + 0], pv[jj * 8 + 1]);
+          w.y = cvt_pk_bf16(pv[jj * 8 + 2], pv[jj * 8 + 3]);
+          w.z = cvt_pk_bf16(pv[jj * 8 + 4], pv[jj * 8 + 5]);
+          w.w = cvt_pk_bf16(pv[jj * 8 + 6], pv[jj * 8 + 7]);
+          pf[qb][jj] = *reinterpret_cast<bf16x8_t*>(&w);
         }
       }
-      l_run[qb] = l_run[qb] * alpha + sum;
+      // ---- O^T += V^T P^T ------------------------------------------------------------------------
 #pragma unroll
       for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[qb][db][r] *= alpha;
-    }
-
-    // ---- O^T += V^T P^T ------------------------------------------------------------------
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
           bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(Vt + (buf * 64 + db * 32 + l31) * LDS_LD + kb * 32 + jj * 16 + lh * 8);
 #pragma unroll
-          for (int qb = 0; qb < QB; ++qb) o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][kb][jj], o[qb][db], 0, 0, 0);
+          for (int qb = 0; qb < QB; ++qb) o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][jj], o[qb][db], 0, 0, 0);
         }
+    }
 
     if (t + 1 < nt) store_tile(buf ^ 1);
     __syncthreads();
@@ -215,7 +213,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const int q = q_tile0 + qb * 32 + l31;
-    float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32);
+    const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32);
     const float inv = 1.0f / l_tot;
     if (q < L) {
       u16* op = Ob + (int64_t)q * p.ldo;
@@ -224,8 +222,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           uint2 w;
-          w.x = pack_bf2(o[qb][db][4 * g + 0] * inv, o[qb][db][4 * g + 1] * inv);
-          w.y = pack_bf2(o[qb][db][4 * g + 2] * inv, o[qb][db][4 * g + 3] * inv);
+          w.x = cvt_pk_bf16(o[qb][db][4 * g + 0] * inv, o[qb][db][4 * g + 1] * inv);
+          w.y = cvt_pk_bf16(o[qb][db][4 * g + 2] * inv, o[qb][db][4 * g + 3] * inv);
           *reinterpret_cast<uint2*>(op + db * 32 + 8 * g + 4 * lh) = w;
         }
     }
@@ -240,18 +238,21 @@ extern "C" int dm4d_attention_bf16(void* stream, const void* Q, const void* K, c
     return dm4d_set_error(DM4D_ERR_ARG, "attention: null pointer or empty shape");
   if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3))
     return dm4d_set_error(DM4D_ERR_ARG, "attention: row strides must be multiples of 8 elements");
-  if (heads > 65535 || batch > 65535) return dm4d_set_error(DM4D_ERR_ARG, "attention: grid too large");
-  AttnParams p{(const u16*)Q, (const u16*)K, (const u16*)V, (u16*)O, ldq, ldk, ldv, ldo, L,
+  AttnParams p{(const u16*)Q, (const u16*)K, (const u16*)V, (u16*)O, ldq, ldk, ldv, ldo, L, heads, 0,
                scale * 1.4426950408889634f};
   hipStream_t st = (hipStream_t)stream;
-  // 64 query rows per wave when there is enough work to fill the chip, else 32
-  const long wgs2 = (long)((L + 255) / 256) * heads * batch;
   static const int force_qb = [] { const char* e = getenv("DM4D_ATTN_QB"); return e ? atoi(e) : 0; }();  // tuning aid
-  const bool use2 = force_qb ? (force_qb == 2) : (wgs2 >= 512);
+  // 32 query rows per wave (120 VGPRs, 4 waves/SIMD) measured faster than 64 (204 VGPRs, 2 waves/SIMD) on
+  // every UNet shape (profiles/r01_attn_v2.log); the 64-row variant is kept for tuning (DM4D_ATTN_QB=2)
+  const bool use2 = force_qb == 2;
+  const int rows = NW * 32 * (use2 ? 2 : 1);
+  p.nqt = (L + rows - 1) / rows;
+  const long nwg = (long)p.nqt * heads * batch;
+  if (nwg > 0x7fffffffL) return dm4d_set_error(DM4D_ERR_ARG, "attention: grid too large");
   if (use2) {
-    hipLaunchKernelGGL((attn_kernel<2>), dim3((L + 255) / 256, heads, batch), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((attn_kernel<2>), dim3((unsigned)nwg), dim3(NW * 64), 0, st, p);
   } else {
-    hipLaunchKernelGGL((attn_kernel<1>), dim3((L + 127) / 128, heads, batch), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((attn_kernel<1>), dim3((unsigned)nwg), dim3(NW * 64), 0, st, p);
   }
   return dm4d_check_launch("attn_kernel");
 }

@@ -14,17 +14,17 @@ struct __attribute__((aligned(16))) U4 {
 
 __device__ __forceinline__ float bf2f(u16 v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
-__device__ __forceinline__ u16 f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (u16)(u >> 16);
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+// fp32 -> bf16, round-to-nearest-even, in hardware (v_cvt_pk_bf16_f32 on gfx950): branch free
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  f32x2_t v = {lo, hi};
+  bf16x2_t b = __builtin_convertvector(v, bf16x2_t);
+  return *reinterpret_cast<uint32_t*>(&b);
 }
 
-__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
-}
+__device__ __forceinline__ u16 f2bf(float f) { return (u16)(pack_bf2(f, 0.f) & 0xffffu); }
 
 __device__ __forceinline__ void unpack8(const U4& v, float* f) {
   f[0] = __uint_as_float(v.x << 16);

@@ -2,19 +2,30 @@
 //
 //   out[M,N] = epilogue( A[M,K] @ W[N,K]^T )          fp32 accumulate, bf16 in/out
 //
-// One kernel template serves the Linear layers (dense A, optionally split over two sources = the
+// One kernel family serves the Linear layers (dense A, optionally split over two sources = the
 // up-block skip concat) and every 3x3 convolution of the UNet/VAE (A gathered on the fly from an
 // NHWC tensor: K = 9*Cin ordered (ky, kx, ci), zero padding, stride 1/2, fused nearest-x2 upsample).
 //
 // Tiling (wave64, v_mfma_f32_32x32x16_bf16): a workgroup of 4 waves owns a BM x BN output tile, each
-// wave a (BM/WM) x (BN/WN) sub-tile of 32x32 MFMA fragments.  A/B k-slabs of 32 are staged through
-// registers into a padded, double-buffered LDS image (row stride 80 B => conflict-free
-// ds_read_b128 fragment reads); global loads for slab k+1 are in flight while slab k is multiplied,
-// one barrier per slab.  The epilogue goes back through LDS (fp32) so that bias / GEGLU / rowbias
-// (time-embedding add) / residual are fused and every global store is a coalesced 16-byte row write.
+// wave a (BM/WM) x (BN/WN) sub-tile of 32x32 MFMA fragments.
+//
+//  * gemm_kernel_glds (main path, K-slab 64): A/B slabs go HBM -> LDS directly with
+//    global_load_lds_dwordx4 (no VGPR round trip, no ds_write pass -- the register-staged version was
+//    LDS-write-bound), double buffered, the DMA of slab k+1 in flight under the MFMAs of slab k, one
+//    barrier per slab.  The LDS image is lane-linear per DMA instruction (8 rows x 128 B), so the
+//    bank-conflict swizzle lives in the SOURCE address: LDS position (row, pos) holds the 16-byte
+//    chunk pos ^ ((row >> 1) & 7) of that row, and fragment reads apply the same XOR -- conflict-free
+//    ds_read_b128 for every 16-lane group.  Convolution padding / stride / upsample only change the
+//    per-lane source address (out-of-image taps read a 16-byte zero page).
+//  * gemm_kernel (fallback, K-slab 32, register staged, padded LDS rows): shapes whose K (or conv
+//    Cin) is a multiple of 32 but not of 64.
+//
+// The epilogue goes back through LDS in fp32 so that bias / GEGLU / SiLU / rowbias (time-embedding
+// add) / residual / scale are fused and every global store is a coalesced 16-byte row write.
 #include "common.h"
 #include "dm4d.h"
 #include "errors.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -42,14 +53,253 @@ struct GemmParams {
   int tiles_n;
 };
 
+__device__ __attribute__((aligned(16))) const uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
+
+// Weight row (B-tile row r) -> global row of W.  GEGLU tiles pair hidden rows with their gate rows
+// inside each wave's column range so the product is formed in registers.
+template <int TN>
+__device__ __forceinline__ int weight_row(const GemmParams& p, int n0, int r, bool geglu) {
+  int n;
+  if (geglu) {
+    int wr = r / TN, rr = r % TN;
+    n = n0 + wr * (TN / 2) + (rr % (TN / 2));
+    if (n > p.N - 1) n = p.N - 1;
+    if (rr >= TN / 2) n += p.N;
+  } else {
+    n = n0 + r;
+    if (n > p.N - 1) n = p.N - 1;
+  }
+  return n;
+}
+
+// D fragment layout (32x32): lane holds column (lane & 31), rows (r&3) + 8*(r>>2) + 4*(lane>>5).
+template <int MI, int NI, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[MI][NI], float* smem_f, int m0, int n0,
+                                              int wm, int wn, int wave, int lane) {
+  const int l31 = lane & 31, lh = lane >> 5;
+  const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
+  const int NJ = geglu ? NI / 2 : NI;
+  const int TNO = NJ * 32;  // output columns per wave
+  const int SLD = TNO + 4;  // fp32 staging row stride
+  float* stage = smem_f + wave * 32 * (TN + 4);
+  const bool do_silu = (p.flags & DM4D_EPI_SILU) != 0;
+  const int ncol0 = n0 + wn * TNO;
+
+  float bias_h[NI], bias_g[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    bias_h[j] = 0.f;
+    bias_g[j] = 0.f;
+    int n = ncol0 + j * 32 + l31;
+    if (p.bias && j < NJ && n < p.N) {
+      bias_h[j] = bf2f(p.bias[n]);
+      if (geglu) bias_g[j] = bf2f(p.bias[p.N + n]);
+    }
+  }
+  const int chunks_per_row = TNO / 8;
+  const int tasks = 32 * chunks_per_row;
+  const bool vec_ok = ((p.ldc & 7) == 0) && ((p.N & 7) == 0) && (!p.res || (p.ld_res & 7) == 0) &&
+                      (!p.rowbias || (p.ld_rb & 7) == 0);
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      if (j < NJ) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          float v = acc[i][j][r] + bias_h[j];
+          if (geglu) {
+            float g = acc[i][(j + NI / 2) % NI][r] + bias_g[j];
+            v = v * gelu_erf_f(g);
+          }
+          if (do_silu) v = silu_f(v);
+          stage[row * SLD + j * 32 + l31] = v;
+        }
+      }
+    }
+    __syncthreads();
+    for (int id = lane; id < tasks; id += 64) {
+      int row = id / chunks_per_row, cc = id % chunks_per_row;
+      int m = m0 + wm * TM + i * 32 + row;
+      int n = ncol0 + cc * 8;
+      if (m >= p.M || n >= p.N) continue;
+      float v[8];
+      const float* s = stage + row * SLD + cc * 8;
+      f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(s);
+      f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(s + 4);
+      v[0] = s0[0]; v[1] = s0[1]; v[2] = s0[2]; v[3] = s0[3];
+      v[4] = s1[0]; v[5] = s1[1]; v[6] = s1[2]; v[7] = s1[3];
+      if (vec_ok) {
+        if (p.rowbias) {
+          float t[8];
+          unpack8(ldg16(p.rowbias + (int64_t)(m / p.rows_per_rb) * p.ld_rb + n), t);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += t[e];
+        }
+        if (p.res) {
+          float t[8];
+          unpack8(ldg16(p.res + (int64_t)m * p.ld_res + n), t);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += t[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+        stg16(p.C + (int64_t)m * p.ldc + n, pack8(v));
+      } else {
+        for (int e = 0; e < 8 && n + e < p.N; ++e) {
+          float x = v[e];
+          if (p.rowbias) x += bf2f(p.rowbias[(int64_t)(m / p.rows_per_rb) * p.ld_rb + n + e]);
+          if (p.res) x += bf2f(p.res[(int64_t)m * p.ld_res + n + e]);
+          p.C[(int64_t)m * p.ldc + n + e] = f2bf(x * p.out_scale);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// main path: K-slab 64, direct-to-LDS DMA, source-swizzled lane-linear LDS image
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, bool CONV>
+__global__ __launch_bounds__(256) void gemm_kernel_glds(GemmParams p) {
+  constexpr int BK = 64;
+  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
+  constexpr int AW = BM / 32, BW = BN / 32;  // 1-KiB DMA instructions per wave per slab (8 rows each)
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int SMEM_MAIN = 2 * (BM + BN) * BK * 2;
+  constexpr int SMEM_EPI = 4 * 32 * (TN + 4) * 4;
+  constexpr int SMEM_BYTES = SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI;
+  __shared__ __attribute__((aligned(16))) u16 smem[SMEM_BYTES / 2];
+  u16* As = smem;                // [2][BM][64]
+  u16* Bs = smem + 2 * BM * BK;  // [2][BN][64]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
+  const int m0 = tm * BM;
+  const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
+  const int n0 = tn * (geglu ? BN / 2 : BN);
+
+  // DMA lane mapping: instruction `ia` covers tile rows [8*ia, 8*ia+8); lane -> (row, LDS position)
+  const int d_row = lane >> 3, d_pos = lane & 7;
+  const u16* a_src[AW];
+  const u16* a2_src[AW];
+  int iy0[AW], ix0[AW];
+#pragma unroll
+  for (int i = 0; i < AW; ++i) {
+    const int row = (wave + 4 * i) * 8 + d_row;
+    const int chunk = d_pos ^ ((row >> 1) & 7);
+    int m = m0 + row;
+    if (m > p.M - 1) m = p.M - 1;
+    if constexpr (CONV) {
+      int ox = m % p.Wo;
+      int t = m / p.Wo;
+      int oy = t % p.Ho;
+      int b = t / p.Ho;
+      iy0[i] = oy * p.stride - p.pad;
+      ix0[i] = ox * p.stride - p.pad;
+      a_src[i] = p.A + (int64_t)b * p.H * p.W * p.Cin + chunk * 8;
+      a2_src[i] = nullptr;
+    } else {
+      a_src[i] = p.A + (int64_t)m * p.lda + chunk * 8;
+      a2_src[i] = p.A2 ? p.A2 + (int64_t)m * p.lda2 + chunk * 8 : nullptr;
+      iy0[i] = ix0[i] = 0;
+    }
+  }
+  const u16* w_src[BW];
+#pragma unroll
+  for (int i = 0; i < BW; ++i) {
+    const int row = (wave + 4 * i) * 8 + d_row;
+    const int chunk = d_pos ^ ((row >> 1) & 7);
+    w_src[i] = p.Wt + (int64_t)weight_row<TN>(p, n0, row, geglu) * p.ldw + chunk * 8;
+  }
+
+  f32x16_t acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / BK;
+  const int Hin = p.upsample ? 2 * p.H : p.H, Win = p.upsample ? 2 * p.W : p.W;
+  int ky = 0, kx = 0, ci0 = 0;  // conv tap of the NEXT slab to be issued
+
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto issue_slab = [&](int kt, int buf) {
+#pragma unroll
+    for (int i = 0; i < AW; ++i) {
+      const u16* src;
+      if constexpr (CONV) {
+        int iy = iy0[i] + ky, ix = ix0[i] + kx;
+        bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+        int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
+        src = ok ? a_src[i] + ((int64_t)sy * p.W + sx) * p.Cin + ci0 : reinterpret_cast<const u16*>(g_zero16);
+      } else {
+        const int kcol = kt * BK;
+        src = (p.A2 != nullptr && kcol >= p.K1) ? a2_src[i] + (kcol - p.K1) : a_src[i] + kcol;
+      }
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (buf * BM + (wave + 4 * i) * 8) * BK), 16, 0, 0);
+    }
+    if constexpr (CONV) {
+      ci0 += BK;
+      if (ci0 >= p.Cin) {
+        ci0 = 0;
+        if (++kx == 3) {
+          kx = 0;
+          ++ky;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BW; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + kt * BK), (lptr_t)(Bs + (buf * BN + (wave + 4 * i) * 8) * BK), 16, 0, 0);
+  };
+
+  const int sw = (l31 >> 1) & 7;  // fragment rows are (32-aligned base + l31): same swizzle key for all fragments
+  issue_slab(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) issue_slab(kt + 1, buf ^ 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int pos = ((ks * 2 + lh) ^ sw) * 8;
+      bf16x8_t af[MI], bfr[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        af[i] = *reinterpret_cast<const bf16x8_t*>(As + (buf * BM + wm * TM + i * 32 + l31) * BK + pos);
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8_t*>(Bs + (buf * BN + wn * TN + j * 32 + l31) * BK + pos);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();  // all waves done with `buf`; the DMA into buf^1 has landed (vmcnt(0) before the barrier)
+  }
+  gemm_epilogue<MI, NI, TM, TN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fallback: K-slab 32, register staged, padded LDS rows (80 B stride => conflict-free fragment reads)
+// ------------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, bool CONV>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
-  constexpr int LDK = 40;  // bf16 elements per LDS row (32 + 8 pad)
+  constexpr int LDK = 40;
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
   constexpr int AI = BM / 64, BI = BN / 64;
   static_assert(WM * WN == 4, "4 waves");
-  constexpr int SMEM_MAIN = 2 * (BM + BN) * LDK * 2;   // bytes, double-buffered A/B slabs
-  constexpr int SMEM_EPI = 4 * 32 * (TN + 4) * 4;      // bytes, per-wave fp32 staging
+  constexpr int SMEM_MAIN = 2 * (BM + BN) * LDK * 2;
+  constexpr int SMEM_EPI = 4 * 32 * (TN + 4) * 4;
   constexpr int SMEM_BYTES = SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI;
   __shared__ __attribute__((aligned(16))) u16 smem[SMEM_BYTES / 2];
   u16* As = smem;
@@ -58,18 +308,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lh = lane >> 5;
-
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
   const int m0 = tm * BM;
   const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
-  const int n0 = tn * (geglu ? BN / 2 : BN);  // first output column of this tile
-
+  const int n0 = tn * (geglu ? BN / 2 : BN);
   const int a_c = tid & 3, a_r = tid >> 2;
 
-  // ---- per-thread source rows -------------------------------------------------------------
-  const u16* a_base[AI];   // dense: row pointer into A ; conv: image base pointer
-  const u16* a2_base[AI];  // dense: row pointer into A2
+  const u16* a_base[AI];
+  const u16* a2_base[AI];
   int iy0[AI], ix0[AI];
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
@@ -92,20 +339,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   }
   const u16* w_base[BI];
 #pragma unroll
-  for (int i = 0; i < BI; ++i) {
-    int r = a_r + 64 * i;  // row inside the B tile
-    int n;
-    if (geglu) {
-      int wr = r / TN, rr = r % TN;
-      n = n0 + wr * (TN / 2) + (rr % (TN / 2));
-      if (n > p.N - 1) n = p.N - 1;
-      if (rr >= TN / 2) n += p.N;  // gate rows live in the second half of W
-    } else {
-      n = n0 + r;
-      if (n > p.N - 1) n = p.N - 1;
-    }
-    w_base[i] = p.Wt + (int64_t)n * p.ldw;
-  }
+  for (int i = 0; i < BI; ++i) w_base[i] = p.Wt + (int64_t)weight_row<TN>(p, n0, a_r + 64 * i, geglu) * p.ldw;
 
   f32x16_t acc[MI][NI];
 #pragma unroll
@@ -117,7 +351,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 
   const int nk = p.K / 32;
   const int Hin = p.upsample ? 2 * p.H : p.H, Win = p.upsample ? 2 * p.W : p.W;
-  int ky = 0, kx = 0, ci0 = 0;  // conv tap state for the NEXT slab to be loaded
+  int ky = 0, kx = 0, ci0 = 0;
 
   U4 ra[AI], rb[BI];
   auto load_slab = [&](int kt) {
@@ -178,113 +412,52 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     if (kt + 1 < nk) store_slab(buf ^ 1);
     __syncthreads();
   }
-
-  // ---- epilogue ---------------------------------------------------------------------------
-  // D fragment layout (32x32): lane holds column (lane & 31), rows (r&3) + 8*(r>>2) + 4*(lane>>5).
-  const int NJ = geglu ? NI / 2 : NI;
-  const int TNO = NJ * 32;            // output columns per wave
-  const int SLD = TNO + 4;            // fp32 staging row stride
-  float* stage = reinterpret_cast<float*>(smem) + wave * 32 * (TN + 4);
-  const bool do_silu = (p.flags & DM4D_EPI_SILU) != 0;
-  const int ncol0 = n0 + wn * TNO;  // first output column of this wave
-
-  float bias_h[NI], bias_g[NI];
-#pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    bias_h[j] = 0.f;
-    bias_g[j] = 0.f;
-    int n = ncol0 + j * 32 + l31;
-    if (p.bias && j < NJ && n < p.N) {
-      bias_h[j] = bf2f(p.bias[n]);
-      if (geglu) bias_g[j] = bf2f(p.bias[p.N + n]);
-    }
-  }
-  const int chunks_per_row = TNO / 8;
-  const int tasks = 32 * chunks_per_row;
-  const bool vec_ok = ((p.ldc & 7) == 0) && ((p.N & 7) == 0) && (!p.res || (p.ld_res & 7) == 0) &&
-                      (!p.rowbias || (p.ld_rb & 7) == 0);
-
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      if (j < NJ) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          float v = acc[i][j][r] + bias_h[j];
-          if (geglu) {
-            float g = acc[i][(j + NI / 2) % NI][r] + bias_g[j];
-            v = v * gelu_erf_f(g);
-          }
-          if (do_silu) v = silu_f(v);
-          stage[row * SLD + j * 32 + l31] = v;
-        }
-      }
-    }
-    __syncthreads();
-    for (int id = lane; id < tasks; id += 64) {
-      int row = id / chunks_per_row, cc = id % chunks_per_row;
-      int m = m0 + wm * TM + i * 32 + row;
-      int n = ncol0 + cc * 8;
-      if (m >= p.M || n >= p.N) continue;
-      float v[8];
-      const float* s = stage + row * SLD + cc * 8;
-      f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(s);
-      f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(s + 4);
-      v[0] = s0[0]; v[1] = s0[1]; v[2] = s0[2]; v[3] = s0[3];
-      v[4] = s1[0]; v[5] = s1[1]; v[6] = s1[2]; v[7] = s1[3];
-      if (vec_ok) {
-        if (p.rowbias) {
-          float t[8];
-          unpack8(ldg16(p.rowbias + (int64_t)(m / p.rows_per_rb) * p.ld_rb + n), t);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += t[e];
-        }
-        if (p.res) {
-          float t[8];
-          unpack8(ldg16(p.res + (int64_t)m * p.ld_res + n), t);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += t[e];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
-        stg16(p.C + (int64_t)m * p.ldc + n, pack8(v));
-      } else {
-        for (int e = 0; e < 8 && n + e < p.N; ++e) {
-          float x = v[e];
-          if (p.rowbias) x += bf2f(p.rowbias[(int64_t)(m / p.rows_per_rb) * p.ld_rb + n + e]);
-          if (p.res) x += bf2f(p.res[(int64_t)m * p.ld_res + n + e]);
-          p.C[(int64_t)m * p.ldc + n + e] = f2bf(x * p.out_scale);
-        }
-      }
-    }
-  }
+  gemm_epilogue<MI, NI, TM, TN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
 }
 
-template <int BM, int BN, int WM, int WN, bool CONV>
+template <int BM, int BN, int WM, int WN, bool CONV, bool GLDS>
 int launch_cfg(hipStream_t st, GemmParams& p) {
   const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
   const int bn_out = geglu ? BN / 2 : BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + bn_out - 1) / bn_out;
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, CONV>), dim3(tiles_m * p.tiles_n), dim3(256), 0, st, p);
+  if constexpr (GLDS) {
+    hipLaunchKernelGGL((gemm_kernel_glds<BM, BN, WM, WN, CONV>), dim3(tiles_m * p.tiles_n), dim3(256), 0, st, p);
+  } else {
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, CONV>), dim3(tiles_m * p.tiles_n), dim3(256), 0, st, p);
+  }
   return dm4d_check_launch("gemm_kernel");
 }
 
 template <bool CONV>
 int launch(hipStream_t st, GemmParams& p) {
+  static const int force_v1 = [] { const char* e = getenv("DM4D_GEMM_V1"); return e ? atoi(e) : 0; }();  // A/B aid
   const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
-  const long tiles_big = (long)((p.M + 255) / 256) * ((p.N + (geglu ? 63 : 127)) / (geglu ? 64 : 128));
   const bool n128 = geglu || (p.N % 128 == 0) || (p.N > 1024);
+  const bool glds = !force_v1 && (CONV ? (p.Cin % 64 == 0) : (p.K % 64 == 0 && (!p.A2 || p.K1 % 64 == 0)));
+  if (glds) {
+    if (n128) {
+      // 128x128 (64 KiB LDS, 2 workgroups per CU) beats 256x128 (96 KiB, 1 per CU) on every UNet shape
+      static const int big = [] { const char* e = getenv("DM4D_GEMM_BM256"); return e ? atoi(e) : 0; }();
+      if (big) return launch_cfg<256, 128, 2, 2, CONV, true>(st, p);
+      // small-M problems (deepest UNet level): shrink the tile until the grid covers the 256 CUs
+      const long t128 = (long)((p.M + 127) / 128) * ((p.N + (geglu ? 63 : 127)) / (geglu ? 64 : 128));
+      if (t128 >= 256) return launch_cfg<128, 128, 2, 2, CONV, true>(st, p);
+      if (2 * t128 >= 200 || geglu) return launch_cfg<128, 64, 4, 1, CONV, true>(st, p);
+      return launch_cfg<64, 64, 2, 2, CONV, true>(st, p);
+    }
+    const long t256 = (long)((p.M + 255) / 256) * ((p.N + 63) / 64);
+    if (t256 >= 512) return launch_cfg<256, 64, 4, 1, CONV, true>(st, p);
+    return launch_cfg<128, 64, 4, 1, CONV, true>(st, p);
+  }
+  const long tiles_big = (long)((p.M + 255) / 256) * ((p.N + (geglu ? 63 : 127)) / (geglu ? 64 : 128));
   if (n128) {
-    if (tiles_big >= 384) return launch_cfg<256, 128, 2, 2, CONV>(st, p);
-    return launch_cfg<128, 128, 2, 2, CONV>(st, p);
+    if (tiles_big >= 384) return launch_cfg<256, 128, 2, 2, CONV, false>(st, p);
+    return launch_cfg<128, 128, 2, 2, CONV, false>(st, p);
   }
   const long tiles64 = (long)((p.M + 255) / 256) * ((p.N + 63) / 64);
-  if (tiles64 >= 384) return launch_cfg<256, 64, 4, 1, CONV>(st, p);
-  return launch_cfg<128, 64, 4, 1, CONV>(st, p);
+  if (tiles64 >= 384) return launch_cfg<256, 64, 4, 1, CONV, false>(st, p);
+  return launch_cfg<128, 64, 4, 1, CONV, false>(st, p);
 }
 
 }  // namespace

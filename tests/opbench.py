@@ -78,6 +78,18 @@ def bench_ln(M, C, tag=""):
 
 
 def main():
+    only = sys.argv[1] if len(sys.argv) > 1 else None
+    if only == "attn":
+        print("attn QB env:", os.environ.get("DM4D_ATTN_QB"), flush=True)
+        bench_attn(32, 5, 2880, " 2D L0")
+        bench_attn(48, 5, 2880, " 2D L0 F24")
+        bench_attn(2, 10, 11520, " 3D L1 F16")
+        bench_attn(2, 10, 17280, " 3D L1 F24")
+        bench_attn(2, 20, 2880, " 3D L2 F16")
+        bench_attn(2, 20, 4320, " 3D L2 F24")
+        bench_attn(2, 20, 720, " 3D mid")
+        bench_attn(2, 10, 65536, " 3D L1 128")
+        return
     print("device:", torch.cuda.get_device_name(0), "attn QB env:", os.environ.get("DM4D_ATTN_QB"), flush=True)
     B = 32  # F=16, CFG
     # GEMMs of one transformer block per level
