@@ -1,0 +1,156 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures in tests/golden/ by running the REFERENCE's own modules.
+
+Run in the build container (needs /root/reference):   python tests/golden/make_golden.py
+The fixtures are small (< 1 MB) and committed; the GPU box never needs /root/reference.
+
+What is executed from /root/reference (unmodified, imported through oracle/refshim.py):
+  * src/diffusers/models/unets/unet_multiview_condition.py  UNetMultiviewConditionModel (+ blocks,
+    transformer_multiview.py, attention.py) -- wiring, num_frames routing, 3-D attention folding
+  * src/diffusers/pipelines/diffuman4d/pipeline_diffuman4d.py  Diffuman4DPipeline
+    .sliding_iterative_denoise / .__call__ -- windows, CFG, aliasing, per-latent scheduler stepping
+  * src/samplers/sliding_iterative_sampler.py  SlidingIterativeSampler -- task lists, grid bookkeeping
+with seeded tiny weights shared with the oracle (``load_state_dict(strict=True)`` also pins the
+state_dict key names) and explicitly injected noise.
+"""
+from __future__ import annotations
+
+import sys
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+OUT = Path(__file__).resolve().parent
+
+from oracle import refshim  # noqa: E402
+
+refshim.install()
+
+import modelcheck as mc  # noqa: E402  (seeded tiny models + synthetic task tensors)
+from oracle.unet import UNetConfig  # noqa: E402
+
+from src.diffusers.models.unets.unet_multiview_condition import UNetMultiviewConditionModel as RefUNet  # noqa: E402
+from src.diffusers.pipelines.diffuman4d.pipeline_diffuman4d import Diffuman4DPipeline as RefPipeline  # noqa: E402
+
+
+def ref_unet_from(cfg: UNetConfig, oracle_model) -> RefUNet:
+    ref = RefUNet(in_channels=cfg.in_channels, out_channels=cfg.out_channels, block_out_channels=cfg.block_out_channels,
+                  layers_per_block=cfg.layers_per_block, attention_head_dim=cfg.attention_head_dim,
+                  norm_num_groups=cfg.norm_num_groups, norm_eps=cfg.norm_eps, cross_attention_dim=None,
+                  use_linear_projection=cfg.use_linear_projection, num_3d_attn_blocks=cfg.num_3d_attn_blocks,
+                  enable_tem_embeds=cfg.enable_tem_embeds, enable_pose_encoder=cfg.enable_pose_encoder).eval()
+    missing = ref.load_state_dict(oracle_model.state_dict(), strict=True)  # pins the key names
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return ref
+
+
+def golden_unet():
+    out = {}
+    for name, kw, nf, dom in (("spatial", dict(), 4, "spatial"),
+                              ("temporal_temb", dict(enable_tem_embeds=True), 4, "temporal"),
+                              ("conv_proj", dict(use_linear_projection=False), 2, "spatial"),
+                              ("2d_only", dict(num_3d_attn_blocks=0), 4, "spatial")):
+        cfg, om = mc.make_unet(3, **kw)
+        if kw.get("enable_tem_embeds"):
+            g = torch.Generator().manual_seed(8)
+            with torch.no_grad():
+                for p in om.temporal_pos_embed.parameters():
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+        ref = ref_unet_from(cfg, om)
+        g = torch.Generator().manual_seed(4)
+        x = torch.randn(2 * nf, cfg.in_channels, 16, 8, generator=g)
+        t = torch.randint(0, 1000, (2 * nf,), generator=g)
+        with torch.no_grad():
+            y = ref(x, timestep=t, skeletons=None, domains=[dom] * 2, num_frames=nf, return_dict=False)[0]
+            y_oracle = om(x, t, domains=[dom] * 2, num_frames=nf)
+        err = float((y - y_oracle).norm() / y.norm())
+        print(f"unet[{name}]: reference vs oracle rel_l2 = {err:.2e}")
+        out[name] = dict(cfg_kw=kw, seed=3, num_frames=nf, domain=dom, x=x, t=t, y=y)
+    torch.save(out, OUT / "unet_forward.pt")
+
+
+def golden_pipeline():
+    from oracle.ddim import DDIMConfig
+    out = {}
+    cases = {
+        "spatial": dict(domain="spatial", n=8, inputs=[1, 5], pred="epsilon",
+                        kw=dict(window_size=4, sliding_stride=2, sliding_shift=0, bidirectional=False,
+                                num_denoising_steps=1, alternation_rounds=1, guidance_scale=2.0)),
+        "temporal_v": dict(domain="temporal", n=8, inputs=[0, 1, 2, 3], pred="v_prediction",
+                           kw=dict(window_size=4, sliding_stride=1, sliding_shift=0, bidirectional=False,
+                                   num_denoising_steps=1, alternation_rounds=1, guidance_scale=2.0)),
+        "bidir_nocfg": dict(domain="spatial", n=8, inputs=[1, 5], pred="epsilon",
+                            kw=dict(window_size=3, sliding_stride=3, sliding_shift=0, bidirectional=True,
+                                    num_denoising_steps=2, alternation_rounds=1, guidance_scale=1.0)),
+        "round2_shift": dict(domain="spatial", n=8, inputs=[1, 5], pred="epsilon", start_idx=2,
+                             kw=dict(window_size=4, sliding_stride=2, sliding_shift=1, bidirectional=False,
+                                     num_denoising_steps=1, alternation_rounds=3, guidance_scale=2.0)),
+    }
+    for name, c in cases.items():
+        cfg_u, ou = mc.make_unet(11)
+        cfg_v, ov = mc.make_vae(12)
+        pipe = RefPipeline(vae=refshim.AutoencoderKL(ov), unet=ref_unet_from(cfg_u, ou),
+                           scheduler=refshim.DDIMSchedulerAdapter(DDIMConfig(prediction_type=c["pred"])))
+        n = c["n"]
+        pv, pl, sk, cm = mc.synthetic_task(n, 64, 64, c["inputs"], 11)
+        g = torch.Generator().manual_seed(13)
+        noise = {k: torch.randn(n, 4, 8, 8, generator=g) for k in ("pixel", "skeleton", "latents")}
+        tidx = torch.zeros(n, dtype=torch.int64)
+        latents_in = None
+        refshim.NOISE_QUEUE.clear()
+        refshim.NOISE_QUEUE.extend([noise["pixel"], noise["skeleton"]])
+        if c.get("start_idx"):  # a later alternation round: latents come from the grid, targets share an index
+            tidx[[i for i in range(n) if i not in c["inputs"]]] = c["start_idx"]
+            latents_in = torch.randn(n, 4, 8, 8, generator=g)
+        else:
+            refshim.NOISE_QUEUE.append(noise["latents"])
+        res = pipe.sliding_iterative_denoise(pixel_values=pv, plucker_embeds=pl, skeletons=sk, cond_masks=cm,
+                                             latents=latents_in, domain=c["domain"], timestep_indices=tidx.clone(),
+                                             tqdm=lambda it, total=None: it, **c["kw"])
+        assert not refshim.NOISE_QUEUE
+        out[name] = dict(case=c, seeds=dict(unet=11, vae=12, task=11, noise=13), noise=noise, latents_in=latents_in,
+                         timestep_indices_in=tidx, latents=res["latents"], images=res["images"].half(),
+                         timestep_indices=res["timestep_indices"], fully_denoised=res["fully_denoised"])
+        print(f"pipeline[{name}]: idx {res['timestep_indices'].tolist()} denoised {int(res['fully_denoised'].sum())}")
+    torch.save(out, OUT / "pipeline_sliding.pt")
+
+
+def golden_sampler():
+    """Task lists, labels and per-call bookkeeping of the reference sampler driving a recording stub."""
+    from src.samplers.sliding_iterative_sampler import SlidingIterativeSampler as RefSampler
+    import src.samplers.sliding_iterative_sampler as ref_mod
+    from diffuman4d_amd.host.dataset import SyntheticSpaTemDataset
+    from stubs import StubPipeline
+    ref_mod.save_sampling_results = lambda *a, **k: None
+    out = {}
+    for name, kw in (("tiny", dict(spa_label_range=[0, 20, 1], tem_label_range=[0, 12, 1], input_spa_labels=[1, 9],
+                                   window_size=6, sliding_stride=2, alternation_rounds=3, bidirectional=False)),
+                     ("demo_4d_tiny", dict(spa_label_range=[0, 48, 1], tem_label_range=[0, 16, 1],
+                                           input_spa_labels=[1, 13, 25, 37], window_size=12, sliding_stride=2,
+                                           alternation_rounds=3, bidirectional=False))):
+        ds = SyntheticSpaTemDataset(height=16, width=16, num_cameras=48)
+        pipe = StubPipeline()
+        s = RefSampler(ds, [pipe], "/tmp/unused", **kw)
+        rec = dict(kw=kw, all_tasks=s.all_tasks, spa_labels=s.spa_labels, tem_labels=s.tem_labels,
+                   target_spa_labels=s.target_spa_labels)
+        if name == "tiny":
+            for tasks in s.all_tasks:
+                for t in tasks:
+                    s.execute_one_task(t)
+            rec["calls"] = pipe.calls
+            rec["final_idx"] = {c: dict(v) for c, v in s.timestep_indices.items()}
+            rec["final_lat0"] = {c: {f: float(l.flatten()[0]) for f, l in v.items()} for c, v in s.latents.items()}
+        out[name] = rec
+        print(f"sampler[{name}]: rounds {[len(t) for t in s.all_tasks]}")
+    torch.save(out, OUT / "sampler_bookkeeping.pt")
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    golden_unet()
+    golden_pipeline()
+    golden_sampler()
+    print("golden fixtures written to", OUT)

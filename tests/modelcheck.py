@@ -186,6 +186,28 @@ def case_pipeline(domain="spatial", n_cams=8, T=4, window=4, stride=2, rounds=1,
     return (max(e_lat, e_img) if exact else 1.0), yard
 
 
+def case_golden_pipeline(name):
+    """HIP sliding_iterative_denoise vs the output of the REFERENCE's own pipeline code (committed
+    fixture tests/golden/pipeline_sliding.pt, fp32): same seeded weights, task tensors and noise."""
+    from diffuman4d_amd.host.pipeline import Diffuman4DPipeline
+    from diffuman4d_amd.host.scheduler import DDIMConfig as HC, DDIMScheduler as HS
+    g = torch.load(Path(__file__).resolve().parent / "golden" / "pipeline_sliding.pt")[name]
+    c, seeds = g["case"], g["seeds"]
+    cfg_u, ou = make_unet(seeds["unet"])
+    cfg_v, ov = make_vae(seeds["vae"])
+    pv, pl, sk, cm = synthetic_task(c["n"], 64, 64, c["inputs"], seeds["task"])
+    hp = Diffuman4DPipeline(hip_vae(cfg_v, ov), hip_unet(cfg_u, ou), HS(HC(prediction_type=c["pred"])), "cuda")
+    lat_in = g["latents_in"].to(BF) if g["latents_in"] is not None else None
+    out = hp.sliding_iterative_denoise(pixel_values=pv, plucker_embeds=pl, skeletons=sk, cond_masks=cm, latents=lat_in,
+                                       domain=c["domain"], timestep_indices=g["timestep_indices_in"],
+                                       noise={k: v.to(BF) for k, v in g["noise"].items()}, **c["kw"])
+    exact = torch.equal(out["timestep_indices"].cpu(), g["timestep_indices"]) and \
+        torch.equal(out["fully_denoised"].cpu(), g["fully_denoised"])
+    e_lat, e_img = rel_l2(out["latents"], g["latents"]), rel_l2(out["images"], g["images"])
+    print(f"    [golden {name}] latents rel_l2={e_lat:.3e} images rel_l2={e_img:.3e} bookkeeping_exact={exact}", flush=True)
+    return (max(e_lat, e_img) if exact else 1.0), 0.0
+
+
 CASES = {
     "unet_spatial": (case_unet, dict(num_frames=4, cfg_batch=2)),
     "unet_temporal_temb": (case_unet, dict(num_frames=4, cfg_batch=2, tem=True, domain="temporal")),
@@ -195,10 +217,15 @@ CASES = {
     "pipeline_spatial": (case_pipeline, dict(domain="spatial")),
     "pipeline_temporal_v": (case_pipeline, dict(domain="temporal", T=4, window=4, stride=1, pred="v_prediction")),
     "pipeline_bidir_nocfg": (case_pipeline, dict(domain="spatial", window=3, stride=3, bidir=True, gs=1.0, steps=2)),
+    "golden_spatial": (case_golden_pipeline, dict(name="spatial")),
+    "golden_temporal_v": (case_golden_pipeline, dict(name="temporal_v")),
+    "golden_bidir_nocfg": (case_golden_pipeline, dict(name="bidir_nocfg")),
+    "golden_round2_shift": (case_golden_pipeline, dict(name="round2_shift")),
 }
 # multi-layer bf16 pipelines: each of ~100 ops adds ~2e-3 of rounding noise; they add in quadrature
 TOL = {"unet_spatial": 3e-2, "unet_temporal_temb": 3e-2, "unet_2d_only": 3e-2, "vae": 3e-2, "resize": 4e-3,
-       "pipeline_spatial": 6e-2, "pipeline_temporal_v": 6e-2, "pipeline_bidir_nocfg": 6e-2}
+       "pipeline_spatial": 6e-2, "pipeline_temporal_v": 6e-2, "pipeline_bidir_nocfg": 6e-2,
+       "golden_spatial": 6e-2, "golden_temporal_v": 6e-2, "golden_bidir_nocfg": 6e-2, "golden_round2_shift": 6e-2}
 
 
 def run_case(name):
