@@ -36,12 +36,14 @@ struct AttnParams {
 };
 
 constexpr int KV = 64;      // keys per staged tile
-constexpr int LDS_LD = 72;  // bf16 per LDS row (64 + 8 pad) = 144 B
+constexpr int LDS_LD = 72;   // K rows: 64 + 8 pad bf16 = 144 B  (conflict-free ds_read_b128 fragments)
+constexpr int LDS_LDV = 96;  // V rows: 64 + 32 pad bf16 = 192 B (4 consecutive rows tile the 64 banks for the tr reads)
 constexpr int NW = 8;       // waves per workgroup
 constexpr float RESCALE_THR = 8.0f;  // in log2 units
 
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_p;
 
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
   f32x2_t v = {lo, hi};
@@ -51,9 +53,9 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
 
 template <int QB>
 __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
-  __shared__ __attribute__((aligned(16))) u16 smem[2 * 2 * KV * LDS_LD];
+  __shared__ __attribute__((aligned(16))) u16 smem[2 * KV * LDS_LD + 2 * KV * LDS_LDV];
   u16* Ks = smem;                    // [2][64 keys][72]
-  u16* Vt = smem + 2 * KV * LDS_LD;  // [2][64 d][72]
+  u16* Vs = smem + 2 * KV * LDS_LD;  // [2][64 keys][96]  row-major, transposed on the way OUT (ds_read_b64_tr_b16)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -82,6 +84,9 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
     }
   }
 
+  // per-lane base of the V tr-reads: 16-lane group g -> d0 = 16*(g&1), key offset 4*(g>>1); lane i -> row i>>2, chunk i&3
+  const u16* v_lane = Vs + (4 * (lane >> 5) + ((lane & 15) >> 2)) * LDS_LDV + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+
   f32x16_t o[QB][2];
   float m_run[QB], l_run[QB];
 #pragma unroll
@@ -105,22 +110,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
   };
   auto store_tile = [&](int buf) {
     *reinterpret_cast<U4*>(Ks + (buf * KV + s_key) * LDS_LD + s_c * 8) = rk;
-    // V transpose.  Lane pairs (key even / key odd = lane ^ 8) exchange half of their chunk so that
-    // each writes 4 dwords {V[k][d], V[k+1][d]} into Vt[d][perm(k)]; perm swaps key bits 2 and 3.
-    const bool odd = (s_key & 1) != 0;
-    const uint32_t x0 = odd ? rv.x : rv.z, x1 = odd ? rv.y : rv.w;
-    const uint32_t r0 = __shfl_xor(x0, 8), r1 = __shfl_xor(x1, 8);
-    // even key k: owns d = 8c+0..3 -> a = (rv.x, rv.y) of key k, b = (r0, r1) of key k+1
-    // odd key k+1: owns d = 8c+4..7 -> a = (r0, r1) of key k, b = (rv.z, rv.w) of key k+1
-    const uint32_t a0 = odd ? r0 : rv.x, a1 = odd ? r1 : rv.y;
-    const uint32_t b0 = odd ? rv.z : r0, b1 = odd ? rv.w : r1;
-    const int k2 = s_key & ~1;
-    const int kperm = (k2 & ~12) | ((k2 & 4) << 1) | ((k2 & 8) >> 1);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(Vt + (buf * 64 + s_c * 8 + (odd ? 4 : 0)) * LDS_LD + kperm);
-    dst[0 * (LDS_LD / 2)] = (a0 & 0xffffu) | (b0 << 16);
-    dst[1 * (LDS_LD / 2)] = (a0 >> 16) | (b0 & 0xffff0000u);
-    dst[2 * (LDS_LD / 2)] = (a1 & 0xffffu) | (b1 << 16);
-    dst[3 * (LDS_LD / 2)] = (a1 >> 16) | (b1 & 0xffff0000u);
+    *reinterpret_cast<U4*>(Vs + (buf * KV + s_key) * LDS_LDV + s_c * 8) = rv;
   };
 
   const int nt = (L + KV - 1) / KV;
@@ -199,7 +189,13 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
       for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
-          bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(Vt + (buf * 64 + db * 32 + l31) * LDS_LD + kb * 32 + jj * 16 + lh * 8);
+          // A operand = V^T[d][8 keys in P's k-slot order]: two hardware-transposing reads of a [4 keys][16 d] block
+          // each (lane i of a 16-lane group supplies row i>>2, d-chunk i&3 and receives column i)
+          const u16* vp = v_lane + (buf * KV + kb * 32 + jj * 16) * LDS_LDV + db * 32;
+          s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)vp);
+          s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vp + 8 * LDS_LDV));
+          s16x8_t v01 = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+          bf16x8_t vf = *reinterpret_cast<bf16x8_t*>(&v01);
 #pragma unroll
           for (int qb = 0; qb < QB; ++qb) o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][jj], o[qb][db], 0, 0, 0);
         }

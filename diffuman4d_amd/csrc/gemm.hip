@@ -189,9 +189,10 @@ __global__ __launch_bounds__(256) void gemm_kernel_glds(GemmParams p) {
   const int d_row = lane >> 3, d_pos = lane & 7;
   const u16* a_src[AW];
   const u16* a2_src[AW];
-  int iy0[AW], ix0[AW];
+  int iy0[AW], ix0[AW], img_off[AW], tap_off[AW];  // tap_off: element offset of the current tap's pixel, -1 = padding
 #pragma unroll
   for (int i = 0; i < AW; ++i) {
+    img_off[i] = tap_off[i] = 0;
     const int row = (wave + 4 * i) * 8 + d_row;
     const int chunk = d_pos ^ ((row >> 1) & 7);
     int m = m0 + row;
@@ -203,7 +204,8 @@ __global__ __launch_bounds__(256) void gemm_kernel_glds(GemmParams p) {
       int b = t / p.Ho;
       iy0[i] = oy * p.stride - p.pad;
       ix0[i] = ox * p.stride - p.pad;
-      a_src[i] = p.A + (int64_t)b * p.H * p.W * p.Cin + chunk * 8;
+      img_off[i] = b * p.H * p.W * p.Cin + chunk * 8;  // element offset of (image b, chunk); tensors are < 2^31 elements
+      a_src[i] = p.A;
       a2_src[i] = nullptr;
     } else {
       a_src[i] = p.A + (int64_t)m * p.lda + chunk * 8;
@@ -234,17 +236,29 @@ __global__ __launch_bounds__(256) void gemm_kernel_glds(GemmParams p) {
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   auto issue_slab = [&](int kt, int buf) {
+    if constexpr (CONV) {
+      if (ci0 == 0) {  // first slab of a (ky,kx) tap: the only place the gather geometry is evaluated
+#pragma unroll
+        for (int i = 0; i < AW; ++i) {
+          int iy = iy0[i] + ky, ix = ix0[i] + kx;
+          bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+          int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
+          tap_off[i] = ok ? img_off[i] + (sy * p.W + sx) * p.Cin : -1;
+        }
+      }
+    } else {
+      if (p.A2 != nullptr && kt * BK == p.K1) {  // crossed into the second source of the split A (once)
+#pragma unroll
+        for (int i = 0; i < AW; ++i) a_src[i] = a2_src[i] - p.K1;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < AW; ++i) {
       const u16* src;
       if constexpr (CONV) {
-        int iy = iy0[i] + ky, ix = ix0[i] + kx;
-        bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
-        int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
-        src = ok ? a_src[i] + ((int64_t)sy * p.W + sx) * p.Cin + ci0 : reinterpret_cast<const u16*>(g_zero16);
+        src = tap_off[i] >= 0 ? p.A + ci0 + tap_off[i] : reinterpret_cast<const u16*>(g_zero16);
       } else {
-        const int kcol = kt * BK;
-        src = (p.A2 != nullptr && kcol >= p.K1) ? a2_src[i] + (kcol - p.K1) : a_src[i] + kcol;
+        src = a_src[i] + kt * BK;
       }
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (buf * BM + (wave + 4 * i) * 8) * BK), 16, 0, 0);
     }
@@ -269,22 +283,173 @@ __global__ __launch_bounds__(256) void gemm_kernel_glds(GemmParams p) {
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) issue_slab(kt + 1, buf ^ 1);
+    // fragment reads are software-pipelined one k-step ahead of the MFMAs that consume them
+    bf16x8_t af[2][MI], bfr[2][NI];
+    auto read_frags = [&](int ks, int slot) {
+      const int pos = ((ks * 2 + lh) ^ sw) * 8;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        af[slot][i] = *reinterpret_cast<const bf16x8_t*>(As + (buf * BM + wm * TM + i * 32 + l31) * BK + pos);
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        bfr[slot][j] = *reinterpret_cast<const bf16x8_t*>(Bs + (buf * BN + wn * TN + j * 32 + l31) * BK + pos);
+    };
+    read_frags(0, 0);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
+      if (ks + 1 < 4) read_frags(ks + 1, (ks + 1) & 1);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();  // all waves done with `buf`; the DMA into buf^1 has landed (vmcnt(0) before the barrier)
+  }
+  gemm_epilogue<MI, NI, TM, TN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// deep pipeline: K-slab 32, NST LDS stages, NST-1 slabs of DMA in flight across barriers
+// (counted s_waitcnt vmcnt + raw s_barrier: a __syncthreads() would drain the DMA queue), 4 or 8
+// waves.  Ablation of the 2-stage kernel showed the DMA side, not the MFMAs, bounds it (one slab of
+// prefetch cannot cover the L2->LDS latency, and a 128x128 tile needs the CU's whole L1 bandwidth at
+// MFMA peak); larger tiles halve the bytes per flop, more stages cover the latency.
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int NST, bool CONV>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_pipe(GemmParams p) {
+  constexpr int NW = WM * WN, BK = 32;
+  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
+  constexpr int AW = BM / 16 / NW, BW = BN / 16 / NW;  // 1-KiB DMA instructions (16 rows x 64 B) per wave per slab
+  static_assert(AW >= 1 && BW >= 1 && NST >= 2 && NST <= 4, "tile/wave/stage combination");
+  constexpr int LD = AW + BW;
+  constexpr int STAGE = (BM + BN) * BK;  // elements per stage
+  constexpr int SMEM_MAIN = NST * STAGE * 2;
+  constexpr int SMEM_EPI = NW * 32 * (TN + 4) * 4;
+  constexpr int SMEM_BYTES = SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI;
+  __shared__ __attribute__((aligned(16))) u16 smem[SMEM_BYTES / 2];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
+  const int m0 = tm * BM;
+  const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
+  const int n0 = tn * (geglu ? BN / 2 : BN);
+
+  // DMA lane mapping: 16 rows x 4 chunks per instruction; LDS position (row, pos) holds chunk pos ^ ((row>>2)&3)
+  const int d_row = lane >> 2, d_pos = lane & 3;
+  const int d_chunk = d_pos ^ ((d_row >> 2) & 3);
+  const u16* a_src[AW];
+  const u16* a2_src[AW];
+  int iy0[AW], ix0[AW];
+#pragma unroll
+  for (int i = 0; i < AW; ++i) {
+    int m = m0 + (wave + NW * i) * 16 + d_row;
+    if (m > p.M - 1) m = p.M - 1;
+    if constexpr (CONV) {
+      int ox = m % p.Wo;
+      int t = m / p.Wo;
+      int oy = t % p.Ho;
+      int b = t / p.Ho;
+      iy0[i] = oy * p.stride - p.pad;
+      ix0[i] = ox * p.stride - p.pad;
+      a_src[i] = p.A + (int64_t)b * p.H * p.W * p.Cin + d_chunk * 8;
+      a2_src[i] = nullptr;
+    } else {
+      a_src[i] = p.A + (int64_t)m * p.lda + d_chunk * 8;
+      a2_src[i] = p.A2 ? p.A2 + (int64_t)m * p.lda2 + d_chunk * 8 : nullptr;
+      iy0[i] = ix0[i] = 0;
+    }
+  }
+  const u16* w_src[BW];
+#pragma unroll
+  for (int i = 0; i < BW; ++i)
+    w_src[i] = p.Wt + (int64_t)weight_row<TN>(p, n0, (wave + NW * i) * 16 + d_row, geglu) * p.ldw + d_chunk * 8;
+
+  f32x16_t acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / BK;
+  const int Hin = p.upsample ? 2 * p.H : p.H, Win = p.upsample ? 2 * p.W : p.W;
+  int ky = 0, kx = 0, ci0 = 0;
+
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto issue_slab = [&](int kt, int st) {
+    u16* As = smem + st * STAGE;
+    u16* Bs = As + BM * BK;
+#pragma unroll
+    for (int i = 0; i < AW; ++i) {
+      const u16* src;
+      if constexpr (CONV) {
+        int iy = iy0[i] + ky, ix = ix0[i] + kx;
+        bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+        int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
+        src = ok ? a_src[i] + ((int64_t)sy * p.W + sx) * p.Cin + ci0 : reinterpret_cast<const u16*>(g_zero16);
+      } else {
+        const int kcol = kt * BK;
+        src = (p.A2 != nullptr && kcol >= p.K1) ? a2_src[i] + (kcol - p.K1) : a_src[i] + kcol;
+      }
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (wave + NW * i) * 16 * BK), 16, 0, 0);
+    }
+    if constexpr (CONV) {
+      ci0 += BK;
+      if (ci0 >= p.Cin) {
+        ci0 = 0;
+        if (++kx == 3) {
+          kx = 0;
+          ++ky;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BW; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + kt * BK), (lptr_t)(Bs + (wave + NW * i) * 16 * BK), 16, 0, 0);
+  };
+
+  const int sw = (l31 >> 2) & 3;
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nk) issue_slab(s, s);
+  int st = 0, st_issue = NST - 1;  // stage holding slab kt / stage receiving slab kt + NST - 1
+  for (int kt = 0; kt < nk; ++kt) {
+    // slab kt has landed once at most min(NST-2, nk-1-kt) younger slabs of THIS wave are outstanding
+    const int younger = nk - 1 - kt;
+    if (NST >= 4 && younger >= 2) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LD) : "memory");
+    } else if (NST >= 3 && younger >= 1) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();  // every wave's part of slab kt is in LDS; everyone is done reading slab kt-1
+    asm volatile("" ::: "memory");
+    if (kt + NST - 1 < nk) issue_slab(kt + NST - 1, st_issue);  // overwrites the stage slab kt-1 lived in
+    const u16* As = smem + st * STAGE;
+    const u16* Bs = As + BM * BK;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
       const int pos = ((ks * 2 + lh) ^ sw) * 8;
       bf16x8_t af[MI], bfr[NI];
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
-        af[i] = *reinterpret_cast<const bf16x8_t*>(As + (buf * BM + wm * TM + i * 32 + l31) * BK + pos);
+      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(As + (wm * TM + i * 32 + l31) * BK + pos);
 #pragma unroll
-      for (int j = 0; j < NI; ++j)
-        bfr[j] = *reinterpret_cast<const bf16x8_t*>(Bs + (buf * BN + wn * TN + j * 32 + l31) * BK + pos);
+      for (int j = 0; j < NI; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(Bs + (wn * TN + j * 32 + l31) * BK + pos);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();  // all waves done with `buf`; the DMA into buf^1 has landed (vmcnt(0) before the barrier)
+    st = (st + 1 == NST) ? 0 : st + 1;
+    st_issue = (st_issue + 1 == NST) ? 0 : st_issue + 1;
   }
   gemm_epilogue<MI, NI, TM, TN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
 }
@@ -429,11 +594,36 @@ int launch_cfg(hipStream_t st, GemmParams& p) {
   return dm4d_check_launch("gemm_kernel");
 }
 
+template <int BM, int BN, int WM, int WN, int NST, bool CONV>
+int launch_pipe(hipStream_t st, GemmParams& p) {
+  const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
+  const int bn_out = geglu ? BN / 2 : BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + bn_out - 1) / bn_out;
+  hipLaunchKernelGGL((gemm_kernel_pipe<BM, BN, WM, WN, NST, CONV>), dim3(tiles_m * p.tiles_n), dim3(WM * WN * 64), 0, st, p);
+  return dm4d_check_launch("gemm_kernel_pipe");
+}
+
 template <bool CONV>
 int launch(hipStream_t st, GemmParams& p) {
   static const int force_v1 = [] { const char* e = getenv("DM4D_GEMM_V1"); return e ? atoi(e) : 0; }();  // A/B aid
+  static const int pipe = [] { const char* e = getenv("DM4D_GEMM_PIPE"); return e ? atoi(e) : 0; }();     // A/B aid
   const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
   const bool n128 = geglu || (p.N % 128 == 0) || (p.N > 1024);
+  if (pipe && !force_v1) {
+    if (!n128) {
+      if (pipe == 5) return launch_pipe<128, 64, 4, 1, 4, CONV>(st, p);
+      return launch_pipe<256, 64, 4, 1, 4, CONV>(st, p);
+    }
+    switch (pipe) {
+      case 1: return launch_pipe<128, 128, 2, 2, 4, CONV>(st, p);
+      case 2: return launch_pipe<256, 128, 4, 2, 4, CONV>(st, p);
+      case 3: return launch_pipe<256, 256, 2, 4, 4, CONV>(st, p);
+      case 4: return launch_pipe<256, 128, 4, 2, 3, CONV>(st, p);
+      case 5: return launch_pipe<128, 128, 2, 2, 3, CONV>(st, p);
+      default: return launch_pipe<256, 256, 2, 4, 3, CONV>(st, p);
+    }
+  }
   const bool glds = !force_v1 && (CONV ? (p.Cin % 64 == 0) : (p.K % 64 == 0 && (!p.A2 || p.K1 % 64 == 0)));
   if (glds) {
     if (n128) {
