@@ -123,37 +123,46 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
     if (t + 1 < nt) load_tile(t + 1);
     const bool tail = (t == nt - 1) && (L % KV) != 0;
 
+    // ---- S^T = K Q^T for both 32-key blocks: two independent accumulator chains, interleaved, so the
+    //      matrix pipe stays busy while block 0's softmax runs on the VALU (software pipelining in-wave)
+    f32x16_t s[QB][2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      // ---- S^T = K Q^T for 32 keys ---------------------------------------------------------
-      f32x16_t s[QB];
+    for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-      for (int qb = 0; qb < QB; ++qb)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[qb][r] = 0.f;
+        for (int r = 0; r < 16; ++r) s[qb][kb][r] = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
         bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (buf * KV + kb * 32 + l31) * LDS_LD + j * 16 + lh * 8);
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) s[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][j], s[qb], 0, 0, 0);
+        for (int qb = 0; qb < QB; ++qb) s[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][j], s[qb][kb], 0, 0, 0);
       }
-      if (tail) {
+    }
+    if (tail) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
         const int key0 = t * KV + kb * 32 + 4 * lh;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           if (key0 + (r & 3) + 8 * (r >> 2) >= L) {
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb) s[qb][r] = -1e30f;
+            for (int qb = 0; qb < QB; ++qb) s[qb][kb][r] = -1e30f;
           }
         }
       }
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
       // ---- online softmax (lazy rescale), P^T fragments ---------------------------------------
       bf16x8_t pf[QB][2];
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
-        float mx = fmaxf(s[qb][0], s[qb][1]);
+        float mx = fmaxf(s[qb][kb][0], s[qb][kb][1]);
 #pragma unroll
-        for (int r = 2; r < 16; ++r) mx = fmaxf(mx, s[qb][r]);
+        for (int r = 2; r < 16; ++r) mx = fmaxf(mx, s[qb][kb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         if (__any((mx - m_run[qb]) * p.c > RESCALE_THR)) {
           const float m_new = fmaxf(m_run[qb], mx);
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
         float sum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          pv[r] = __builtin_amdgcn_exp2f(s[qb][r] * p.c - mc);
+          pv[r] = __builtin_amdgcn_exp2f(s[qb][kb][r] * p.c - mc);
           sum += pv[r];
         }
         l_run[qb] += sum;

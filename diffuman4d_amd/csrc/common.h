@@ -50,7 +50,17 @@ __device__ __forceinline__ U4 ldg16(const void* p) { return *reinterpret_cast<co
 __device__ __forceinline__ void stg16(void* p, const U4& v) { *reinterpret_cast<U4*>(p) = v; }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf(x) by Abramowitz & Stegun 7.1.26: |abs error| <= 1.5e-7, branch free, ~12 VALU (libm erff is ~4x that
+// and dominated the GEGLU epilogue of the K=320 feed-forward GEMMs)
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float y = fmaf(fmaf(fmaf(fmaf(1.061405429f, t, -1.453152027f), t, 1.421413741f), t, -0.284496736f), t, 0.254829592f) * t;
+  y = 1.0f - y * __expf(-ax * ax);
+  return copysignf(y, x);
+}
+// exact (erf) GELU, as F.gelu(approximate="none") used by diffusers' GEGLU
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
 
 // XCD-aware block remap (8 XCDs, block b runs on XCD b % 8): give each XCD a contiguous range of
 // logical tiles so neighbouring tiles share one L2.  Bijective for any grid size.
