@@ -344,9 +344,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_pipe(GemmParams p) {
   const int d_chunk = d_pos ^ ((d_row >> 2) & 3);
   const u16* a_src[AW];
   const u16* a2_src[AW];
-  int iy0[AW], ix0[AW];
+  int iy0[AW], ix0[AW], img_off[AW], tap_off[AW];  // tap_off: element offset of the current tap's pixel, -1 = padding
 #pragma unroll
   for (int i = 0; i < AW; ++i) {
+    img_off[i] = tap_off[i] = 0;
     int m = m0 + (wave + NW * i) * 16 + d_row;
     if (m > p.M - 1) m = p.M - 1;
     if constexpr (CONV) {
@@ -356,7 +357,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_pipe(GemmParams p) {
       int b = t / p.Ho;
       iy0[i] = oy * p.stride - p.pad;
       ix0[i] = ox * p.stride - p.pad;
-      a_src[i] = p.A + (int64_t)b * p.H * p.W * p.Cin + d_chunk * 8;
+      img_off[i] = b * p.H * p.W * p.Cin + d_chunk * 8;
+      a_src[i] = p.A;
       a2_src[i] = nullptr;
     } else {
       a_src[i] = p.A + (int64_t)m * p.lda + d_chunk * 8;
@@ -386,17 +388,29 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_pipe(GemmParams p) {
   auto issue_slab = [&](int kt, int st) {
     u16* As = smem + st * STAGE;
     u16* Bs = As + BM * BK;
+    if constexpr (CONV) {
+      if (ci0 == 0) {  // first slab of a (ky,kx) tap: the only place the gather geometry is evaluated
+#pragma unroll
+        for (int i = 0; i < AW; ++i) {
+          int iy = iy0[i] + ky, ix = ix0[i] + kx;
+          bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+          int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
+          tap_off[i] = ok ? img_off[i] + (sy * p.W + sx) * p.Cin : -1;
+        }
+      }
+    } else {
+      if (p.A2 != nullptr && kt * BK == p.K1) {  // crossed into the second source of the split A (once)
+#pragma unroll
+        for (int i = 0; i < AW; ++i) a_src[i] = a2_src[i] - p.K1;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < AW; ++i) {
       const u16* src;
       if constexpr (CONV) {
-        int iy = iy0[i] + ky, ix = ix0[i] + kx;
-        bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
-        int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
-        src = ok ? a_src[i] + ((int64_t)sy * p.W + sx) * p.Cin + ci0 : reinterpret_cast<const u16*>(g_zero16);
+        src = tap_off[i] >= 0 ? p.A + ci0 + tap_off[i] : reinterpret_cast<const u16*>(g_zero16);
       } else {
-        const int kcol = kt * BK;
-        src = (p.A2 != nullptr && kcol >= p.K1) ? a2_src[i] + (kcol - p.K1) : a_src[i] + kcol;
+        src = a_src[i] + kt * BK;
       }
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (wave + NW * i) * 16 * BK), 16, 0, 0);
     }
@@ -604,53 +618,82 @@ int launch_pipe(hipStream_t st, GemmParams& p) {
   return dm4d_check_launch("gemm_kernel_pipe");
 }
 
+int g_tune_cfg = 0;  // 0 = heuristic; otherwise a kernel-configuration id (tuning hook, dm4d_tune_set_gemm_config)
+
+// Kernel configurations.  glds: K-slab 64, 2 LDS stages, 4 waves.  pipe: K-slab 32, 3-4 stages, 4 or 8 waves.
+template <bool CONV>
+int launch_by_id(int id, hipStream_t st, GemmParams& p) {
+  const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
+  const bool k64 = CONV ? (p.Cin % 64 == 0) : (p.K % 64 == 0 && (!p.A2 || p.K1 % 64 == 0));
+  if (id >= 1 && id <= 5 && !k64) return DM4D_ERR_ARG;
+  switch (id) {
+    case 1: return launch_cfg<128, 128, 2, 2, CONV, true>(st, p);
+    case 2: return launch_cfg<256, 64, 4, 1, CONV, true>(st, p);
+    case 3: return launch_cfg<128, 64, 4, 1, CONV, true>(st, p);
+    case 4: return geglu ? DM4D_ERR_ARG : launch_cfg<64, 64, 2, 2, CONV, true>(st, p);
+    case 5: return launch_cfg<256, 128, 2, 2, CONV, true>(st, p);
+    case 11: return launch_pipe<128, 128, 2, 2, 4, CONV>(st, p);
+    case 12: return launch_pipe<256, 128, 4, 2, 4, CONV>(st, p);
+    case 13: return launch_pipe<256, 256, 2, 4, 4, CONV>(st, p);
+    case 14: return launch_pipe<256, 128, 4, 2, 3, CONV>(st, p);
+    case 15: return launch_pipe<128, 128, 2, 2, 3, CONV>(st, p);
+    case 16: return launch_pipe<256, 256, 2, 4, 3, CONV>(st, p);
+    case 17: return launch_pipe<256, 64, 4, 1, 4, CONV>(st, p);
+    case 18: return launch_pipe<128, 64, 4, 1, 4, CONV>(st, p);
+    case 21: return launch_cfg<256, 128, 2, 2, CONV, false>(st, p);
+    case 22: return launch_cfg<128, 128, 2, 2, CONV, false>(st, p);
+    case 23: return launch_cfg<256, 64, 4, 1, CONV, false>(st, p);
+    case 24: return launch_cfg<128, 64, 4, 1, CONV, false>(st, p);
+    default: return DM4D_ERR_ARG;
+  }
+}
+
+// Heuristic (tuned on the UNet shapes at 72x40 latents, profiles/r01_gemm_tune.log)
+template <bool CONV>
+int choose_cfg(const GemmParams& p) {
+  const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
+  const bool k64 = CONV ? (p.Cin % 64 == 0) : (p.K % 64 == 0 && (!p.A2 || p.K1 % 64 == 0));
+  const bool n128 = geglu || (p.N % 128 == 0) || (p.N > 1024);
+  if (!k64) {  // K-slab 32 register-staged fallback
+    const long tiles_big = (long)((p.M + 255) / 256) * ((p.N + (geglu ? 63 : 127)) / (geglu ? 64 : 128));
+    if (n128) return tiles_big >= 384 ? 21 : 22;
+    return (long)((p.M + 255) / 256) * ((p.N + 63) / 64) >= 384 ? 23 : 24;
+  }
+  const int bn = geglu ? 64 : 128;  // output columns of a 128-wide B tile
+  const long tm256 = (p.M + 255) / 256, tm128 = (p.M + 127) / 128, tn = (p.N + bn - 1) / bn;
+  if (!CONV) {
+    // Linear layers stream A once with little reuse (K = C or 4C): they are bound by L2->LDS bytes and DMA latency,
+    // so the 8-wave 256x128 tile with 2 slabs of DMA in flight wins whenever it still fills the chip (1.2-1.35x)
+    const long t = tm256 * tn;  // one 8-wave workgroup per CU => 256 slots per round; avoid a mostly empty last round
+    if (t >= 256 && 5 * t >= 4 * ((t + 255) / 256) * 256) return 14;
+  } else {
+    // convs have 9x the K depth; 128x128 / 2 workgroups per CU is best except for wide, tall problems
+    if (!geglu && p.N % 256 == 0 && tm256 * (p.N / 256) >= 384) return 13;
+  }
+  if (n128) {
+    if (tm128 * tn >= 256) return 1;
+    if (geglu) return 3;
+    return tm128 * tn >= 200 ? 3 : 4;  // deepest UNet level: shrink the tile until the grid covers the 256 CUs
+  }
+  return tm256 * ((p.N + 63) / 64) >= 384 ? 2 : 3;
+}
+
 template <bool CONV>
 int launch(hipStream_t st, GemmParams& p) {
-  static const int force_v1 = [] { const char* e = getenv("DM4D_GEMM_V1"); return e ? atoi(e) : 0; }();  // A/B aid
-  static const int pipe = [] { const char* e = getenv("DM4D_GEMM_PIPE"); return e ? atoi(e) : 0; }();     // A/B aid
-  const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
-  const bool n128 = geglu || (p.N % 128 == 0) || (p.N > 1024);
-  if (pipe && !force_v1) {
-    if (!n128) {
-      if (pipe == 5) return launch_pipe<128, 64, 4, 1, 4, CONV>(st, p);
-      return launch_pipe<256, 64, 4, 1, 4, CONV>(st, p);
-    }
-    switch (pipe) {
-      case 1: return launch_pipe<128, 128, 2, 2, 4, CONV>(st, p);
-      case 2: return launch_pipe<256, 128, 4, 2, 4, CONV>(st, p);
-      case 3: return launch_pipe<256, 256, 2, 4, 4, CONV>(st, p);
-      case 4: return launch_pipe<256, 128, 4, 2, 3, CONV>(st, p);
-      case 5: return launch_pipe<128, 128, 2, 2, 3, CONV>(st, p);
-      default: return launch_pipe<256, 256, 2, 4, 3, CONV>(st, p);
-    }
+  if (g_tune_cfg) {
+    int rc = launch_by_id<CONV>(g_tune_cfg, st, p);
+    if (rc == DM4D_ERR_ARG) return dm4d_set_error(DM4D_ERR_ARG, "gemm: forced configuration does not support this shape");
+    return rc;
   }
-  const bool glds = !force_v1 && (CONV ? (p.Cin % 64 == 0) : (p.K % 64 == 0 && (!p.A2 || p.K1 % 64 == 0)));
-  if (glds) {
-    if (n128) {
-      // 128x128 (64 KiB LDS, 2 workgroups per CU) beats 256x128 (96 KiB, 1 per CU) on every UNet shape
-      static const int big = [] { const char* e = getenv("DM4D_GEMM_BM256"); return e ? atoi(e) : 0; }();
-      if (big) return launch_cfg<256, 128, 2, 2, CONV, true>(st, p);
-      // small-M problems (deepest UNet level): shrink the tile until the grid covers the 256 CUs
-      const long t128 = (long)((p.M + 127) / 128) * ((p.N + (geglu ? 63 : 127)) / (geglu ? 64 : 128));
-      if (t128 >= 256) return launch_cfg<128, 128, 2, 2, CONV, true>(st, p);
-      if (2 * t128 >= 200 || geglu) return launch_cfg<128, 64, 4, 1, CONV, true>(st, p);
-      return launch_cfg<64, 64, 2, 2, CONV, true>(st, p);
-    }
-    const long t256 = (long)((p.M + 255) / 256) * ((p.N + 63) / 64);
-    if (t256 >= 512) return launch_cfg<256, 64, 4, 1, CONV, true>(st, p);
-    return launch_cfg<128, 64, 4, 1, CONV, true>(st, p);
-  }
-  const long tiles_big = (long)((p.M + 255) / 256) * ((p.N + (geglu ? 63 : 127)) / (geglu ? 64 : 128));
-  if (n128) {
-    if (tiles_big >= 384) return launch_cfg<256, 128, 2, 2, CONV, false>(st, p);
-    return launch_cfg<128, 128, 2, 2, CONV, false>(st, p);
-  }
-  const long tiles64 = (long)((p.M + 255) / 256) * ((p.N + 63) / 64);
-  if (tiles64 >= 384) return launch_cfg<256, 64, 4, 1, CONV, false>(st, p);
-  return launch_cfg<128, 64, 4, 1, CONV, false>(st, p);
+  return launch_by_id<CONV>(choose_cfg<CONV>(p), st, p);
 }
 
 }  // namespace
+
+extern "C" int dm4d_tune_set_gemm_config(int id) {
+  g_tune_cfg = id;
+  return DM4D_OK;
+}
 
 extern "C" int dm4d_gemm_bf16(void* stream, const void* A, int64_t lda, const void* A2, int64_t lda2, int K1,
                               const void* W, int64_t ldw, void* C, int64_t ldc, int M, int N, int K, const void* bias,

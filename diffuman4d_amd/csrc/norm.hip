@@ -92,19 +92,37 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GNParams p) {
   const int C = p.C1 + p.C2, CV = C / 8, CV1 = p.C1 / 8;
   float* sc = sm;
   float* sh = sm + C;
-  float* mean = sm + 2 * C;
+  float* mean = sm + (2 * C > 2 * GN_THREADS ? 2 * C : 2 * GN_THREADS);  // sc/sh double as reduction scratch
   float* rstd = mean + p.groups;
   const int b = blockIdx.x / p.nchunk, chunk = blockIdx.x % p.nchunk;
   const int per = (p.HW + p.nchunk - 1) / p.nchunk;
   const int p0 = chunk * per, p1 = min(p0 + per, p.HW);
   const int tid = threadIdx.x;
   const int gs = C / p.groups;
-  for (int g = tid; g < p.groups; g += GN_THREADS) {
+  // reduce the per-chunk partials: all 256 threads fetch (fixed association order => deterministic), then one
+  // thread per group combines the GN_THREADS/groups slices -- the serial 64-deep loop this replaces was the
+  // latency floor of the kernel
+  {
+    const int slices = GN_THREADS / p.groups > 0 ? GN_THREADS / p.groups : 1;
+    const int g = tid % p.groups, sl = tid / p.groups;
     float s = 0.f, q = 0.f;
-    for (int k = 0; k < p.nchunk; ++k) {
-      const float* w = p.ws + (((int64_t)b * p.nchunk + k) * p.groups + g) * 2;
-      s += w[0];
-      q += w[1];
+    if (sl < slices) {
+      for (int k = sl; k < p.nchunk; k += slices) {
+        const float* w = p.ws + (((int64_t)b * p.nchunk + k) * p.groups + g) * 2;
+        s += w[0];
+        q += w[1];
+      }
+      sc[(sl * p.groups + g) * 2 + 0] = s;  // sc/sh are free until the next phase; 2*slices*groups <= 2*GN_THREADS floats
+      sc[(sl * p.groups + g) * 2 + 1] = q;
+    }
+    __syncthreads();
+  }
+  for (int g = tid; g < p.groups; g += GN_THREADS) {
+    const int slices = GN_THREADS / p.groups > 0 ? GN_THREADS / p.groups : 1;
+    float s = 0.f, q = 0.f;
+    for (int sl = 0; sl < slices; ++sl) {
+      s += sc[(sl * p.groups + g) * 2 + 0];
+      q += sc[(sl * p.groups + g) * 2 + 1];
     }
     const float n = (float)gs * (float)p.HW;
     const float mu = s / n;
@@ -238,7 +256,7 @@ extern "C" int dm4d_groupnorm_nhwc_bf16(void* stream, const void* X1, int C1, co
   const int CV = C / 8;
   const int PPB = CV >= GN_THREADS ? 1 : GN_THREADS / CV;
   const size_t sm1 = (size_t)PPB * C * 2 * sizeof(float);
-  const size_t sm2 = ((size_t)2 * C + 2 * groups) * sizeof(float);
+  const size_t sm2 = ((size_t)(2 * C > 2 * GN_THREADS ? 2 * C : 2 * GN_THREADS) + 2 * groups) * sizeof(float);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(B * p.nchunk), dim3(GN_THREADS), sm1, st, p);
   int rc = dm4d_check_launch("gn_stats_kernel");
   if (rc) return rc;

@@ -34,6 +34,7 @@ SIGNATURES = {
     "dm4d_scale_pad_bf16": (_i, [_vp, _vp, _i64, _vp, _i, _i64, _i, _f]),
     "dm4d_resize_nchw_f32_to_nhwc_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
     "dm4d_postprocess_images_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),
+    "dm4d_tune_set_gemm_config": (_i, [_i]),
     "dm4d_nchw_to_nhwc_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),
     "dm4d_nhwc_to_nchw_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),
 }

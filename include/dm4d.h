@@ -127,6 +127,10 @@ int dm4d_resize_nchw_f32_to_nhwc_bf16(void* stream, const float* X, void* Y, int
 /* VaeImageProcessor.postprocess(do_denormalize): (x/2 + 0.5).clamp(0,1), NHWC(ldx) -> NCHW (:282-284)  */
 int dm4d_postprocess_images_bf16(void* stream, const void* X, void* Y, int B, int C, int HW, int ldx);
 
+/* Tuning hook (not part of the operator surface): force one GEMM/conv kernel configuration id for all
+ * subsequent launches of this process; 0 restores the built-in heuristic.  Used by tools/gemm_tune.py. */
+int dm4d_tune_set_gemm_config(int id);
+
 /* layout converters at the pipeline boundary (NCHW <-> NHWC, any C) */
 int dm4d_nchw_to_nhwc_bf16(void* stream, const void* X, void* Y, int B, int C, int HW, int cpad);
 int dm4d_nhwc_to_nchw_bf16(void* stream, const void* X, void* Y, int B, int C, int HW, int ldx);
