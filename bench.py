@@ -172,6 +172,14 @@ def main():
         dt = float(tt.item())
 
     finite = bool(torch.isfinite(tasks["spatial"]["lat"].float()).all() and torch.isfinite(tasks["temporal"]["lat"].float()).all())
+    # HBM traffic of the attention kernel from PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+    # this same command, tools/… -> profiles/r01_attn_traffic_pmc.json): bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB,
+    # the factor 2 being the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md (HBM section).  Static file, not live.
+    traffic = None
+    tf = ROOT / "profiles" / "r01_attn_traffic_pmc.json"
+    if tf.exists():
+        t = json.loads(tf.read_text())
+        traffic = int((2 * t["FETCH_SIZE"]["avg_kb"] + t["WRITE_SIZE"]["avg_kb"]) * 1024)
     attn_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in timer)
     attn_fl = sum(f for _, f, _, _ in timer)
     achieved = attn_fl / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
@@ -196,7 +204,9 @@ def main():
             "roofline": {
                 "kernel": "attn_kernel (2-D + 3-D view/time attention, all 48 launches of a step)",
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_note": "avg HBM bytes per attn launch, PMC (2*FETCH_SIZE+WRITE_SIZE), profiles/r01_attn_traffic_pmc.json; "
+                                "algorithmic Q+K+V+O bytes average 152e6 per launch",
                 "avg_launch_ms": round(attn_ms / max(1, len(timer)), 4), "launches": len(timer),
                 "share_of_step_time": round(attn_ms * 1e-3 / dt, 4),
             },

@@ -31,7 +31,7 @@ struct AttnParams {
   const u16 *Q, *K, *V;
   u16* O;
   int64_t ldq, ldk, ldv, ldo;
-  int L, heads, nqt;
+  int L, Lk, heads, nqt;  // L = queries per (batch, head), Lk = keys (== L for plain self-attention)
   float c;  // scale * log2(e)
 };
 
@@ -51,7 +51,7 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
   return *reinterpret_cast<uint32_t*>(&b);
 }
 
-template <int QB>
+template <int QB, bool MSUM>
 __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) u16 smem[2 * KV * LDS_LD + 2 * KV * LDS_LDV];
   u16* Ks = smem;                    // [2][64 keys][72]
@@ -59,15 +59,15 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int L = p.L;
+  const int L = p.L, Lk = p.Lk;
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int qt = lid % p.nqt, bh = lid / p.nqt;
   const int head = bh % p.heads, batch = bh / p.heads;
   const int q_tile0 = qt * (NW * 32 * QB) + wave * (32 * QB);
 
   const u16* Qb = p.Q + (int64_t)batch * L * p.ldq + head * 64;
-  const u16* Kb = p.K + (int64_t)batch * L * p.ldk + head * 64;
-  const u16* Vb = p.V + (int64_t)batch * L * p.ldv + head * 64;
+  const u16* Kb = p.K + (int64_t)batch * Lk * p.ldk + head * 64;
+  const u16* Vb = p.V + (int64_t)batch * Lk * p.ldv + head * 64;
   u16* Ob = p.O + (int64_t)batch * L * p.ldo + head * 64;
 
   // Q fragments (B operand of S^T = K Q^T): lane holds Q[q][j*16 + lh*8 .. +7]
@@ -89,10 +89,17 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
 
   f32x16_t o[QB][2];
   float m_run[QB], l_run[QB];
+  // MSUM: row sums come out of the matrix pipe (P^T times a block of ones) instead of 16 VALU adds per block --
+  // the kernel is VALU-bound on the softmax, the MFMA pipe has slack
+  f32x16_t lacc[QB];
+  const U4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+  const bf16x8_t ones = *reinterpret_cast<const bf16x8_t*>(&ones_u);
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     m_run[qb] = -1e30f;
     l_run[qb] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lacc[qb][r] = 0.f;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -104,7 +111,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
   const int s_key = tid >> 3, s_c = tid & 7;  // key 0..63, d-chunk 0..7
   auto load_tile = [&](int t) {
     int key = t * KV + s_key;
-    if (key > L - 1) key = L - 1;
+    if (key > Lk - 1) key = Lk - 1;
     rk = ldg16(Kb + (int64_t)key * p.ldk + s_c * 8);
     rv = ldg16(Vb + (int64_t)key * p.ldv + s_c * 8);
   };
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
     *reinterpret_cast<U4*>(Vs + (buf * KV + s_key) * LDS_LDV + s_c * 8) = rv;
   };
 
-  const int nt = (L + KV - 1) / KV;
+  const int nt = (Lk + KV - 1) / KV;
   load_tile(0);
   store_tile(0);
   __syncthreads();
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     if (t + 1 < nt) load_tile(t + 1);
-    const bool tail = (t == nt - 1) && (L % KV) != 0;
+    const bool tail = (t == nt - 1) && (Lk % KV) != 0;
 
     // ---- S^T = K Q^T for both 32-key blocks: two independent accumulator chains, interleaved, so the
     //      matrix pipe stays busy while block 0's softmax runs on the VALU (software pipelining in-wave)
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
         const int key0 = t * KV + kb * 32 + 4 * lh;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          if (key0 + (r & 3) + 8 * (r >> 2) >= L) {
+          if (key0 + (r & 3) + 8 * (r >> 2) >= Lk) {
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) s[qb][kb][r] = -1e30f;
           }
@@ -169,6 +176,10 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
           const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * p.c);
           m_run[qb] = m_new;
           l_run[qb] *= alpha;
+          if (MSUM) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lacc[qb][r] *= alpha;
+          }
 #pragma unroll
           for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           pv[r] = __builtin_amdgcn_exp2f(s[qb][kb][r] * p.c - mc);
-          sum += pv[r];
+          if (!MSUM) sum += pv[r];
         }
         l_run[qb] += sum;
 #pragma unroll
@@ -191,6 +202,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
           w.z = cvt_pk_bf16(pv[jj * 8 + 4], pv[jj * 8 + 5]);
           w.w = cvt_pk_bf16(pv[jj * 8 + 6], pv[jj * 8 + 7]);
           pf[qb][jj] = *reinterpret_cast<bf16x8_t*>(&w);
+          if (MSUM) lacc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[qb][jj], lacc[qb], 0, 0, 0);
         }
       }
       // ---- O^T += V^T P^T ------------------------------------------------------------------------
@@ -218,7 +230,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const int q = q_tile0 + qb * 32 + l31;
-    const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32);
+    const float l_tot = MSUM ? lacc[qb][0] : l_run[qb] + __shfl_xor(l_run[qb], 32);
     const float inv = 1.0f / l_tot;
     if (q < L) {
       u16* op = Ob + (int64_t)q * p.ldo;
@@ -237,27 +249,36 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
 
 }  // namespace
 
-extern "C" int dm4d_attention_bf16(void* stream, const void* Q, const void* K, const void* V, void* O, int64_t ldq,
-                                   int64_t ldk, int64_t ldv, int64_t ldo, int batch, int heads, int L, float scale) {
-  if (!Q || !K || !V || !O || batch <= 0 || heads <= 0 || L <= 0)
+extern "C" int dm4d_attention_kv_bf16(void* stream, const void* Q, const void* K, const void* V, void* O, int64_t ldq,
+                                      int64_t ldk, int64_t ldv, int64_t ldo, int batch, int heads, int Lq, int Lk,
+                                      float scale) {
+  if (!Q || !K || !V || !O || batch <= 0 || heads <= 0 || Lq <= 0 || Lk <= 0)
     return dm4d_set_error(DM4D_ERR_ARG, "attention: null pointer or empty shape");
   if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3))
     return dm4d_set_error(DM4D_ERR_ARG, "attention: row strides must be multiples of 8 elements");
-  AttnParams p{(const u16*)Q, (const u16*)K, (const u16*)V, (u16*)O, ldq, ldk, ldv, ldo, L, heads, 0,
+  AttnParams p{(const u16*)Q, (const u16*)K, (const u16*)V, (u16*)O, ldq, ldk, ldv, ldo, Lq, Lk, heads, 0,
                scale * 1.4426950408889634f};
   hipStream_t st = (hipStream_t)stream;
   static const int force_qb = [] { const char* e = getenv("DM4D_ATTN_QB"); return e ? atoi(e) : 0; }();  // tuning aid
-  // 32 query rows per wave (120 VGPRs, 4 waves/SIMD) measured faster than 64 (204 VGPRs, 2 waves/SIMD) on
-  // every UNet shape (profiles/r01_attn_v2.log); the 64-row variant is kept for tuning (DM4D_ATTN_QB=2)
+  // 32 query rows per wave (4 waves/SIMD) measured faster than 64 (2 waves/SIMD) on every UNet shape
+  // (profiles/r01_*); the 64-row variant is kept for tuning (DM4D_ATTN_QB=2)
   const bool use2 = force_qb == 2;
   const int rows = NW * 32 * (use2 ? 2 : 1);
-  p.nqt = (L + rows - 1) / rows;
+  p.nqt = (Lq + rows - 1) / rows;
   const long nwg = (long)p.nqt * heads * batch;
   if (nwg > 0x7fffffffL) return dm4d_set_error(DM4D_ERR_ARG, "attention: grid too large");
+  static const int msum = [] { const char* e = getenv("DM4D_ATTN_MSUM"); return e ? atoi(e) : 0; }();  // tuning aid
   if (use2) {
-    hipLaunchKernelGGL((attn_kernel<2>), dim3((unsigned)nwg), dim3(NW * 64), 0, st, p);
+    hipLaunchKernelGGL((attn_kernel<2, false>), dim3((unsigned)nwg), dim3(NW * 64), 0, st, p);
+  } else if (msum) {
+    hipLaunchKernelGGL((attn_kernel<1, true>), dim3((unsigned)nwg), dim3(NW * 64), 0, st, p);
   } else {
-    hipLaunchKernelGGL((attn_kernel<1>), dim3((unsigned)nwg), dim3(NW * 64), 0, st, p);
+    hipLaunchKernelGGL((attn_kernel<1, false>), dim3((unsigned)nwg), dim3(NW * 64), 0, st, p);
   }
   return dm4d_check_launch("attn_kernel");
+}
+
+extern "C" int dm4d_attention_bf16(void* stream, const void* Q, const void* K, const void* V, void* O, int64_t ldq,
+                                   int64_t ldk, int64_t ldv, int64_t ldo, int batch, int heads, int L, float scale) {
+  return dm4d_attention_kv_bf16(stream, Q, K, V, O, ldq, ldk, ldv, ldo, batch, heads, L, L, scale);
 }

@@ -126,11 +126,15 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, heads: int, seq: int,
-              scale: Optional[float] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """q/k/v: [batch*seq, >=heads*64] row-strided views (e.g. column slices of the fused QKV output)."""
+              scale: Optional[float] = None, out: Optional[torch.Tensor] = None,
+              kv_seq: Optional[int] = None) -> torch.Tensor:
+    """q/k/v: [batch*seq, >=heads*64] row-strided views (e.g. column slices of the fused QKV output).
+    kv_seq: keys per batch when K/V hold more tokens than Q (frame-sharded 3-D attention); default = seq."""
     lib = _l.load()
     _req(q, "q"), _req(k, "k"), _req(v, "v")
     assert q.shape[0] == batch * seq and q.shape[1] == heads * 64, (q.shape, batch, seq, heads)
+    kv_seq = seq if kv_seq is None else kv_seq
+    assert k.shape[0] == batch * kv_seq and v.shape[0] == batch * kv_seq, (k.shape, batch, kv_seq)
     if out is None:
         out = torch.empty((batch * seq, heads * 64), dtype=BF16, device=q.device)
     if scale is None:
@@ -139,12 +143,12 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, hea
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    rc = lib.dm4d_attention_bf16(_stream(), _p(q), _p(k), _p(v), _p(out), q.stride(0), k.stride(0), v.stride(0),
-                                 out.stride(0), batch, heads, seq, scale)
+    rc = lib.dm4d_attention_kv_bf16(_stream(), _p(q), _p(k), _p(v), _p(out), q.stride(0), k.stride(0), v.stride(0),
+                                    out.stride(0), batch, heads, seq, kv_seq, scale)
     if prof is not None:
         e1.record()
-        prof.append(("attn_kernel", 4.0 * batch * heads * seq * seq * 64, e0, e1))
-    _l.check(rc, "dm4d_attention_bf16")
+        prof.append(("attn_kernel", 4.0 * batch * heads * seq * kv_seq * 64, e0, e1))
+    _l.check(rc, "dm4d_attention_kv_bf16")
     return out
 
 

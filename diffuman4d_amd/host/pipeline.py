@@ -96,8 +96,10 @@ class Diffuman4DPipeline:
         return pv_lat, pl_lat, sk_lat, cm_lat, lat
 
     # ------------------------------------------------------------------------------------------
-    def upload_plan(self, plan: SweepPlan, guidance_scale: float):
-        """Host plan -> device index / timestep / coefficient tables (one H2D each, no syncs later)."""
+    def upload_plan(self, plan: SweepPlan, guidance_scale: float, shard=None):
+        """Host plan -> device index / timestep / coefficient tables (one H2D each, no syncs later).
+        With `shard` (parallel.FrameShard) the per-call rows are cut down to this rank's frames of every window;
+        `win_full` keeps the whole window for the latent all-gather."""
         ts = self.scheduler.set_timesteps(plan.num_inference_steps)
         cfg = 2 if guidance_scale > 1 else 1
         win = np.stack(plan.windows).astype(np.int32)              # [calls, F]
@@ -105,32 +107,49 @@ class Diffuman4DPipeline:
         t = ts[np.stack(plan.timestep_index)].astype(np.int64)     # [calls, F]
         t[cond] = 0                                                # get_timestep :277
         coef = self.scheduler.step_coefficients(t)                 # [calls, F, 4]
+        win_full = win
+        if shard is not None:
+            sl = shard.local_frames(win.shape[1])
+            win, cond, t, coef = win[:, sl], cond[:, sl], t[:, sl], coef[:, sl]
         t_in = np.concatenate([t] * cfg, axis=1).astype(np.float32)
         dev = self._device
-        return dict(
-            win=torch.from_numpy(win).to(dev), cond=torch.from_numpy(cond.astype(np.int32)).to(dev),
-            t=torch.from_numpy(t_in).to(dev), coef=torch.from_numpy(coef).to(dev), calls=win.shape[0], cfg=cfg,
-        )
+
+        def up(a):
+            return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+        return dict(win=up(win), cond=up(cond.astype(np.int32)), t=up(t_in), coef=up(coef), calls=win.shape[0], cfg=cfg,
+                    win_full=up(win_full.astype(np.int64)))
 
     def denoise_latents(self, pv_lat, pl_lat, sk_lat, cm_lat, lat, plan: SweepPlan, domain: str, guidance_scale: float,
-                        tqdm: Callable = _identity_tqdm, tables=None):
-        """The window sweep (:521-543) on device-resident NHWC tensors; `lat` is updated in place."""
-        tb = tables or self.upload_plan(plan, guidance_scale)
+                        tqdm: Callable = _identity_tqdm, tables=None, shard=None):
+        """The window sweep (:521-543) on device-resident NHWC tensors; `lat` is updated in place.
+        shard (parallel.FrameShard): every rank holds the whole task tensors but runs only its F/P frames of each
+        window through the UNet (K/V all-gather inside the 3-D attention layers), then the updated latent rows are
+        all-gathered so that all copies of `lat` stay identical."""
+        tb = tables or self.upload_plan(plan, guidance_scale, shard)
         use_cfg = tb["cfg"] == 2
         N, h, w, _ = lat.shape
         HW = h * w
         lat3, pv3, pl3, cm3 = lat.view(N, HW, 4), pv_lat.view(N, HW, 4), pl_lat.view(N, HW, 6), cm_lat.view(N, HW, 1)
         sk3 = sk_lat.view(N, HW, 4) if sk_lat is not None else None
         vpred = self.scheduler.config.prediction_type == "v_prediction"
-        F = tb["win"].shape[1]
+        F = tb["win"].shape[1]  # frames of a window handled by THIS rank
         domains = [domain] * tb["cfg"]
         for i in tqdm(range(tb["calls"]), total=tb["calls"]):
-            widx, cond = tb["win"][i], tb["cond"][i]
-            x = ops.pack_model_input(lat3, pv3, pl3, sk3, cm3, cond, self.unet.IN_PAD, use_cfg, frame_idx=widx)
-            eps = self.unet(x.view(tb["cfg"] * F, h, w, self.unet.IN_PAD), tb["t"][i], domains=domains, num_frames=F)
-            ops.cfg_ddim_step(lat3, eps.view(tb["cfg"] * F, HW, -1), tb["coef"][i], cond, use_cfg, float(guidance_scale),
-                              vpred, frame_idx=widx)
+            self.window_call(lat3, pv3, pl3, sk3, cm3, tb, i, h, w, domains, guidance_scale, use_cfg, vpred, shard)
         return lat
+
+    def window_call(self, lat3, pv3, pl3, sk3, cm3, tb, i, h, w, domains, guidance_scale, use_cfg, vpred, shard=None):
+        """One window: pack -> UNet -> CFG + DDIM (pipeline_diffuman4d.py:369-423), all on device, no host sync."""
+        widx, cond = tb["win"][i], tb["cond"][i]
+        F, HW = widx.shape[0], h * w
+        x = ops.pack_model_input(lat3, pv3, pl3, sk3, cm3, cond, self.unet.IN_PAD, use_cfg, frame_idx=widx)
+        eps = self.unet(x.view(tb["cfg"] * F, h, w, self.unet.IN_PAD), tb["t"][i], domains=domains, num_frames=F, shard=shard)
+        ops.cfg_ddim_step(lat3, eps.view(tb["cfg"] * F, HW, -1), tb["coef"][i], cond, use_cfg, float(guidance_scale), vpred,
+                          frame_idx=widx)
+        if shard is not None:  # F/P updated rows per rank -> every rank's copy of the task latents
+            rows = shard.gather_rows(lat3.index_select(0, widx.long()))
+            lat3.index_copy_(0, tb["win_full"][i], rows)
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()

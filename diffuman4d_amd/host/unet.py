@@ -141,13 +141,20 @@ class _TransformerBlock:
             raise NotImplementedError("cross-attention (attn2) checkpoints are not supported: the reference never "
                                       "passes encoder_hidden_states (SURVEY.md section 0)")
 
-    def __call__(self, h: torch.Tensor, batch: int, seq: int) -> torch.Tensor:
-        """h [M, C] token-major; attention over `batch` sequences of `seq` tokens (attention.py:68-90)."""
+    def __call__(self, h: torch.Tensor, batch: int, seq: int, shard=None) -> torch.Tensor:
+        """h [M, C] token-major; attention over `batch` sequences of `seq` tokens (attention.py:68-90).
+        shard (parallel.FrameShard): `seq` is this rank's share of the frame-folded sequence; K/V are all-gathered."""
         C = h.shape[1]
         n = ops.layernorm(h, self.n1w, self.n1b, 1e-5)
-        qkv = ops.gemm(n, self.qkv)
-        a = ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], batch, self.heads, seq,
-                          scale=(C // self.heads) ** -0.5)
+        scale = (C // self.heads) ** -0.5
+        if shard is None:
+            qkv = ops.gemm(n, self.qkv)
+            a = ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], batch, self.heads, seq, scale=scale)
+        else:
+            q = ops.gemm(n, self.qkv[:C])
+            kv = ops.gemm(n, self.qkv[C:])  # [M, 2C] contiguous so the collective needs no repack
+            kvg = shard.gather_kv(kv.view(batch, seq, 2 * C)).view(batch * shard.world * seq, 2 * C)
+            a = ops.attention(q, kvg[:, :C], kvg[:, C:], batch, self.heads, seq, scale=scale, kv_seq=shard.world * seq)
         h = ops.gemm(a, self.ow, bias=self.ob, residual=h)
         n = ops.layernorm(h, self.n3w, self.n3b, 1e-5)
         f = ops.gemm(n, self.f1w, bias=self.f1b, geglu=True)
@@ -170,13 +177,13 @@ class _Transformer:
         if (self.piw.shape[0] // heads) != 64:
             raise NotImplementedError("the HIP attention kernel is specialised for head_dim 64")
 
-    def __call__(self, x: torch.Tensor, num_frames: int) -> torch.Tensor:
+    def __call__(self, x: torch.Tensor, num_frames: int, shard=None) -> torch.Tensor:
         B, H, Wd, C = x.shape
         M, HW = B * H * Wd, H * Wd
         n = ops.groupnorm(x, self.nw, self.nb, self.groups, 1e-6, silu=False)  # eps 1e-6: transformer_multiview.py:43-45
         h = ops.gemm(n.view(M, C), self.piw, bias=self.pib)
         for blk in self.blocks:
-            h = blk(h, B // num_frames, num_frames * HW)
+            h = blk(h, B // num_frames, num_frames * HW, shard)
         return ops.gemm(h, self.pow, bias=self.pob, residual=x.view(M, C)).view(B, H, Wd, C)
 
 
@@ -255,7 +262,7 @@ class UNetMultiviewConditionModel:
         return cls(cfg, load_file(str(files[0])), device)
 
     # -- forward --------------------------------------------------------------------------------
-    def _temb(self, timestep: torch.Tensor, domains: Sequence[str], num_frames: int) -> torch.Tensor:
+    def _temb(self, timestep: torch.Tensor, domains: Sequence[str], num_frames: int, shard=None) -> torch.Tensor:
         cfg = self.config
         c0 = cfg.block_out_channels[0]
         t_emb = ops.timestep_embedding(timestep.to(self.device, torch.float32), c0, cfg.flip_sin_to_cos, float(cfg.freq_shift))
@@ -264,13 +271,15 @@ class UNetMultiviewConditionModel:
             if len(domains) * num_frames != emb.shape[0]:
                 raise ValueError(f"num_frames: {num_frames} * len(domains): {len(domains)} != len(emb): {emb.shape[0]}")
             idx = []
+            world = shard.world if shard is not None else 1
             for d in domains:
                 if d == "spatial":
-                    idx.append(torch.zeros(num_frames))
+                    full = torch.zeros(num_frames * world)
                 elif d == "temporal":
-                    idx.append(torch.arange(num_frames // 2).repeat(2).float())
+                    full = torch.arange(num_frames * world // 2).repeat(2).float()
                 else:
                     raise ValueError(f"Invalid domain for temporal embedding: {d}")
+                idx.append(full if shard is None else full[shard.local_frames(num_frames * world)])
             f_emb = ops.timestep_embedding(torch.cat(idx).to(self.device), c0, True, 0.0)
             emb = ops.gemm(ops.gemm(f_emb, self.tpe[0], bias=self.tpe[1], silu=True), self.tpe[2], bias=self.tpe[3],
                            residual=emb)
@@ -278,36 +287,37 @@ class UNetMultiviewConditionModel:
 
     @torch.no_grad()
     def forward(self, sample: torch.Tensor, timestep: torch.Tensor, skeletons=None, domains: Sequence[str] = ("spatial",),
-                num_frames: int = 1) -> torch.Tensor:
-        """sample [B, h, w, 32] NHWC bf16 (channels beyond in_channels zero); timestep [B]; -> [B, h, w, out_channels]."""
+                num_frames: int = 1, shard=None) -> torch.Tensor:
+        """sample [B, h, w, 32] NHWC bf16 (channels beyond in_channels zero); timestep [B]; -> [B, h, w, out_channels].
+        With `shard` (parallel.FrameShard) sample/timestep hold this rank's frames and num_frames is the LOCAL count."""
         cfg = self.config
         if sample.shape[-1] != self.IN_PAD:
             raise ValueError(f"sample must be NHWC with {self.IN_PAD} (padded) channels")
         if sample.shape[0] % num_frames != 0:
             raise ValueError("batch must be a multiple of num_frames")
-        tproj = self._temb(timestep, domains, num_frames)
+        tproj = self._temb(timestep, domains, num_frames, shard)
         x = ops.conv3x3(sample, self.conv_in_w, bias=self.conv_in_b)
         skips = [x]
         nd = len(self.down)
         for i, (res, att, ds) in enumerate(self.down):
-            nf = num_frames if (att is not None and nd - i - 1 < cfg.num_3d_attn_blocks) else 1  # :560
+            is3d = att is not None and nd - i - 1 < cfg.num_3d_attn_blocks  # :560
             for j, r in enumerate(res):
                 x = r(x, tproj)
                 if att is not None:
-                    x = att[j](x, nf)
+                    x = att[j](x, num_frames if is3d else 1, shard if is3d else None)
                 skips.append(x)
             if ds is not None:
                 x = ops.conv3x3(x, ds[0], bias=ds[1], stride=2, pad=1)
                 skips.append(x)
         x = self.mid[0][0](x, tproj)
-        x = self.mid[1](x, num_frames)  # :570
+        x = self.mid[1](x, num_frames, shard)  # :570
         x = self.mid[0][1](x, tproj)
         for i, (res, att, us) in enumerate(self.up):
-            nf = num_frames if (att is not None and i < cfg.num_3d_attn_blocks) else 1  # :582
+            is3d = att is not None and i < cfg.num_3d_attn_blocks  # :582
             for j, r in enumerate(res):
                 x = r(x, tproj, skip=skips.pop())
                 if att is not None:
-                    x = att[j](x, nf)
+                    x = att[j](x, num_frames if is3d else 1, shard if is3d else None)
             if us is not None:
                 x = ops.conv3x3(x, us[0], bias=us[1], upsample=True)
         x = ops.groupnorm(x, self.no_w, self.no_b, cfg.norm_num_groups, cfg.norm_eps, silu=True)

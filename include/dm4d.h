@@ -81,6 +81,12 @@ int dm4d_layernorm_bf16(void* stream, const void* X, int64_t ldx, const void* ga
 int dm4d_attention_bf16(void* stream, const void* Q, const void* K, const void* V, void* O, int64_t ldq, int64_t ldk,
                         int64_t ldv, int64_t ldo, int batch, int heads, int L, float scale);
 
+/* Same kernel with separate query / key lengths: queries are the Lq local tokens of this rank, keys/values the Lk
+ *   tokens gathered from every rank (in-window frame sharding).  Element (b, t) of K/V lives at
+ *   ptr[(b*Lk + t)*ld + h*64 + d]; of Q/O at ptr[(b*Lq + t)*ld + h*64 + d].                                        */
+int dm4d_attention_kv_bf16(void* stream, const void* Q, const void* K, const void* V, void* O, int64_t ldq, int64_t ldk,
+                           int64_t ldv, int64_t ldo, int batch, int heads, int Lq, int Lk, float scale);
+
 /* Generic-head-dim attention pieces for the VAE mid block (single head, d = 512): row softmax.   */
 int dm4d_softmax_rows_bf16(void* stream, const void* S, int64_t lds, void* P, int64_t ldp, int M, int N, float scale);
 

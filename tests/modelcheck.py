@@ -90,6 +90,66 @@ def case_unet(num_frames=4, cfg_batch=2, h=16, w=8, tem=False, domain="spatial",
     return rel_l2(out, ref), rel_l2(ref_bf, ref)
 
 
+class _RecordShard:
+    """world-size-1 stand-in for parallel.FrameShard that records every K|V block it is asked to gather."""
+    rank, world = 0, 1
+
+    def __init__(self):
+        self.kv = []
+
+    def local_frames(self, n):
+        return slice(0, n)
+
+    def gather_kv(self, kv_local):
+        self.kv.append(kv_local.clone())
+        return kv_local
+
+
+class _ReplayShard:
+    """Rank r of P, single process: the all-gather is answered from the recording of the unsharded run, after
+    checking that this rank's contribution is bitwise the slice the real collective would have sent."""
+
+    def __init__(self, rank, world, recorded):
+        self.rank, self.world, self.rec, self.i, self.max_dev = rank, world, recorded, 0, 0.0
+
+    def local_frames(self, n):
+        fl = n // self.world
+        return slice(self.rank * fl, (self.rank + 1) * fl)
+
+    def gather_kv(self, kv_local):
+        full = self.rec[self.i]
+        self.i += 1
+        ls = kv_local.shape[1]
+        mine = full[:, self.rank * ls:(self.rank + 1) * ls]
+        self.max_dev = max(self.max_dev, float((mine.float() - kv_local.float()).abs().max()))
+        return full
+
+
+def case_unet_frame_shard(P=4, num_frames=8, h=16, w=8, tem=True, seed=0):
+    """In-window frame sharding: every rank's slice of the UNet output must equal the unsharded
+    output bitwise, and what it would contribute to each K/V all-gather must equal the unsharded K/V slice."""
+    from diffuman4d_amd.host import ops
+    cfg, om = make_unet(seed, enable_tem_embeds=tem)
+    hm = hip_unet(cfg, om)
+    g = torch.Generator().manual_seed(seed + 1)
+    B = 2 * num_frames
+    x = ops.nchw_to_nhwc(torch.randn(B, cfg.in_channels, h, w, generator=g).to(BF).cuda(), hm.IN_PAD)
+    t = torch.randint(0, 1000, (B,), generator=g).float().cuda()
+    rec = _RecordShard()
+    full = hm(x, t, domains=["temporal"] * 2, num_frames=num_frames, shard=rec)
+    base = hm(x, t, domains=["temporal"] * 2, num_frames=num_frames)
+    worst = float((full.float() - base.float()).abs().max())  # split Q / KV projection vs fused QKV
+    fl = num_frames // P
+    for r in range(P):
+        rows = torch.cat([torch.arange(r * fl, (r + 1) * fl), num_frames + torch.arange(r * fl, (r + 1) * fl)]).cuda()
+        sh = _ReplayShard(r, P, rec.kv)
+        out = hm(x.index_select(0, rows).contiguous(), t.index_select(0, rows).contiguous(), domains=["temporal"] * 2,
+                 num_frames=fl, shard=sh)
+        assert sh.i == len(rec.kv)
+        worst = max(worst, float((out.float() - full.index_select(0, rows).float()).abs().max()), sh.max_dev)
+    return worst, 0.0
+
+
 def case_vae(h=64, w=64, seed=1):
     from diffuman4d_amd.host import ops
     cfg, ov = make_vae(seed)
@@ -212,6 +272,8 @@ CASES = {
     "unet_spatial": (case_unet, dict(num_frames=4, cfg_batch=2)),
     "unet_temporal_temb": (case_unet, dict(num_frames=4, cfg_batch=2, tem=True, domain="temporal")),
     "unet_2d_only": (case_unet, dict(num_frames=1, cfg_batch=3, h=8, w=8)),
+    "unet_frame_shard_p4": (case_unet_frame_shard, dict(P=4, num_frames=8)),
+    "unet_frame_shard_p8": (case_unet_frame_shard, dict(P=8, num_frames=8, tem=False)),
     "vae": (case_vae, dict()),
     "resize": (case_resize, dict()),
     "pipeline_spatial": (case_pipeline, dict(domain="spatial")),
@@ -223,7 +285,7 @@ CASES = {
     "golden_round2_shift": (case_golden_pipeline, dict(name="round2_shift")),
 }
 # multi-layer bf16 pipelines: each of ~100 ops adds ~2e-3 of rounding noise; they add in quadrature
-TOL = {"unet_spatial": 3e-2, "unet_temporal_temb": 3e-2, "unet_2d_only": 3e-2, "vae": 3e-2, "resize": 4e-3,
+TOL = {"unet_frame_shard_p4": 0.0, "unet_frame_shard_p8": 0.0, "unet_spatial": 3e-2, "unet_temporal_temb": 3e-2, "unet_2d_only": 3e-2, "vae": 3e-2, "resize": 4e-3,
        "pipeline_spatial": 6e-2, "pipeline_temporal_v": 6e-2, "pipeline_bidir_nocfg": 6e-2,
        "golden_spatial": 6e-2, "golden_temporal_v": 6e-2, "golden_bidir_nocfg": 6e-2, "golden_round2_shift": 6e-2}
 

@@ -114,6 +114,24 @@ def case_attention(batch, heads, L, seed=0, spike=False):
     return rel_l2(out, ref), float((out.float().cpu() - ref).abs().max())
 
 
+def case_attention_kv_split(batch, heads, L, parts, seed=0):
+    """Frame-sharded 3-D attention: each rank's queries against the all-gathered K/V must reproduce the
+    unsharded result BITWISE (same key order, same tile boundaries)."""
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    C = heads * 64
+    qkv = _rnd((batch * L, 3 * C), g).to("cuda")
+    full = ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], batch, heads, L).view(batch, L, C)
+    ls = L // parts
+    kv = qkv[:, C:].contiguous()  # [batch*L, 2C] = what the all-gather assembles
+    worst = 0.0
+    for r in range(parts):
+        q_loc = qkv[:, :C].view(batch, L, C)[:, r * ls:(r + 1) * ls].reshape(batch * ls, C).contiguous()
+        out = ops.attention(q_loc, kv[:, :C], kv[:, C:], batch, heads, ls, kv_seq=L).view(batch, ls, C)
+        worst = max(worst, float((out.float() - full[:, r * ls:(r + 1) * ls].float()).abs().max()))
+    return worst, worst
+
+
 def case_groupnorm(B, HW, C1, C2, groups, silu, eps=1e-5, seed=0):
     from diffuman4d_amd.host import ops
     g = torch.Generator().manual_seed(seed)
@@ -262,6 +280,8 @@ CASES = {
     "attn_2d": (case_attention, dict(batch=8, heads=5, L=2880)),
     "attn_3d": (case_attention, dict(batch=2, heads=10, L=4320)),
     "attn_spike": (case_attention, dict(batch=1, heads=2, L=1000, spike=True)),
+    "attn_kv_split": (case_attention_kv_split, dict(batch=2, heads=2, L=16 * 180, parts=8)),
+    "attn_kv_split3": (case_attention_kv_split, dict(batch=2, heads=1, L=24 * 45, parts=3)),
     # --- norms -----------------------------------------------------------------------------------
     "gn_320": (case_groupnorm, dict(B=4, HW=720, C1=320, C2=0, groups=32, silu=True)),
     "gn_concat_1920": (case_groupnorm, dict(B=3, HW=180, C1=1280, C2=640, groups=32, silu=True)),
@@ -281,7 +301,7 @@ CASES = {
     "pack_ddim_noskel": (case_pack_ddim, dict(F_=8, HW=30, use_cfg=True, vpred=False, skel=False)),
 }
 
-TOLS = {"layout": 0.0, "temb": 6e-3}
+TOLS = {"layout": 0.0, "temb": 6e-3, "attn_kv_split": 0.0, "attn_kv_split3": 0.0}
 
 
 def run_case(name):
