@@ -48,12 +48,15 @@ def parse():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["task", "frame-shard"], default="task",
+                    help="multi-GPU decomposition: independent tasks per rank (default, weak scaling) or every window "
+                         "frame-sharded over all ranks with RCCL K/V all-gathers (strong scaling, BASELINE config 4)")
     ap.add_argument("--cpu-frames", type=int, default=4,
                     help="frames of the CPU-baseline UNet call (16 = a full spatial window, ~150 s on 256 cores)")
     return ap.parse_args()
 
 
-def build_tasks(pipe, dev):
+def build_tasks(pipe, dev, shard=None):
     """Device-resident synthetic task tensors + window plans for one spatial and one temporal task."""
     from diffuman4d_amd.host.schedule import plan_sweep
     g = torch.Generator(device=dev).manual_seed(1234)
@@ -66,34 +69,26 @@ def build_tasks(pipe, dev):
                             ("temporal", 2 * N_FRAMES, [i < N_FRAMES for i in range(2 * N_FRAMES)])):
         plan = plan_sweep(cond, [0] * n, domain, WINDOW, STRIDE, 0, False, 1, ROUNDS)
         mask = torch.tensor([0.0 if c else 1.0 for c in cond], device=dev).to(torch.bfloat16)
+        hw = LAT_H * LAT_W
         tasks[domain] = dict(
-            pv=rnd(n, LAT_H, LAT_W, 4, scale=0.18215 * 4), pl=rnd(n, LAT_H, LAT_W, 6, scale=0.5).clamp(-1, 1),
-            sk=rnd(n, LAT_H, LAT_W, 4, scale=0.18215 * 4), lat=rnd(n, LAT_H, LAT_W, 4),
-            cm=mask[:, None, None, None].expand(n, LAT_H, LAT_W, 1).contiguous(), plan=plan,
-            tables=pipe.upload_plan(plan, GUIDANCE), domain=domain)
+            pv=rnd(n, hw, 4, scale=0.18215 * 4), pl=rnd(n, hw, 6, scale=0.5).clamp(-1, 1),
+            sk=rnd(n, hw, 4, scale=0.18215 * 4), lat=rnd(n, hw, 4),
+            cm=mask[:, None, None].expand(n, hw, 1).contiguous(), plan=plan,
+            tables=pipe.upload_plan(plan, GUIDANCE, shard), domain=domain)
     return tasks
 
 
-def run_call(pipe, task, call_idx):
-    """One window call: pack -> UNet -> CFG + DDIM (Diffuman4DPipeline.denoise_latents body, one iteration)."""
-    from diffuman4d_amd.host import ops
+def run_call(pipe, task, call_idx, shard=None):
+    """One window call: pack -> UNet -> CFG + DDIM (Diffuman4DPipeline.window_call, the body of denoise_latents)."""
     tb = task["tables"]
-    i = call_idx % tb["calls"]
-    n = task["lat"].shape[0]
-    HW = LAT_H * LAT_W
-    F = tb["win"].shape[1]
-    lat3 = task["lat"].view(n, HW, 4)
-    x = ops.pack_model_input(lat3, task["pv"].view(n, HW, 4), task["pl"].view(n, HW, 6), task["sk"].view(n, HW, 4),
-                             task["cm"].view(n, HW, 1), tb["cond"][i], pipe.unet.IN_PAD, True, frame_idx=tb["win"][i])
-    eps = pipe.unet(x.view(2 * F, LAT_H, LAT_W, pipe.unet.IN_PAD), tb["t"][i], domains=[task["domain"]] * 2, num_frames=F)
-    ops.cfg_ddim_step(lat3, eps.view(2 * F, HW, -1), tb["coef"][i], tb["cond"][i], True, GUIDANCE, False,
-                      frame_idx=tb["win"][i])
+    pipe.window_call(task["lat"], task["pv"], task["pl"], task["sk"], task["cm"], tb, call_idx % tb["calls"], LAT_H, LAT_W,
+                     [task["domain"]] * 2, GUIDANCE, True, False, shard)
 
 
-def run_unit(pipe, tasks, u):
-    run_call(pipe, tasks["spatial"], 2 * u)
-    run_call(pipe, tasks["spatial"], 2 * u + 1)
-    run_call(pipe, tasks["temporal"], u)
+def run_unit(pipe, tasks, u, shard=None):
+    run_call(pipe, tasks["spatial"], 2 * u, shard)
+    run_call(pipe, tasks["spatial"], 2 * u + 1, shard)
+    run_call(pipe, tasks["temporal"], u, shard)
 
 
 def cpu_baseline(frames: int):
@@ -148,7 +143,13 @@ def main():
     cfg = UNetConfig()
     unet = UNetMultiviewConditionModel(cfg, random_state_dict(unet_param_shapes(cfg), 0, dev), dev)
     pipe = Diffuman4DPipeline(None, unet, DDIMScheduler(), dev)
-    tasks = build_tasks(pipe, dev)
+    shard = None
+    if args.mode == "frame-shard" and world > 1:
+        from diffuman4d_amd.host.parallel import FrameShard
+        shard = FrameShard()
+        if 16 % world or 24 % world:
+            raise SystemExit("frame-shard mode needs a rank count dividing both window sizes (16 and 24): 1, 2, 4 or 8")
+    tasks = build_tasks(pipe, dev, shard)
 
     def barrier():
         if world > 1:
@@ -157,12 +158,12 @@ def main():
 
     with torch.no_grad():
         for u in range(args.warmup):
-            run_unit(pipe, tasks, u)
+            run_unit(pipe, tasks, u, shard)
         barrier()
         ops.KERNEL_TIMER = timer = []
         t0 = time.perf_counter()
         for u in range(args.steps):
-            run_unit(pipe, tasks, args.warmup + u)
+            run_unit(pipe, tasks, args.warmup + u, shard)
         barrier()
         dt = time.perf_counter() - t0
         ops.KERNEL_TIMER = None
@@ -187,18 +188,20 @@ def main():
     if rank == 0:
         out = {
             "metric": "denoised view-frame latents/sec (44cam x 150fr grid)",
-            "value": round(world * args.steps * LATENTS_PER_UNIT / dt, 4),
+            "value": round((1 if shard is not None else world) * args.steps * LATENTS_PER_UNIT / dt, 4),
             "unit": "latents/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if shard is not None else "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {
                 "workload": "demo_4d 44cam x 150fr, sliding_fast (window 12, stride 2, 3 rounds, 18 steps/latent), "
                             "CFG 2.0, 72x40x4 latents; step = 2 spatial (F=16) + 1 temporal (F=24) window calls "
                             "= 2 denoised latents; VAE excluded",
                 "unet": "SD-2.1 geometry (320,640,1280,1280), 815.6M params, random init seed 0",
-                "parallelism": f"task-parallel x{world} (independent tasks per round)",
+                "parallelism": (f"frame-shard x{world} (every window split over all ranks, RCCL K/V all-gather per 3-D "
+                                f"attention layer)" if shard is not None else
+                                f"task-parallel x{world} (independent tasks per round, no data-path collective)"),
                 "finite_outputs": finite,
             },
             "roofline": {

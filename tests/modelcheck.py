@@ -150,6 +150,39 @@ def case_unet_frame_shard(P=4, num_frames=8, h=16, w=8, tem=True, seed=0):
     return worst, 0.0
 
 
+def case_pipeline_shard_world1(seed=21):
+    """denoise_latents with a REAL process group (RCCL, world size 1): the sharded code path (table slicing, K/V and
+    latent-row all-gathers, index_copy) must reproduce the plain path bitwise."""
+    import os
+    import torch.distributed as dist
+    from diffuman4d_amd.host.parallel import FrameShard
+    from diffuman4d_amd.host.pipeline import Diffuman4DPipeline
+    from diffuman4d_amd.host.schedule import plan_sweep
+    from diffuman4d_amd.host.scheduler import DDIMScheduler
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        cfg, om = make_unet(seed)
+        pipe = Diffuman4DPipeline(None, hip_unet(cfg, om), DDIMScheduler(), "cuda")
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        n, h, w = 8, 16, 8
+        rnd = lambda c, s=1.0: (torch.randn(n, h, w, c, generator=g, device="cuda") * s).to(BF)  # noqa: E731
+        cond = [i in (1, 5) for i in range(n)]
+        mask = torch.tensor([0.0 if c else 1.0 for c in cond], device="cuda").to(BF)[:, None, None, None].expand(n, h, w, 1).contiguous()
+        pv, pl, sk, lat0 = rnd(4), rnd(6, 0.5), rnd(4), rnd(4)
+        plan = plan_sweep(cond, [0] * n, "spatial", 4, 2, 0, False, 1, 1)
+        a = pipe.denoise_latents(pv, pl, sk, mask, lat0.clone(), plan, "spatial", 2.0)
+        b = pipe.denoise_latents(pv, pl, sk, mask, lat0.clone(), plan, "spatial", 2.0, shard=FrameShard())
+        return float((a.float() - b.float()).abs().max()), 0.0
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def case_vae(h=64, w=64, seed=1):
     from diffuman4d_amd.host import ops
     cfg, ov = make_vae(seed)
@@ -274,6 +307,7 @@ CASES = {
     "unet_2d_only": (case_unet, dict(num_frames=1, cfg_batch=3, h=8, w=8)),
     "unet_frame_shard_p4": (case_unet_frame_shard, dict(P=4, num_frames=8)),
     "unet_frame_shard_p8": (case_unet_frame_shard, dict(P=8, num_frames=8, tem=False)),
+    "pipeline_shard_rccl_world1": (case_pipeline_shard_world1, dict()),
     "vae": (case_vae, dict()),
     "resize": (case_resize, dict()),
     "pipeline_spatial": (case_pipeline, dict(domain="spatial")),
@@ -285,7 +319,7 @@ CASES = {
     "golden_round2_shift": (case_golden_pipeline, dict(name="round2_shift")),
 }
 # multi-layer bf16 pipelines: each of ~100 ops adds ~2e-3 of rounding noise; they add in quadrature
-TOL = {"unet_frame_shard_p4": 0.0, "unet_frame_shard_p8": 0.0, "unet_spatial": 3e-2, "unet_temporal_temb": 3e-2, "unet_2d_only": 3e-2, "vae": 3e-2, "resize": 4e-3,
+TOL = {"pipeline_shard_rccl_world1": 0.0, "unet_frame_shard_p4": 0.0, "unet_frame_shard_p8": 0.0, "unet_spatial": 3e-2, "unet_temporal_temb": 3e-2, "unet_2d_only": 3e-2, "vae": 3e-2, "resize": 4e-3,
        "pipeline_spatial": 6e-2, "pipeline_temporal_v": 6e-2, "pipeline_bidir_nocfg": 6e-2,
        "golden_spatial": 6e-2, "golden_temporal_v": 6e-2, "golden_bidir_nocfg": 6e-2, "golden_round2_shift": 6e-2}
 
