@@ -100,9 +100,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
   const int tasks = 32 * chunks_per_row;
   const bool vec_ok = ((p.ldc & 7) == 0) && ((p.N & 7) == 0) && (!p.res || (p.ld_res & 7) == 0) &&
                       (!p.rowbias || (p.ld_rb & 7) == 0);
+  // The staging area is private to a wave and LDS operations of one wave complete in program order, so only one
+  // workgroup barrier is needed: the one that retires every wave's main-loop fragment reads before the area is reused.
+  __syncthreads();
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    __syncthreads();
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       if (j < NJ) {
@@ -119,7 +121,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
         }
       }
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // compiler: keep the staging stores ahead of the row reads
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int id = lane; id < tasks; id += 64) {
       int row = id / chunks_per_row, cc = id % chunks_per_row;
       int m = m0 + wm * TM + i * 32 + row;
