@@ -4,18 +4,20 @@
 // MultiviewTransformerBlock (reference attention.py:68-83): the fold "(b t) hw c -> b (t hw) c" is
 // free because activations are token-major, so the kernel just sees batch = B/F, L = F*HW.
 //
-// Work decomposition: a workgroup = 8 waves (2 per SIMD, so one wave's softmax VALU work overlaps the
-// other's MFMAs); each wave owns QB blocks of 32 query rows; K/V tiles of 64 keys are staged
-// register-prefetch -> LDS, double buffered, one barrier per tile:
-//   Ks[key][d]   row-major, 144-byte rows          -> conflict-free ds_read_b128 A-fragments
-//   Vt[d][key']  TRANSPOSED, 144-byte rows, key' = key with bits 2 and 3 swapped, so that the
-//                8 keys a lane needs for one PV MFMA are one contiguous 16-byte read.
-// Math (v_mfma_f32_32x32x16_bf16), per 32-key block:
+// Work decomposition: a workgroup = 8 waves, each wave owns QB blocks of 32 query rows (QB = 1: 128 VGPRs,
+// 4 waves per SIMD, so other waves' softmax VALU work overlaps this wave's MFMAs); K/V tiles of 64 keys are
+// staged register-prefetch -> LDS, double buffered, one barrier per tile, both row-major:
+//   Ks[key][d]  144-byte rows  -> conflict-free ds_read_b128 A-fragments of S^T = K Q^T
+//   Vs[key][d]  192-byte rows  -> the V^T A-fragments of O^T = V^T P^T come out of ds_read_b64_tr_b16 (hardware
+//               transposing read of a [4 keys][16 d] block per 16-lane group; 4 consecutive rows tile the 64 banks)
+// Math (v_mfma_f32_32x32x16_bf16), per 32-key block, the two blocks of a tile software-pipelined:
 //   S^T = K Q^T   ("swapped" QK^T): lane (q = lane&31) holds 16 of the 32 scores of its query row,
 //                  so the row max needs a single cross-half exchange and the row sum none at all;
 //   O^T = V^T P^T: the P^T B-operand is exactly the packed bf16 (v_cvt_pk_bf16_f32) of the S^T
-//                  accumulator registers -- the k-index permutation is shared with the Vt image, so
-//                  no lane shuffles are needed between the two MFMAs.
+//                  accumulator registers: k-slot e of lane half h is key 4h + (e&3) + 8*(e>>2), and the
+//                  two tr-reads (keys 4h..4h+3 and 8+4h..) deliver V in that same order, so there are
+//                  no lane shuffles between the two MFMAs.
+// Keys may outnumber queries (Lk >= Lq): frame-sharded 3-D attention runs local queries against all-gathered K/V.
 // The O rescale is lazy: O and l are only rescaled when some row's running max grows by more than
 // 2^8 (exact arithmetic, P stays <= 256 in bf16); on typical data that is the first tiles only.
 // The 1-D grid is remapped so that all query tiles of one (batch, head) run on one XCD and share
