@@ -17,6 +17,10 @@
 //    chunk pos ^ ((row >> 1) & 7) of that row, and fragment reads apply the same XOR -- conflict-free
 //    ds_read_b128 for every 16-lane group.  Convolution padding / stride / upsample only change the
 //    per-lane source address (out-of-image taps read a 16-byte zero page).
+//  * conv_strip_kernel (stride-1 convs): same staging, but the A operand is loaded once per kernel row
+//    and read at three row offsets for kx = 0,1,2 (see the comment at the kernel).
+//  * gemm_kernel_pipe (K-slab 32, 3-4 LDS stages, counted vmcnt + raw s_barrier, 4 or 8 waves): the
+//    Linear layers, whose short K leaves the two-stage loop latency-bound.
 //  * gemm_kernel (fallback, K-slab 32, register staged, padded LDS rows): shapes whose K (or conv
 //    Cin) is a multiple of 32 but not of 64.
 //
@@ -308,6 +312,155 @@ __global__ __launch_bounds__(256) void gemm_kernel_glds(GemmParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();  // all waves done with `buf`; the DMA into buf^1 has landed (vmcnt(0) before the barrier)
+  }
+  gemm_epilogue<MI, NI, TM, TN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// stride-1 3x3 convolution with horizontal tap reuse ("strip" kernel)
+//
+// The M tile is BM consecutive output pixels of the flattened (b, y, x) index.  For one kernel row ky the three
+// taps kx = 0,1,2 read the SAME input pixels shifted by one flat position, so the A operand is staged once per
+// (ky, 64-channel slab) as a strip of BM+2 pixel rows (flat pixels m0-1 .. m0+BM, moved by (ky-1) image rows) and
+// the three taps read it at row offsets 0/1/2: A traffic into LDS drops 3x, total DMA bytes by about a third for a
+// 128x128 tile.  A strip row is zero-filled when ITS centre pixel's row y+ky-1 leaves the image; the only other
+// out-of-image case -- x-1 at x == 0 for kx = 0, x+1 at x == W-1 for kx = 2, where the flat shift wraps into the
+// neighbouring image row -- is removed by zeroing those lanes' A fragments.  K order is (ky, ci-slab, kx).
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void conv_strip_kernel(GemmParams p) {
+  constexpr int BK = 64;
+  constexpr int NW = WM * WN;
+  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
+  constexpr int SR = BM + 8;  // strip rows held in LDS (BM + 2 needed, DMA granularity is 8 rows)
+  constexpr int NA = SR / 8;  // 1-KiB DMA instructions per strip
+  constexpr int AW = (NA + NW - 1) / NW, BW = BN / (8 * NW);
+  constexpr int SMEM_MAIN = 2 * (SR + BN) * BK * 2;
+  constexpr int SMEM_EPI = NW * 32 * (TN + 4) * 4;
+  constexpr int SMEM_BYTES = SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI;
+  __shared__ __attribute__((aligned(16))) u16 smem[SMEM_BYTES / 2];
+  u16* As = smem;                // [2][SR][64]
+  u16* Bs = smem + 2 * SR * BK;  // [2][BN][64]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int d_row = lane >> 3, d_pos = lane & 7;
+
+  int a_off[AW];
+  unsigned a_ok[AW];  // bit ky: the strip row is inside the image for kernel row ky
+#pragma unroll
+  for (int i = 0; i < AW; ++i) {
+    const int row = (wave + NW * i) * 8 + d_row;
+    const int chunk = d_pos ^ ((row >> 1) & 7);
+    const int mc = m0 - 1 + row;  // centre output pixel served by this strip row
+    const bool inr = mc >= 0 && mc < p.M;
+    const int mcl = mc < 0 ? 0 : (mc > p.M - 1 ? p.M - 1 : mc);
+    const int y = (mcl / p.W) % p.H;
+    a_off[i] = mcl * p.Cin + chunk * 8;
+    a_ok[i] = inr ? ((y >= 1 ? 1u : 0u) | 2u | (y <= p.H - 2 ? 4u : 0u)) : 0u;
+  }
+  const u16* w_src[BW];
+#pragma unroll
+  for (int i = 0; i < BW; ++i) {
+    const int row = (wave + NW * i) * 8 + d_row;
+    const int chunk = d_pos ^ ((row >> 1) & 7);
+    int n = n0 + row;
+    if (n > p.N - 1) n = p.N - 1;
+    w_src[i] = p.Wt + (int64_t)n * p.ldw + chunk * 8;
+  }
+  bool x_first[MI], x_last[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int x = (m0 + wm * TM + i * 32 + l31) % p.W;
+    x_first[i] = x == 0;
+    x_last[i] = x == p.W - 1;
+  }
+
+  f32x16_t acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nci = p.Cin / BK;
+  const int nstrips = 3 * nci, nsteps = 3 * nstrips;
+  int i_ky = 0, i_cs = 0, i_kx = 0, i_step = 0, i_strip = 0;  // next step to be issued
+
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto issue_step = [&]() {
+    if (i_kx == 0) {
+      const int abuf = i_strip & 1;
+      const int dky = (i_ky - 1) * p.W * p.Cin + i_cs * BK;
+#pragma unroll
+      for (int i = 0; i < AW; ++i) {
+        const int ia = wave + NW * i;
+        if (ia < NA) {
+          const u16* src = ((a_ok[i] >> i_ky) & 1u) ? p.A + (a_off[i] + dky) : reinterpret_cast<const u16*>(g_zero16);
+          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (abuf * SR + ia * 8) * BK), 16, 0, 0);
+        }
+      }
+    }
+    const int bbuf = i_step & 1;
+    const int koff = (i_ky * 3 + i_kx) * p.Cin + i_cs * BK;
+#pragma unroll
+    for (int i = 0; i < BW; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + koff), (lptr_t)(Bs + (bbuf * BN + (wave + NW * i) * 8) * BK), 16, 0, 0);
+    ++i_step;
+    if (++i_kx == 3) {
+      i_kx = 0;
+      ++i_strip;
+      if (++i_cs == nci) {
+        i_cs = 0;
+        ++i_ky;
+      }
+    }
+  };
+
+  const int swb = (l31 >> 1) & 7;
+  issue_step();
+  __syncthreads();
+  for (int g = 0; g < nstrips; ++g) {
+    const int abuf = g & 1;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int bbuf = (g + kx) & 1;  // == (3 g + kx) & 1
+      if (g * 3 + kx + 1 < nsteps) issue_step();
+      const int swa = ((l31 + kx) >> 1) & 7;
+      bf16x8_t af[2][MI], bfr[2][NI];
+      auto read_frags = [&](int ks, int slot) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(As + (abuf * SR + wm * TM + i * 32 + l31 + kx) * BK +
+                                                          ((ks * 2 + lh) ^ swa) * 8);
+          if (kx == 0 && x_first[i]) a = bf16x8_t{};
+          if (kx == 2 && x_last[i]) a = bf16x8_t{};
+          af[slot][i] = a;
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          bfr[slot][j] =
+              *reinterpret_cast<const bf16x8_t*>(Bs + (bbuf * BN + wn * TN + j * 32 + l31) * BK + ((ks * 2 + lh) ^ swb) * 8);
+      };
+      read_frags(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks + 1 < 4) read_frags(ks + 1, (ks + 1) & 1);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
   }
   gemm_epilogue<MI, NI, TM, TN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
 }
@@ -621,6 +774,14 @@ int launch_pipe(hipStream_t st, GemmParams& p) {
   return dm4d_check_launch("gemm_kernel_pipe");
 }
 
+template <int BM, int BN, int WM, int WN>
+int launch_strip(hipStream_t st, GemmParams& p) {
+  const int tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  hipLaunchKernelGGL((conv_strip_kernel<BM, BN, WM, WN>), dim3(tiles_m * p.tiles_n), dim3(WM * WN * 64), 0, st, p);
+  return dm4d_check_launch("conv_strip_kernel");
+}
+
 int g_tune_cfg = 0;  // 0 = heuristic; otherwise a kernel-configuration id (tuning hook, dm4d_tune_set_gemm_config)
 
 // Kernel configurations.  glds: K-slab 64, 2 LDS stages, 4 waves.  pipe: K-slab 32, 3-4 stages, 4 or 8 waves.
@@ -643,6 +804,16 @@ int launch_by_id(int id, hipStream_t st, GemmParams& p) {
     case 16: return launch_pipe<256, 256, 2, 4, 3, CONV>(st, p);
     case 17: return launch_pipe<256, 64, 4, 1, 4, CONV>(st, p);
     case 18: return launch_pipe<128, 64, 4, 1, 4, CONV>(st, p);
+    case 31: case 32: case 33: case 34:
+      if constexpr (CONV) {
+        if (!(k64 && p.stride == 1 && p.pad == 1 && !p.upsample && p.Ho == p.H && p.Wo == p.W)) return DM4D_ERR_ARG;
+        if (id == 31) return launch_strip<128, 128, 2, 2>(st, p);
+        if (id == 32) return launch_strip<256, 128, 4, 2>(st, p);
+        if (id == 33) return launch_strip<128, 64, 4, 1>(st, p);
+        return launch_strip<256, 256, 2, 4>(st, p);
+      } else {
+        return DM4D_ERR_ARG;
+      }
     case 21: return launch_cfg<256, 128, 2, 2, CONV, false>(st, p);
     case 22: return launch_cfg<128, 128, 2, 2, CONV, false>(st, p);
     case 23: return launch_cfg<256, 64, 4, 1, CONV, false>(st, p);
@@ -670,7 +841,18 @@ int choose_cfg(const GemmParams& p) {
     const long t = tm256 * tn;  // one 8-wave workgroup per CU => 256 slots per round; avoid a mostly empty last round
     if (t >= 256 && 5 * t >= 4 * ((t + 255) / 256) * 256) return 14;
   } else {
-    // convs have 9x the K depth; 128x128 / 2 workgroups per CU is best except for wide, tall problems
+    // stride-1 convs: the strip kernels stage A once per kernel row (profiles/r01_conv_strip.log)
+    if (p.stride == 1 && p.pad == 1 && !p.upsample && p.Ho == p.H && p.Wo == p.W) {
+      if (!n128) {
+        if (tm128 * ((p.N + 63) / 64) >= 256) return 33;
+      } else {
+        const long t = tm256 * tn;
+        if (p.N % 256 == 0 && tm256 * (p.N / 256) >= 160) return 34;
+        if (t >= 200 && 5 * t >= 4 * ((t + 255) / 256) * 256) return 32;
+        if (tm128 * tn >= 256) return 31;
+      }
+    }
+    // other convs: 128x128 / 2 workgroups per CU is best except for wide, tall problems
     if (!geglu && p.N % 256 == 0 && tm256 * (p.N / 256) >= 384) return 13;
   }
   if (n128) {

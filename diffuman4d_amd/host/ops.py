@@ -93,6 +93,23 @@ def conv3x3(x: torch.Tensor, wt: torch.Tensor, *, bias=None, rowbias=None, resid
     return y
 
 
+def conv2d_direct(x: torch.Tensor, wt: torch.Tensor, *, ksize: int, bias=None, stride: int = 1, pad: int = 1,
+                  silu: bool = False) -> torch.Tensor:
+    """Thin-layer convolution (PoseEncoder): x [B,H,W,Cin] NHWC, wt [Cout, ksize*ksize*Cin] ((ky,kx,ci) order)."""
+    lib = _l.load()
+    _req(x, "x"), _req(wt, "wt")
+    assert x.is_contiguous() and wt.is_contiguous()
+    B, H, W, Cin = x.shape
+    Cout = wt.shape[0]
+    assert wt.shape[1] == ksize * ksize * Cin, (wt.shape, ksize, Cin)
+    Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
+    y = torch.empty((B, Ho, Wo, Cout), dtype=BF16, device=x.device)
+    rc = lib.dm4d_conv2d_direct_nhwc_bf16(_stream(), _p(x), B, H, W, Cin, _p(wt), _p(bias), _p(y), Ho, Wo, Cout, ksize,
+                                          stride, pad, 1 if silu else 0)
+    _l.check(rc, "dm4d_conv2d_direct_nhwc_bf16")
+    return y
+
+
 def groupnorm(x1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, *,
               x2: Optional[torch.Tensor] = None, silu: bool = False) -> torch.Tensor:
     """GroupNorm(+SiLU) over the channel concat [x1 | x2]; x [B, HW, C] (any leading spatial shape)."""

@@ -16,7 +16,7 @@ from __future__ import annotations
 
 import json
 from pathlib import Path
-from typing import Callable, Dict, Optional
+from typing import Callable, Dict, NamedTuple, Optional
 
 import numpy as np
 import torch
@@ -31,6 +31,12 @@ BF16 = torch.bfloat16
 
 def _identity_tqdm(it, **kw):
     return it
+
+
+class PoseFeatures(NamedTuple):
+    """enable_pose_encoder checkpoints: PoseEncoder outputs for the task's skeleton images and for the CFG negative."""
+    feat: torch.Tensor  # [N, h, w, C0]
+    neg: torch.Tensor   # [1, h, w, C0]  (all -1 image, pipeline_diffuman4d.py:352-353)
 
 
 class Diffuman4DPipeline:
@@ -84,8 +90,14 @@ class Diffuman4DPipeline:
         h, w = pv_lat.shape[1:3]
         pl_lat = self.vae.resize_to_nhwc(plucker_embeds, (h, w), "bilinear")
         if self.unet.config.enable_pose_encoder:
-            raise NotImplementedError("enable_pose_encoder")
-        sk_lat = self.vae.encode_scaled(skeletons, noise.get("skeleton")) if skeletons is not None else None
+            # the reference hands the raw skeleton images to the UNet, which re-encodes them on every call
+            # (:229-231; unet_multiview_condition.py:551-552); they do not change, so encode once per task
+            sk = self._to_dev_nhwc(skeletons, 4)
+            neg = torch.full_like(sk[:1], -1.0)
+            neg[..., 3] = 0.0  # channel 3 is padding
+            sk_lat = PoseFeatures(self.unet.pose_encoder(sk), self.unet.pose_encoder(neg))
+        else:
+            sk_lat = self.vae.encode_scaled(skeletons, noise.get("skeleton")) if skeletons is not None else None
         cm_lat = self.vae.resize_to_nhwc(cond_masks, (h, w), "nearest")
         if latents is None:
             if "latents" in noise:
@@ -131,7 +143,10 @@ class Diffuman4DPipeline:
         N, h, w, _ = lat.shape
         HW = h * w
         lat3, pv3, pl3, cm3 = lat.view(N, HW, 4), pv_lat.view(N, HW, 4), pl_lat.view(N, HW, 6), cm_lat.view(N, HW, 1)
-        sk3 = sk_lat.view(N, HW, 4) if sk_lat is not None else None
+        if isinstance(sk_lat, PoseFeatures):
+            sk3 = sk_lat
+        else:
+            sk3 = sk_lat.view(N, HW, 4) if sk_lat is not None else None
         vpred = self.scheduler.config.prediction_type == "v_prediction"
         F = tb["win"].shape[1]  # frames of a window handled by THIS rank
         domains = [domain] * tb["cfg"]
@@ -143,8 +158,15 @@ class Diffuman4DPipeline:
         """One window: pack -> UNet -> CFG + DDIM (pipeline_diffuman4d.py:369-423), all on device, no host sync."""
         widx, cond = tb["win"][i], tb["cond"][i]
         F, HW = widx.shape[0], h * w
+        pose = None
+        if isinstance(sk3, PoseFeatures):  # negative half: features of the all -1 skeleton image (:352-353)
+            pose = sk3.feat.index_select(0, widx.long())
+            if use_cfg:
+                pose = torch.cat([sk3.neg.expand(F, -1, -1, -1), pose])
+            sk3 = None
         x = ops.pack_model_input(lat3, pv3, pl3, sk3, cm3, cond, self.unet.IN_PAD, use_cfg, frame_idx=widx)
-        eps = self.unet(x.view(tb["cfg"] * F, h, w, self.unet.IN_PAD), tb["t"][i], domains=domains, num_frames=F, shard=shard)
+        eps = self.unet(x.view(tb["cfg"] * F, h, w, self.unet.IN_PAD), tb["t"][i], domains=domains, num_frames=F, shard=shard,
+                        pose_features=pose)
         ops.cfg_ddim_step(lat3, eps.view(tb["cfg"] * F, HW, -1), tb["coef"][i], cond, use_cfg, float(guidance_scale), vpred,
                           frame_idx=widx)
         if shard is not None:  # F/P updated rows per rank -> every rank's copy of the task latents

@@ -97,6 +97,41 @@ class _Weights:
         return wp.reshape(cout_pad, 9 * cin_pad).to(self.device, BF16).contiguous()
 
 
+class _PoseEncoder:
+    """pose_encoder.py:11-54: eight thin conv+SiLU layers (direct-conv kernel), a 1x1 projection and a learned scale.
+    Input: skeleton images NHWC bf16 [B, 8h, 8w, 4] (3 channels + one zero pad); output [B, h, w, C0]."""
+
+    LAYERS = ((3, 3, 3, 1), (3, 16, 4, 2), (16, 16, 3, 1), (16, 32, 4, 2), (32, 32, 3, 1), (32, 64, 4, 2),
+              (64, 64, 3, 1), (64, 128, 3, 1))  # (Cin, Cout, kernel, stride), padding 1
+
+    def __init__(self, W: _Weights, pfx: str):
+        self.layers = []
+        for n, (ci, co, k, s) in enumerate(self.LAYERS):
+            w = W.get(pfx + f"conv_layers.{2 * n}.weight").float()
+            b = W.get(pfx + f"conv_layers.{2 * n}.bias").float()
+            if tuple(w.shape) != (co, ci, k, k):
+                raise ValueError(f"pose_encoder.conv_layers.{2 * n}: unexpected weight shape {tuple(w.shape)}")
+            cip, cop = _round_up(ci, 4), _round_up(co, 4)
+            wp, bp = torch.zeros(cop, k, k, cip), torch.zeros(cop)
+            wp[:co, :, :, :ci] = w.permute(0, 2, 3, 1)
+            bp[:co] = b
+            self.layers.append((wp.reshape(cop, k * k * cip).to(W.device, BF16).contiguous(), bp.to(W.device, BF16), k, s))
+        self.proj_w, self.proj_b = W.linear(pfx + "final_proj.weight"), W.vec(pfx + "final_proj.bias")
+        self.scale = float(W.get(pfx + "scale").to(BF16).float().reshape(-1)[0])
+
+    def __call__(self, x: torch.Tensor, batch: int = 16) -> torch.Tensor:
+        if x.shape[-1] != 4:
+            raise ValueError("pose encoder input must be NHWC with 4 (3 + pad) channels")
+        outs = []
+        for xb in x.split(batch):
+            y = xb.contiguous()
+            for (w, b, k, s) in self.layers:
+                y = ops.conv2d_direct(y, w, ksize=k, bias=b, stride=s, pad=1, silu=True)
+            B, h, wd, C = y.shape
+            outs.append(ops.gemm(y.view(B * h * wd, C), self.proj_w, bias=self.proj_b, out_scale=self.scale).view(B, h, wd, -1))
+        return outs[0] if len(outs) == 1 else torch.cat(outs)
+
+
 class _Resnet:
     def __init__(self, W: _Weights, pfx: str, groups: int, eps: float, scale: float, temb_list: List):
         self.groups, self.eps, self.scale = groups, eps, scale
@@ -195,8 +230,6 @@ class UNetMultiviewConditionModel:
     def __init__(self, config: UNetConfig, state_dict: Dict[str, torch.Tensor], device="cuda"):
         cfg = self.config = config
         self.device = torch.device(device)
-        if cfg.enable_pose_encoder:
-            raise NotImplementedError("enable_pose_encoder checkpoints are not supported by the HIP path yet")
         if cfg.cross_attention_dim is not None:
             raise NotImplementedError("cross_attention_dim must be None (SURVEY.md section 0)")
         if cfg.in_channels > self.IN_PAD:
@@ -209,6 +242,7 @@ class UNetMultiviewConditionModel:
         self.conv_in_b = W.vec("conv_in.bias")
         self.te = [W.linear("time_embedding.linear_1.weight"), W.vec("time_embedding.linear_1.bias"),
                    W.linear("time_embedding.linear_2.weight"), W.vec("time_embedding.linear_2.bias")]
+        self.pose_encoder = _PoseEncoder(W, "pose_encoder.") if cfg.enable_pose_encoder else None
         self.tpe = None
         if cfg.enable_tem_embeds:
             self.tpe = [W.linear("temporal_pos_embed.linear_1.weight"), W.vec("temporal_pos_embed.linear_1.bias"),
@@ -287,16 +321,28 @@ class UNetMultiviewConditionModel:
 
     @torch.no_grad()
     def forward(self, sample: torch.Tensor, timestep: torch.Tensor, skeletons=None, domains: Sequence[str] = ("spatial",),
-                num_frames: int = 1, shard=None) -> torch.Tensor:
+                num_frames: int = 1, shard=None, pose_features: Optional[torch.Tensor] = None) -> torch.Tensor:
         """sample [B, h, w, 32] NHWC bf16 (channels beyond in_channels zero); timestep [B]; -> [B, h, w, out_channels].
-        With `shard` (parallel.FrameShard) sample/timestep hold this rank's frames and num_frames is the LOCAL count."""
+        With `shard` (parallel.FrameShard) sample/timestep hold this rank's frames and num_frames is the LOCAL count.
+        enable_pose_encoder checkpoints (:551-552): pass `skeletons` [B, 8h, 8w, 4] NHWC (encoded here, as the
+        reference does on every call) or `pose_features` [B, h, w, C0] computed once with ``self.pose_encoder``."""
         cfg = self.config
         if sample.shape[-1] != self.IN_PAD:
             raise ValueError(f"sample must be NHWC with {self.IN_PAD} (padded) channels")
         if sample.shape[0] % num_frames != 0:
             raise ValueError("batch must be a multiple of num_frames")
         tproj = self._temb(timestep, domains, num_frames, shard)
-        x = ops.conv3x3(sample, self.conv_in_w, bias=self.conv_in_b)
+        if self.pose_encoder is not None:
+            if pose_features is None:
+                if skeletons is None:
+                    raise ValueError("enable_pose_encoder: skeletons or pose_features are required")
+                pose_features = self.pose_encoder(skeletons)
+            if pose_features.shape[:3] != sample.shape[:3]:
+                raise ValueError("pose features do not match the sample's batch / latent size")
+            pose_features = pose_features.contiguous()
+        else:
+            pose_features = None
+        x = ops.conv3x3(sample, self.conv_in_w, bias=self.conv_in_b, residual=pose_features)
         skips = [x]
         nd = len(self.down)
         for i, (res, att, ds) in enumerate(self.down):

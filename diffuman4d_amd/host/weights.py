@@ -66,6 +66,14 @@ def unet_param_shapes(cfg: UNetConfig) -> Shapes:
         s[n + ".linear_1.bias"] = (temb,)
         s[n + ".linear_2.weight"] = (temb, temb)
         s[n + ".linear_2.bias"] = (temb,)
+    if cfg.enable_pose_encoder:  # pose_encoder.py:11-36
+        from .unet import _PoseEncoder
+        for n, (ci, co, k, _) in enumerate(_PoseEncoder.LAYERS):
+            s[f"pose_encoder.conv_layers.{2 * n}.weight"] = (co, ci, k, k)
+            s[f"pose_encoder.conv_layers.{2 * n}.bias"] = (co,)
+        s["pose_encoder.final_proj.weight"] = (boc[0], 128, 1, 1)
+        s["pose_encoder.final_proj.bias"] = (boc[0],)
+        s["pose_encoder.scale"] = (1,)
     out_c = boc[0]
     for i, t in enumerate(cfg.down_block_types):
         in_c, out_c = out_c, boc[i]

@@ -61,6 +61,14 @@ int dm4d_conv3x3_nhwc_bf16(void* stream, const void* X, int B, int H, int W, int
                            int Wo, int Cout, int stride, int pad, int upsample, const void* bias, const void* rowbias,
                            int64_t ld_rowbias, const void* residual, int64_t ld_res, float out_scale);
 
+/* Direct (fp32 FMA) convolution for thin layers, NHWC: the PoseEncoder's conv stack
+ *   (pose_encoder.py:14-31: 3x3 stride 1 / 4x4 stride 2, padding 1, 3..64 input channels, SiLU after each).
+ *   X [B,H,W,Cin], Wt [Cout][ksize*ksize][Cin], Y [B,Ho,Wo,Cout]; Cin, Cout multiples of 4 (zero-pad the 3-channel
+ *   image and the first layer's filters); ksize <= 4; Ho = (H + 2*pad - ksize)/stride + 1.                        */
+int dm4d_conv2d_direct_nhwc_bf16(void* stream, const void* X, int B, int H, int W, int Cin, const void* Wt,
+                                 const void* bias, void* Y, int Ho, int Wo, int Cout, int ksize, int stride, int pad,
+                                 int apply_silu);
+
 /* GroupNorm (+SiLU) over [X1 | X2] (channel concat, X2 may be NULL), NHWC.
  *   replaces nn.GroupNorm + SiLU in ResnetBlock2D.norm1/norm2, TransformerMultiviewModel.norm
  *   (transformer_multiview.py:43-45), conv_norm_out (unet_multiview_condition.py:590-592).

@@ -65,9 +65,9 @@ def hip_vae(cfg, oracle_model):
     return AutoencoderKL(VAEConfig.from_dict(asdict(cfg)), oracle_model.state_dict(), "cuda")
 
 
-def case_unet(num_frames=4, cfg_batch=2, h=16, w=8, tem=False, domain="spatial", seed=0):
+def case_unet(num_frames=4, cfg_batch=2, h=16, w=8, tem=False, domain="spatial", seed=0, pose=False):
     from diffuman4d_amd.host import ops
-    cfg, om = make_unet(seed, enable_tem_embeds=tem)
+    cfg, om = make_unet(seed, enable_tem_embeds=tem, **(dict(enable_pose_encoder=True, in_channels=11) if pose else {}))
     if tem:  # the temporal embedding MLP is zero-initialised in training; randomise it so it is exercised
         g = torch.Generator().manual_seed(seed + 5)
         with torch.no_grad():
@@ -79,13 +79,15 @@ def case_unet(num_frames=4, cfg_batch=2, h=16, w=8, tem=False, domain="spatial",
     x = (torch.randn(B, cfg.in_channels, h, w, generator=g)).to(BF)
     t = torch.randint(0, 1000, (B,), generator=g)
     domains = [domain] * cfg_batch
+    sk = (torch.rand(B, 3, 8 * h, 8 * w, generator=g) * 2 - 1).to(BF) if pose else None  # raw skeleton images (:551)
     with torch.no_grad():
-        ref = om(x.float(), t, domains=domains, num_frames=num_frames)
+        ref = om(x.float(), t, skeletons=sk.float() if pose else None, domains=domains, num_frames=num_frames)
         om_bf = om.to(BF)
-        ref_bf = om_bf(x, t, domains=domains, num_frames=num_frames).float()
+        ref_bf = om_bf(x, t, skeletons=sk, domains=domains, num_frames=num_frames).float()
         om.float()
     xd = ops.nchw_to_nhwc(x.cuda(), hm.IN_PAD)
-    out = hm(xd, t.float().cuda(), domains=domains, num_frames=num_frames)
+    out = hm(xd, t.float().cuda(), skeletons=ops.nchw_to_nhwc(sk.cuda(), 4) if pose else None, domains=domains,
+             num_frames=num_frames)
     out = ops.nhwc_to_nchw(out)
     return rel_l2(out, ref), rel_l2(ref_bf, ref)
 
@@ -240,13 +242,13 @@ def synthetic_task(n, H, W, input_rows, seed=7):
 
 
 def case_pipeline(domain="spatial", n_cams=8, T=4, window=4, stride=2, rounds=1, steps=1, bidir=False, gs=2.0,
-                  pred="epsilon", seed=11):
+                  pred="epsilon", seed=11, pose=False):
     """One full task through sliding_iterative_denoise (VAE encode -> window sweep -> VAE decode)."""
     from diffuman4d_amd.host.pipeline import Diffuman4DPipeline
     from diffuman4d_amd.host.scheduler import DDIMConfig as HC, DDIMScheduler as HS
     from oracle.ddim import DDIMConfig, DDIMScheduler
     from oracle.pipeline import OraclePipeline
-    cfg_u, ou = make_unet(seed)
+    cfg_u, ou = make_unet(seed, **(dict(enable_pose_encoder=True, in_channels=11) if pose else {}))
     cfg_v, ov = make_vae(seed + 1)
     H, W = 64, 64
     if domain == "spatial":
@@ -308,6 +310,8 @@ CASES = {
     "unet_frame_shard_p4": (case_unet_frame_shard, dict(P=4, num_frames=8)),
     "unet_frame_shard_p8": (case_unet_frame_shard, dict(P=8, num_frames=8, tem=False)),
     "pipeline_shard_rccl_world1": (case_pipeline_shard_world1, dict()),
+    "unet_pose_encoder": (case_unet, dict(num_frames=4, cfg_batch=2, pose=True)),
+    "pipeline_pose_encoder": (case_pipeline, dict(domain="spatial", pose=True)),
     "vae": (case_vae, dict()),
     "resize": (case_resize, dict()),
     "pipeline_spatial": (case_pipeline, dict(domain="spatial")),
@@ -319,7 +323,7 @@ CASES = {
     "golden_round2_shift": (case_golden_pipeline, dict(name="round2_shift")),
 }
 # multi-layer bf16 pipelines: each of ~100 ops adds ~2e-3 of rounding noise; they add in quadrature
-TOL = {"pipeline_shard_rccl_world1": 0.0, "unet_frame_shard_p4": 0.0, "unet_frame_shard_p8": 0.0, "unet_spatial": 3e-2, "unet_temporal_temb": 3e-2, "unet_2d_only": 3e-2, "vae": 3e-2, "resize": 4e-3,
+TOL = {"pipeline_shard_rccl_world1": 0.0, "unet_frame_shard_p4": 0.0, "unet_frame_shard_p8": 0.0, "unet_spatial": 3e-2, "unet_temporal_temb": 3e-2, "unet_2d_only": 3e-2, "unet_pose_encoder": 3e-2, "pipeline_pose_encoder": 6e-2, "vae": 3e-2, "resize": 4e-3,
        "pipeline_spatial": 6e-2, "pipeline_temporal_v": 6e-2, "pipeline_bidir_nocfg": 6e-2,
        "golden_spatial": 6e-2, "golden_temporal_v": 6e-2, "golden_bidir_nocfg": 6e-2, "golden_round2_shift": 6e-2}
 

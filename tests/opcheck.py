@@ -95,6 +95,31 @@ def case_conv(B, H, W, Cin, Cout, stride=1, pad=1, pad_hi=None, upsample=False, 
     return rel_l2(out, ref), float((out.float().cpu() - ref).abs().max())
 
 
+def case_conv_direct(B, H, W, Cin, Cout, k, stride, silu=True, seed=0):
+    """PoseEncoder layers (pose_encoder.py:14-31): thin direct convolution, channels zero-padded to multiples of 4."""
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    x = _rnd((B, Cin, H, W), g)
+    w = _rnd((Cout, Cin, k, k), g, 1.0 / math.sqrt(k * k * Cin))
+    b = _rnd((Cout,), g, 0.5)
+    ref = F.conv2d(x.float(), w.float(), b.float(), stride=stride, padding=1)
+    if silu:
+        ref = F.silu(ref)
+    cip, cop = (Cin + 3) // 4 * 4, (Cout + 3) // 4 * 4
+    xp = torch.zeros(B, H, W, cip, dtype=BF)
+    xp[..., :Cin] = x.permute(0, 2, 3, 1)
+    wp = torch.zeros(cop, k, k, cip, dtype=BF)
+    wp[:Cout, :, :, :Cin] = w.permute(0, 2, 3, 1)
+    bp = torch.zeros(cop, dtype=BF)
+    bp[:Cout] = b
+    out = ops.conv2d_direct(xp.cuda(), wp.reshape(cop, -1).contiguous().cuda(), ksize=k, bias=bp.cuda(), stride=stride,
+                            pad=1, silu=silu)
+    pad_ok = bool((out[..., Cout:] == 0).all())
+    out = out[..., :Cout].permute(0, 3, 1, 2)
+    assert tuple(out.shape) == tuple(ref.shape), (out.shape, ref.shape)
+    return (rel_l2(out, ref) if pad_ok else 1.0), float((out.float().cpu() - ref).abs().max())
+
+
 def case_attention(batch, heads, L, seed=0, spike=False):
     from diffuman4d_amd.host import ops
     g = torch.Generator().manual_seed(seed)
@@ -273,6 +298,18 @@ CASES = {
     "conv_vae_down": (case_conv, dict(B=2, H=16, W=12, Cin=32, Cout=32, stride=2, pad=0, pad_hi=1)),
     "conv_cin32_cout4": (case_conv, dict(B=4, H=36, W=20, Cin=32, Cout=4)),
     "conv_big": (case_conv, dict(B=8, H=36, W=20, Cin=320, Cout=320, rowbias=True, residual=True)),
+    # stride-1 strip kernels (horizontal tap reuse): one case per tile configuration the heuristic picks
+    "conv_strip_128x64": (case_conv, dict(B=10, H=36, W=20, Cin=64, Cout=320, rowbias=True)),
+    "conv_strip_256x128": (case_conv, dict(B=256, H=9, W=5, Cin=64, Cout=640, residual=True)),
+    "conv_strip_256x256": (case_conv, dict(B=16, H=36, W=20, Cin=64, Cout=1024)),
+    "conv_strip_128x128": (case_conv, dict(B=11, H=36, W=20, Cin=128, Cout=640, rowbias=True, residual=True)),
+    "conv_strip_w1": (case_conv, dict(B=2, H=5800, W=1, Cin=64, Cout=640)),
+    # --- thin direct convs (PoseEncoder) ---------------------------------------------------------
+    "convd_3to3_k3": (case_conv_direct, dict(B=2, H=40, W=24, Cin=3, Cout=3, k=3, stride=1)),
+    "convd_3to16_k4s2": (case_conv_direct, dict(B=2, H=40, W=24, Cin=3, Cout=16, k=4, stride=2)),
+    "convd_16to32_k4s2": (case_conv_direct, dict(B=3, H=20, W=12, Cin=16, Cout=32, k=4, stride=2)),
+    "convd_32to64_k4s2_odd": (case_conv_direct, dict(B=2, H=11, W=7, Cin=32, Cout=64, k=4, stride=2)),
+    "convd_64to128_k3": (case_conv_direct, dict(B=2, H=9, W=5, Cin=64, Cout=128, k=3, stride=1, silu=False)),
     # --- attention -------------------------------------------------------------------------------
     "attn_small": (case_attention, dict(batch=2, heads=2, L=128)),
     "attn_tail45": (case_attention, dict(batch=3, heads=1, L=45)),
