@@ -118,6 +118,49 @@ def golden_pipeline():
     torch.save(out, OUT / "pipeline_sliding.pt")
 
 
+def golden_pose():
+    """enable_pose_encoder checkpoints (pose_encoder.py; unet_multiview_condition.py:551-552;
+    pipeline_diffuman4d.py:229-231,352-353,389-395): the reference UNet and pipeline with raw skeleton images."""
+    from oracle.ddim import DDIMConfig
+    pose_kw = dict(enable_pose_encoder=True, in_channels=11)
+    cfg, om = mc.make_unet(5, **pose_kw)
+    ref = ref_unet_from(cfg, om)
+    nf = 4
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2 * nf, cfg.in_channels, 16, 8, generator=g)
+    t = torch.randint(0, 1000, (2 * nf,), generator=g)
+    sk = torch.rand(2 * nf, 3, 128, 64, generator=g) * 2 - 1
+    with torch.no_grad():
+        y = ref(x, timestep=t, skeletons=sk, domains=["spatial"] * 2, num_frames=nf, return_dict=False)[0]
+        y_oracle = om(x, t, skeletons=sk, domains=["spatial"] * 2, num_frames=nf)
+    print(f"unet[pose_encoder]: reference vs oracle rel_l2 = {float((y - y_oracle).norm() / y.norm()):.2e}")
+    out = dict(unet=dict(cfg_kw=pose_kw, seed=5, data_seed=6, num_frames=nf, y=y))
+
+    c = dict(domain="spatial", n=8, inputs=[1, 5], pred="epsilon",
+             kw=dict(window_size=4, sliding_stride=2, sliding_shift=0, bidirectional=False, num_denoising_steps=1,
+                     alternation_rounds=1, guidance_scale=2.0))
+    cfg_u, ou = mc.make_unet(11, **pose_kw)
+    cfg_v, ov = mc.make_vae(12)
+    pipe = RefPipeline(vae=refshim.AutoencoderKL(ov), unet=ref_unet_from(cfg_u, ou),
+                       scheduler=refshim.DDIMSchedulerAdapter(DDIMConfig(prediction_type=c["pred"])))
+    n = c["n"]
+    pv, pl, sk, cm = mc.synthetic_task(n, 64, 64, c["inputs"], 11)
+    g = torch.Generator().manual_seed(13)
+    noise = {k: torch.randn(n, 4, 8, 8, generator=g) for k in ("pixel", "latents")}
+    tidx = torch.zeros(n, dtype=torch.int64)
+    refshim.NOISE_QUEUE.clear()
+    refshim.NOISE_QUEUE.extend([noise["pixel"], noise["latents"]])  # skeletons are not VAE-encoded in this mode
+    res = pipe.sliding_iterative_denoise(pixel_values=pv, plucker_embeds=pl, skeletons=sk, cond_masks=cm, latents=None,
+                                         domain=c["domain"], timestep_indices=tidx.clone(),
+                                         tqdm=lambda it, total=None: it, **c["kw"])
+    assert not refshim.NOISE_QUEUE
+    out["pipeline"] = dict(case=c, cfg_kw=pose_kw, seeds=dict(unet=11, vae=12, task=11, noise=13), noise=noise,
+                           latents_in=None, timestep_indices_in=tidx, latents=res["latents"], images=res["images"].half(),
+                           timestep_indices=res["timestep_indices"], fully_denoised=res["fully_denoised"])
+    print(f"pipeline[pose_encoder]: idx {res['timestep_indices'].tolist()} denoised {int(res['fully_denoised'].sum())}")
+    torch.save(out, OUT / "pose_encoder.pt")
+
+
 def golden_sampler():
     """Task lists, labels and per-call bookkeeping of the reference sampler driving a recording stub."""
     from src.samplers.sliding_iterative_sampler import SlidingIterativeSampler as RefSampler
@@ -150,7 +193,9 @@ def golden_sampler():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    golden_unet()
-    golden_pipeline()
-    golden_sampler()
+    only = sys.argv[1:]  # e.g. `make_golden.py pose` regenerates one fixture file
+    for name, fn in (("unet", golden_unet), ("pipeline", golden_pipeline), ("sampler", golden_sampler),
+                     ("pose", golden_pose)):
+        if not only or name in only:
+            fn()
     print("golden fixtures written to", OUT)

@@ -286,9 +286,10 @@ def case_golden_pipeline(name):
     fixture tests/golden/pipeline_sliding.pt, fp32): same seeded weights, task tensors and noise."""
     from diffuman4d_amd.host.pipeline import Diffuman4DPipeline
     from diffuman4d_amd.host.scheduler import DDIMConfig as HC, DDIMScheduler as HS
-    g = torch.load(Path(__file__).resolve().parent / "golden" / "pipeline_sliding.pt")[name]
+    gdir = Path(__file__).resolve().parent / "golden"
+    g = torch.load(gdir / "pose_encoder.pt")["pipeline"] if name == "pose_encoder" else torch.load(gdir / "pipeline_sliding.pt")[name]
     c, seeds = g["case"], g["seeds"]
-    cfg_u, ou = make_unet(seeds["unet"])
+    cfg_u, ou = make_unet(seeds["unet"], **g.get("cfg_kw", {}))
     cfg_v, ov = make_vae(seeds["vae"])
     pv, pl, sk, cm = synthetic_task(c["n"], 64, 64, c["inputs"], seeds["task"])
     hp = Diffuman4DPipeline(hip_vae(cfg_v, ov), hip_unet(cfg_u, ou), HS(HC(prediction_type=c["pred"])), "cuda")
@@ -321,11 +322,12 @@ CASES = {
     "golden_temporal_v": (case_golden_pipeline, dict(name="temporal_v")),
     "golden_bidir_nocfg": (case_golden_pipeline, dict(name="bidir_nocfg")),
     "golden_round2_shift": (case_golden_pipeline, dict(name="round2_shift")),
+    "golden_pose_encoder": (case_golden_pipeline, dict(name="pose_encoder")),
 }
 # multi-layer bf16 pipelines: each of ~100 ops adds ~2e-3 of rounding noise; they add in quadrature
 TOL = {"pipeline_shard_rccl_world1": 0.0, "unet_frame_shard_p4": 0.0, "unet_frame_shard_p8": 0.0, "unet_spatial": 3e-2, "unet_temporal_temb": 3e-2, "unet_2d_only": 3e-2, "unet_pose_encoder": 3e-2, "pipeline_pose_encoder": 6e-2, "vae": 3e-2, "resize": 4e-3,
        "pipeline_spatial": 6e-2, "pipeline_temporal_v": 6e-2, "pipeline_bidir_nocfg": 6e-2,
-       "golden_spatial": 6e-2, "golden_temporal_v": 6e-2, "golden_bidir_nocfg": 6e-2, "golden_round2_shift": 6e-2}
+       "golden_spatial": 6e-2, "golden_temporal_v": 6e-2, "golden_bidir_nocfg": 6e-2, "golden_round2_shift": 6e-2, "golden_pose_encoder": 6e-2}
 
 
 def run_case(name):

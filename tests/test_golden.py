@@ -35,6 +35,33 @@ def test_oracle_unet_matches_reference_unet(name):
     assert rel(y, g["y"]) <= 1e-6
 
 
+def test_oracle_pose_encoder_unet_matches_reference():
+    g = torch.load(G / "pose_encoder.pt")["unet"]
+    cfg, om = mc.make_unet(g["seed"], **g["cfg_kw"])
+    nf = g["num_frames"]
+    gen = torch.Generator().manual_seed(g["data_seed"])
+    x = torch.randn(2 * nf, cfg.in_channels, 16, 8, generator=gen)
+    t = torch.randint(0, 1000, (2 * nf,), generator=gen)
+    sk = torch.rand(2 * nf, 3, 128, 64, generator=gen) * 2 - 1
+    with torch.no_grad():
+        y = om(x, t, skeletons=sk, domains=["spatial"] * 2, num_frames=nf)
+    assert rel(y, g["y"]) <= 1e-6
+
+
+def test_oracle_pose_encoder_pipeline_matches_reference():
+    g = torch.load(G / "pose_encoder.pt")["pipeline"]
+    c, seeds = g["case"], g["seeds"]
+    _, ou = mc.make_unet(seeds["unet"], **g["cfg_kw"])
+    _, ov = mc.make_vae(seeds["vae"])
+    pv, pl, sk, cm = mc.synthetic_task(c["n"], 64, 64, c["inputs"], seeds["task"])
+    op = OraclePipeline(ov, ou, DDIMScheduler(DDIMConfig(prediction_type=c["pred"])), torch.float32)
+    res = op.sliding_iterative_denoise(pv, pl, sk, cm, None, c["domain"], g["timestep_indices_in"], g["noise"], **c["kw"])
+    assert torch.equal(res["timestep_indices"], g["timestep_indices"])
+    assert torch.equal(res["fully_denoised"], g["fully_denoised"])
+    assert rel(res["latents"], g["latents"]) <= 1e-5
+    assert rel(res["images"], g["images"]) <= 1e-3
+
+
 @pytest.mark.parametrize("name", ["spatial", "temporal_v", "bidir_nocfg", "round2_shift"])
 def test_oracle_pipeline_matches_reference_pipeline(name):
     g = torch.load(G / "pipeline_sliding.pt")[name]
