@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--mode", choices=["task", "frame-shard"], default="task",
                     help="multi-GPU decomposition: independent tasks per rank (default, weak scaling) or every window "
                          "frame-sharded over all ranks with RCCL K/V all-gathers (strong scaling, BASELINE config 4)")
+    ap.add_argument("--latent", default="72x40",
+                    help="latent grid HxW: 72x40 = BASELINE.json's synthetic grid (default, the judged line); 128x128 = the "
+                         "1024^2 images the reference's demo configs run (SURVEY.md 8d asks for both)")
     ap.add_argument("--cpu-frames", type=int, default=4,
                     help="frames of the CPU-baseline UNet call (16 = a full spatial window, ~150 s on 256 cores)")
     return ap.parse_args()
@@ -112,14 +115,18 @@ def cpu_baseline(frames: int):
         "value": round(targets / STEPS_PER_LATENT / dt, 5), "unit": "latents/s", "cores": torch.get_num_threads(),
         "kind": "port",
         "sample": f"one spatial-window UNet forward of the CPU oracle (fp32, F={frames} of 16 frames, CFG batch {B}, "
-                  f"72x40 latents) = {dt:.1f} s; {targets:.1f} latent-steps / {STEPS_PER_LATENT} steps per latent "
+                  f"{LAT_H}x{LAT_W} latents) = {dt:.1f} s; {targets:.1f} latent-steps / {STEPS_PER_LATENT} steps per latent "
                   f"(3-D attention cost grows with F^2, so the full F=16 window is slower per latent: 148 s measured)",
         "seconds": round(dt, 2),
     }
 
 
 def main():
+    global LAT_H, LAT_W
     args = parse()
+    LAT_H, LAT_W = (int(v) for v in args.latent.lower().split("x"))
+    if LAT_H % 8 or LAT_W % 8:
+        raise SystemExit("--latent: both sides must be multiples of 8 (three UNet down-samplings)")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -178,7 +185,7 @@ def main():
     # the factor 2 being the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md (HBM section).  Static file, not live.
     traffic = None
     tf = ROOT / "profiles" / "r01_attn_traffic_pmc.json"
-    if tf.exists():
+    if tf.exists() and (LAT_H, LAT_W) == (72, 40):
         t = json.loads(tf.read_text())
         traffic = int((2 * t["FETCH_SIZE"]["avg_kb"] + t["WRITE_SIZE"]["avg_kb"]) * 1024)
     attn_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in timer)
@@ -196,7 +203,7 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {
                 "workload": "demo_4d 44cam x 150fr, sliding_fast (window 12, stride 2, 3 rounds, 18 steps/latent), "
-                            "CFG 2.0, 72x40x4 latents; step = 2 spatial (F=16) + 1 temporal (F=24) window calls "
+                            f"CFG 2.0, {LAT_H}x{LAT_W}x4 latents; step = 2 spatial (F=16) + 1 temporal (F=24) window calls "
                             "= 2 denoised latents; VAE excluded",
                 "unet": "SD-2.1 geometry (320,640,1280,1280), 815.6M params, random init seed 0",
                 "parallelism": (f"frame-shard x{world} (every window split over all ranks, RCCL K/V all-gather per 3-D "

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Profiles of the bench command on a GPU box (run through gpurun from the repo root):
+#   gpurun --timeout 900 -- 'bash tools/profile_bench.sh <tag>'
+# 1. rocprofv3 --kernel-trace --stats      -> gpurun_out/<tag>_kernel_stats.txt   (per-kernel time table)
+# 2. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel trace only, as MI355X_MICROARCH.md's HBM section
+#    prescribes)                            -> gpurun_out/<tag>_attn_traffic_pmc.json (per-launch averages for attn_kernel)
+# Copy the two files into profiles/ to have them judged.
+set -u
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+BENCH="python bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
+OUT=gpurun_out/prof_$TAG
+rm -rf "$OUT"
+rocprofv3 --kernel-trace --stats -d "$OUT" -o stats -- $BENCH > "$OUT.bench.log" 2> "$OUT.stats.err"
+DB=$(find "$OUT" -name "stats*results.db" | head -1)
+python tools/profile_summary.py "$DB" "rocprofv3 --kernel-trace --stats -- $BENCH ($TAG; 3 units incl. warmup + weight-init kernels)" \
+  > gpurun_out/${TAG}_kernel_stats.txt
+tail -1 "$OUT.bench.log" > gpurun_out/${TAG}_bench_under_rocprof.json
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $C -d "$OUT" -o pmc_$C -- $BENCH > /dev/null 2> "$OUT.pmc_$C.err"
+done
+python tools/pmc_summary.py "$OUT" attn_kernel FETCH_SIZE WRITE_SIZE > gpurun_out/${TAG}_attn_traffic_pmc.json
+head -12 gpurun_out/${TAG}_kernel_stats.txt
+cat gpurun_out/${TAG}_attn_traffic_pmc.json
