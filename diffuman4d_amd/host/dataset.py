@@ -19,6 +19,7 @@ class SyntheticSpaTemDataset:
                  data_dir: str = "", seed: int = 1234, **_ignored):
         self.scene_label, self.height, self.width = scene_label, height, width
         self.num_cameras, self.data_dir, self.seed = num_cameras, data_dir, seed
+        self._plucker_cache: Dict[int, torch.Tensor] = {}
 
     # -- geometry ---------------------------------------------------------------------------------
     def _camera(self, cam: int):
@@ -33,6 +34,8 @@ class SyntheticSpaTemDataset:
 
     def _plucker(self, cam: int) -> torch.Tensor:
         """[6, H, W]: unit ray direction d and moment o x d (ray_utils.py:101-112 convention)."""
+        if cam in self._plucker_cache:  # a camera's map is the same for every frame
+            return self._plucker_cache[cam]
         H, W = self.height, self.width
         o, R = self._camera(cam)
         f = 1.2 * W
@@ -40,9 +43,10 @@ class SyntheticSpaTemDataset:
                                 indexing="ij")
         d_cam = torch.stack([(xs - W / 2) / f, -(ys - H / 2) / f, torch.ones_like(xs)], dim=0)
         d = torch.einsum("ij,jhw->ihw", R, d_cam)
-        d = d / d.norm(dim=0, keepdim=True)
+        d = d / torch.sqrt((d * d).sum(0, keepdim=True))
         m = torch.linalg.cross(o[:, None, None].expand_as(d), d, dim=0)
-        return torch.cat([d, m], dim=0)
+        out = self._plucker_cache[cam] = torch.cat([d, m], dim=0)
+        return out
 
     def nearest_input_camera(self, cam: int, input_cams: Sequence[int]) -> int:
         o = self._camera(cam)[0]

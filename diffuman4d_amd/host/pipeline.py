@@ -48,6 +48,10 @@ class Diffuman4DPipeline:
         self._device = dev
         self.dtype = BF16
         self.vae_scale_factor = vae.scale_factor if vae is not None else 8
+        self._vae_cache: Dict[str, dict] = {"pixel": {}, "skeleton": {}}  # encoder moments by caller-supplied key
+
+    def clear_vae_cache(self):
+        self._vae_cache = {"pixel": {}, "skeleton": {}}
 
     @property
     def device(self) -> torch.device:
@@ -82,11 +86,15 @@ class Diffuman4DPipeline:
         x = x.to(device=self._device, dtype=BF16).contiguous()
         return ops.nchw_to_nhwc(x, cpad)
 
-    def prepare_all_latents(self, pixel_values, plucker_embeds, skeletons, cond_masks, latents, noise: Optional[Dict]):
-        """pipeline_diffuman4d.py:193-263 (sliding entry).  Returns NHWC bf16 device tensors."""
+    def prepare_all_latents(self, pixel_values, plucker_embeds, skeletons, cond_masks, latents, noise: Optional[Dict],
+                            cache_keys=None):
+        """pipeline_diffuman4d.py:193-263 (sliding entry).  Returns NHWC bf16 device tensors.
+        cache_keys: one hashable key per frame (e.g. (camera, frame) labels) -> VAE encoder moments are reused
+        across tasks and alternation rounds (see AutoencoderKL.encode_scaled)."""
         noise = noise or {}
         n = pixel_values.shape[0]
-        pv_lat = self.vae.encode_scaled(pixel_values, noise.get("pixel"))  # [N,h,w,4], x scaling_factor
+        ck = dict(cache=self._vae_cache["pixel"], keys=cache_keys) if cache_keys is not None else {}
+        pv_lat = self.vae.encode_scaled(pixel_values, noise.get("pixel"), **ck)  # [N,h,w,4], x scaling_factor
         h, w = pv_lat.shape[1:3]
         pl_lat = self.vae.resize_to_nhwc(plucker_embeds, (h, w), "bilinear")
         if self.unet.config.enable_pose_encoder:
@@ -97,7 +105,8 @@ class Diffuman4DPipeline:
             neg[..., 3] = 0.0  # channel 3 is padding
             sk_lat = PoseFeatures(self.unet.pose_encoder(sk), self.unet.pose_encoder(neg))
         else:
-            sk_lat = self.vae.encode_scaled(skeletons, noise.get("skeleton")) if skeletons is not None else None
+            ck = dict(cache=self._vae_cache["skeleton"], keys=cache_keys) if cache_keys is not None else {}
+            sk_lat = self.vae.encode_scaled(skeletons, noise.get("skeleton"), **ck) if skeletons is not None else None
         cm_lat = self.vae.resize_to_nhwc(cond_masks, (h, w), "nearest")
         if latents is None:
             if "latents" in noise:
@@ -179,8 +188,15 @@ class Diffuman4DPipeline:
                                   latents=None, domain: str = "spatial", timestep_indices=None, window_size: int = 12,
                                   sliding_stride: int = 1, sliding_shift: int = 0, bidirectional: bool = True,
                                   num_denoising_steps: int = 1, alternation_rounds: int = 3, guidance_scale: float = 2.0,
-                                  tqdm: Callable = _identity_tqdm, noise: Optional[Dict] = None):
-        """Same contract as pipeline_diffuman4d.py:439-559 (inputs are not mutated)."""
+                                  tqdm: Callable = _identity_tqdm, noise: Optional[Dict] = None, cache_keys=None,
+                                  decode: str = "all"):
+        """Same contract as pipeline_diffuman4d.py:439-559 (inputs are not mutated).
+        Extensions, off by default (= the reference's behaviour): `noise` injects the random draws; `cache_keys`
+        (one hashable per frame) reuses VAE encoder moments across calls; `decode="denoised"` runs the VAE decoder
+        only for fully denoised rows -- the only ones the sampler saves (sampling_utils.py:103-104) -- and returns
+        zero images for the rest."""
+        if decode not in ("all", "denoised"):
+            raise ValueError("decode must be 'all' or 'denoised'")
         if self.vae is None:
             raise RuntimeError("this pipeline was built without a VAE; use denoise_latents()")
         torch.cuda.set_device(self._device)  # worker threads inherit device 0 (sampling_runner.py:36)
@@ -188,10 +204,11 @@ class Diffuman4DPipeline:
         plan = plan_sweep(cond_flags, torch.as_tensor(timestep_indices).cpu().numpy(), domain, window_size,
                           sliding_stride, sliding_shift, bidirectional, num_denoising_steps, alternation_rounds)
         pv_lat, pl_lat, sk_lat, cm_lat, lat = self.prepare_all_latents(pixel_values, plucker_embeds, skeletons,
-                                                                       cond_masks, latents, noise)
+                                                                       cond_masks, latents, noise, cache_keys)
         self.denoise_latents(pv_lat, pl_lat, sk_lat, cm_lat, lat, plan, domain, guidance_scale, tqdm)
-        images = self.vae.decode_to_images(lat)  # [N,3,H,W] in [0,1]
         tidx = torch.from_numpy(plan.final_timestep_indices)
+        rows = (tidx == plan.num_inference_steps) if decode == "denoised" else None
+        images = self.vae.decode_to_images(lat, rows=rows)  # [N,3,H,W] in [0,1]
         return {
             "images": images,
             "latents": ops.nhwc_to_nchw(lat),

@@ -47,6 +47,9 @@ class SlidingIterativeSampler:
         tem_labels: Optional[Sequence[int]] = None,
         input_spa_labels: Sequence[int] = (1, 13, 25, 37),
         result_writer: Optional[Callable] = None,
+        # MI355X pipeline extensions (off = the reference's behaviour; need a pipeline that accepts the kwargs)
+        vae_cache: bool = False,
+        decode_policy: str = "all",
     ):
         self.dataset = dataset
         self.pipelines = pipelines
@@ -61,6 +64,12 @@ class SlidingIterativeSampler:
         if result_writer is None:
             from .results import save_sampling_results as result_writer
         self.result_writer = result_writer
+        if decode_policy not in ("all", "denoised"):
+            raise ValueError("decode_policy must be 'all' or 'denoised'")
+        self.vae_cache, self.decode_policy = bool(vae_cache), decode_policy
+        if self.vae_cache:
+            for p in pipelines:
+                p.clear_vae_cache()
 
         if spa_labels is not None:
             self.spa_labels = [f"{int(i):02d}" for i in spa_labels]
@@ -191,6 +200,7 @@ class SlidingIterativeSampler:
             alternation_rounds=self.alternation_rounds,
             guidance_scale=self.guidance_scale,
             tqdm=partial(_tqdm, desc=f"Denoising {task_label} on {pipeline.device}"),
+            **self._pipeline_extensions(sample),
         )
         with self.lock:
             for label, latent, timestep_index in zip(sample["labels"], result["latents"], result["timestep_indices"]):
@@ -201,6 +211,17 @@ class SlidingIterativeSampler:
         sample["timestep_indices"] = result["timestep_indices"].cpu()
         sample["fully_denoised"] = result["fully_denoised"].cpu()
         return sample
+
+    def _pipeline_extensions(self, sample: dict) -> dict:
+        """Keyword arguments beyond the reference protocol: VAE encoder-moment reuse keyed by (camera, frame) -- every
+        image is otherwise re-encoded by each task that touches it, in every round (pipeline_diffuman4d.py:208-239) --
+        and decoding only the rows that are saved (sampling_utils.py:103-104)."""
+        kw = {}
+        if self.vae_cache:
+            kw["cache_keys"] = [(spa, tem) for _, spa, tem in sample["labels"]]
+        if self.decode_policy != "all":
+            kw["decode"] = self.decode_policy
+        return kw
 
     def execute_one_task(self, task: dict, pipe_idx: int = 0) -> dict:
         sample = self.load_sample(**task)

@@ -179,14 +179,37 @@ class AutoencoderKL:
         B, h, w, _ = x.shape
         return ops.gemm(x.view(-1, PAD), self.quant_w, bias=self.quant_b).view(B, h, w, -1)
 
-    def encode_scaled(self, images: torch.Tensor, noise: Optional[torch.Tensor], batch_size: int = 8) -> torch.Tensor:
+    def encode_scaled(self, images: torch.Tensor, noise: Optional[torch.Tensor], batch_size: int = 8,
+                      cache: Optional[dict] = None, keys=None) -> torch.Tensor:
         """pipeline_diffuman4d.py:47-56: images NCHW in [-1,1] (CPU or GPU) -> latents NHWC * scaling_factor.
-        `noise` NCHW [N, lc, h, w] (any device) is the posterior draw; drawn on the device if None."""
+        `noise` NCHW [N, lc, h, w] (any device) is the posterior draw; drawn on the device if None.
+        `cache` / `keys` (one hashable key per image): the encoder's posterior MOMENTS are deterministic, so images
+        seen before (the reference re-encodes all 2N images of every task in every alternation round) skip the
+        encoder; the stochastic draw is still fresh for every call, i.e. the sampled distribution is unchanged."""
         lc = self.config.latent_channels
+        n = images.shape[0]
+        if cache is None:
+            todo = list(range(n))
+        else:
+            if keys is None or len(keys) != n:
+                raise ValueError("encode_scaled: one cache key per image is required")
+            todo = [i for i in range(n) if keys[i] not in cache]
+        fresh = {}
+        for j in range(0, len(todo), batch_size):
+            idx = todo[j:j + batch_size]
+            sel = images[idx[0]:idx[-1] + 1] if idx == list(range(idx[0], idx[-1] + 1)) else images[idx]
+            m = self.moments(ops.nchw_to_nhwc(sel.to(self.device, BF16).contiguous(), PAD))
+            for k, i in enumerate(idx):
+                fresh[i] = m[k]
+        if cache is not None:
+            for i, m in fresh.items():
+                cache[keys[i]] = m.clone()
+            rows = [cache[keys[i]] for i in range(n)]
+        else:
+            rows = [fresh[i] for i in range(n)]
         outs = []
-        for i in range(0, images.shape[0], batch_size):
-            xb = images[i:i + batch_size].to(self.device, BF16).contiguous()
-            m = self.moments(ops.nchw_to_nhwc(xb, PAD))
+        for i in range(0, n, batch_size):
+            m = torch.stack(rows[i:i + batch_size])
             B, h, w, _ = m.shape
             if noise is not None:
                 nb = ops.nchw_to_nhwc(noise[i:i + batch_size].to(self.device, BF16).contiguous())
@@ -210,13 +233,28 @@ class AutoencoderKL:
         x = ops.groupnorm(x, self.d_nw, self.d_nb, self.config.norm_num_groups, 1e-6, silu=True)
         return ops.conv3x3(x, self.d_out_w, bias=self.d_out_b)
 
-    def decode_to_images(self, lat_nhwc: torch.Tensor, batch_size: int = 8) -> torch.Tensor:
-        """pipeline_diffuman4d.py:59-72,280-285: latents NHWC -> images NCHW in [0,1]."""
+    def decode_to_images(self, lat_nhwc: torch.Tensor, batch_size: int = 8, rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """pipeline_diffuman4d.py:59-72,280-285: latents NHWC -> images NCHW in [0,1].
+        `rows` (bool [N]): decode only these latents; the other output images are zero."""
+        if rows is None:
+            sel = lat_nhwc
+        else:
+            idx = torch.nonzero(rows.to(lat_nhwc.device)).flatten()
+            sel = lat_nhwc.index_select(0, idx)
         outs = []
-        for i in range(0, lat_nhwc.shape[0], batch_size):
-            z = ops.scale_pad(lat_nhwc[i:i + batch_size].contiguous(), PAD, 1.0 / self.config.scaling_factor)
+        for i in range(0, sel.shape[0], batch_size):
+            z = ops.scale_pad(sel[i:i + batch_size].contiguous(), PAD, 1.0 / self.config.scaling_factor)
             outs.append(ops.postprocess_images(self.decode(z), self.config.out_channels))
-        return torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
+        if rows is None:
+            return torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
+        f = self.scale_factor
+        if not outs:  # nothing to decode (an early alternation round): a zero-stride host tensor, no device traffic
+            return torch.zeros(1).expand(lat_nhwc.shape[0], self.config.out_channels, lat_nhwc.shape[1] * f,
+                                         lat_nhwc.shape[2] * f)
+        full = torch.zeros((lat_nhwc.shape[0], self.config.out_channels, lat_nhwc.shape[1] * f, lat_nhwc.shape[2] * f),
+                           dtype=outs[0].dtype, device=lat_nhwc.device)
+        full.index_copy_(0, idx, torch.cat(outs, dim=0) if len(outs) > 1 else outs[0])
+        return full
 
     # ---- conditioning resize (encode_image_resizing, :90-100) -----------------------------------
     def resize_to_nhwc(self, images: torch.Tensor, size, mode: str, batch_size: int = 16) -> torch.Tensor:

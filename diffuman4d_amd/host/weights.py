@@ -177,3 +177,36 @@ def random_state_dict(shapes: Shapes, seed: int = 0, device="cpu", dtype=torch.b
             t = 0.05 * torch.randn(shp, generator=g, device=device, dtype=torch.float32)
         out[k] = t.to(dtype)
     return out
+
+
+def write_synthetic_checkpoint(model_dir, unet_cfg: UNetConfig = None, vae_cfg: VAEConfig = None, seed: int = 0,
+                               prediction_type: str = "epsilon", device="cpu") -> str:
+    """Write a diffusers-layout checkpoint directory with seeded random weights (the layout `load_pipelines` /
+    `Diffuman4DPipeline.from_pretrained` read: sampling_utils.py:28-33):
+        model_index.json, unet/{config.json, diffusion_pytorch_model.safetensors}, vae/{...}, scheduler/scheduler_config.json
+    Used by tools/e2e_demo.py and the loader tests -- there is no public checkpoint in the build environment."""
+    import json
+    from dataclasses import asdict
+    from pathlib import Path
+
+    from safetensors.torch import save_file
+
+    unet_cfg, vae_cfg = unet_cfg or UNetConfig(), vae_cfg or VAEConfig()
+    root = Path(model_dir)
+    for sub in ("unet", "vae", "scheduler"):
+        (root / sub).mkdir(parents=True, exist_ok=True)
+    (root / "model_index.json").write_text(json.dumps({
+        "_class_name": "Diffuman4DPipeline",
+        "unet": ["src.diffusers.models.unets.unet_multiview_condition", "UNetMultiviewConditionModel"],
+        "vae": ["diffusers", "AutoencoderKL"], "scheduler": ["diffusers", "DDIMScheduler"]}, indent=1))
+    (root / "unet" / "config.json").write_text(json.dumps(dict(asdict(unet_cfg), _class_name="UNetMultiviewConditionModel"), indent=1))
+    (root / "vae" / "config.json").write_text(json.dumps(dict(asdict(vae_cfg), _class_name="AutoencoderKL"), indent=1))
+    (root / "scheduler" / "scheduler_config.json").write_text(json.dumps({
+        "_class_name": "DDIMScheduler", "num_train_timesteps": 1000, "beta_start": 0.00085, "beta_end": 0.012,
+        "beta_schedule": "scaled_linear", "clip_sample": False, "set_alpha_to_one": False, "steps_offset": 1,
+        "prediction_type": prediction_type, "timestep_spacing": "leading"}, indent=1))
+    usd = {k: v.cpu().contiguous() for k, v in random_state_dict(unet_param_shapes(unet_cfg), seed, device).items()}
+    save_file(usd, str(root / "unet" / "diffusion_pytorch_model.safetensors"))
+    vsd = {k: v.cpu().contiguous() for k, v in random_state_dict(vae_param_shapes(vae_cfg), seed + 1, device).items()}
+    save_file(vsd, str(root / "vae" / "diffusion_pytorch_model.safetensors"))
+    return str(root)

@@ -281,6 +281,42 @@ def case_pipeline(domain="spatial", n_cams=8, T=4, window=4, stride=2, rounds=1,
     return (max(e_lat, e_img) if exact else 1.0), yard
 
 
+def case_pipeline_cache_lazy(seed=31):
+    """Pipeline extensions vs the strict path on the same inputs and injected noise: VAE moments served from the
+    cache (second call: every image is a hit) and decode restricted to fully denoised rows must give bitwise
+    identical latents, identical images on the decoded rows and zero images elsewhere."""
+    from diffuman4d_amd.host.pipeline import Diffuman4DPipeline
+    from diffuman4d_amd.host.scheduler import DDIMConfig as HC, DDIMScheduler as HS
+    cfg_u, ou = make_unet(seed)
+    cfg_v, ov = make_vae(seed + 1)
+    n, inputs = 8, [1, 5]
+    pv, pl, sk, cm = synthetic_task(n, 64, 64, inputs, seed)
+    g = torch.Generator().manual_seed(seed + 2)
+    noise = {k: torch.randn(n, 4, 8, 8, generator=g).to(BF) for k in ("pixel", "skeleton", "latents")}
+    tidx = torch.zeros(n, dtype=torch.int64)
+    # window 4, stride 2, ONE round of 1: two steps per latent = fully denoised after this call
+    kw = dict(pixel_values=pv, plucker_embeds=pl, skeletons=sk, cond_masks=cm, latents=None, domain="spatial",
+              timestep_indices=tidx, window_size=4, sliding_stride=2, sliding_shift=0, bidirectional=False,
+              num_denoising_steps=1, alternation_rounds=1, guidance_scale=2.0, noise=noise)
+    hp = Diffuman4DPipeline(hip_vae(cfg_v, ov), hip_unet(cfg_u, ou), HS(HC()), "cuda")
+    ref = hp.sliding_iterative_denoise(**kw)
+    keys = [("cam%02d" % i, "000000") for i in range(n)]
+    bad = 0.0
+    for rep in range(2):  # rep 0 fills the cache, rep 1 is served from it
+        out = hp.sliding_iterative_denoise(cache_keys=keys, decode="denoised", **kw)
+        fd = out["fully_denoised"]
+        ok = torch.equal(out["latents"], ref["latents"]) and torch.equal(out["timestep_indices"], ref["timestep_indices"])
+        ok = ok and torch.equal(out["images"][fd], ref["images"][fd]) and bool((out["images"][~fd] == 0).all())
+        ok = ok and int(fd.sum()) == n - len(inputs) and len(hp._vae_cache["pixel"]) == n
+        bad += 0.0 if ok else 1.0
+    # a later round: latents handed back, nothing fully denoised -> no decode at all
+    kw2 = dict(kw, alternation_rounds=3, latents=None)
+    out = hp.sliding_iterative_denoise(cache_keys=keys, decode="denoised", **kw2)
+    if bool(out["fully_denoised"].any()) or not bool((out["images"] == 0).all()):
+        bad += 1.0
+    return bad, 0.0
+
+
 def case_golden_pipeline(name):
     """HIP sliding_iterative_denoise vs the output of the REFERENCE's own pipeline code (committed
     fixture tests/golden/pipeline_sliding.pt, fp32): same seeded weights, task tensors and noise."""
@@ -313,6 +349,7 @@ CASES = {
     "pipeline_shard_rccl_world1": (case_pipeline_shard_world1, dict()),
     "unet_pose_encoder": (case_unet, dict(num_frames=4, cfg_batch=2, pose=True)),
     "pipeline_pose_encoder": (case_pipeline, dict(domain="spatial", pose=True)),
+    "pipeline_cache_lazy_decode": (case_pipeline_cache_lazy, dict()),
     "vae": (case_vae, dict()),
     "resize": (case_resize, dict()),
     "pipeline_spatial": (case_pipeline, dict(domain="spatial")),
@@ -325,7 +362,7 @@ CASES = {
     "golden_pose_encoder": (case_golden_pipeline, dict(name="pose_encoder")),
 }
 # multi-layer bf16 pipelines: each of ~100 ops adds ~2e-3 of rounding noise; they add in quadrature
-TOL = {"pipeline_shard_rccl_world1": 0.0, "unet_frame_shard_p4": 0.0, "unet_frame_shard_p8": 0.0, "unet_spatial": 3e-2, "unet_temporal_temb": 3e-2, "unet_2d_only": 3e-2, "unet_pose_encoder": 3e-2, "pipeline_pose_encoder": 6e-2, "vae": 3e-2, "resize": 4e-3,
+TOL = {"pipeline_shard_rccl_world1": 0.0, "unet_frame_shard_p4": 0.0, "unet_frame_shard_p8": 0.0, "unet_spatial": 3e-2, "unet_temporal_temb": 3e-2, "unet_2d_only": 3e-2, "unet_pose_encoder": 3e-2, "pipeline_pose_encoder": 6e-2, "pipeline_cache_lazy_decode": 0.0, "vae": 3e-2, "resize": 4e-3,
        "pipeline_spatial": 6e-2, "pipeline_temporal_v": 6e-2, "pipeline_bidir_nocfg": 6e-2,
        "golden_spatial": 6e-2, "golden_temporal_v": 6e-2, "golden_bidir_nocfg": 6e-2, "golden_round2_shift": 6e-2, "golden_pose_encoder": 6e-2}
 
