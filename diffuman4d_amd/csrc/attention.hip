@@ -4,9 +4,8 @@
 // MultiviewTransformerBlock (reference attention.py:68-83): the fold "(b t) hw c -> b (t hw) c" is
 // free because activations are token-major, so the kernel just sees batch = B/F, L = F*HW.
 //
-// Work decomposition: a workgroup = 8 waves, each wave owns QB blocks of 32 query rows (QB = 1: 128 VGPRs,
-// 4 waves per SIMD, so other waves' softmax VALU work overlaps this wave's MFMAs); K/V tiles of 64 keys are
-// staged register-prefetch -> LDS, double buffered, one barrier per tile, both row-major:
+// Work decomposition: a workgroup = 8 waves, each wave owns 32 query rows (128 VGPRs, 4 waves per SIMD);
+// K/V tiles of 64 keys are staged register-prefetch -> LDS, double buffered, one barrier per tile, both row-major:
 //   Ks[key][d]  144-byte rows  -> conflict-free ds_read_b128 A-fragments of S^T = K Q^T
 //   Vs[key][d]  192-byte rows  -> the V^T A-fragments of O^T = V^T P^T come out of ds_read_b64_tr_b16 (hardware
 //               transposing read of a [4 keys][16 d] block per 16-lane group; 4 consecutive rows tile the 64 banks)
@@ -18,8 +17,8 @@
 //                  two tr-reads (keys 4h..4h+3 and 8+4h..) deliver V in that same order, so there are
 //                  no lane shuffles between the two MFMAs.
 // Keys may outnumber queries (Lk >= Lq): frame-sharded 3-D attention runs local queries against all-gathered K/V.
-// The O rescale is lazy: O and l are only rescaled when some row's running max grows by more than
-// 2^8 (exact arithmetic, P stays <= 256 in bf16); on typical data that is the first tiles only.
+// Softmax: an optimistic pass (row max taken from the first tile only) with an exact running-max pass (lazy O/l
+// rescale when a row max grows by more than 2^8) as the in-kernel fallback; see the comment at kv_loop.
 // The 1-D grid is remapped so that all query tiles of one (batch, head) run on one XCD and share
 // its L2 copy of K/V.
 #include "common.h"
@@ -34,7 +33,8 @@ struct AttnParams {
   u16* O;
   int64_t ldq, ldk, ldv, ldo;
   int L, Lk, heads, nqt;  // L = queries per (batch, head), Lk = keys (== L for plain self-attention)
-  float c;  // scale * log2(e)
+  float c;         // scale * log2(e)
+  int exact_only;  // tuning / debugging: skip the optimistic pass (DM4D_ATTN_EXACT=1)
 };
 
 constexpr int KV = 64;      // keys per staged tile
@@ -53,64 +53,23 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
   return *reinterpret_cast<uint32_t*>(&b);
 }
 
-template <int QB, bool MSUM>
-__global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
-  __shared__ __attribute__((aligned(16))) u16 smem[2 * KV * LDS_LD + 2 * KV * LDS_LDV];
-  u16* Ks = smem;                    // [2][64 keys][72]
-  u16* Vs = smem + 2 * KV * LDS_LD;  // [2][64 keys][96]  row-major, transposed on the way OUT (ds_read_b64_tr_b16)
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, lh = lane >> 5;
-  const int L = p.L, Lk = p.Lk;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int qt = lid % p.nqt, bh = lid / p.nqt;
-  const int head = bh % p.heads, batch = bh / p.heads;
-  const int q_tile0 = qt * (NW * 32 * QB) + wave * (32 * QB);
-
-  const u16* Qb = p.Q + (int64_t)batch * L * p.ldq + head * 64;
-  const u16* Kb = p.K + (int64_t)batch * Lk * p.ldk + head * 64;
-  const u16* Vb = p.V + (int64_t)batch * Lk * p.ldv + head * 64;
-  u16* Ob = p.O + (int64_t)batch * L * p.ldo + head * 64;
-
-  // Q fragments (B operand of S^T = K Q^T): lane holds Q[q][j*16 + lh*8 .. +7]
-  bf16x8_t qf[QB][4];
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    int q = q_tile0 + qb * 32 + l31;
-    if (q > L - 1) q = L - 1;
-    const u16* qp = Qb + (int64_t)q * p.ldq + lh * 8;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      U4 v = ldg16(qp + j * 16);
-      qf[qb][j] = *reinterpret_cast<bf16x8_t*>(&v);
-    }
-  }
-
-  // per-lane base of the V tr-reads: 16-lane group g -> d0 = 16*(g&1), key offset 4*(g>>1); lane i -> row i>>2, chunk i&3
-  const u16* v_lane = Vs + (4 * (lane >> 5) + ((lane & 15) >> 2)) * LDS_LDV + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-
-  f32x16_t o[QB][2];
-  float m_run[QB], l_run[QB];
-  // MSUM: row sums come out of the matrix pipe (P^T times a block of ones) instead of 16 VALU adds per block --
-  // the kernel is VALU-bound on the softmax, the MFMA pipe has slack
-  f32x16_t lacc[QB];
-  const U4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
-  const bf16x8_t ones = *reinterpret_cast<const bf16x8_t*>(&ones_u);
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    m_run[qb] = -1e30f;
-    l_run[qb] = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) lacc[qb][r] = 0.f;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[qb][db][r] = 0.f;
-  }
-
-  // staging: every thread moves one 16-byte chunk of K and one of V per tile
+// ------------------------------------------------------------------------------------------------
+// "Optimistic" softmax variant (default).  tools/probes/issue_probe.hip shows that on a gfx950 SIMD a wave that
+// streams MFMAs starves its co-resident waves' VALU instructions, so a tile costs (MFMA cycles + VALU cycles), and at
+// head_dim 64 the softmax VALU work (826 of ~1340 cycles per 64-key tile per wave) is the larger half.  A quarter of
+// it is the running row max (v_max_f32 costs 6.7 cycles, v_max3_f32 6.2) whose only purpose is to keep exp2() in
+// range: bf16 has fp32's exponent range, so P = exp2(s - m) is as accurate for m = "max of the first tile" as for
+// the true running max as long as nothing overflows.  So: take m from tile 0, never look at the max again, and
+// check the row sums at the end; a workgroup in which some sum left [0, 2^60) (or is NaN) simply redoes its rows
+// with the exact running-max loop (SAFE).  Results do not depend on how rows are grouped into waves (no vote).
+// ------------------------------------------------------------------------------------------------
+template <bool SAFE>
+__device__ __forceinline__ void kv_loop(const AttnParams& p, const u16* Kb, const u16* Vb, u16* Ks, u16* Vs, const u16* v_lane,
+                                        const bf16x8_t (&qf)[4], f32x16_t (&o)[2], float& m_run, float& l_run, int tid,
+                                        int l31, int lh) {
+  const int Lk = p.Lk;
   U4 rk, rv;
-  const int s_key = tid >> 3, s_c = tid & 7;  // key 0..63, d-chunk 0..7
+  const int s_key = tid >> 3, s_c = tid & 7;
   auto load_tile = [&](int t) {
     int key = t * KV + s_key;
     if (key > Lk - 1) key = Lk - 1;
@@ -121,131 +80,154 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
     *reinterpret_cast<U4*>(Ks + (buf * KV + s_key) * LDS_LD + s_c * 8) = rk;
     *reinterpret_cast<U4*>(Vs + (buf * KV + s_key) * LDS_LDV + s_c * 8) = rv;
   };
-
   const int nt = (Lk + KV - 1) / KV;
   load_tile(0);
   store_tile(0);
   __syncthreads();
-
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     if (t + 1 < nt) load_tile(t + 1);
-    const bool tail = (t == nt - 1) && (Lk % KV) != 0;
-
-    // ---- S^T = K Q^T for both 32-key blocks: two independent accumulator chains, interleaved, so the
-    //      matrix pipe stays busy while block 0's softmax runs on the VALU (software pipelining in-wave)
-    f32x16_t s[QB][2];
+    f32x16_t s[2];
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb)
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[qb][kb][r] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (buf * KV + kb * 32 + l31) * LDS_LD + j * 16 + lh * 8);
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) s[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][j], s[qb][kb], 0, 0, 0);
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[j], s[kb], 0, 0, 0);
       }
-    }
-    if (tail) {
+    if ((t == nt - 1) && (Lk % KV) != 0) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         const int key0 = t * KV + kb * 32 + 4 * lh;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if (key0 + (r & 3) + 8 * (r >> 2) >= Lk) {
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) s[qb][kb][r] = -1e30f;
-          }
-        }
+        for (int r = 0; r < 16; ++r)
+          if (key0 + (r & 3) + 8 * (r >> 2) >= Lk) s[kb][r] = -1e30f;
       }
     }
+    if (SAFE || t == 0) {
+      float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s[0][r], s[1][r]));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      if (!SAFE) {
+        m_run = mx;  // o and l are still zero: nothing to rescale
+      } else if (__any((mx - m_run) * p.c > RESCALE_THR)) {
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.c);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+      }
+    }
+    const float mc = m_run * p.c;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      // ---- online softmax (lazy rescale), P^T fragments ---------------------------------------
-      bf16x8_t pf[QB][2];
+      float pv[16];
+      float sum = 0.f;
 #pragma unroll
-      for (int qb = 0; qb < QB; ++qb) {
-        float mx = fmaxf(s[qb][kb][0], s[qb][kb][1]);
-#pragma unroll
-        for (int r = 2; r < 16; ++r) mx = fmaxf(mx, s[qb][kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        if (__any((mx - m_run[qb]) * p.c > RESCALE_THR)) {
-          const float m_new = fmaxf(m_run[qb], mx);
-          const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * p.c);
-          m_run[qb] = m_new;
-          l_run[qb] *= alpha;
-          if (MSUM) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) lacc[qb][r] *= alpha;
-          }
-#pragma unroll
-          for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[qb][db][r] *= alpha;
-        }
-        const float mc = m_run[qb] * p.c;
-        float pv[16];
-        float sum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          pv[r] = __builtin_amdgcn_exp2f(s[qb][kb][r] * p.c - mc);
-          if (!MSUM) sum += pv[r];
-        }
-        l_run[qb] += sum;
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-          U4 w;
-          w.x = cvt_pk_bf16(pv[jj * 8 + 0], pv[jj * 8 + 1]);
-          w.y = cvt_pk_bf16(pv[jj * 8 + 2], pv[jj * 8 + 3]);
-          w.z = cvt_pk_bf16(pv[jj * 8 + 4], pv[jj * 8 + 5]);
-          w.w = cvt_pk_bf16(pv[jj * 8 + 6], pv[jj * 8 + 7]);
-          pf[qb][jj] = *reinterpret_cast<bf16x8_t*>(&w);
-          if (MSUM) lacc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[qb][jj], lacc[qb], 0, 0, 0);
-        }
+      for (int r = 0; r < 16; ++r) {
+        pv[r] = __builtin_amdgcn_exp2f(s[kb][r] * p.c - mc);
+        sum += pv[r];
       }
-      // ---- O^T += V^T P^T ------------------------------------------------------------------------
+      l_run += sum;
+      bf16x8_t pf[2];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        U4 w;
+        w.x = cvt_pk_bf16(pv[jj * 8 + 0], pv[jj * 8 + 1]);
+        w.y = cvt_pk_bf16(pv[jj * 8 + 2], pv[jj * 8 + 3]);
+        w.z = cvt_pk_bf16(pv[jj * 8 + 4], pv[jj * 8 + 5]);
+        w.w = cvt_pk_bf16(pv[jj * 8 + 6], pv[jj * 8 + 7]);
+        pf[jj] = *reinterpret_cast<bf16x8_t*>(&w);
+      }
 #pragma unroll
       for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
-          // A operand = V^T[d][8 keys in P's k-slot order]: two hardware-transposing reads of a [4 keys][16 d] block
-          // each (lane i of a 16-lane group supplies row i>>2, d-chunk i&3 and receives column i)
           const u16* vp = v_lane + (buf * KV + kb * 32 + jj * 16) * LDS_LDV + db * 32;
           s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)vp);
           s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vp + 8 * LDS_LDV));
           s16x8_t v01 = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
           bf16x8_t vf = *reinterpret_cast<bf16x8_t*>(&v01);
-#pragma unroll
-          for (int qb = 0; qb < QB; ++qb) o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][jj], o[qb][db], 0, 0, 0);
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[jj], o[db], 0, 0, 0);
         }
     }
-
     if (t + 1 < nt) store_tile(buf ^ 1);
     __syncthreads();
   }
+}
 
-  // ---- normalise and store: lane holds O[q = lane&31][d = db*32 + (r&3) + 8*(r>>2) + 4*lh] ----
+__global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) u16 smem[2 * KV * LDS_LD + 2 * KV * LDS_LDV];
+  u16* Ks = smem;
+  u16* Vs = smem + 2 * KV * LDS_LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int L = p.L, Lk = p.Lk;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int qt = lid % p.nqt, bh = lid / p.nqt;
+  const int head = bh % p.heads, batch = bh / p.heads;
+  const int q_tile0 = qt * (NW * 32) + wave * 32;
+  const u16* Qb = p.Q + (int64_t)batch * L * p.ldq + head * 64;
+  const u16* Kb = p.K + (int64_t)batch * Lk * p.ldk + head * 64;
+  const u16* Vb = p.V + (int64_t)batch * Lk * p.ldv + head * 64;
+  u16* Ob = p.O + (int64_t)batch * L * p.ldo + head * 64;
+
+  bf16x8_t qf[4];
+  {
+    int q = q_tile0 + l31;
+    if (q > L - 1) q = L - 1;
+    const u16* qp = Qb + (int64_t)q * p.ldq + lh * 8;
 #pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    const int q = q_tile0 + qb * 32 + l31;
-    const float l_tot = MSUM ? lacc[qb][0] : l_run[qb] + __shfl_xor(l_run[qb], 32);
-    const float inv = 1.0f / l_tot;
-    if (q < L) {
-      u16* op = Ob + (int64_t)q * p.ldo;
-#pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          uint2 w;
-          w.x = cvt_pk_bf16(o[qb][db][4 * g + 0] * inv, o[qb][db][4 * g + 1] * inv);
-          w.y = cvt_pk_bf16(o[qb][db][4 * g + 2] * inv, o[qb][db][4 * g + 3] * inv);
-          *reinterpret_cast<uint2*>(op + db * 32 + 8 * g + 4 * lh) = w;
-        }
+    for (int j = 0; j < 4; ++j) {
+      U4 v = ldg16(qp + j * 16);
+      qf[j] = *reinterpret_cast<bf16x8_t*>(&v);
     }
+  }
+  const u16* v_lane = Vs + (4 * (lane >> 5) + ((lane & 15) >> 2)) * LDS_LDV + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+
+  f32x16_t o[2];
+  float m_run = -1e30f, l_run = 0.f;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+  float l_tot = -1.f;
+  if (!p.exact_only) {
+    kv_loop<false>(p, Kb, Vb, Ks, Vs, v_lane, qf, o, m_run, l_run, tid, l31, lh);
+    l_tot = l_run + __shfl_xor(l_run, 32);
+  }
+  // out of range (a later tile outgrew the first tile's max by more than 2^60) or NaN: redo with the exact loop
+  if (__syncthreads_or(!(l_tot < 0x1p60f) || !(l_tot > 0x1p-100f))) {
+    m_run = -1e30f;
+    l_run = 0.f;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    kv_loop<true>(p, Kb, Vb, Ks, Vs, v_lane, qf, o, m_run, l_run, tid, l31, lh);
+    l_tot = l_run + __shfl_xor(l_run, 32);
+  }
+  const int q = q_tile0 + l31;
+  const float inv = 1.0f / l_tot;
+  if (q < L) {
+    u16* op = Ob + (int64_t)q * p.ldo;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 w;
+        w.x = cvt_pk_bf16(o[db][4 * g + 0] * inv, o[db][4 * g + 1] * inv);
+        w.y = cvt_pk_bf16(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+        *reinterpret_cast<uint2*>(op + db * 32 + 8 * g + 4 * lh) = w;
+      }
   }
 }
 
@@ -258,25 +240,14 @@ extern "C" int dm4d_attention_kv_bf16(void* stream, const void* Q, const void* K
     return dm4d_set_error(DM4D_ERR_ARG, "attention: null pointer or empty shape");
   if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3))
     return dm4d_set_error(DM4D_ERR_ARG, "attention: row strides must be multiples of 8 elements");
+  static const int exact = [] { const char* e = getenv("DM4D_ATTN_EXACT"); return e ? atoi(e) : 0; }();  // tuning aid
   AttnParams p{(const u16*)Q, (const u16*)K, (const u16*)V, (u16*)O, ldq, ldk, ldv, ldo, Lq, Lk, heads, 0,
-               scale * 1.4426950408889634f};
-  hipStream_t st = (hipStream_t)stream;
-  static const int force_qb = [] { const char* e = getenv("DM4D_ATTN_QB"); return e ? atoi(e) : 0; }();  // tuning aid
-  // 32 query rows per wave (4 waves/SIMD) measured faster than 64 (2 waves/SIMD) on every UNet shape
-  // (profiles/r01_*); the 64-row variant is kept for tuning (DM4D_ATTN_QB=2)
-  const bool use2 = force_qb == 2;
-  const int rows = NW * 32 * (use2 ? 2 : 1);
+               scale * 1.4426950408889634f, exact};
+  const int rows = NW * 32;  // 32 query rows per wave: 128 VGPRs, 4 waves per SIMD (64 rows per wave measured slower)
   p.nqt = (Lq + rows - 1) / rows;
   const long nwg = (long)p.nqt * heads * batch;
   if (nwg > 0x7fffffffL) return dm4d_set_error(DM4D_ERR_ARG, "attention: grid too large");
-  static const int msum = [] { const char* e = getenv("DM4D_ATTN_MSUM"); return e ? atoi(e) : 0; }();  // tuning aid
-  if (use2) {
-    hipLaunchKernelGGL((attn_kernel<2, false>), dim3((unsigned)nwg), dim3(NW * 64), 0, st, p);
-  } else if (msum) {
-    hipLaunchKernelGGL((attn_kernel<1, true>), dim3((unsigned)nwg), dim3(NW * 64), 0, st, p);
-  } else {
-    hipLaunchKernelGGL((attn_kernel<1, false>), dim3((unsigned)nwg), dim3(NW * 64), 0, st, p);
-  }
+  hipLaunchKernelGGL(attn_kernel, dim3((unsigned)nwg), dim3(NW * 64), 0, (hipStream_t)stream, p);
   return dm4d_check_launch("attn_kernel");
 }
 

@@ -120,13 +120,16 @@ def case_conv_direct(B, H, W, Cin, Cout, k, stride, silu=True, seed=0):
     return (rel_l2(out, ref) if pad_ok else 1.0), float((out.float().cpu() - ref).abs().max())
 
 
-def case_attention(batch, heads, L, seed=0, spike=False):
+def case_attention(batch, heads, L, seed=0, spike=False, ramp=False):
     from diffuman4d_amd.host import ops
     g = torch.Generator().manual_seed(seed)
     C = heads * 64
     qkv = _rnd((batch * L, 3 * C), g)
     if spike:  # force large online-softmax rescales (one key dominates late in the sequence)
         qkv[L - 3, C:2 * C] *= 8.0
+    if ramp:  # logits far above anything in the first 64-key tile (> 2^60 in exp2 terms for a good share of the rows):
+        qkv[100, C:2 * C] *= 64.0  # the optimistic first-tile max must be abandoned for the exact running-max loop
+        qkv[L - 70, C:2 * C] *= 48.0
     q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
 
     def heads_view(t):
@@ -317,6 +320,7 @@ CASES = {
     "attn_2d": (case_attention, dict(batch=8, heads=5, L=2880)),
     "attn_3d": (case_attention, dict(batch=2, heads=10, L=4320)),
     "attn_spike": (case_attention, dict(batch=1, heads=2, L=1000, spike=True)),
+    "attn_ramp_fallback": (case_attention, dict(batch=2, heads=2, L=1500, ramp=True)),
     "attn_kv_split": (case_attention_kv_split, dict(batch=2, heads=2, L=16 * 180, parts=8)),
     "attn_kv_split3": (case_attention_kv_split, dict(batch=2, heads=1, L=24 * 45, parts=3)),
     # --- norms -----------------------------------------------------------------------------------

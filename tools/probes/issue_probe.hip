@@ -11,7 +11,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-enum { NONE = 0, MFMA = 1, FMA = 2, PKFMA = 3, EXP = 4, PKADD = 5, CVT = 6, MAX3 = 7 };
+enum { NONE = 0, MFMA = 1, FMA = 2, PKFMA = 3, EXP = 4, PKADD = 5, CVT = 6, MAX3 = 7, ADD = 8, MOV = 9, MAX2 = 10, DOT2 = 11, DOT2C = 12, EXPH = 13 };
 
 template <int OP>
 __device__ __forceinline__ float run_op(int iters, float seed) {
@@ -72,6 +72,21 @@ __device__ __forceinline__ float run_op(int iters, float seed) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) asm volatile("v_max3_f32 %0, %0, %1, %1" : "+v"(x[i]) : "v"(seed));
     float s = 0; for (int i = 0; i < 16; ++i) s += x[i]; return s;
+  } else if constexpr (OP == ADD || OP == MOV || OP == MAX2 || OP == DOT2 || OP == DOT2C || OP == EXPH) {
+    float x[16];
+    const float y = seed * 0.5f;
+    for (int i = 0; i < 16; ++i) x[i] = seed * 0.001f + i * 0.01f;
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if constexpr (OP == ADD) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[i]) : "v"(y));
+        if constexpr (OP == MOV) asm volatile("v_mov_b32 %0, %1" : "+v"(x[i]) : "v"(y));
+        if constexpr (OP == MAX2) asm volatile("v_max_f32 %0, %0, %1" : "+v"(x[i]) : "v"(y));
+        if constexpr (OP == DOT2) asm volatile("v_dot2_f32_bf16 %0, %1, %1, %0" : "+v"(x[i]) : "v"(y));
+        if constexpr (OP == DOT2C) asm volatile("v_dot2c_f32_bf16 %0, %1, %1" : "+v"(x[i]) : "v"(y));
+        if constexpr (OP == EXPH) asm volatile("v_exp_f16 %0, %0" : "+v"(x[i]));
+      }
+    float s = 0; for (int i = 0; i < 16; ++i) s += x[i]; return s;
   } else {
     return seed;
   }
@@ -112,9 +127,12 @@ int main() {
   printf("calibrated clock %.0f MHz\n", cyc_us);
 #define ONE(name, A) { float us = time_it<A, A>(out, it); printf("%-22s two waves / SIMD  %9.1f us  %6.2f cycles/instr per SIMD\n", name, us, us * cyc_us / (2 * n)); }
   ONE("mfma 32x32x16 bf16", MFMA) ONE("v_fma_f32", FMA) ONE("v_pk_fma_f32", PKFMA) ONE("v_pk_add_f32", PKADD)
-  ONE("v_exp_f32", EXP) ONE("v_cvt_pk_bf16_f32", CVT) ONE("v_max3_f32", MAX3)
+  ONE("v_exp_f32", EXP) ONE("v_cvt_pk_bf16_f32", CVT) ONE("v_max3_f32", MAX3) ONE("v_add_f32", ADD) ONE("v_mov_b32", MOV)
+  ONE("v_max_f32", MAX2) ONE("v_dot2_f32_bf16", DOT2) ONE("v_dot2c_f32_bf16", DOT2C) ONE("v_exp_f16", EXPH)
 #define TWO(name, A, B) { float us = time_it<A, B>(out, it); printf("%-22s one wave each     %9.1f us  %6.2f cycles per (A,B) instruction pair per SIMD\n", name, us, us * cyc_us / n); }
   TWO("mfma | none", MFMA, NONE) TWO("mfma | v_fma", MFMA, FMA) TWO("mfma | v_exp", MFMA, EXP) TWO("mfma | v_pk_fma", MFMA, PKFMA)
   TWO("mfma | v_cvt_pk", MFMA, CVT) TWO("mfma | v_max3", MFMA, MAX3) TWO("v_fma | v_exp", FMA, EXP)
+  TWO("mfma | v_add", MFMA, ADD) TWO("mfma | v_mov", MFMA, MOV) TWO("mfma | v_max", MFMA, MAX2) TWO("mfma | v_dot2", MFMA, DOT2)
+  TWO("mfma | v_dot2c", MFMA, DOT2C) TWO("mfma | v_exp_f16", MFMA, EXPH) TWO("mfma | v_pk_add", MFMA, PKADD)
   return 0;
 }
