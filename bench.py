@@ -135,11 +135,19 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    # DM4D_BENCH_SHARED_GPU=1 (testing only): all ranks share device 0 and rendezvous over gloo, so that the N > 1 code
+    # paths can be exercised on a 1-GPU box; the numbers of such a run mean nothing
+    shared = os.environ.get("DM4D_BENCH_SHARED_GPU") == "1"
+    if shared:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from diffuman4d_amd.host import ops
     from diffuman4d_amd.host.pipeline import Diffuman4DPipeline
