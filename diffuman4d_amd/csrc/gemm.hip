@@ -325,7 +325,9 @@ __global__ __launch_bounds__(256) void gemm_kernel_glds(GemmParams p) {
 // the three taps read it at row offsets 0/1/2: A traffic into LDS drops 3x, total DMA bytes by about a third for a
 // 128x128 tile.  A strip row is zero-filled when ITS centre pixel's row y+ky-1 leaves the image; the only other
 // out-of-image case -- x-1 at x == 0 for kx = 0, x+1 at x == W-1 for kx = 2, where the flat shift wraps into the
-// neighbouring image row -- is removed by zeroing those lanes' A fragments.  K order is (ky, ci-slab, kx).
+// neighbouring image row -- is removed by pointing those lanes' fragment reads at a zero row in LDS (one address
+// select per fragment row and tap; masking the fragment registers instead costs 32 VALU instructions per 16 MFMAs,
+// and VALU work is not hidden behind other waves' MFMAs on this chip).  K order is (ky, ci-slab, kx).
 // ------------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM* WN * 64) void conv_strip_kernel(GemmParams p) {
@@ -335,12 +337,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip_kernel(GemmParams p) {
   constexpr int SR = BM + 8;  // strip rows held in LDS (BM + 2 needed, DMA granularity is 8 rows)
   constexpr int NA = SR / 8;  // 1-KiB DMA instructions per strip
   constexpr int AW = (NA + NW - 1) / NW, BW = BN / (8 * NW);
-  constexpr int SMEM_MAIN = 2 * (SR + BN) * BK * 2;
+  constexpr int SMEM_MAIN = 2 * (SR + BN) * BK * 2 + BK * 2;  // + one zero row
   constexpr int SMEM_EPI = NW * 32 * (TN + 4) * 4;
   constexpr int SMEM_BYTES = SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI;
   __shared__ __attribute__((aligned(16))) u16 smem[SMEM_BYTES / 2];
-  u16* As = smem;                // [2][SR][64]
-  u16* Bs = smem + 2 * SR * BK;  // [2][BN][64]
+  u16* As = smem;                       // [2][SR][64]
+  u16* Bs = smem + 2 * SR * BK;         // [2][BN][64]
+  u16* Zs = smem + 2 * (SR + BN) * BK;  // [64] zeros: the A "row" of taps that fall off the left / right image edge
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -350,6 +353,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip_kernel(GemmParams p) {
   const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int d_row = lane >> 3, d_pos = lane & 7;
+  if (tid < 8) *reinterpret_cast<U4*>(Zs + tid * 8) = U4{0u, 0u, 0u, 0u};  // visible after the first barrier
 
   int a_off[AW];
   unsigned a_ok[AW];  // bit ky: the strip row is inside the image for kernel row ky
@@ -435,15 +439,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip_kernel(GemmParams p) {
       if (g * 3 + kx + 1 < nsteps) issue_step();
       const int swa = ((l31 + kx) >> 1) & 7;
       bf16x8_t af[2][MI], bfr[2][NI];
+      const u16* arow[MI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        arow[i] = As + (abuf * SR + wm * TM + i * 32 + l31 + kx) * BK;
+        if (kx == 0 && x_first[i]) arow[i] = Zs;
+        if (kx == 2 && x_last[i]) arow[i] = Zs;
+      }
       auto read_frags = [&](int ks, int slot) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(As + (abuf * SR + wm * TM + i * 32 + l31 + kx) * BK +
-                                                          ((ks * 2 + lh) ^ swa) * 8);
-          if (kx == 0 && x_first[i]) a = bf16x8_t{};
-          if (kx == 2 && x_last[i]) a = bf16x8_t{};
-          af[slot][i] = a;
-        }
+        for (int i = 0; i < MI; ++i)
+          af[slot][i] = *reinterpret_cast<const bf16x8_t*>(arow[i] + ((ks * 2 + lh) ^ swa) * 8);
 #pragma unroll
         for (int j = 0; j < NI; ++j)
           bfr[slot][j] =

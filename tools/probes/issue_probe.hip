@@ -11,7 +11,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-enum { NONE = 0, MFMA = 1, FMA = 2, PKFMA = 3, EXP = 4, PKADD = 5, CVT = 6, MAX3 = 7, ADD = 8, MOV = 9, MAX2 = 10, DOT2 = 11, DOT2C = 12, EXPH = 13 };
+enum { NONE = 0, MFMA = 1, FMA = 2, PKFMA = 3, EXP = 4, PKADD = 5, CVT = 6, MAX3 = 7, ADD = 8, MOV = 9, MAX2 = 10, DOT2 = 11, DOT2C = 12, EXPH = 13, DSREAD = 14, DSTR = 15 };
 
 template <int OP>
 __device__ __forceinline__ float run_op(int iters, float seed) {
@@ -87,6 +87,29 @@ __device__ __forceinline__ float run_op(int iters, float seed) {
         if constexpr (OP == EXPH) asm volatile("v_exp_f16 %0, %0" : "+v"(x[i]));
       }
     float s = 0; for (int i = 0; i < 16; ++i) s += x[i]; return s;
+  } else if constexpr (OP == DSREAD || OP == DSTR) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    for (int i = lane; i < 4096; i += 64) lds[(threadIdx.x >> 6) * 4096 + i] = seed;
+    const unsigned base = (unsigned)(size_t)(lds + (threadIdx.x >> 6) * 4096) + lane * (OP == DSREAD ? 16 : 8);
+    f32x4 acc = {0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it) {
+      f32x4 v[16];
+      s16x4 w[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if constexpr (OP == DSREAD) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[i]) : "v"(base), "n"(i * 1024));
+        else asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(w[i]) : "v"(base), "n"(i * 512));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if constexpr (OP == DSREAD) asm volatile("" :: "v"(v[i])); else asm volatile("" :: "v"(w[i]));
+      }
+    }
+    return acc[0];
   } else {
     return seed;
   }
@@ -104,10 +127,10 @@ template <int A, int B>
 float time_it(float* out, int iters) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL((probe<A, B>), dim3(256), dim3(512), 0, 0, out, iters, 1.0f);
+  hipLaunchKernelGGL((probe<A, B>), dim3(256), dim3(512), 8 * 4096 * 4, 0, out, iters, 1.0f);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((probe<A, B>), dim3(256), dim3(512), 0, 0, out, iters, 1.0f);
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((probe<A, B>), dim3(256), dim3(512), 8 * 4096 * 4, 0, out, iters, 1.0f);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -128,11 +151,13 @@ int main() {
 #define ONE(name, A) { float us = time_it<A, A>(out, it); printf("%-22s two waves / SIMD  %9.1f us  %6.2f cycles/instr per SIMD\n", name, us, us * cyc_us / (2 * n)); }
   ONE("mfma 32x32x16 bf16", MFMA) ONE("v_fma_f32", FMA) ONE("v_pk_fma_f32", PKFMA) ONE("v_pk_add_f32", PKADD)
   ONE("v_exp_f32", EXP) ONE("v_cvt_pk_bf16_f32", CVT) ONE("v_max3_f32", MAX3) ONE("v_add_f32", ADD) ONE("v_mov_b32", MOV)
+  ONE("ds_read_b128", DSREAD) ONE("ds_read_b64_tr_b16", DSTR)
   ONE("v_max_f32", MAX2) ONE("v_dot2_f32_bf16", DOT2) ONE("v_dot2c_f32_bf16", DOT2C) ONE("v_exp_f16", EXPH)
 #define TWO(name, A, B) { float us = time_it<A, B>(out, it); printf("%-22s one wave each     %9.1f us  %6.2f cycles per (A,B) instruction pair per SIMD\n", name, us, us * cyc_us / n); }
   TWO("mfma | none", MFMA, NONE) TWO("mfma | v_fma", MFMA, FMA) TWO("mfma | v_exp", MFMA, EXP) TWO("mfma | v_pk_fma", MFMA, PKFMA)
   TWO("mfma | v_cvt_pk", MFMA, CVT) TWO("mfma | v_max3", MFMA, MAX3) TWO("v_fma | v_exp", FMA, EXP)
   TWO("mfma | v_add", MFMA, ADD) TWO("mfma | v_mov", MFMA, MOV) TWO("mfma | v_max", MFMA, MAX2) TWO("mfma | v_dot2", MFMA, DOT2)
+  TWO("mfma | ds_read_b128", MFMA, DSREAD) TWO("mfma | ds_read_tr", MFMA, DSTR)
   TWO("mfma | v_dot2c", MFMA, DOT2C) TWO("mfma | v_exp_f16", MFMA, EXPH) TWO("mfma | v_pk_add", MFMA, PKADD)
   return 0;
 }
