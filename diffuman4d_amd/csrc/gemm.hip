@@ -914,6 +914,8 @@ extern "C" int dm4d_conv3x3_nhwc_bf16(void* stream, const void* X, int B, int H,
   if (Cin % 32 != 0) return dm4d_set_error(DM4D_ERR_ARG, "conv3x3: Cin must be a multiple of 32 (pad the input)");
   if (stride != 1 && stride != 2) return dm4d_set_error(DM4D_ERR_ARG, "conv3x3: stride must be 1 or 2");
   if (upsample && stride != 1) return dm4d_set_error(DM4D_ERR_ARG, "conv3x3: upsample needs stride 1");
+  if ((int64_t)B * H * W * Cin >= (int64_t)1 << 31 || (int64_t)B * Ho * Wo * Cout >= (int64_t)1 << 31)
+    return dm4d_set_error(DM4D_ERR_ARG, "conv3x3: tensors of 2^31 or more elements are not supported (split the batch)");
   GemmParams p{};
   p.A = (const u16*)X; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.pad = pad;
   p.upsample = upsample;

@@ -164,6 +164,12 @@ class AutoencoderKL:
     def scale_factor(self) -> int:
         return 2 ** (len(self.config.block_out_channels) - 1)
 
+    def micro_batch(self, height: int, width: int, limit: int = 8) -> int:
+        """Images per VAE pass: the reference's 8 (pipeline_diffuman4d.py:47,59), reduced for large images so that the
+        widest full-resolution activation ([B, H, W, 2*C0] in the decoder) stays below the kernels' 2^31-element limit."""
+        c = 2 * self.config.block_out_channels[0]
+        return max(1, min(limit, ((1 << 31) - 1) // (height * width * c)))
+
     # ---- encode --------------------------------------------------------------------------------
     def moments(self, x_nhwc32: torch.Tensor) -> torch.Tensor:
         """x [B,H,W,32] (3 image channels + zero pad) -> moments [B,h,w,2*lc] (mean | logvar)."""
@@ -188,6 +194,7 @@ class AutoencoderKL:
         encoder; the stochastic draw is still fresh for every call, i.e. the sampled distribution is unchanged."""
         lc = self.config.latent_channels
         n = images.shape[0]
+        batch_size = self.micro_batch(images.shape[-2], images.shape[-1], batch_size)
         if cache is None:
             todo = list(range(n))
         else:
@@ -236,6 +243,8 @@ class AutoencoderKL:
     def decode_to_images(self, lat_nhwc: torch.Tensor, batch_size: int = 8, rows: Optional[torch.Tensor] = None) -> torch.Tensor:
         """pipeline_diffuman4d.py:59-72,280-285: latents NHWC -> images NCHW in [0,1].
         `rows` (bool [N]): decode only these latents; the other output images are zero."""
+        f = self.scale_factor
+        batch_size = self.micro_batch(lat_nhwc.shape[1] * f, lat_nhwc.shape[2] * f, batch_size)
         if rows is None:
             sel = lat_nhwc
         else:
@@ -247,7 +256,6 @@ class AutoencoderKL:
             outs.append(ops.postprocess_images(self.decode(z), self.config.out_channels))
         if rows is None:
             return torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
-        f = self.scale_factor
         if not outs:  # nothing to decode (an early alternation round): a zero-stride host tensor, no device traffic
             return torch.zeros(1).expand(lat_nhwc.shape[0], self.config.out_channels, lat_nhwc.shape[1] * f,
                                          lat_nhwc.shape[2] * f)
