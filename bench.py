@@ -229,6 +229,19 @@ def main():
                 "share_of_step_time": round(attn_ms * 1e-3 / dt, 4),
             },
         }
+        # secondary figures of SURVEY.md 8d (whole job): latent-steps/s, UNet window calls/s, sustained UNet TFLOP/s
+        ranks_units = (1 if shard is not None else world) * args.steps
+        if (LAT_H, LAT_W) == (72, 40):
+            unit_tflop = 2 * 20.13 + 33.06  # F=16 / F=24 UNet calls at 72x40
+        elif (LAT_H, LAT_W) == (128, 128):
+            unit_tflop = 2 * 261.9 + 485.8
+        else:
+            unit_tflop = None
+        out["secondary"] = {
+            "latent_steps_per_s": round(ranks_units * 3 * WINDOW / dt, 2),
+            "unet_calls_per_s": round(ranks_units * 3 / dt, 3),
+            "unet_tflops_sustained": round(ranks_units * unit_tflop / dt, 1) if unit_tflop else None,
+        }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_frames)
         print(json.dumps(out), flush=True)
