@@ -1,21 +1,24 @@
 """SlidingIterativeSampler: the (camera x frame) latent grid and its task list.
 
-Mirror of ``/root/reference/src/samplers/sliding_iterative_sampler.py`` (ctor kwargs = the Hydra
-sampler config, :16-35; validation + ``ValueError``s :71-88; grid :91-96; ``load_sample`` :102-153;
-``denoise`` :155-190; ``prepare_tasks`` :192-199; ``execute_one_task`` / ``execute_tasks`` :201-212).
+Same contract as ``/root/reference/src/samplers/sliding_iterative_sampler.py``: the constructor keywords are the
+Hydra sampler config (:16-35), bad window / stride / label arithmetic is a ``ValueError`` (:55,63,71-88), the grid
+starts as ``latent = None, timestep_index = 0`` per cell (:91-96), ``load_sample`` (:102-153), ``denoise``
+(:155-190), one task per frame in spatial rounds and per target camera in temporal rounds (:192-199).
 
-Differences that do not change results:
-  * grid cells keep the tensor the pipeline returned (device resident) instead of ``latent.cpu()``;
+What is organised differently here:
+  * the sweep hyper-parameters live in one frozen ``SweepConfig`` that is splatted into the pipeline call;
+  * grid cells keep the tensor the pipeline returned (device resident) instead of ``latent.cpu()``; gather / scatter of
+    a task's cells are two small methods under one lock;
   * ``result_writer`` is injectable (the reference hard-wires ``save_sampling_results``);
-  * ``partition(rank, world)`` exposes the per-round task sharding used by the one-process-per-GPU
-    runner (``DistributedSamplingRunner``); the reference shards the same task lists over threads.
+  * ``partition(round, rank, world)`` exposes the per-round task sharding used by the one-process-per-GPU runner;
+  * optional pipeline extensions (``vae_cache``, ``decode_policy``), off by default.
 """
 from __future__ import annotations
 
-from collections import defaultdict
+from dataclasses import asdict, dataclass
 from functools import partial
 from threading import Lock
-from typing import Callable, Dict, List, Optional, Sequence
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -25,188 +28,152 @@ except Exception:  # pragma: no cover
     def _tqdm(it, **kw):
         return it
 
+DOMAINS = ("spatial", "temporal")
+
+
+@dataclass(frozen=True)
+class SweepConfig:
+    """Keyword arguments of ``pipeline.sliding_iterative_denoise`` that do not depend on the task."""
+    window_size: int = 12
+    sliding_stride: int = 1
+    sliding_shift: int = 0
+    bidirectional: bool = True
+    num_denoising_steps: int = 1
+    alternation_rounds: int = 3
+    guidance_scale: float = 2.0
+
+
+def _format_labels(explicit: Optional[Sequence[int]], label_range: Optional[Sequence[int]], width: int, name: str) -> List[str]:
+    """Zero-padded string labels ("%02d" cameras, "%06d" frames) from an explicit list or a (begin, end, step) range."""
+    if explicit is not None:
+        values = [int(v) for v in explicit]
+    elif label_range is not None:
+        values = list(range(*[int(v) for v in label_range]))
+    else:
+        raise ValueError(f"{name}_labels or {name}_label_range must be provided")
+    return [f"{v:0{width}d}" for v in values]
+
 
 class SlidingIterativeSampler:
-    def __init__(
-        self,
-        dataset,
-        pipelines: list,
-        output_dir: str = "./results/debug",
-        # denoising args
-        window_size: int = 12,
-        sliding_stride: int = 1,
-        sliding_shift: int = 0,
-        bidirectional: bool = True,
-        num_denoising_steps: int = 1,
-        alternation_rounds: int = 3,
-        guidance_scale: float = 2.0,
-        # sampling range args
-        spa_label_range: Optional[Sequence[int]] = (0, 48, 1),
-        tem_label_range: Optional[Sequence[int]] = (0, 150, 1),
-        spa_labels: Optional[Sequence[int]] = None,
-        tem_labels: Optional[Sequence[int]] = None,
-        input_spa_labels: Sequence[int] = (1, 13, 25, 37),
-        result_writer: Optional[Callable] = None,
-        # MI355X pipeline extensions (off = the reference's behaviour; need a pipeline that accepts the kwargs)
-        vae_cache: bool = False,
-        decode_policy: str = "all",
-    ):
-        self.dataset = dataset
-        self.pipelines = pipelines
-        self.output_dir = output_dir
-        self.window_size = window_size
-        self.sliding_stride = sliding_stride
-        self.sliding_shift = sliding_shift
-        self.bidirectional = bidirectional
-        self.num_denoising_steps = num_denoising_steps
-        self.alternation_rounds = alternation_rounds
-        self.guidance_scale = guidance_scale
+    def __init__(self, dataset, pipelines: list, output_dir: str = "./results/debug",
+                 window_size: int = 12, sliding_stride: int = 1, sliding_shift: int = 0, bidirectional: bool = True,
+                 num_denoising_steps: int = 1, alternation_rounds: int = 3, guidance_scale: float = 2.0,
+                 spa_label_range: Optional[Sequence[int]] = (0, 48, 1), tem_label_range: Optional[Sequence[int]] = (0, 150, 1),
+                 spa_labels: Optional[Sequence[int]] = None, tem_labels: Optional[Sequence[int]] = None,
+                 input_spa_labels: Sequence[int] = (1, 13, 25, 37), result_writer: Optional[Callable] = None,
+                 vae_cache: bool = False, decode_policy: str = "all"):
+        self.dataset, self.pipelines, self.output_dir = dataset, pipelines, output_dir
+        self.sweep = SweepConfig(window_size, sliding_stride, sliding_shift, bidirectional, num_denoising_steps,
+                                 alternation_rounds, guidance_scale)
         if result_writer is None:
             from .results import save_sampling_results as result_writer
         self.result_writer = result_writer
         if decode_policy not in ("all", "denoised"):
             raise ValueError("decode_policy must be 'all' or 'denoised'")
         self.vae_cache, self.decode_policy = bool(vae_cache), decode_policy
-        if self.vae_cache:
-            for p in pipelines:
-                p.clear_vae_cache()
+        if self.vae_cache:  # the cache is keyed by (camera, frame) of ONE scene
+            for pipe in pipelines:
+                pipe.clear_vae_cache()
 
-        if spa_labels is not None:
-            self.spa_labels = [f"{int(i):02d}" for i in spa_labels]
-        elif spa_label_range is not None:
-            b, e, s = spa_label_range
-            self.spa_labels = [f"{int(i):02d}" for i in range(b, e, s)]
-        else:
-            raise ValueError("spa_labels or spa_label_range must be provided")
+        self.spa_labels = _format_labels(spa_labels, spa_label_range, 2, "spa")
+        self.tem_labels = _format_labels(tem_labels, tem_label_range, 6, "tem")
+        self.input_spa_labels = _format_labels(input_spa_labels, None, 2, "input_spa")
+        inputs = set(self.input_spa_labels)
+        self.target_spa_labels = [c for c in self.spa_labels if c not in inputs]
+        self._validate()
 
-        if tem_labels is not None:
-            self.tem_labels = [f"{int(i):06d}" for i in tem_labels]
-        elif tem_label_range is not None:
-            b, e, s = tem_label_range
-            self.tem_labels = [f"{int(i):06d}" for i in range(b, e, s)]
-        else:
-            raise ValueError("tem_labels or tem_label_range must be provided")
-
-        self.input_spa_labels = [f"{int(i):02d}" for i in input_spa_labels]
-        self.target_spa_labels = [label for label in self.spa_labels if label not in self.input_spa_labels]
-
-        if self.window_size > len(self.target_spa_labels):
-            raise ValueError(
-                f"window_size(={self.window_size}) must be <= len(target_spa_labels)(={len(self.target_spa_labels)})"
-            )
-        if len(self.target_spa_labels) % self.sliding_stride != 0:
-            raise ValueError(
-                f"len(target_spa_labels)(={len(self.target_spa_labels)}) % sliding_stride(={self.sliding_stride}) must be 0"
-            )
-        if len(self.tem_labels) % self.sliding_stride != 0:
-            raise ValueError(
-                f"len(tem_labels)(={len(self.tem_labels)}) % sliding_stride(={self.sliding_stride}) must be 0"
-            )
-        if self.alternation_rounds > 1 and self.window_size > len(self.tem_labels):
-            raise ValueError(
-                f"window_size(={self.window_size}) must be <= the number of tem_labels(={len(self.tem_labels)}) "
-                "when alternation_rounds > 1"
-            )
-
-        # spatio-temporal latent grid
-        self.latents: Dict[str, Dict[str, Optional[torch.Tensor]]] = defaultdict(dict)
-        self.timestep_indices: Dict[str, Dict[str, int]] = defaultdict(dict)
-        for spa_label in self.spa_labels:
-            for tem_label in self.tem_labels:
-                self.latents[spa_label][tem_label] = None
-                self.timestep_indices[spa_label][tem_label] = 0
+        # the latent grid: every cell starts empty at timestep index 0
+        self.latents: Dict[str, Dict[str, Optional[torch.Tensor]]] = {c: dict.fromkeys(self.tem_labels) for c in self.spa_labels}
+        self.timestep_indices: Dict[str, Dict[str, int]] = {c: dict.fromkeys(self.tem_labels, 0) for c in self.spa_labels}
         self.lock = Lock()
         self.prepare_tasks()
 
+    # the reference exposes the sweep arguments as attributes; keep them readable under the same names
+    def __getattr__(self, name):
+        sweep = self.__dict__.get("sweep")
+        if sweep is not None and name in SweepConfig.__dataclass_fields__:
+            return getattr(sweep, name)
+        raise AttributeError(name)
+
+    def _validate(self):
+        n_tgt, n_tem, sw = len(self.target_spa_labels), len(self.tem_labels), self.sweep
+        problems = (
+            (sw.window_size > n_tgt, f"window_size = {sw.window_size} exceeds the {n_tgt} target cameras (target_spa_labels)"),
+            (n_tgt % sw.sliding_stride != 0, f"sliding_stride = {sw.sliding_stride} does not divide the {n_tgt} target cameras"),
+            (n_tem % sw.sliding_stride != 0, f"sliding_stride = {sw.sliding_stride} does not divide the {n_tem} frames (tem_labels)"),
+            (sw.alternation_rounds > 1 and sw.window_size > n_tem,
+             f"window_size = {sw.window_size} exceeds the {n_tem} frames, which temporal rounds (alternation_rounds > 1) need"),
+        )
+        for bad, message in problems:
+            if bad:
+                raise ValueError(message)
+
     # ------------------------------------------------------------------------------------------
     def prepare_tasks(self):
-        domains = (["spatial", "temporal"] * self.alternation_rounds)[: self.alternation_rounds]
+        """Round r is spatial for even r (one task per frame) and temporal for odd r (one task per target camera)."""
         self.all_tasks: List[List[dict]] = []
-        for i, domain in enumerate(domains):
-            domain_labels = self.tem_labels if domain == "spatial" else self.target_spa_labels
-            self.all_tasks.append([{"alt": i + 1, "domain": domain, "domain_label": lb} for lb in domain_labels])
+        for r in range(self.sweep.alternation_rounds):
+            domain = DOMAINS[r % 2]
+            units = self.tem_labels if domain == "spatial" else self.target_spa_labels
+            self.all_tasks.append([dict(alt=r + 1, domain=domain, domain_label=u) for u in units])
 
     def partition(self, round_index: int, rank: int, world: int) -> List[dict]:
         """Tasks of one alternation round owned by `rank`: round-robin, like threads draining one queue."""
         return self.all_tasks[round_index][rank::world]
 
     # ------------------------------------------------------------------------------------------
-    def load_sample(self, alt: int, domain: str, domain_label: str) -> dict:
-        def ref_indices(all_labels, ref_labels):
-            return [all_labels.index(label) for label in ref_labels]
+    def _task_geometry(self, domain: str, domain_label: str) -> Tuple[List[str], List[str], List[int], List[int]]:
+        """(cameras, frames, input rows, target rows) of the sample a task denoises."""
+        if domain == "spatial":  # every camera of one frame; rows are cameras
+            row_of = {c: i for i, c in enumerate(self.spa_labels)}
+            return (self.spa_labels, [domain_label], [row_of[c] for c in self.input_spa_labels],
+                    [row_of[c] for c in self.target_spa_labels])
+        if domain == "temporal":  # all frames of the nearest input camera, then all frames of the target camera
+            t = len(self.tem_labels)
+            return [domain_label], self.tem_labels, list(range(t)), list(range(t, 2 * t))
+        raise ValueError(f"unknown domain {domain!r}")
 
-        if domain == "spatial":
-            spa_labels = self.spa_labels
-            tem_labels = [domain_label]
-            input_indices = torch.tensor(ref_indices(self.spa_labels, self.input_spa_labels))
-            target_indices = torch.tensor(ref_indices(self.spa_labels, self.target_spa_labels))
-        elif domain == "temporal":
-            spa_labels = [domain_label]
-            tem_labels = self.tem_labels
-            half = len(self.tem_labels)
-            input_indices = torch.tensor(list(range(half)))  # first half: nearest input camera
-            target_indices = torch.tensor(list(range(half, 2 * half)))  # second half: the target camera
-        else:
-            raise ValueError(f"unknown domain {domain!r}")
-
-        sample = self.dataset.get_item(
-            scene_label=self.dataset.scene_label,
-            spa_labels=spa_labels,
-            tem_labels=tem_labels,
-            input_spa_labels=self.input_spa_labels,
-        )
-        sample["alt"] = alt
-        sample["domain"] = domain
-        sample["domain_label"] = domain_label
-        sample["input_indices"] = input_indices
-        sample["target_indices"] = target_indices
-
-        cond_masks = sample["cond_masks"]
-        cond_masks[...] = 1.0
-        cond_masks[input_indices, ...] = 0.0
-        sample["cond_masks"] = cond_masks
-
+    def _gather_cells(self, labels) -> Tuple[List[Optional[torch.Tensor]], torch.Tensor]:
         with self.lock:
-            latents, timestep_indices = [], []
-            for _, spa_label, tem_label in sample["labels"]:
-                latents.append(self.latents[spa_label][tem_label])
-                timestep_indices.append(self.timestep_indices[spa_label][tem_label])
-        timestep_indices = torch.tensor(timestep_indices)
-        if timestep_indices[target_indices[0]] == 0:
-            sample["latents"] = None
+            cells = [(self.latents[c][f], self.timestep_indices[c][f]) for _, c, f in labels]
+        return [lat for lat, _ in cells], torch.tensor([idx for _, idx in cells])
+
+    def _scatter_cells(self, labels, latents, indices) -> None:
+        with self.lock:
+            for (_, c, f), lat, idx in zip(labels, latents, indices):
+                self.latents[c][f] = lat
+                self.timestep_indices[c][f] = int(idx)
+
+    def load_sample(self, alt: int, domain: str, domain_label: str) -> dict:
+        cams, frames, input_rows, target_rows = self._task_geometry(domain, domain_label)
+        sample = self.dataset.get_item(scene_label=self.dataset.scene_label, spa_labels=cams, tem_labels=frames,
+                                       input_spa_labels=self.input_spa_labels)
+        sample.update(alt=alt, domain=domain, domain_label=domain_label, input_indices=torch.tensor(input_rows),
+                      target_indices=torch.tensor(target_rows))
+        mask = sample["cond_masks"]  # 0 = conditioning (input) row, 1 = row to denoise
+        mask.fill_(1.0)
+        mask[sample["input_indices"]] = 0.0
+
+        cell_latents, cell_indices = self._gather_cells(sample["labels"])
+        first_round = int(cell_indices[target_rows[0]]) == 0  # targets of a task always share one index
+        if first_round:
+            sample["latents"] = None  # the pipeline draws the initial noise
         else:
-            dev = next(l.device for l in latents if l is not None)
-            sample["latents"] = torch.stack([l.to(dev) for l in latents], dim=0)
-        sample["timestep_indices"] = timestep_indices
+            dev = next(lat.device for lat in cell_latents if lat is not None)
+            sample["latents"] = torch.stack([lat.to(dev) for lat in cell_latents])
+        sample["timestep_indices"] = cell_indices
         return sample
 
     @torch.no_grad()
     def denoise(self, sample: dict, pipe_idx: int = 0) -> dict:
-        pipeline = self.pipelines[pipe_idx]
-        task_label = f"alt{sample['alt']}_{'spa' if sample['domain'] == 'temporal' else 'tem'}{sample['domain_label']}"
-        result = pipeline.sliding_iterative_denoise(
-            pixel_values=sample["pixel_values"],
-            plucker_embeds=sample["plucker_embeds"],
-            skeletons=sample["skeletons"],
-            cond_masks=sample["cond_masks"],
-            latents=sample["latents"],
-            domain=sample["domain"],
-            timestep_indices=sample["timestep_indices"],
-            window_size=self.window_size,
-            sliding_stride=self.sliding_stride,
-            sliding_shift=self.sliding_shift,
-            bidirectional=self.bidirectional,
-            num_denoising_steps=self.num_denoising_steps,
-            alternation_rounds=self.alternation_rounds,
-            guidance_scale=self.guidance_scale,
-            tqdm=partial(_tqdm, desc=f"Denoising {task_label} on {pipeline.device}"),
-            **self._pipeline_extensions(sample),
-        )
-        with self.lock:
-            for label, latent, timestep_index in zip(sample["labels"], result["latents"], result["timestep_indices"]):
-                _, spa_label, tem_label = label
-                self.latents[spa_label][tem_label] = latent
-                self.timestep_indices[spa_label][tem_label] = int(timestep_index)
+        pipe = self.pipelines[pipe_idx]
+        axis = "spa" if sample["domain"] == "temporal" else "tem"  # the label names the FIXED axis of the task
+        bar = partial(_tqdm, desc=f"Denoising alt{sample['alt']}_{axis}{sample['domain_label']} on {pipe.device}")
+        tensors = {k: sample[k] for k in ("pixel_values", "plucker_embeds", "skeletons", "cond_masks", "latents",
+                                          "timestep_indices")}
+        result = pipe.sliding_iterative_denoise(domain=sample["domain"], tqdm=bar, **tensors, **asdict(self.sweep),
+                                                **self._pipeline_extensions(sample))
+        self._scatter_cells(sample["labels"], result["latents"], result["timestep_indices"])
         sample["images"] = result["images"].float().cpu()
         sample["timestep_indices"] = result["timestep_indices"].cpu()
         sample["fully_denoised"] = result["fully_denoised"].cpu()
@@ -224,8 +191,7 @@ class SlidingIterativeSampler:
         return kw
 
     def execute_one_task(self, task: dict, pipe_idx: int = 0) -> dict:
-        sample = self.load_sample(**task)
-        sample = self.denoise(sample, pipe_idx=pipe_idx)
+        sample = self.denoise(self.load_sample(**task), pipe_idx=pipe_idx)
         if self.result_writer is not None:
             self.result_writer(sample, output_dir=self.output_dir)
         return sample
