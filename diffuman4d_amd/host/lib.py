@@ -63,6 +63,10 @@ def load():
             f"{_LIB_PATH} not found: build the HIP extension first (python -m diffuman4d_amd.build). "
             "diffuman4d_amd has no CPU/PyTorch fallback path."
         )
+    # PyTorch ships its own libamdhip64; load it FIRST so that libdm4d.so binds to the same HIP runtime instance as the
+    # tensors and streams it is handed (loading libdm4d.so first pulls in /opt/rocm's copy and every launch then
+    # fails with "no ROCm-capable device is detected")
+    import torch  # noqa: F401
     lib = C.CDLL(str(_LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
