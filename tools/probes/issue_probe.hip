@@ -115,6 +115,46 @@ __device__ __forceinline__ float run_op(int iters, float seed) {
   }
 }
 
+// one wave per SIMD; per loop iteration 4 x { 1 MFMA ; KV independent VALU instructions (v_fma or v_exp) }
+template <int KV, bool EXPOP>
+__global__ __launch_bounds__(256) void mix_probe(float* out, int iters, float seed) {
+  f32x16 acc[4];
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = seed;
+  bf16x8 a, b;
+  for (int r = 0; r < 8; ++r) { a[r] = (__bf16)seed; b[r] = (__bf16)(seed + 1.f); }
+  float x[8];
+  for (int i = 0; i < 8; ++i) x[i] = seed * 0.001f + i * 0.01f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[u], 0, 0, 0);
+#pragma unroll
+      for (int k = 0; k < KV; ++k) {
+        if constexpr (EXPOP) asm volatile("v_exp_f32 %0, %0" : "+v"(x[k & 7]));
+        else asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(x[k & 7]) : "v"(seed));
+      }
+    }
+  }
+  float r = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
+  for (int i = 0; i < 8; ++i) r += x[i];
+  if (r == 12345.678f) out[threadIdx.x] = r;
+}
+
+template <int KV, bool EXPOP>
+float time_mix(float* out, int iters) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((mix_probe<KV, EXPOP>), dim3(256), dim3(256), 0, 0, out, iters, 1.0f);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((mix_probe<KV, EXPOP>), dim3(256), dim3(256), 0, 0, out, iters, 1.0f);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  return ms / 5 * 1e3f;
+}
+
 template <int A, int B>
 __global__ __launch_bounds__(512) void probe(float* out, int iters, float seed) {
   const int wave = threadIdx.x >> 6;
@@ -159,5 +199,9 @@ int main() {
   TWO("mfma | v_add", MFMA, ADD) TWO("mfma | v_mov", MFMA, MOV) TWO("mfma | v_max", MFMA, MAX2) TWO("mfma | v_dot2", MFMA, DOT2)
   TWO("mfma | ds_read_b128", MFMA, DSREAD) TWO("mfma | ds_read_tr", MFMA, DSTR)
   TWO("mfma | v_dot2c", MFMA, DOT2C) TWO("mfma | v_exp_f16", MFMA, EXPH) TWO("mfma | v_pk_add", MFMA, PKADD)
+  // VALU work issued by the SAME wave between its MFMAs ("MFMA shadow"): cycles per {1 MFMA + KV VALU}
+#define MIX(KV) { float f = time_mix<KV, false>(out, it * 4); float e = time_mix<KV, true>(out, it * 4); \
+    printf("same wave: 1 mfma + %2d v_fma  %6.2f cycles   | 1 mfma + %2d v_exp  %6.2f cycles\n", KV, f * cyc_us / n, KV, e * cyc_us / n); }
+  MIX(0) MIX(2) MIX(4) MIX(6) MIX(8) MIX(12) MIX(16)
   return 0;
 }
