@@ -4,8 +4,8 @@
 // MultiviewTransformerBlock (reference attention.py:68-83): the fold "(b t) hw c -> b (t hw) c" is
 // free because activations are token-major, so the kernel just sees batch = B/F, L = F*HW.
 //
-// Work decomposition: a workgroup = 8 waves, each wave owns 32 query rows (128 VGPRs, 4 waves per SIMD);
-// K/V tiles of 64 keys are staged register-prefetch -> LDS, double buffered, one barrier per tile, both row-major:
+// Work decomposition: a workgroup = 8 waves, each wave owns 32 query rows; K/V tiles of 64 keys are staged
+// register-prefetch -> LDS, double buffered, one barrier per tile, both row-major:
 //   Ks[key][d]  144-byte rows  -> conflict-free ds_read_b128 A-fragments of S^T = K Q^T
 //   Vs[key][d]  192-byte rows  -> the V^T A-fragments of O^T = V^T P^T come out of ds_read_b64_tr_b16 (hardware
 //               transposing read of a [4 keys][16 d] block per 16-lane group; 4 consecutive rows tile the 64 banks)
@@ -18,7 +18,8 @@
 //                  no lane shuffles between the two MFMAs.
 // Keys may outnumber queries (Lk >= Lq): frame-sharded 3-D attention runs local queries against all-gathered K/V.
 // Softmax: an optimistic pass (row max taken from the first tile only) with an exact running-max pass (lazy O/l
-// rescale when a row max grows by more than 2^8) as the in-kernel fallback; see the comment at kv_loop.
+// rescale when a row max grows by more than 2^8) as the in-kernel fallback; see the comments at kv_loop and
+// kv_loop_pipelined (the software-pipelined optimistic loop that normally runs).
 // The 1-D grid is remapped so that all query tiles of one (batch, head) run on one XCD and share
 // its L2 copy of K/V.
 #include "common.h"
@@ -164,6 +165,137 @@ __device__ __forceinline__ void kv_loop(const AttnParams& p, const u16* Kb, cons
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Software-pipelined form of the optimistic loop.  A wave can issue VALU instructions in the shadow of its OWN
+// MFMAs (issue probe: 1 MFMA + 4 v_fma = 34 cycles, + 4 v_exp = 48, against 32 for the bare MFMA), but only if
+// independent VALU work sits next to every MFMA and the MFMA's LDS fragments were requested well before it.  QK^T
+// therefore runs one tile ahead of its softmax (K staged one tile ahead of V in LDS) and the loop body is straight-line
+// code in which the compiler alternates MFMAs and VALU work (216 VGPRs, one workgroup per CU).  +3..7 % on every UNet
+// shape; forcing the order with sched_group_barrier ({reads ; 1 MFMA ; 8 VALU} x 16) was 2 % slower than the
+// compiler's own interleave.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void kv_loop_pipelined(const AttnParams& p, const u16* Kb, const u16* Vb, u16* Ks, u16* Vs,
+                                                  const u16* v_lane, const bf16x8_t (&qf)[4], f32x16_t (&o)[2], float& m_run,
+                                                  float& l_run, int tid, int l31, int lh) {
+  const int Lk = p.Lk;
+  const int nt = (Lk + KV - 1) / KV;
+  const int s_key = tid >> 3, s_c = tid & 7;
+  auto key_row = [&](int t) {
+    int key = t * KV + s_key;
+    return key > Lk - 1 ? Lk - 1 : key;
+  };
+  auto qk_block = [&](int buf, int kb, f32x16_t& s) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (buf * KV + kb * 32 + l31) * LDS_LD + j * 16 + lh * 8);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[j], s, 0, 0, 0);
+    }
+  };
+  auto mask_tail = [&](int t, f32x16_t (&s)[2]) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int key0 = t * KV + kb * 32 + 4 * lh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (key0 + (r & 3) + 8 * (r >> 2) >= Lk) s[kb][r] = -1e30f;
+    }
+  };
+  float mc = 0.f;
+  auto softmax_block = [&](const f32x16_t& s, bf16x8_t (&pf)[2]) {
+    float pv[16];
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      pv[r] = __builtin_amdgcn_exp2f(s[r] * p.c - mc);
+      sum += pv[r];
+    }
+    l_run += sum;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      U4 w;
+      w.x = cvt_pk_bf16(pv[jj * 8 + 0], pv[jj * 8 + 1]);
+      w.y = cvt_pk_bf16(pv[jj * 8 + 2], pv[jj * 8 + 3]);
+      w.z = cvt_pk_bf16(pv[jj * 8 + 4], pv[jj * 8 + 5]);
+      w.w = cvt_pk_bf16(pv[jj * 8 + 6], pv[jj * 8 + 7]);
+      pf[jj] = *reinterpret_cast<bf16x8_t*>(&w);
+    }
+  };
+  auto pv_block = [&](int buf, int kb, const bf16x8_t (&pf)[2]) {
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const u16* vp = v_lane + (buf * KV + kb * 32 + jj * 16) * LDS_LDV + db * 32;
+        s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)vp);
+        s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vp + 8 * LDS_LDV));
+        s16x8_t v01 = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+        bf16x8_t vf = *reinterpret_cast<bf16x8_t*>(&v01);
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[jj], o[db], 0, 0, 0);
+      }
+  };
+
+  {  // prologue: K(0), V(0), K(1) -> LDS
+    U4 k0 = ldg16(Kb + (int64_t)key_row(0) * p.ldk + s_c * 8);
+    U4 v0 = ldg16(Vb + (int64_t)key_row(0) * p.ldv + s_c * 8);
+    U4 k1 = ldg16(Kb + (int64_t)key_row(1) * p.ldk + s_c * 8);  // clamped when nt == 1
+    *reinterpret_cast<U4*>(Ks + (0 * KV + s_key) * LDS_LD + s_c * 8) = k0;
+    *reinterpret_cast<U4*>(Vs + (0 * KV + s_key) * LDS_LDV + s_c * 8) = v0;
+    *reinterpret_cast<U4*>(Ks + (1 * KV + s_key) * LDS_LD + s_c * 8) = k1;
+  }
+  __syncthreads();
+  f32x16_t s_cur[2], s_nxt[2];
+  qk_block(0, 0, s_cur[0]);
+  qk_block(0, 1, s_cur[1]);
+  if (nt == 1 && (Lk % KV) != 0) mask_tail(0, s_cur);
+  {
+    float mx = fmaxf(s_cur[0][0], s_cur[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s_cur[0][r], s_cur[1][r]));
+    m_run = fmaxf(mx, __shfl_xor(mx, 32));
+    mc = m_run * p.c;
+  }
+  __syncthreads();  // every wave has read K(0): its buffer is overwritten at the end of iteration 0
+
+  // one pipelined step: consumes S(t) from `sa`, produces S(t+1) into `sb`; straight-line code (no branches)
+  auto step = [&](int t, f32x16_t (&sa)[2], f32x16_t (&sb)[2]) {
+    const int kbuf = (t + 1) & 1, vbuf = t & 1;
+    const U4 rk = ldg16(Kb + (int64_t)key_row(t + 2) * p.ldk + s_c * 8);  // clamped past the end of the sequence
+    const U4 rv = ldg16(Vb + (int64_t)key_row(t + 1) * p.ldv + s_c * 8);
+    bf16x8_t pf[2];
+    qk_block(kbuf, 0, sb[0]);
+    softmax_block(sa[0], pf);
+    pv_block(vbuf, 0, pf);
+    qk_block(kbuf, 1, sb[1]);
+    softmax_block(sa[1], pf);
+    pv_block(vbuf, 1, pf);
+    *reinterpret_cast<U4*>(Ks + ((t & 1) * KV + s_key) * LDS_LD + s_c * 8) = rk;         // K(t+2) over K(t)
+    *reinterpret_cast<U4*>(Vs + (((t + 1) & 1) * KV + s_key) * LDS_LDV + s_c * 8) = rv;  // V(t+1) over V(t-1)
+    __syncthreads();
+  };
+  int t = 0;
+  for (; t + 3 < nt; t += 2) {  // two steps per trip: the S register sets swap roles instead of being copied
+    step(t, s_cur, s_nxt);
+    step(t + 1, s_nxt, s_cur);
+  }
+  for (; t < nt; ++t) {  // last <= 3 tiles: tail mask, no look-ahead on the final one
+    if (t + 1 < nt) {
+      step(t, s_cur, s_nxt);
+      if (t + 2 == nt && (Lk % KV) != 0) mask_tail(t + 1, s_nxt);
+      s_cur[0] = s_nxt[0];
+      s_cur[1] = s_nxt[1];
+    } else {
+      bf16x8_t pf[2];
+      softmax_block(s_cur[0], pf);
+      pv_block(t & 1, 0, pf);
+      softmax_block(s_cur[1], pf);
+      pv_block(t & 1, 1, pf);
+      __syncthreads();
+    }
+  }
+}
+
 __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) u16 smem[2 * KV * LDS_LD + 2 * KV * LDS_LDV];
   u16* Ks = smem;
@@ -201,7 +333,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
     for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
   float l_tot = -1.f;
   if (!p.exact_only) {
-    kv_loop<false>(p, Kb, Vb, Ks, Vs, v_lane, qf, o, m_run, l_run, tid, l31, lh);
+    kv_loop_pipelined(p, Kb, Vb, Ks, Vs, v_lane, qf, o, m_run, l_run, tid, l31, lh);
     l_tot = l_run + __shfl_xor(l_run, 32);
   }
   // out of range (a later tile outgrew the first tile's max by more than 2^60) or NaN: redo with the exact loop
