@@ -316,6 +316,12 @@ CASES = {
     # --- attention -------------------------------------------------------------------------------
     "attn_small": (case_attention, dict(batch=2, heads=2, L=128)),
     "attn_tail45": (case_attention, dict(batch=3, heads=1, L=45)),
+    # tile-count edge cases of the software-pipelined loop (64-key tiles, look-ahead, tail mask on the last one)
+    "attn_L64": (case_attention, dict(batch=2, heads=1, L=64)),
+    "attn_L65": (case_attention, dict(batch=2, heads=1, L=65)),
+    "attn_L129": (case_attention, dict(batch=1, heads=2, L=129)),
+    "attn_L191": (case_attention, dict(batch=1, heads=1, L=191)),
+    "attn_L256": (case_attention, dict(batch=1, heads=1, L=256)),
     "attn_tail720": (case_attention, dict(batch=2, heads=3, L=720)),
     "attn_2d": (case_attention, dict(batch=8, heads=5, L=2880)),
     "attn_3d": (case_attention, dict(batch=2, heads=10, L=4320)),
