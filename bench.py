@@ -246,7 +246,7 @@ def main():
             "unet_calls_per_s": round(ranks_units * 3 / dt, 3),
             "unet_tflops_sustained": round(ranks_units * unit_tflop / dt, 1) if unit_tflop else None,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only (the CPU sample would skew multi-rank timing)
             out["cpu_baseline"] = cpu_baseline(args.cpu_frames, args.cpu_threads)
         print(json.dumps(out), flush=True)
     if world > 1:
