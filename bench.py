@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--latent", default="72x40",
                     help="latent grid HxW: 72x40 = BASELINE.json's synthetic grid (default, the judged line); 128x128 = the "
                          "1024^2 images the reference's demo configs run (SURVEY.md 8d asks for both)")
+    ap.add_argument("--prune-cond-rows", action="store_true",
+                    help="opt-in extension, NOT the judged configuration: skip the per-frame tail of the UNet (after the last "
+                         "3-D attention) for conditioning frames, whose noise prediction the reference discards")
     ap.add_argument("--cpu-frames", type=int, default=16,
                     help="frames of the CPU-baseline UNet call (16 = a full spatial window); the default is the full window,"
                          " about 20 s with 32 threads")
@@ -162,6 +165,7 @@ def main():
     cfg = UNetConfig()
     unet = UNetMultiviewConditionModel(cfg, random_state_dict(unet_param_shapes(cfg), 0, dev), dev)
     pipe = Diffuman4DPipeline(None, unet, DDIMScheduler(), dev)
+    pipe.prune_cond_rows = bool(args.prune_cond_rows)
     shard = None
     if args.mode == "frame-shard" and world > 1:
         from diffuman4d_amd.host.parallel import FrameShard
@@ -222,6 +226,7 @@ def main():
                                 f"attention layer)" if shard is not None else
                                 f"task-parallel x{world} (independent tasks per round, no data-path collective)"),
                 "finite_outputs": finite,
+                "extensions": ["prune_cond_rows"] if args.prune_cond_rows else [],
             },
             "roofline": {
                 "kernel": "attn_kernel (2-D + 3-D view/time attention, all 48 launches of a step)",

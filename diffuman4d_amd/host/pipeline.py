@@ -49,6 +49,9 @@ class Diffuman4DPipeline:
         self.dtype = BF16
         self.vae_scale_factor = vae.scale_factor if vae is not None else 8
         self._vae_cache: Dict[str, dict] = {"pixel": {}, "skeleton": {}}  # encoder moments by caller-supplied key
+        # extension (off = compute what the reference computes): after the last 3-D attention layer run only the rows
+        # whose noise prediction the DDIM step reads, i.e. drop the conditioning frames from the per-frame tail of the UNet
+        self.prune_cond_rows = False
 
     def clear_vae_cache(self):
         self._vae_cache = {"pixel": {}, "skeleton": {}}
@@ -138,8 +141,11 @@ class Diffuman4DPipeline:
         def up(a):
             return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
+        # rows of the CFG batch whose noise prediction is consumed (non-conditioning frames, both halves), per call
+        F = win.shape[1]
+        keep = [up(np.concatenate([np.nonzero(~c)[0] + h * F for h in range(cfg)]).astype(np.int64)) for c in cond]
         return dict(win=up(win), cond=up(cond.astype(np.int32)), t=up(t_in), coef=up(coef), calls=win.shape[0], cfg=cfg,
-                    win_full=up(win_full.astype(np.int64)))
+                    win_full=up(win_full.astype(np.int64)), keep=keep)
 
     def denoise_latents(self, pv_lat, pl_lat, sk_lat, cm_lat, lat, plan: SweepPlan, domain: str, guidance_scale: float,
                         tqdm: Callable = _identity_tqdm, tables=None, shard=None):
@@ -174,8 +180,12 @@ class Diffuman4DPipeline:
                 pose = torch.cat([sk3.neg.expand(F, -1, -1, -1), pose])
             sk3 = None
         x = ops.pack_model_input(lat3, pv3, pl3, sk3, cm3, cond, self.unet.IN_PAD, use_cfg, frame_idx=widx)
+        keep = tb["keep"][i] if self.prune_cond_rows else None
         eps = self.unet(x.view(tb["cfg"] * F, h, w, self.unet.IN_PAD), tb["t"][i], domains=domains, num_frames=F, shard=shard,
-                        pose_features=pose)
+                        pose_features=pose, keep_rows=keep)
+        if keep is not None:  # back to one row per CFG-batch entry; the rows left at zero are never read by the step kernel
+            full = torch.zeros((tb["cfg"] * F,) + tuple(eps.shape[1:]), dtype=eps.dtype, device=eps.device)
+            eps = full.index_copy_(0, keep, eps)
         ops.cfg_ddim_step(lat3, eps.view(tb["cfg"] * F, HW, -1), tb["coef"][i], cond, use_cfg, float(guidance_scale), vpred,
                           frame_idx=widx)
         if shard is not None:  # F/P updated rows per rank -> every rank's copy of the task latents

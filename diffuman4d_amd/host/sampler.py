@@ -11,7 +11,7 @@ What is organised differently here:
     a task's cells are two small methods under one lock;
   * ``result_writer`` is injectable (the reference hard-wires ``save_sampling_results``);
   * ``partition(round, rank, world)`` exposes the per-round task sharding used by the one-process-per-GPU runner;
-  * optional pipeline extensions (``vae_cache``, ``decode_policy``), off by default.
+  * optional pipeline extensions (``vae_cache``, ``decode_policy``, ``prune_cond_rows``), off by default.
 """
 from __future__ import annotations
 
@@ -61,7 +61,7 @@ class SlidingIterativeSampler:
                  spa_label_range: Optional[Sequence[int]] = (0, 48, 1), tem_label_range: Optional[Sequence[int]] = (0, 150, 1),
                  spa_labels: Optional[Sequence[int]] = None, tem_labels: Optional[Sequence[int]] = None,
                  input_spa_labels: Sequence[int] = (1, 13, 25, 37), result_writer: Optional[Callable] = None,
-                 vae_cache: bool = False, decode_policy: str = "all"):
+                 vae_cache: bool = False, decode_policy: str = "all", prune_cond_rows: bool = False):
         self.dataset, self.pipelines, self.output_dir = dataset, pipelines, output_dir
         self.sweep = SweepConfig(window_size, sliding_stride, sliding_shift, bidirectional, num_denoising_steps,
                                  alternation_rounds, guidance_scale)
@@ -74,6 +74,9 @@ class SlidingIterativeSampler:
         if self.vae_cache:  # the cache is keyed by (camera, frame) of ONE scene
             for pipe in pipelines:
                 pipe.clear_vae_cache()
+        if prune_cond_rows:  # per-frame tail of the UNet only for rows whose noise prediction is consumed
+            for pipe in pipelines:
+                pipe.prune_cond_rows = True
 
         self.spa_labels = _format_labels(spa_labels, spa_label_range, 2, "spa")
         self.tem_labels = _format_labels(tem_labels, tem_label_range, 6, "tem")

@@ -321,8 +321,12 @@ class UNetMultiviewConditionModel:
 
     @torch.no_grad()
     def forward(self, sample: torch.Tensor, timestep: torch.Tensor, skeletons=None, domains: Sequence[str] = ("spatial",),
-                num_frames: int = 1, shard=None, pose_features: Optional[torch.Tensor] = None) -> torch.Tensor:
+                num_frames: int = 1, shard=None, pose_features: Optional[torch.Tensor] = None,
+                keep_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
         """sample [B, h, w, 32] NHWC bf16 (channels beyond in_channels zero); timestep [B]; -> [B, h, w, out_channels].
+        keep_rows (int64 [R], optional extension): batch rows whose output is wanted.  Every layer after the last 3-D
+        attention is per-frame, so from there on only these rows are computed and the result has R rows (the pipeline
+        discards the noise prediction of conditioning rows, pipeline_diffuman4d.py:413-421).
         With `shard` (parallel.FrameShard) sample/timestep hold this rank's frames and num_frames is the LOCAL count.
         enable_pose_encoder checkpoints (:551-552): pass `skeletons` [B, 8h, 8w, 4] NHWC (encoded here, as the
         reference does on every call) or `pose_features` [B, h, w, C0] computed once with ``self.pose_encoder``."""
@@ -358,12 +362,21 @@ class UNetMultiviewConditionModel:
         x = self.mid[0][0](x, tproj)
         x = self.mid[1](x, num_frames, shard)  # :570
         x = self.mid[0][1](x, tproj)
+        def prune(x, tproj, skips):  # rows past the last frame-mixing layer that nobody reads are dropped
+            return (x.index_select(0, keep_rows), tproj.index_select(0, keep_rows),
+                    [sk.index_select(0, keep_rows) for sk in skips])
+
+        last3d = max((i for i, (_, att, _) in enumerate(self.up) if att is not None and i < cfg.num_3d_attn_blocks), default=-1)
+        if keep_rows is not None and last3d < 0:
+            x, tproj, skips = prune(x, tproj, skips)
         for i, (res, att, us) in enumerate(self.up):
             is3d = att is not None and i < cfg.num_3d_attn_blocks  # :582
             for j, r in enumerate(res):
                 x = r(x, tproj, skip=skips.pop())
                 if att is not None:
                     x = att[j](x, num_frames if is3d else 1, shard if is3d else None)
+            if keep_rows is not None and i == last3d:
+                x, tproj, skips = prune(x, tproj, skips)
             if us is not None:
                 x = ops.conv3x3(x, us[0], bias=us[1], upsample=True)
         x = ops.groupnorm(x, self.no_w, self.no_b, cfg.norm_num_groups, cfg.norm_eps, silu=True)

@@ -317,6 +317,30 @@ def case_pipeline_cache_lazy(seed=31):
     return bad, 0.0
 
 
+def case_pipeline_prune(domain="spatial", seed=41):
+    """prune_cond_rows extension: the UNet tail after the last 3-D attention runs only for non-conditioning rows.  The
+    latents must agree with the strict path to within kernel-configuration noise (other tile shapes for the smaller
+    batch) and the bookkeeping exactly."""
+    from diffuman4d_amd.host.pipeline import Diffuman4DPipeline
+    from diffuman4d_amd.host.scheduler import DDIMConfig as HC, DDIMScheduler as HS
+    cfg_u, ou = make_unet(seed)
+    cfg_v, ov = make_vae(seed + 1)
+    n, inputs = (8, [1, 5]) if domain == "spatial" else (8, [0, 1, 2, 3])
+    pv, pl, sk, cm = synthetic_task(n, 64, 64, inputs, seed)
+    g = torch.Generator().manual_seed(seed + 2)
+    noise = {k: torch.randn(n, 4, 8, 8, generator=g).to(BF) for k in ("pixel", "skeleton", "latents")}
+    kw = dict(pixel_values=pv, plucker_embeds=pl, skeletons=sk, cond_masks=cm, latents=None, domain=domain,
+              timestep_indices=torch.zeros(n, dtype=torch.int64), window_size=4, sliding_stride=2 if domain == "spatial" else 1,
+              sliding_shift=0, bidirectional=False, num_denoising_steps=1, alternation_rounds=1, guidance_scale=2.0, noise=noise)
+    hp = Diffuman4DPipeline(hip_vae(cfg_v, ov), hip_unet(cfg_u, ou), HS(HC()), "cuda")
+    ref = hp.sliding_iterative_denoise(**kw)
+    hp.prune_cond_rows = True
+    out = hp.sliding_iterative_denoise(**kw)
+    exact = torch.equal(out["timestep_indices"], ref["timestep_indices"]) and torch.equal(out["fully_denoised"], ref["fully_denoised"])
+    err = max(rel_l2(out["latents"], ref["latents"]), rel_l2(out["images"], ref["images"]))
+    return (err if exact else 1.0), 0.0
+
+
 def case_golden_pipeline(name):
     """HIP sliding_iterative_denoise vs the output of the REFERENCE's own pipeline code (committed
     fixture tests/golden/pipeline_sliding.pt, fp32): same seeded weights, task tensors and noise."""
@@ -350,6 +374,8 @@ CASES = {
     "unet_pose_encoder": (case_unet, dict(num_frames=4, cfg_batch=2, pose=True)),
     "pipeline_pose_encoder": (case_pipeline, dict(domain="spatial", pose=True)),
     "pipeline_cache_lazy_decode": (case_pipeline_cache_lazy, dict()),
+    "pipeline_prune_cond_rows": (case_pipeline_prune, dict(domain="spatial")),
+    "pipeline_prune_cond_rows_temporal": (case_pipeline_prune, dict(domain="temporal")),
     "vae": (case_vae, dict()),
     "resize": (case_resize, dict()),
     "pipeline_spatial": (case_pipeline, dict(domain="spatial")),
@@ -362,7 +388,7 @@ CASES = {
     "golden_pose_encoder": (case_golden_pipeline, dict(name="pose_encoder")),
 }
 # multi-layer bf16 pipelines: each of ~100 ops adds ~2e-3 of rounding noise; they add in quadrature
-TOL = {"pipeline_shard_rccl_world1": 0.0, "unet_frame_shard_p4": 0.0, "unet_frame_shard_p8": 0.0, "unet_spatial": 3e-2, "unet_temporal_temb": 3e-2, "unet_2d_only": 3e-2, "unet_pose_encoder": 3e-2, "pipeline_pose_encoder": 6e-2, "pipeline_cache_lazy_decode": 0.0, "vae": 3e-2, "resize": 4e-3,
+TOL = {"pipeline_shard_rccl_world1": 0.0, "unet_frame_shard_p4": 0.0, "unet_frame_shard_p8": 0.0, "unet_spatial": 3e-2, "unet_temporal_temb": 3e-2, "unet_2d_only": 3e-2, "unet_pose_encoder": 3e-2, "pipeline_pose_encoder": 6e-2, "pipeline_cache_lazy_decode": 0.0, "pipeline_prune_cond_rows": 5e-3, "pipeline_prune_cond_rows_temporal": 5e-3, "vae": 3e-2, "resize": 4e-3,
        "pipeline_spatial": 6e-2, "pipeline_temporal_v": 6e-2, "pipeline_bidir_nocfg": 6e-2,
        "golden_spatial": 6e-2, "golden_temporal_v": 6e-2, "golden_bidir_nocfg": 6e-2, "golden_round2_shift": 6e-2, "golden_pose_encoder": 6e-2}
 

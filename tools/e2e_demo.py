@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--fast-vae", action="store_true",
                     help="sampler.vae_cache=true sampler.decode_policy=denoised (encoder moments cached per grid cell, "
                          "decode only the rows that are saved)")
+    ap.add_argument("--prune", action="store_true", help="sampler.prune_cond_rows=true (UNet tail only for consumed rows)")
     ap.add_argument("--workdir", default=None)
     ap.add_argument("overrides", nargs="*")
     a = ap.parse_args()
@@ -49,7 +50,8 @@ def main():
     t_ckpt = time.perf_counter() - t0
     cfg = cfglib.compose([f"exp={a.exp}", "model=diffuman4d_mi355x", "data=synthetic", f"model.model_dir={ckpt}",
                           "model.gpu_ids=[0]", f"data.height={H}", f"data.width={W}", f"result_dir={work / 'results'}"]
-                         + (["sampler.vae_cache=true", "sampler.decode_policy=denoised"] if a.fast_vae else []) + a.overrides)
+                         + (["sampler.vae_cache=true", "sampler.decode_policy=denoised"] if a.fast_vae else [])
+                         + (["sampler.prune_cond_rows=true"] if a.prune else []) + a.overrides)
     t0 = time.perf_counter()
     dataset = cfglib.instantiate(cfg["data"])
     pipelines = cfglib.instantiate(cfg["model"])
@@ -83,7 +85,7 @@ def main():
     done = sum(sampler.timestep_indices[c][f] > 0 for c in sampler.target_spa_labels for f in sampler.tem_labels)
     n_img = len(list(Path(sampler.output_dir).rglob("*.jpg")))
     print(json.dumps({
-        "exp": a.exp, "image_size": [H, W], "prefetch_depth": a.depth, "writers": a.writers, "fast_vae": a.fast_vae, "tasks": n_tasks,
+        "exp": a.exp, "image_size": [H, W], "prefetch_depth": a.depth, "writers": a.writers, "fast_vae": a.fast_vae, "prune_cond_rows": a.prune, "tasks": n_tasks,
         "target_latents": n_lat, "denoised": int(done), "images_written": n_img, "wall_s": round(wall, 3),
         "latents_per_s_end_to_end": round(n_lat / wall, 3),
         "stage_seconds": {k: round(v, 3) for k, v in acc.items()},
