@@ -151,10 +151,22 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        if shared:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        # RCCL prints a version banner on stdout when the communicator comes up; this program's stdout carries exactly
+        # one JSON line, so fd 1 points at stderr until the first collective has run
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if shared:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     from diffuman4d_amd.host import ops
     from diffuman4d_amd.host.pipeline import Diffuman4DPipeline
