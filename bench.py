@@ -207,6 +207,27 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # per-family breakdown from one extra, UNTIMED unit with an event pair around every launch (the event records
+    # themselves would cost about 1 % inside the timed region)
+    breakdown = None
+    if rank == 0:
+        with torch.no_grad():
+            ops.PROFILE = prof = []
+            run_unit(pipe, tasks, args.warmup + args.steps, shard)
+            torch.cuda.synchronize()
+            ops.PROFILE = None
+        fam = {}
+        for name, work, unit, e0, e1 in prof:
+            f = fam.setdefault(name, {"launches": 0, "ms": 0.0, "work": 0.0, "unit": unit})
+            f["launches"] += 1
+            f["ms"] += e0.elapsed_time(e1)
+            f["work"] += work
+        breakdown = {k: {"launches": v["launches"], "ms": round(v["ms"], 2),
+                         ("tflops" if v["unit"] == "flop" else "gb_per_s"):
+                             round(v["work"] / (v["ms"] * 1e-3) / (1e12 if v["unit"] == "flop" else 1e9), 1)}
+                     for k, v in fam.items()}
+    if world > 1:
+        dist.barrier()
     finite = bool(torch.isfinite(tasks["spatial"]["lat"].float()).all() and torch.isfinite(tasks["temporal"]["lat"].float()).all())
     # HBM traffic of the attention kernel from PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
     # this same command, tools/… -> profiles/r01_attn_traffic_pmc.json): bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB,
@@ -258,6 +279,7 @@ def main():
             unit_tflop = 2 * 261.9 + 485.8
         else:
             unit_tflop = None
+        out["kernel_breakdown_one_step"] = breakdown
         out["secondary"] = {
             "latent_steps_per_s": round(ranks_units * 3 * WINDOW / dt, 2),
             "unet_calls_per_s": round(ranks_units * 3 / dt, 3),

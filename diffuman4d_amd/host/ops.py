@@ -53,10 +53,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
         out = torch.empty((M, N), dtype=BF16, device=a.device)
     _req(out, "out")
     flags = (_l.EPI_GEGLU if geglu else 0) | (_l.EPI_SILU if silu else 0)
-    rc = lib.dm4d_gemm_bf16(_stream(), _p(a), a.stride(0), _p(a2), a2.stride(0) if a2 is not None else 0,
-                            K1 if a2 is not None else 0, _p(w), w.stride(0), _p(out), out.stride(0), M, N, K,
-                            _p(bias), _p(rowbias), rowbias.stride(0) if rowbias is not None else 0, rows_per_rowbias,
-                            _p(residual), residual.stride(0) if residual is not None else 0, flags, out_scale)
+    with _Prof("linear", 2.0 * M * w.shape[0] * K, "flop"):
+        rc = lib.dm4d_gemm_bf16(_stream(), _p(a), a.stride(0), _p(a2), a2.stride(0) if a2 is not None else 0,
+                                K1 if a2 is not None else 0, _p(w), w.stride(0), _p(out), out.stride(0), M, N, K,
+                                _p(bias), _p(rowbias), rowbias.stride(0) if rowbias is not None else 0,
+                                rows_per_rowbias, _p(residual), residual.stride(0) if residual is not None else 0,
+                                flags, out_scale)
     _l.check(rc, "dm4d_gemm_bf16")
     return out
 
@@ -85,10 +87,11 @@ def conv3x3(x: torch.Tensor, wt: torch.Tensor, *, bias=None, rowbias=None, resid
     if rowbias is not None:
         _req(rowbias, "rowbias")
         assert rowbias.shape[0] == B
-    rc = lib.dm4d_conv3x3_nhwc_bf16(_stream(), _p(x), B, H, W, Cin, _p(wt), _p(y), Ho, Wo, Cout, stride, pad,
-                                    1 if upsample else 0, _p(bias), _p(rowbias),
-                                    rowbias.stride(0) if rowbias is not None else 0, _p(residual),
-                                    Cout if residual is not None else 0, out_scale)
+    with _Prof("conv3x3", 2.0 * B * Ho * Wo * 9 * Cin * Cout, "flop"):
+        rc = lib.dm4d_conv3x3_nhwc_bf16(_stream(), _p(x), B, H, W, Cin, _p(wt), _p(y), Ho, Wo, Cout, stride, pad,
+                                        1 if upsample else 0, _p(bias), _p(rowbias),
+                                        rowbias.stride(0) if rowbias is not None else 0, _p(residual),
+                                        Cout if residual is not None else 0, out_scale)
     _l.check(rc, "dm4d_conv3x3_nhwc_bf16")
     return y
 
@@ -125,8 +128,9 @@ def groupnorm(x1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups:
         C2 = x2.shape[-1]
     y = torch.empty(x1.shape[:-1] + (C1 + C2,), dtype=BF16, device=x1.device)
     ws = torch.empty(lib.dm4d_groupnorm_ws_bytes(B, HW, groups) // 4, dtype=torch.float32, device=x1.device)
-    rc = lib.dm4d_groupnorm_nhwc_bf16(_stream(), _p(x1), C1, _p(x2), C2, B, HW, groups, eps, _p(gamma), _p(beta),
-                                      _p(y), 1 if silu else 0, _p(ws))
+    with _Prof("groupnorm", 3.0 * y.numel() * 2, "byte"):  # statistics read + apply read + write
+        rc = lib.dm4d_groupnorm_nhwc_bf16(_stream(), _p(x1), C1, _p(x2), C2, B, HW, groups, eps, _p(gamma), _p(beta),
+                                          _p(y), 1 if silu else 0, _p(ws))
     _l.check(rc, "dm4d_groupnorm_nhwc_bf16")
     return y
 
@@ -136,8 +140,9 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     _req(x, "x"), _req(gamma, "gamma"), _req(beta, "beta")
     x2 = x.reshape(-1, x.shape[-1])
     y = torch.empty_like(x2)
-    rc = lib.dm4d_layernorm_bf16(_stream(), _p(x2), x2.stride(0), _p(gamma), _p(beta), _p(y), y.stride(0), x2.shape[0],
-                                 x2.shape[1], eps)
+    with _Prof("layernorm", 2.0 * y.numel() * 2, "byte"):
+        rc = lib.dm4d_layernorm_bf16(_stream(), _p(x2), x2.stride(0), _p(gamma), _p(beta), _p(y), y.stride(0), x2.shape[0],
+                                     x2.shape[1], eps)
     _l.check(rc, "dm4d_layernorm_bf16")
     return y.view(x.shape)
 
@@ -160,8 +165,9 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, hea
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    rc = lib.dm4d_attention_kv_bf16(_stream(), _p(q), _p(k), _p(v), _p(out), q.stride(0), k.stride(0), v.stride(0),
-                                    out.stride(0), batch, heads, seq, kv_seq, scale)
+    with _Prof("attention", 4.0 * batch * heads * seq * kv_seq * 64, "flop"):
+        rc = lib.dm4d_attention_kv_bf16(_stream(), _p(q), _p(k), _p(v), _p(out), q.stride(0), k.stride(0), v.stride(0),
+                                        out.stride(0), batch, heads, seq, kv_seq, scale)
     if prof is not None:
         e1.record()
         prof.append(("attn_kernel", 4.0 * batch * heads * seq * kv_seq * 64, e0, e1))
@@ -172,6 +178,29 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, hea
 # bench.py sets this to a list to time individual launches with HIP events on the launch stream:
 # entries are (kernel, algorithmic flops, start_event, end_event).  None = no instrumentation.
 KERNEL_TIMER = None
+# Same idea for every kernel family (bench.py's untimed breakdown pass): entries are (family, work, unit, start, end)
+# with unit "flop" or "byte".  None = no instrumentation.
+PROFILE = None
+
+
+class _Prof:
+    """with _Prof(family, work, unit): <one launch>   -- records two events when ops.PROFILE is a list."""
+
+    def __init__(self, family: str, work: float, unit: str):
+        self.args = (family, work, unit)
+        self.on = PROFILE is not None
+
+    def __enter__(self):
+        if self.on:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.e1.record()
+            PROFILE.append(self.args + (self.e0, self.e1))
+        return False
 
 
 def softmax_rows(s: torch.Tensor, scale: float) -> torch.Tensor:
