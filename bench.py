@@ -16,7 +16,11 @@ Multi-GPU (one process per GPU, torchrun): tasks of a round are independent, so 
 own units with no data-path collective (the only exchange of the real run, the grid transpose at
 the 2 round boundaries, moves < 0.2 GB and is not part of a unit): weak scaling.
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0: the contract fields (metric, value = whole-job denoised latents/s, ...), `roofline`
+(attention kernel: HIP-event timing inside the timed region, PMC traffic from profiles/), `cpu_baseline` (N = 1 only:
+the CPU oracle on one full spatial window), `secondary` (latent-steps/s, UNet calls/s, sustained TFLOP/s) and
+`kernel_breakdown_one_step` (per kernel family, from one extra untimed instrumented step).
+Options beyond the contract: --latent HxW, --mode frame-shard, --prune-cond-rows (opt-in extension).
 """
 from __future__ import annotations
 
