@@ -4,24 +4,26 @@
 // MultiviewTransformerBlock (reference attention.py:68-83): the fold "(b t) hw c -> b (t hw) c" is
 // free because activations are token-major, so the kernel just sees batch = B/F, L = F*HW.
 //
-// Work decomposition: a workgroup = 8 waves, each wave owns 32 query rows; K/V tiles of 64 keys are staged
-// register-prefetch -> LDS, double buffered, one barrier per tile, both row-major:
-//   Ks[key][d]  144-byte rows  -> conflict-free ds_read_b128 A-fragments of S^T = K Q^T
-//   Vs[key][d]  192-byte rows  -> the V^T A-fragments of O^T = V^T P^T come out of ds_read_b64_tr_b16 (hardware
-//               transposing read of a [4 keys][16 d] block per 16-lane group; 4 consecutive rows tile the 64 banks)
-// Math (v_mfma_f32_32x32x16_bf16), per 32-key block, the two blocks of a tile software-pipelined:
+// Work decomposition: a workgroup = 8 waves, each wave owns 32 query rows; K/V tiles of 64 keys live in two LDS
+// stages each.  Math (v_mfma_f32_32x32x16_bf16), per 32-key block:
 //   S^T = K Q^T   ("swapped" QK^T): lane (q = lane&31) holds 16 of the 32 scores of its query row,
 //                  so the row max needs a single cross-half exchange and the row sum none at all;
 //   O^T = V^T P^T: the P^T B-operand is exactly the packed bf16 (v_cvt_pk_bf16_f32) of the S^T
 //                  accumulator registers: k-slot e of lane half h is key 4h + (e&3) + 8*(e>>2), and the
-//                  two tr-reads (keys 4h..4h+3 and 8+4h..) deliver V in that same order, so there are
-//                  no lane shuffles between the two MFMAs.
+//                  two transposing reads (ds_read_b64_tr_b16; keys 4h..4h+3 and 8+4h..) deliver V in that same
+//                  order, so there are no lane shuffles between the two MFMAs.
+// Main loop (kv_loop_pipelined): K/V tiles go HBM -> LDS by DMA (global_load_lds_dwordx4, one 1-KiB piece = 8 key
+// rows per wave and tile, no VGPR round trip, no ds_write), issued at the top of a step and awaited at its end, so
+// a whole step of MFMA work covers the latency; QK^T runs one tile ahead of its softmax.  LDS rows are 128 B,
+// un-padded (the DMA writes lane-linear), made conflict-free by permuting the 16-byte chunks of a row on the
+// SOURCE side: K chunk c of row r sits in slot c ^ ((r >> 1) & 7) (ds_read_b128 fragments), V chunk c in slot
+// c ^ (4 * ((r >> 1) & 1)) (tr reads of [4 keys][16 d] blocks).
 // Keys may outnumber queries (Lk >= Lq): frame-sharded 3-D attention runs local queries against all-gathered K/V.
 // Softmax: an optimistic pass (row max taken from the first tile only) with an exact running-max pass (lazy O/l
-// rescale when a row max grows by more than 2^8) as the in-kernel fallback; see the comments at kv_loop and
-// kv_loop_pipelined (the software-pipelined optimistic loop that normally runs).
-// The 1-D grid is remapped so that all query tiles of one (batch, head) run on one XCD and share
-// its L2 copy of K/V.
+// rescale when a row max grows by more than 2^8; register-staged, padded LDS rows) as the in-kernel fallback.
+// FOLD = true (dm4d_attention_qscaled_kv_bf16): Q already carries scale*log2(e), the QK^T accumulator starts from -m
+// (a constant register set used as the first MFMA's C operand) and P = exp2(S) needs no per-score v_fma.
+// The 1-D grid is remapped so that all query tiles of one (batch, head) run on one XCD and share its L2 copy of K/V.
 #include "common.h"
 #include "dm4d.h"
 #include "errors.h"
@@ -34,19 +36,46 @@ struct AttnParams {
   u16* O;
   int64_t ldq, ldk, ldv, ldo;
   int L, Lk, heads, nqt;  // L = queries per (batch, head), Lk = keys (== L for plain self-attention)
-  float c;         // scale * log2(e)
+  float c;         // scale * log2(e)   (unused when Q is pre-scaled)
   int exact_only;  // tuning / debugging: skip the optimistic pass (DM4D_ATTN_EXACT=1)
 };
 
-constexpr int KV = 64;      // keys per staged tile
-constexpr int LDS_LD = 72;   // K rows: 64 + 8 pad bf16 = 144 B  (conflict-free ds_read_b128 fragments)
-constexpr int LDS_LDV = 96;  // V rows: 64 + 32 pad bf16 = 192 B (4 consecutive rows tile the 64 banks for the tr reads)
-constexpr int NW = 8;       // waves per workgroup
+constexpr int KV = 64;       // keys per staged tile
+constexpr int LDS_LD = 72;   // exact loop, K rows: 64 + 8 pad bf16 = 144 B  (conflict-free ds_read_b128 fragments)
+constexpr int LDS_LDV = 96;  // exact loop, V rows: 64 + 32 pad bf16 = 192 B (4 consecutive rows tile the 64 banks)
+constexpr int LDS_LDO = 72;  // O staging rows: 64 + 8 pad bf16 = 144 B
+constexpr int TILE = KV * 64;  // elements of one un-padded [64 keys][64 d] stage of the pipelined loop
+constexpr int NW = 8;        // waves per workgroup
 constexpr float RESCALE_THR = 8.0f;  // in log2 units
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef short s16x8_t __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_p;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// LDS-DMA pieces (global_load_lds_dwordx4: lane i's 16 bytes land at lds_dst + 16 i) as volatile asm.  The builtin form
+// makes hipcc put an s_waitcnt vmcnt(0) in front of the next ds_read of the same array (it cannot tell the stages
+// apart), i.e. right behind the issue; an asm DMA has no VGPR destination, so hiding it from the compiler's counter
+// is register-safe, and its completion is awaited by hand (dma_wait_barrier).  M0 is written and restored inside the
+// statement; `lds_dst` and `uniform_base` must be wave-uniform.
+__device__ __forceinline__ void dma16(const void* uniform_base, uint32_t byte_off, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(byte_off), "s"(uniform_base), "s"(lds_dst)
+               : "memory");
+}
+__device__ __forceinline__ void dma16(const void* ptr, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(ptr), "s"(lds_dst)
+               : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* shared_ptr) {
+  return (uint32_t)(uintptr_t)(lptr_t)shared_ptr;  // byte offset inside the workgroup's LDS allocation
+}
 
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
   f32x2_t v = {lo, hi};
@@ -64,11 +93,12 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
 // check the row sums at the end; a workgroup in which some sum left [0, 2^60) (or is NaN) simply redoes its rows
 // with the exact running-max loop (SAFE).  Results do not depend on how rows are grouped into waves (no vote).
 // ------------------------------------------------------------------------------------------------
-template <bool SAFE>
+template <bool SAFE, bool FOLD>
 __device__ __forceinline__ void kv_loop(const AttnParams& p, const u16* Kb, const u16* Vb, u16* Ks, u16* Vs, const u16* v_lane,
                                         const bf16x8_t (&qf)[4], f32x16_t (&o)[2], float& m_run, float& l_run, int tid,
                                         int l31, int lh) {
   const int Lk = p.Lk;
+  const float cs = FOLD ? 1.0f : p.c;  // FOLD: Q already carries scale*log2(e)
   U4 rk, rv;
   const int s_key = tid >> 3, s_c = tid & 7;
   auto load_tile = [&](int t) {
@@ -116,9 +146,9 @@ __device__ __forceinline__ void kv_loop(const AttnParams& p, const u16* Kb, cons
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       if (!SAFE) {
         m_run = mx;  // o and l are still zero: nothing to rescale
-      } else if (__any((mx - m_run) * p.c > RESCALE_THR)) {
+      } else if (__any((mx - m_run) * cs > RESCALE_THR)) {
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.c);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);
         m_run = m_new;
         l_run *= alpha;
 #pragma unroll
@@ -127,14 +157,14 @@ __device__ __forceinline__ void kv_loop(const AttnParams& p, const u16* Kb, cons
           for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
       }
     }
-    const float mc = m_run * p.c;
+    const float mc = m_run * cs;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       float pv[16];
       float sum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        pv[r] = __builtin_amdgcn_exp2f(s[kb][r] * p.c - mc);
+        pv[r] = __builtin_amdgcn_exp2f(s[kb][r] * cs - mc);
         sum += pv[r];
       }
       l_run += sum;
@@ -166,31 +196,71 @@ __device__ __forceinline__ void kv_loop(const AttnParams& p, const u16* Kb, cons
 }
 
 // ------------------------------------------------------------------------------------------------
-// Software-pipelined form of the optimistic loop.  A wave can issue VALU instructions in the shadow of its OWN
-// MFMAs (issue probe: 1 MFMA + 4 v_fma = 34 cycles, + 4 v_exp = 48, against 32 for the bare MFMA), but only if
-// independent VALU work sits next to every MFMA and the MFMA's LDS fragments were requested well before it.  QK^T
-// therefore runs one tile ahead of its softmax (K staged one tile ahead of V in LDS) and the loop body is straight-line
-// code in which the compiler alternates MFMAs and VALU work (216 VGPRs, one workgroup per CU).  +3..7 % on every UNet
-// shape; forcing the order with sched_group_barrier ({reads ; 1 MFMA ; 8 VALU} x 16) was 2 % slower than the
-// compiler's own interleave.
+// Software-pipelined optimistic loop (the one that normally runs).  Step t: issue the DMA of K(t+2) and V(t+1) into
+// the stages that held K(t) / V(t-1); QK^T of tile t+1, softmax + PV of tile t (straight-line code, the compiler
+// interleaves MFMAs and VALU work); s_waitcnt vmcnt(0) + s_barrier.  An empty asm that "reads" the step's MFMA
+// results sits in front of the wait: without it the scheduler sinks half of the MFMAs below the barrier into the next
+// step, which puts the wait a few MFMAs after the issue and exposes the L2/HBM latency once per tile.
 // ------------------------------------------------------------------------------------------------
+template <bool FOLD>
 __device__ __forceinline__ void kv_loop_pipelined(const AttnParams& p, const u16* Kb, const u16* Vb, u16* Ks, u16* Vs,
-                                                  const u16* v_lane, const bf16x8_t (&qf)[4], f32x16_t (&o)[2], float& m_run,
-                                                  float& l_run, int tid, int l31, int lh) {
+                                                  const bf16x8_t (&qf)[4], f32x16_t (&o)[2], float& m_run, float& l_run,
+                                                  int lane, int wave, int l31, int lh) {
   const int Lk = p.Lk;
   const int nt = (Lk + KV - 1) / KV;
-  const int s_key = tid >> 3, s_c = tid & 7;
-  auto key_row = [&](int t) {
-    int key = t * KV + s_key;
-    return key > Lk - 1 ? Lk - 1 : key;
+  const float cs = FOLD ? 1.0f : p.c;
+  // DMA geometry: wave w moves key rows 8w..8w+7 of a tile; lane i fills slot (i & 7) of row 8w + (i >> 3)
+  const int d_row = wave * 8 + (lane >> 3), d_slot = lane & 7;
+  const int k_chunk = d_slot ^ ((d_row >> 1) & 7), v_chunk = d_slot ^ (((d_row >> 1) & 1) << 2);
+  const uint32_t koff = (uint32_t)d_row * (uint32_t)p.ldk + (uint32_t)k_chunk * 8u;  // elements inside a full tile
+  const uint32_t voff = (uint32_t)d_row * (uint32_t)p.ldv + (uint32_t)v_chunk * 8u;
+  const uint32_t k_dst = lds_addr(Ks) + wave * 1024, v_dst = lds_addr(Vs) + wave * 1024;  // + stage * 8192 bytes
+  auto issue_k = [&](int t, int stage, bool clamp) {
+    if (clamp) {
+      int key = t * KV + d_row;
+      key = key > Lk - 1 ? Lk - 1 : key;
+      dma16(Kb + (int64_t)key * p.ldk + k_chunk * 8, k_dst + stage * (TILE * 2));
+    } else {
+      dma16(Kb + (int64_t)t * KV * p.ldk, koff * 2u, k_dst + stage * (TILE * 2));
+    }
   };
-  auto qk_block = [&](int buf, int kb, f32x16_t& s) {
+  auto issue_v = [&](int t, int stage, bool clamp) {
+    if (clamp) {
+      int key = t * KV + d_row;
+      key = key > Lk - 1 ? Lk - 1 : key;
+      dma16(Vb + (int64_t)key * p.ldv + v_chunk * 8, v_dst + stage * (TILE * 2));
+    } else {
+      dma16(Vb + (int64_t)t * KV * p.ldv, voff * 2u, v_dst + stage * (TILE * 2));
+    }
+  };
+  auto dma_wait_barrier = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed
+    __builtin_amdgcn_s_barrier();                      // ... and everybody else's; all reads of the old stages are done
+    asm volatile("" ::: "memory");
+  };
+  // fragment addresses (elements): K row l31, chunk (2j + lh) ^ swizzle;  V row 4*lh + ((lane & 15) >> 2),
+  // chunk (4 db + 2 ((lane >> 4) & 1) + ((lane & 3) >> 1)) ^ swizzle, 8-byte half (lane & 1)
+  int k_lane[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+  for (int j = 0; j < 4; ++j) k_lane[j] = l31 * 64 + (((2 * j + lh) ^ ((l31 >> 1) & 7)) * 8);
+  int v_lane[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+    v_lane[db] = (4 * lh + ((lane & 15) >> 2)) * 64 + ((4 * (db ^ ((lane >> 3) & 1)) + 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1)) * 8) +
+                 4 * (lane & 1);
+
+  f32x16_t negm;  // -m in every register: the C operand of the first QK^T MFMA of a block (FOLD)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+  auto qk_block = [&](int stage, int kb, f32x16_t& s) {
+    if (!FOLD) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (buf * KV + kb * 32 + l31) * LDS_LD + j * 16 + lh * 8);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[j], s, 0, 0, 0);
+      bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + stage * TILE + kb * 32 * 64 + k_lane[j]);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[j], (FOLD && j == 0) ? negm : s, 0, 0, 0);
     }
   };
   auto mask_tail = [&](int t, f32x16_t (&s)[2]) {
@@ -205,12 +275,11 @@ __device__ __forceinline__ void kv_loop_pipelined(const AttnParams& p, const u16
   float mc = 0.f;
   auto softmax_block = [&](const f32x16_t& s, bf16x8_t (&pf)[2]) {
     float pv[16];
-    float sum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      pv[r] = __builtin_amdgcn_exp2f(s[r] * p.c - mc);
-      sum += pv[r];
-    }
+    for (int r = 0; r < 16; ++r) pv[r] = FOLD ? __builtin_amdgcn_exp2f(s[r]) : __builtin_amdgcn_exp2f(s[r] * cs - mc);
+    float sum = pv[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) sum += pv[r];
     l_run += sum;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
@@ -222,31 +291,27 @@ __device__ __forceinline__ void kv_loop_pipelined(const AttnParams& p, const u16
       pf[jj] = *reinterpret_cast<bf16x8_t*>(&w);
     }
   };
-  auto pv_block = [&](int buf, int kb, const bf16x8_t (&pf)[2]) {
+  auto pv_block = [&](int stage, int kb, const bf16x8_t (&pf)[2]) {
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
-        const u16* vp = v_lane + (buf * KV + kb * 32 + jj * 16) * LDS_LDV + db * 32;
+        const u16* vp = Vs + stage * TILE + (kb * 32 + jj * 16) * 64 + v_lane[db];
         s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)vp);
-        s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vp + 8 * LDS_LDV));
+        s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vp + 8 * 64));
         s16x8_t v01 = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
         bf16x8_t vf = *reinterpret_cast<bf16x8_t*>(&v01);
         o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[jj], o[db], 0, 0, 0);
       }
   };
 
-  {  // prologue: K(0), V(0), K(1) -> LDS
-    U4 k0 = ldg16(Kb + (int64_t)key_row(0) * p.ldk + s_c * 8);
-    U4 v0 = ldg16(Vb + (int64_t)key_row(0) * p.ldv + s_c * 8);
-    U4 k1 = ldg16(Kb + (int64_t)key_row(1) * p.ldk + s_c * 8);  // clamped when nt == 1
-    *reinterpret_cast<U4*>(Ks + (0 * KV + s_key) * LDS_LD + s_c * 8) = k0;
-    *reinterpret_cast<U4*>(Vs + (0 * KV + s_key) * LDS_LDV + s_c * 8) = v0;
-    *reinterpret_cast<U4*>(Ks + (1 * KV + s_key) * LDS_LD + s_c * 8) = k1;
-  }
-  __syncthreads();
+  // prologue: K(0), V(0), K(1) -> LDS (K(1) clamped when nt == 1)
+  issue_k(0, 0, true);
+  issue_v(0, 0, true);
+  issue_k(1, 1, true);
+  dma_wait_barrier();
   f32x16_t s_cur[2], s_nxt[2];
-  qk_block(0, 0, s_cur[0]);
+  qk_block(0, 0, s_cur[0]);  // negm is still zero here
   qk_block(0, 1, s_cur[1]);
   if (nt == 1 && (Lk % KV) != 0) mask_tail(0, s_cur);
   {
@@ -254,34 +319,43 @@ __device__ __forceinline__ void kv_loop_pipelined(const AttnParams& p, const u16
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s_cur[0][r], s_cur[1][r]));
     m_run = fmaxf(mx, __shfl_xor(mx, 32));
-    mc = m_run * p.c;
+    mc = m_run * cs;
+    if (FOLD) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        negm[r] = -m_run;
+        s_cur[0][r] -= m_run;
+        s_cur[1][r] -= m_run;
+      }
+    }
   }
-  __syncthreads();  // every wave has read K(0): its buffer is overwritten at the end of iteration 0
+  __syncthreads();  // every wave has read K(0): step 0 overwrites its stage
 
   // one pipelined step: consumes S(t) from `sa`, produces S(t+1) into `sb`; straight-line code (no branches)
-  auto step = [&](int t, f32x16_t (&sa)[2], f32x16_t (&sb)[2]) {
-    const int kbuf = (t + 1) & 1, vbuf = t & 1;
-    const U4 rk = ldg16(Kb + (int64_t)key_row(t + 2) * p.ldk + s_c * 8);  // clamped past the end of the sequence
-    const U4 rv = ldg16(Vb + (int64_t)key_row(t + 1) * p.ldv + s_c * 8);
+  auto step = [&](int t, f32x16_t (&sa)[2], f32x16_t (&sb)[2], bool clamp) {
+    const int kst = (t + 1) & 1, vst = t & 1;
+    issue_k(t + 2, t & 1, clamp);        // over K(t), last read in step t-1 (clamped past the end of the sequence)
+    issue_v(t + 1, (t + 1) & 1, clamp);  // over V(t-1)
     bf16x8_t pf[2];
-    qk_block(kbuf, 0, sb[0]);
+    qk_block(kst, 0, sb[0]);
     softmax_block(sa[0], pf);
-    pv_block(vbuf, 0, pf);
-    qk_block(kbuf, 1, sb[1]);
+    pv_block(vst, 0, pf);
+    qk_block(kst, 1, sb[1]);
     softmax_block(sa[1], pf);
-    pv_block(vbuf, 1, pf);
-    *reinterpret_cast<U4*>(Ks + ((t & 1) * KV + s_key) * LDS_LD + s_c * 8) = rk;         // K(t+2) over K(t)
-    *reinterpret_cast<U4*>(Vs + (((t + 1) & 1) * KV + s_key) * LDS_LDV + s_c * 8) = rv;  // V(t+1) over V(t-1)
-    __syncthreads();
+    pv_block(vst, 1, pf);
+    asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(sb[0]), "v"(sb[1]));  // every MFMA of the step is issued before the wait
+    dma_wait_barrier();
   };
   int t = 0;
-  for (; t + 3 < nt; t += 2) {  // two steps per trip: the S register sets swap roles instead of being copied
-    step(t, s_cur, s_nxt);
-    step(t + 1, s_nxt, s_cur);
+  // main loop: every tile it loads (up to t + 3) is a full tile, so the uniform-base addressing applies
+  const int n_full = Lk / KV;
+  for (; t + 3 < n_full; t += 2) {  // two steps per trip: the S register sets swap roles instead of being copied
+    step(t, s_cur, s_nxt, false);
+    step(t + 1, s_nxt, s_cur, false);
   }
-  for (; t < nt; ++t) {  // last <= 3 tiles: tail mask, no look-ahead on the final one
+  for (; t < nt; ++t) {  // last tiles: clamped source rows, tail mask, no look-ahead on the final one
     if (t + 1 < nt) {
-      step(t, s_cur, s_nxt);
+      step(t, s_cur, s_nxt, true);
       if (t + 2 == nt && (Lk % KV) != 0) mask_tail(t + 1, s_nxt);
       s_cur[0] = s_nxt[0];
       s_cur[1] = s_nxt[1];
@@ -296,11 +370,11 @@ __device__ __forceinline__ void kv_loop_pipelined(const AttnParams& p, const u16
   }
 }
 
+template <bool FOLD>
 __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
-  __shared__ __attribute__((aligned(16))) u16 smem[2 * KV * LDS_LD + 2 * KV * LDS_LDV];
-  u16* Ks = smem;
-  u16* Vs = smem + 2 * KV * LDS_LD;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ __attribute__((aligned(16))) u16 smem[2 * KV * LDS_LD + 2 * KV * LDS_LDV];  // >= 4 * TILE, >= NW * 32 * LDS_LDO
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
   const int L = p.L, Lk = p.Lk;
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -323,7 +397,6 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
       qf[j] = *reinterpret_cast<bf16x8_t*>(&v);
     }
   }
-  const u16* v_lane = Vs + (4 * (lane >> 5) + ((lane & 15) >> 2)) * LDS_LDV + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
 
   f32x16_t o[2];
   float m_run = -1e30f, l_run = 0.f;
@@ -333,7 +406,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
     for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
   float l_tot = -1.f;
   if (!p.exact_only) {
-    kv_loop_pipelined(p, Kb, Vb, Ks, Vs, v_lane, qf, o, m_run, l_run, tid, l31, lh);
+    kv_loop_pipelined<FOLD>(p, Kb, Vb, smem, smem + 2 * TILE, qf, o, m_run, l_run, lane, wave, l31, lh);
     l_tot = l_run + __shfl_xor(l_run, 32);
   }
   // out of range (a later tile outgrew the first tile's max by more than 2^60) or NaN: redo with the exact loop
@@ -344,46 +417,75 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
     for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-    kv_loop<true>(p, Kb, Vb, Ks, Vs, v_lane, qf, o, m_run, l_run, tid, l31, lh);
+    u16* Ks = smem;
+    u16* Vs = smem + 2 * KV * LDS_LD;
+    const u16* v_lane = Vs + (4 * (lane >> 5) + ((lane & 15) >> 2)) * LDS_LDV + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    kv_loop<true, FOLD>(p, Kb, Vb, Ks, Vs, v_lane, qf, o, m_run, l_run, tid, l31, lh);
     l_tot = l_run + __shfl_xor(l_run, 32);
   }
-  const int q = q_tile0 + l31;
+  // Both loops end with a workgroup barrier, so the K/V stages are free: O goes through a wave-private LDS tile
+  // (32 rows x 144 B) and leaves as whole 128-byte rows, 4 dwordx4 stores per wave (per-lane stores at the row
+  // stride touch a different row per lane: 8 dwordx2 instructions whose every lane opens its own line).
   const float inv = 1.0f / l_tot;
-  if (q < L) {
-    u16* op = Ob + (int64_t)q * p.ldo;
+  u16* Os = smem + wave * (32 * LDS_LDO);
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+  for (int db = 0; db < 2; ++db)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        uint2 w;
-        w.x = cvt_pk_bf16(o[db][4 * g + 0] * inv, o[db][4 * g + 1] * inv);
-        w.y = cvt_pk_bf16(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
-        *reinterpret_cast<uint2*>(op + db * 32 + 8 * g + 4 * lh) = w;
-      }
+    for (int g = 0; g < 4; ++g) {
+      uint2 w;
+      w.x = cvt_pk_bf16(o[db][4 * g + 0] * inv, o[db][4 * g + 1] * inv);
+      w.y = cvt_pk_bf16(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+      *reinterpret_cast<uint2*>(Os + l31 * LDS_LDO + db * 32 + 8 * g + 4 * lh) = w;
+    }
+  // the same wave reads back what it wrote (the LDS executes a wave's accesses in order): no barrier
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int row = 8 * k + (lane >> 3), ch = lane & 7;
+    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(Os + row * LDS_LDO + ch * 8);
+    const int q = q_tile0 + row;
+    if (q < L) *reinterpret_cast<u32x4_t*>(Ob + (int64_t)q * p.ldo + ch * 8) = v;
   }
 }
 
 }  // namespace
 
-extern "C" int dm4d_attention_kv_bf16(void* stream, const void* Q, const void* K, const void* V, void* O, int64_t ldq,
-                                      int64_t ldk, int64_t ldv, int64_t ldo, int batch, int heads, int Lq, int Lk,
-                                      float scale) {
+static int attention_launch(void* stream, const void* Q, const void* K, const void* V, void* O, int64_t ldq, int64_t ldk,
+                            int64_t ldv, int64_t ldo, int batch, int heads, int Lq, int Lk, float scale, bool q_scaled) {
   if (!Q || !K || !V || !O || batch <= 0 || heads <= 0 || Lq <= 0 || Lk <= 0)
     return dm4d_set_error(DM4D_ERR_ARG, "attention: null pointer or empty shape");
-  if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3))
+  if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 7))
     return dm4d_set_error(DM4D_ERR_ARG, "attention: row strides must be multiples of 8 elements");
+  if ((((uintptr_t)Q) | ((uintptr_t)K) | ((uintptr_t)V) | ((uintptr_t)O)) & 15)
+    return dm4d_set_error(DM4D_ERR_ARG, "attention: Q, K, V and O must be 16-byte aligned");
+  if (ldk <= 0 || ldv <= 0 || ldk >= (1 << 24) || ldv >= (1 << 24))
+    return dm4d_set_error(DM4D_ERR_ARG, "attention: K/V row stride out of range");
   static const int exact = [] { const char* e = getenv("DM4D_ATTN_EXACT"); return e ? atoi(e) : 0; }();  // tuning aid
   AttnParams p{(const u16*)Q, (const u16*)K, (const u16*)V, (u16*)O, ldq, ldk, ldv, ldo, Lq, Lk, heads, 0,
                scale * 1.4426950408889634f, exact};
-  const int rows = NW * 32;  // 32 query rows per wave: 128 VGPRs, 4 waves per SIMD (64 rows per wave measured slower)
+  const int rows = NW * 32;  // 32 query rows per wave (64 rows per wave measured slower)
   p.nqt = (Lq + rows - 1) / rows;
   const long nwg = (long)p.nqt * heads * batch;
   if (nwg > 0x7fffffffL) return dm4d_set_error(DM4D_ERR_ARG, "attention: grid too large");
-  hipLaunchKernelGGL(attn_kernel, dim3((unsigned)nwg), dim3(NW * 64), 0, (hipStream_t)stream, p);
+  if (q_scaled)
+    hipLaunchKernelGGL(attn_kernel<true>, dim3((unsigned)nwg), dim3(NW * 64), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(attn_kernel<false>, dim3((unsigned)nwg), dim3(NW * 64), 0, (hipStream_t)stream, p);
   return dm4d_check_launch("attn_kernel");
+}
+
+extern "C" int dm4d_attention_kv_bf16(void* stream, const void* Q, const void* K, const void* V, void* O, int64_t ldq,
+                                      int64_t ldk, int64_t ldv, int64_t ldo, int batch, int heads, int Lq, int Lk,
+                                      float scale) {
+  return attention_launch(stream, Q, K, V, O, ldq, ldk, ldv, ldo, batch, heads, Lq, Lk, scale, false);
 }
 
 extern "C" int dm4d_attention_bf16(void* stream, const void* Q, const void* K, const void* V, void* O, int64_t ldq,
                                    int64_t ldk, int64_t ldv, int64_t ldo, int batch, int heads, int L, float scale) {
-  return dm4d_attention_kv_bf16(stream, Q, K, V, O, ldq, ldk, ldv, ldo, batch, heads, L, L, scale);
+  return attention_launch(stream, Q, K, V, O, ldq, ldk, ldv, ldo, batch, heads, L, L, scale, false);
+}
+
+extern "C" int dm4d_attention_qscaled_kv_bf16(void* stream, const void* Q, const void* K, const void* V, void* O,
+                                              int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int batch, int heads,
+                                              int Lq, int Lk) {
+  return attention_launch(stream, Q, K, V, O, ldq, ldk, ldv, ldo, batch, heads, Lq, Lk, 1.0f, true);
 }

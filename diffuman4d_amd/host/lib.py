@@ -27,6 +27,7 @@ SIGNATURES = {
     "dm4d_layernorm_bf16": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _f]),
     "dm4d_attention_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _f]),
     "dm4d_attention_kv_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _f]),
+    "dm4d_attention_qscaled_kv_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i]),
     "dm4d_softmax_rows_bf16": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _f]),
     "dm4d_timestep_embedding_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _f]),
     "dm4d_silu_bf16": (_i, [_vp, _vp, _vp, _i64]),

@@ -147,11 +147,15 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     return y.view(x.shape)
 
 
+LOG2E = 1.4426950408889634
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, heads: int, seq: int,
               scale: Optional[float] = None, out: Optional[torch.Tensor] = None,
-              kv_seq: Optional[int] = None) -> torch.Tensor:
+              kv_seq: Optional[int] = None, q_scaled: bool = False) -> torch.Tensor:
     """q/k/v: [batch*seq, >=heads*64] row-strided views (e.g. column slices of the fused QKV output).
-    kv_seq: keys per batch when K/V hold more tokens than Q (frame-sharded 3-D attention); default = seq."""
+    kv_seq: keys per batch when K/V hold more tokens than Q (frame-sharded 3-D attention); default = seq.
+    q_scaled: q already carries scale * LOG2E (folded into the to_q weights, unet._TransformerBlock)."""
     lib = _l.load()
     _req(q, "q"), _req(k, "k"), _req(v, "v")
     assert q.shape[0] == batch * seq and q.shape[1] == heads * 64, (q.shape, batch, seq, heads)
@@ -166,8 +170,12 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, hea
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     with _Prof("attention", 4.0 * batch * heads * seq * kv_seq * 64, "flop"):
-        rc = lib.dm4d_attention_kv_bf16(_stream(), _p(q), _p(k), _p(v), _p(out), q.stride(0), k.stride(0), v.stride(0),
-                                        out.stride(0), batch, heads, seq, kv_seq, scale)
+        if q_scaled:
+            rc = lib.dm4d_attention_qscaled_kv_bf16(_stream(), _p(q), _p(k), _p(v), _p(out), q.stride(0), k.stride(0),
+                                                    v.stride(0), out.stride(0), batch, heads, seq, kv_seq)
+        else:
+            rc = lib.dm4d_attention_kv_bf16(_stream(), _p(q), _p(k), _p(v), _p(out), q.stride(0), k.stride(0),
+                                            v.stride(0), out.stride(0), batch, heads, seq, kv_seq, scale)
     if prof is not None:
         e1.record()
         prof.append(("attn_kernel", 4.0 * batch * heads * seq * kv_seq * 64, e0, e1))

@@ -167,7 +167,10 @@ class _TransformerBlock:
         self.heads = heads
         self.n1w, self.n1b = W.vec(pfx + "norm1.weight"), W.vec(pfx + "norm1.bias")
         q, k, v = (W.get(pfx + f"attn1.to_{n}.weight") for n in "qkv")
-        self.qkv = torch.cat([q, k, v], dim=0).to(W.device, BF16).contiguous()  # fused [3C, C], bias-free
+        # SDPA's q * scale (and the exp -> exp2 factor) folded into the bias-free to_q rows in fp32, before the single
+        # bf16 rounding: the attention kernel then needs no per-score multiply (dm4d_attention_qscaled_kv_bf16)
+        q = q.float() * ((q.shape[0] // heads) ** -0.5 * ops.LOG2E)
+        self.qkv = torch.cat([q, k.float(), v.float()], dim=0).to(W.device, BF16).contiguous()  # fused [3C, C], bias-free
         self.ow, self.ob = W.linear(pfx + "attn1.to_out.0.weight"), W.vec(pfx + "attn1.to_out.0.bias")
         self.n3w, self.n3b = W.vec(pfx + "norm3.weight"), W.vec(pfx + "norm3.bias")
         self.f1w, self.f1b = W.linear(pfx + "ff.net.0.proj.weight"), W.vec(pfx + "ff.net.0.proj.bias")
@@ -181,15 +184,14 @@ class _TransformerBlock:
         shard (parallel.FrameShard): `seq` is this rank's share of the frame-folded sequence; K/V are all-gathered."""
         C = h.shape[1]
         n = ops.layernorm(h, self.n1w, self.n1b, 1e-5)
-        scale = (C // self.heads) ** -0.5
         if shard is None:
             qkv = ops.gemm(n, self.qkv)
-            a = ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], batch, self.heads, seq, scale=scale)
+            a = ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], batch, self.heads, seq, q_scaled=True)
         else:
             q = ops.gemm(n, self.qkv[:C])
             kv = ops.gemm(n, self.qkv[C:])  # [M, 2C] contiguous so the collective needs no repack
             kvg = shard.gather_kv(kv.view(batch, seq, 2 * C)).view(batch * shard.world * seq, 2 * C)
-            a = ops.attention(q, kvg[:, :C], kvg[:, C:], batch, self.heads, seq, scale=scale, kv_seq=shard.world * seq)
+            a = ops.attention(q, kvg[:, :C], kvg[:, C:], batch, self.heads, seq, kv_seq=shard.world * seq, q_scaled=True)
         h = ops.gemm(a, self.ow, bias=self.ob, residual=h)
         n = ops.layernorm(h, self.n3w, self.n3b, 1e-5)
         f = ops.gemm(n, self.f1w, bias=self.f1b, geglu=True)

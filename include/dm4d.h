@@ -85,7 +85,8 @@ int dm4d_layernorm_bf16(void* stream, const void* X, int64_t ldx, const void* ga
  *   replaces AttnProcessor2_0 / F.scaled_dot_product_attention reached from attention.py:73-78;
  *   the "(b t) hw c -> b (t hw) c" frame folding (attention.py:69-71,81-83) is expressed by
  *   batch = B / num_frames, L = num_frames * HW on the SAME memory (token-major rows).
- *   Q/K/V/O rows are tokens; element (b, t, h, d) lives at ptr[(b*L + t)*ld + h*64 + d].           */
+ *   Q/K/V/O rows are tokens; element (b, t, h, d) lives at ptr[(b*L + t)*ld + h*64 + d].
+ *   Pointers 16-byte aligned, row strides multiples of 8 elements.                                    */
 int dm4d_attention_bf16(void* stream, const void* Q, const void* K, const void* V, void* O, int64_t ldq, int64_t ldk,
                         int64_t ldv, int64_t ldo, int batch, int heads, int L, float scale);
 
@@ -94,6 +95,15 @@ int dm4d_attention_bf16(void* stream, const void* Q, const void* K, const void* 
  *   ptr[(b*Lk + t)*ld + h*64 + d]; of Q/O at ptr[(b*Lq + t)*ld + h*64 + d].                                        */
 int dm4d_attention_kv_bf16(void* stream, const void* Q, const void* K, const void* V, void* O, int64_t ldq, int64_t ldk,
                            int64_t ldv, int64_t ldo, int batch, int heads, int Lq, int Lk, float scale);
+
+/* Same attention for a Q that already carries the softmax scale: Q' = Q * scale * log2(e)  (DM4D_LOG2E), i.e.
+ *   O = softmax2(Q' K^T) V with softmax2 in base 2.  The model folds the factor into the to_q rows of the fused
+ *   QKV weight when the checkpoint is loaded (attention.py:73-78 computes to_q(x) then SDPA's q*scale), so the
+ *   scale costs no instruction at all: the kernel starts its QK^T accumulator from -rowmax and P = exp2(S).
+ *   Layout, strides and Lq/Lk as in dm4d_attention_kv_bf16.                                                    */
+#define DM4D_LOG2E 1.4426950408889634
+int dm4d_attention_qscaled_kv_bf16(void* stream, const void* Q, const void* K, const void* V, void* O, int64_t ldq,
+                                   int64_t ldk, int64_t ldv, int64_t ldo, int batch, int heads, int Lq, int Lk);
 
 /* Generic-head-dim attention pieces for the VAE mid block (single head, d = 512): row softmax.   */
 int dm4d_softmax_rows_bf16(void* stream, const void* S, int64_t lds, void* P, int64_t ldp, int M, int N, float scale);

@@ -53,10 +53,15 @@ def bench_conv(B, H, W, Cin, Cout, stride=1, upsample=False, tag=""):
     print(f"conv{tag:10s} B={B:3d} {H}x{W} {Cin:5d}->{Cout:5d} s{stride} up{int(upsample)}  {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s", flush=True)
 
 
+QS = os.environ.get("DM4D_BENCH_QSCALED", "1") != "0"  # the entry the model uses (Q pre-scaled); 0 = scale inside the kernel
+
+
 def bench_attn(batch, heads, L, tag=""):
     C = heads * 64
     qkv = rnd(batch * L, 3 * C)
-    t = timeit(lambda: ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], batch, heads, L), iters=10)
+    if QS:
+        qkv[:, :C] *= 0.125 * ops.LOG2E
+    t = timeit(lambda: ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], batch, heads, L, q_scaled=QS), iters=10)
     fl = 4.0 * batch * heads * L * L * 64
     print(f"attn{tag:10s} b={batch:3d} h={heads:3d} L={L:6d}  {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s", flush=True)
 
@@ -80,7 +85,7 @@ def bench_ln(M, C, tag=""):
 def main():
     only = sys.argv[1] if len(sys.argv) > 1 else None
     if only == "attn":
-        print("attn QB env:", os.environ.get("DM4D_ATTN_QB"), flush=True)
+        print("attn q_scaled:", QS, flush=True)
         bench_attn(32, 5, 2880, " 2D L0")
         bench_attn(48, 5, 2880, " 2D L0 F24")
         bench_attn(2, 10, 11520, " 3D L1 F16")
@@ -90,7 +95,7 @@ def main():
         bench_attn(2, 20, 720, " 3D mid")
         bench_attn(2, 10, 65536, " 3D L1 128")
         return
-    print("device:", torch.cuda.get_device_name(0), "attn QB env:", os.environ.get("DM4D_ATTN_QB"), flush=True)
+    print("device:", torch.cuda.get_device_name(0), "attn q_scaled:", QS, flush=True)
     B = 32  # F=16, CFG
     # GEMMs of one transformer block per level
     for lvl, (hw, c) in enumerate([(2880, 320), (720, 640), (180, 1280), (45, 1280)]):

@@ -120,11 +120,16 @@ def case_conv_direct(B, H, W, Cin, Cout, k, stride, silu=True, seed=0):
     return (rel_l2(out, ref) if pad_ok else 1.0), float((out.float().cpu() - ref).abs().max())
 
 
-def case_attention(batch, heads, L, seed=0, spike=False, ramp=False):
+def case_attention(batch, heads, L, seed=0, spike=False, ramp=False, q_scaled=False):
+    """q_scaled: the kernel gets Q' = bf16(Q * scale * log2 e) (what the model's scaled to_q rows produce) through
+    dm4d_attention_qscaled_kv_bf16; the reference is SDPA on Q'/(scale * log2 e), i.e. the same numbers."""
     from diffuman4d_amd.host import ops
     g = torch.Generator().manual_seed(seed)
     C = heads * 64
     qkv = _rnd((batch * L, 3 * C), g)
+    fac = 0.125 * ops.LOG2E
+    if q_scaled:
+        qkv[:, :C] = (qkv[:, :C].float() * fac).to(qkv.dtype)
     if spike:  # force large online-softmax rescales (one key dominates late in the sequence)
         qkv[L - 3, C:2 * C] *= 8.0
     if ramp:  # logits far above anything in the first 64-key tile (> 2^60 in exp2 terms for a good share of the rows):
@@ -135,27 +140,28 @@ def case_attention(batch, heads, L, seed=0, spike=False, ramp=False):
     def heads_view(t):
         return t.float().view(batch, L, heads, 64).transpose(1, 2)
 
-    ref = F.scaled_dot_product_attention(heads_view(q), heads_view(k), heads_view(v))
+    q_ref = heads_view(q) / fac if q_scaled else heads_view(q)
+    ref = F.scaled_dot_product_attention(q_ref, heads_view(k), heads_view(v))
     ref = ref.transpose(1, 2).reshape(batch * L, C)
     dq = qkv.to("cuda")
-    out = ops.attention(dq[:, :C], dq[:, C:2 * C], dq[:, 2 * C:], batch, heads, L)
+    out = ops.attention(dq[:, :C], dq[:, C:2 * C], dq[:, 2 * C:], batch, heads, L, q_scaled=q_scaled)
     return rel_l2(out, ref), float((out.float().cpu() - ref).abs().max())
 
 
-def case_attention_kv_split(batch, heads, L, parts, seed=0):
+def case_attention_kv_split(batch, heads, L, parts, seed=0, q_scaled=False):
     """Frame-sharded 3-D attention: each rank's queries against the all-gathered K/V must reproduce the
     unsharded result BITWISE (same key order, same tile boundaries)."""
     from diffuman4d_amd.host import ops
     g = torch.Generator().manual_seed(seed)
     C = heads * 64
     qkv = _rnd((batch * L, 3 * C), g).to("cuda")
-    full = ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], batch, heads, L).view(batch, L, C)
+    full = ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], batch, heads, L, q_scaled=q_scaled).view(batch, L, C)
     ls = L // parts
     kv = qkv[:, C:].contiguous()  # [batch*L, 2C] = what the all-gather assembles
     worst = 0.0
     for r in range(parts):
         q_loc = qkv[:, :C].view(batch, L, C)[:, r * ls:(r + 1) * ls].reshape(batch * ls, C).contiguous()
-        out = ops.attention(q_loc, kv[:, :C], kv[:, C:], batch, heads, ls, kv_seq=L).view(batch, ls, C)
+        out = ops.attention(q_loc, kv[:, :C], kv[:, C:], batch, heads, ls, kv_seq=L, q_scaled=q_scaled).view(batch, ls, C)
         worst = max(worst, float((out.float() - full[:, r * ls:(r + 1) * ls].float()).abs().max()))
     return worst, worst
 
@@ -322,6 +328,12 @@ CASES = {
     "attn_L129": (case_attention, dict(batch=1, heads=2, L=129)),
     "attn_L191": (case_attention, dict(batch=1, heads=1, L=191)),
     "attn_L256": (case_attention, dict(batch=1, heads=1, L=256)),
+    # 5 / 6 / 7 / 8 tiles: first trips of the unclamped two-step main loop, with and without a ragged last tile
+    "attn_L320": (case_attention, dict(batch=1, heads=2, L=320)),
+    "attn_L321": (case_attention, dict(batch=1, heads=1, L=321)),
+    "attn_L383": (case_attention, dict(batch=2, heads=1, L=383)),
+    "attn_L448": (case_attention, dict(batch=1, heads=1, L=448)),
+    "attn_L512": (case_attention, dict(batch=1, heads=2, L=512)),
     "attn_tail720": (case_attention, dict(batch=2, heads=3, L=720)),
     "attn_2d": (case_attention, dict(batch=8, heads=5, L=2880)),
     "attn_3d": (case_attention, dict(batch=2, heads=10, L=4320)),
@@ -329,6 +341,18 @@ CASES = {
     "attn_ramp_fallback": (case_attention, dict(batch=2, heads=2, L=1500, ramp=True)),
     "attn_kv_split": (case_attention_kv_split, dict(batch=2, heads=2, L=16 * 180, parts=8)),
     "attn_kv_split3": (case_attention_kv_split, dict(batch=2, heads=1, L=24 * 45, parts=3)),
+    # the entry the model uses: Q pre-scaled by scale * log2(e) (QK^T accumulator starts from -rowmax)
+    "attn_qs_small": (case_attention, dict(batch=2, heads=2, L=128, q_scaled=True)),
+    "attn_qs_tail45": (case_attention, dict(batch=3, heads=1, L=45, q_scaled=True)),
+    "attn_qs_L65": (case_attention, dict(batch=2, heads=1, L=65, q_scaled=True)),
+    "attn_qs_L321": (case_attention, dict(batch=1, heads=1, L=321, q_scaled=True)),
+    "attn_qs_L448": (case_attention, dict(batch=1, heads=1, L=448, q_scaled=True)),
+    "attn_qs_tail720": (case_attention, dict(batch=2, heads=3, L=720, q_scaled=True)),
+    "attn_qs_2d": (case_attention, dict(batch=8, heads=5, L=2880, q_scaled=True)),
+    "attn_qs_3d": (case_attention, dict(batch=2, heads=10, L=4320, q_scaled=True)),
+    "attn_qs_spike": (case_attention, dict(batch=1, heads=2, L=1000, spike=True, q_scaled=True)),
+    "attn_qs_ramp_fallback": (case_attention, dict(batch=2, heads=2, L=1500, ramp=True, q_scaled=True)),
+    "attn_qs_kv_split": (case_attention_kv_split, dict(batch=2, heads=2, L=16 * 180, parts=8, q_scaled=True)),
     # --- norms -----------------------------------------------------------------------------------
     "gn_320": (case_groupnorm, dict(B=4, HW=720, C1=320, C2=0, groups=32, silu=True)),
     "gn_concat_1920": (case_groupnorm, dict(B=3, HW=180, C1=1280, C2=640, groups=32, silu=True)),
@@ -348,7 +372,7 @@ CASES = {
     "pack_ddim_noskel": (case_pack_ddim, dict(F_=8, HW=30, use_cfg=True, vpred=False, skel=False)),
 }
 
-TOLS = {"layout": 0.0, "temb": 6e-3, "attn_kv_split": 0.0, "attn_kv_split3": 0.0}
+TOLS = {"layout": 0.0, "temb": 6e-3, "attn_kv_split": 0.0, "attn_kv_split3": 0.0, "attn_qs_kv_split": 0.0}
 
 
 def run_case(name):
@@ -360,7 +384,9 @@ def run_case(name):
 def main():
     torch.manual_seed(0)
     bad = 0
-    for name in CASES:
+    prefix = sys.argv[1] if len(sys.argv) > 1 else ""  # e.g. `opcheck.py attn`
+    names = [n for n in CASES if n.startswith(prefix)]
+    for name in names:
         try:
             err, mx, tol = run_case(name)
             ok = err <= tol and math.isfinite(err)
@@ -370,7 +396,7 @@ def main():
             bad += 1
             print(f"ERROR {name}: {type(e).__name__}: {e}", flush=True)
             traceback.print_exc()
-    print(f"opcheck: {len(CASES) - bad}/{len(CASES)} passed", flush=True)
+    print(f"opcheck: {len(names) - bad}/{len(names)} passed", flush=True)
     return 1 if bad else 0
 
 
