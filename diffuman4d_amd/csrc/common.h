@@ -49,7 +49,9 @@ __device__ __forceinline__ U4 pack8(const float* f) {
 __device__ __forceinline__ U4 ldg16(const void* p) { return *reinterpret_cast<const U4*>(p); }
 __device__ __forceinline__ void stg16(void* p, const U4& v) { *reinterpret_cast<U4*>(p) = v; }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with the hardware reciprocal (1 ulp; an IEEE fp32 division is ~10 VALU instructions, and the
+// GroupNorm / epilogue consumers round the result to bf16 anyway)
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // erf(x) by Abramowitz & Stegun 7.1.26: |abs error| <= 1.5e-7, branch free, ~12 VALU (libm erff is ~4x that
 // and dominated the GEGLU epilogue of the K=320 feed-forward GEMMs)
 __device__ __forceinline__ float erf_as(float x) {

@@ -90,8 +90,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(GNParams p) {
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GNParams p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];  // scale[C], shift[C], mean[g], rstd[g]
   const int C = p.C1 + p.C2, CV = C / 8, CV1 = p.C1 / 8;
-  float* sc = sm;
-  float* sh = sm + C;
+  float* sc = sm;  // reduction scratch
   float* mean = sm + (2 * C > 2 * GN_THREADS ? 2 * C : 2 * GN_THREADS);  // sc/sh double as reduction scratch
   float* rstd = mean + p.groups;
   const int b = blockIdx.x / p.nchunk, chunk = blockIdx.x % p.nchunk;
@@ -132,26 +131,44 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GNParams p) {
     rstd[g] = rsqrtf(var + p.eps);
   }
   __syncthreads();
-  for (int c = tid; c < C; c += GN_THREADS) {
-    const int g = c / gs;
-    const float a = bf2f(p.gamma[c]) * rstd[g];
-    sc[c] = a;
-    sh[c] = bf2f(p.beta[c]) - mean[g] * a;
-  }
-  __syncthreads();
-  const int64_t total = (int64_t)(p1 - p0) * CV;
-  for (int64_t i = tid; i < total; i += GN_THREADS) {
-    const int px = p0 + (int)(i / CV), cv = (int)(i % CV);
-    const u16* src = cv < CV1 ? p.X1 + ((int64_t)b * p.HW + px) * p.C1 + cv * 8
-                              : p.X2 + ((int64_t)b * p.HW + px) * p.C2 + (cv - CV1) * 8;
-    float v[8];
-    unpack8(ldg16(src), v);
+  // A thread keeps one 8-channel vector (its scale / shift in registers) and walks the chunk's pixels: no index
+  // division and no LDS traffic in the streaming loop; 256 threads cover GN_THREADS / CV consecutive pixels per pass.
+  const int PPB = CV >= GN_THREADS ? 1 : GN_THREADS / CV;
+  for (int slot = tid; slot < CV * PPB; slot += GN_THREADS) {
+    const int cv = slot % CV, prow = slot / CV;
+    float a[8], sft[8];
+    {
+      float gm[8], bt[8];
+      unpack8(ldg16(p.gamma + cv * 8), gm);
+      unpack8(ldg16(p.beta + cv * 8), bt);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float y = v[e] * sc[cv * 8 + e] + sh[cv * 8 + e];
-      v[e] = p.silu ? silu_f(y) : y;
+      for (int e = 0; e < 8; ++e) {
+        const int g = (cv * 8 + e) / gs;
+        a[e] = gm[e] * rstd[g];
+        sft[e] = bt[e] - mean[g] * a[e];
+      }
     }
-    stg16(p.Y + ((int64_t)b * p.HW + px) * C + cv * 8, pack8(v));
+    const u16* src;
+    int ld;
+    if (cv < CV1) {
+      src = p.X1 + (int64_t)b * p.HW * p.C1 + cv * 8;
+      ld = p.C1;
+    } else {
+      src = p.X2 + (int64_t)b * p.HW * p.C2 + (cv - CV1) * 8;
+      ld = p.C2;
+    }
+    u16* dst = p.Y + (int64_t)b * p.HW * C + cv * 8;
+#pragma unroll 2
+    for (int px = p0 + prow; px < p1; px += PPB) {
+      float v[8];
+      unpack8(ldg16(src + (int64_t)px * ld), v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float y = v[e] * a[e] + sft[e];
+        v[e] = p.silu ? silu_f(y) : y;
+      }
+      stg16(dst + (int64_t)px * C, pack8(v));
+    }
   }
 }
 

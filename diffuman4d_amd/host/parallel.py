@@ -38,10 +38,26 @@ class FrameShard:
         self.dist.all_gather(list(out.unbind(0)), x_local, group=self.group)
         return out.view((self.world * x_local.shape[0],) + tuple(x_local.shape[1:]))
 
-    def gather_kv(self, kv_local: torch.Tensor) -> torch.Tensor:
-        """kv_local [cfg, Ls, 2C] (this rank's frames) -> [cfg, world*Ls, 2C] with ranks (= frames) in order."""
+    def gather_kv_start(self, kv_local: torch.Tensor):
+        """Start the all-gather of kv_local [cfg, Ls, 2C] (this rank's frames) and return a handle for gather_kv_finish.
+        With RCCL the collective runs on the communicator's own stream, so whatever is launched on the compute
+        stream between start and finish (the Q projection of the same layer) overlaps with the xGMI transfer."""
         cfg, ls, c2 = kv_local.shape
         out = torch.empty((cfg, self.world, ls, c2), dtype=kv_local.dtype, device=kv_local.device)
+        works = []
         for b in range(cfg):  # one collective per CFG half: each output block is contiguous and in frame order
-            self.dist.all_gather(list(out[b].unbind(0)), kv_local[b].contiguous(), group=self.group)
-        return out.view(cfg, self.world * ls, c2)
+            works.append(self.dist.all_gather(list(out[b].unbind(0)), kv_local[b].contiguous(), group=self.group,
+                                              async_op=True))
+        return out, works
+
+    def gather_kv_finish(self, handle) -> torch.Tensor:
+        """-> [cfg, world*Ls, 2C] with ranks (= frames) in order; the compute stream waits for the collectives."""
+        out, works = handle
+        for w in works:
+            w.wait()
+        cfg, world, ls, c2 = out.shape
+        return out.view(cfg, world * ls, c2)
+
+    def gather_kv(self, kv_local: torch.Tensor) -> torch.Tensor:
+        """kv_local [cfg, Ls, 2C] (this rank's frames) -> [cfg, world*Ls, 2C] with ranks (= frames) in order."""
+        return self.gather_kv_finish(self.gather_kv_start(kv_local))

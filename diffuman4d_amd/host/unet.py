@@ -188,9 +188,10 @@ class _TransformerBlock:
             qkv = ops.gemm(n, self.qkv)
             a = ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], batch, self.heads, seq, q_scaled=True)
         else:
-            q = ops.gemm(n, self.qkv[:C])
             kv = ops.gemm(n, self.qkv[C:])  # [M, 2C] contiguous so the collective needs no repack
-            kvg = shard.gather_kv(kv.view(batch, seq, 2 * C)).view(batch * shard.world * seq, 2 * C)
+            pending = shard.gather_kv_start(kv.view(batch, seq, 2 * C))
+            q = ops.gemm(n, self.qkv[:C])  # runs while the K|V blocks travel
+            kvg = shard.gather_kv_finish(pending).view(batch * shard.world * seq, 2 * C)
             a = ops.attention(q, kvg[:, :C], kvg[:, C:], batch, self.heads, seq, kv_seq=shard.world * seq, q_scaled=True)
         h = ops.gemm(a, self.ow, bias=self.ob, residual=h)
         n = ops.layernorm(h, self.n3w, self.n3b, 1e-5)

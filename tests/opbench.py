@@ -95,6 +95,17 @@ def main():
         bench_attn(2, 20, 720, " 3D mid")
         bench_attn(2, 10, 65536, " 3D L1 128")
         return
+    if only == "gn":
+        for B in (32, 48):
+            bench_gn(B, 2880, 320, f" L0 B{B}")
+            bench_gn(B, 2880, 640, f" L0c B{B}")
+            bench_gn(B, 2880, 960, f" L0cc B{B}")
+            bench_gn(B, 720, 640, f" L1 B{B}")
+            bench_gn(B, 720, 1920, f" L1cc B{B}")
+            bench_gn(B, 180, 1280, f" L2 B{B}")
+            bench_gn(B, 180, 2560, f" L2cc B{B}")
+            bench_gn(B, 45, 1280, f" L3 B{B}")
+        return
     print("device:", torch.cuda.get_device_name(0), "attn q_scaled:", QS, flush=True)
     B = 32  # F=16, CFG
     # GEMMs of one transformer block per level

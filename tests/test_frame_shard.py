@@ -19,6 +19,9 @@ def _worker(rank, world, port, outdir):
         full = torch.arange(cfg * world * ls * c2, dtype=torch.float32).view(cfg, world * ls, c2)
         local = full[:, rank * ls:(rank + 1) * ls].contiguous()
         got = sh.gather_kv(local)
+        pending = sh.gather_kv_start(local)  # split form used by the UNet (Q projection between start and finish)
+        got2 = sh.gather_kv_finish(pending)
+        assert torch.equal(got, got2)
         rows = sh.gather_rows(torch.full((2, 5), float(rank)))
         assert sh.local_frames(16) == slice(rank * 8, rank * 8 + 8)
         with pytest.raises(ValueError):
