@@ -45,7 +45,8 @@ constexpr int LDS_LD = 72;   // exact loop, K rows: 64 + 8 pad bf16 = 144 B  (co
 constexpr int LDS_LDV = 96;  // exact loop, V rows: 64 + 32 pad bf16 = 192 B (4 consecutive rows tile the 64 banks)
 constexpr int LDS_LDO = 72;  // O staging rows: 64 + 8 pad bf16 = 144 B
 constexpr int TILE = KV * 64;  // elements of one un-padded [64 keys][64 d] stage of the pipelined loop
-constexpr int NW = 8;        // waves per workgroup
+// waves per workgroup (template parameter NW): 8 = 256 query rows per workgroup, one workgroup per CU; 4 = 128 rows, two
+// independent workgroups per CU, so that a wave waiting at its workgroup's barrier shares its SIMD with a wave that is not
 constexpr float RESCALE_THR = 8.0f;  // in log2 units
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
@@ -93,23 +94,30 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
 // check the row sums at the end; a workgroup in which some sum left [0, 2^60) (or is NaN) simply redoes its rows
 // with the exact running-max loop (SAFE).  Results do not depend on how rows are grouped into waves (no vote).
 // ------------------------------------------------------------------------------------------------
-template <bool SAFE, bool FOLD>
+template <bool SAFE, bool FOLD, int NW>
 __device__ __forceinline__ void kv_loop(const AttnParams& p, const u16* Kb, const u16* Vb, u16* Ks, u16* Vs, const u16* v_lane,
                                         const bf16x8_t (&qf)[4], f32x16_t (&o)[2], float& m_run, float& l_run, int tid,
                                         int l31, int lh) {
   const int Lk = p.Lk;
   const float cs = FOLD ? 1.0f : p.c;  // FOLD: Q already carries scale*log2(e)
-  U4 rk, rv;
+  constexpr int RPT = 8 / NW;  // key rows per thread and tile (NW * 64 threads stage 64 rows of 8 chunks)
+  U4 rk[RPT], rv[RPT];
   const int s_key = tid >> 3, s_c = tid & 7;
   auto load_tile = [&](int t) {
-    int key = t * KV + s_key;
-    if (key > Lk - 1) key = Lk - 1;
-    rk = ldg16(Kb + (int64_t)key * p.ldk + s_c * 8);
-    rv = ldg16(Vb + (int64_t)key * p.ldv + s_c * 8);
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      int key = t * KV + s_key + i * (NW * 8);
+      if (key > Lk - 1) key = Lk - 1;
+      rk[i] = ldg16(Kb + (int64_t)key * p.ldk + s_c * 8);
+      rv[i] = ldg16(Vb + (int64_t)key * p.ldv + s_c * 8);
+    }
   };
   auto store_tile = [&](int buf) {
-    *reinterpret_cast<U4*>(Ks + (buf * KV + s_key) * LDS_LD + s_c * 8) = rk;
-    *reinterpret_cast<U4*>(Vs + (buf * KV + s_key) * LDS_LDV + s_c * 8) = rv;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      *reinterpret_cast<U4*>(Ks + (buf * KV + s_key + i * (NW * 8)) * LDS_LD + s_c * 8) = rk[i];
+      *reinterpret_cast<U4*>(Vs + (buf * KV + s_key + i * (NW * 8)) * LDS_LDV + s_c * 8) = rv[i];
+    }
   };
   const int nt = (Lk + KV - 1) / KV;
   load_tile(0);
@@ -202,35 +210,45 @@ __device__ __forceinline__ void kv_loop(const AttnParams& p, const u16* Kb, cons
 // results sits in front of the wait: without it the scheduler sinks half of the MFMAs below the barrier into the next
 // step, which puts the wait a few MFMAs after the issue and exposes the L2/HBM latency once per tile.
 // ------------------------------------------------------------------------------------------------
-template <bool FOLD>
+template <bool FOLD, int NW>
 __device__ __forceinline__ void kv_loop_pipelined(const AttnParams& p, const u16* Kb, const u16* Vb, u16* Ks, u16* Vs,
                                                   const bf16x8_t (&qf)[4], f32x16_t (&o)[2], float& m_run, float& l_run,
                                                   int lane, int wave, int l31, int lh) {
   const int Lk = p.Lk;
   const int nt = (Lk + KV - 1) / KV;
   const float cs = FOLD ? 1.0f : p.c;
-  // DMA geometry: wave w moves key rows 8w..8w+7 of a tile; lane i fills slot (i & 7) of row 8w + (i >> 3)
+  // DMA geometry: a tile is 8 pieces of 8 key rows; wave w moves pieces w, w + NW, ...; lane i fills slot (i & 7) of
+  // row 8 * piece + (i >> 3).  Pieces of one wave are NW * 8 rows apart (a multiple of 32), so they share the swizzle.
+  constexpr int PPW = 8 / NW;
   const int d_row = wave * 8 + (lane >> 3), d_slot = lane & 7;
   const int k_chunk = d_slot ^ ((d_row >> 1) & 7), v_chunk = d_slot ^ (((d_row >> 1) & 1) << 2);
   const uint32_t koff = (uint32_t)d_row * (uint32_t)p.ldk + (uint32_t)k_chunk * 8u;  // elements inside a full tile
   const uint32_t voff = (uint32_t)d_row * (uint32_t)p.ldv + (uint32_t)v_chunk * 8u;
   const uint32_t k_dst = lds_addr(Ks) + wave * 1024, v_dst = lds_addr(Vs) + wave * 1024;  // + stage * 8192 bytes
   auto issue_k = [&](int t, int stage, bool clamp) {
-    if (clamp) {
-      int key = t * KV + d_row;
-      key = key > Lk - 1 ? Lk - 1 : key;
-      dma16(Kb + (int64_t)key * p.ldk + k_chunk * 8, k_dst + stage * (TILE * 2));
-    } else {
-      dma16(Kb + (int64_t)t * KV * p.ldk, koff * 2u, k_dst + stage * (TILE * 2));
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int r0 = i * NW * 8;  // first row of this wave's i-th piece, relative to its first piece
+      if (clamp) {
+        int key = t * KV + d_row + r0;
+        key = key > Lk - 1 ? Lk - 1 : key;
+        dma16(Kb + (int64_t)key * p.ldk + k_chunk * 8, k_dst + stage * (TILE * 2) + r0 * 128);
+      } else {
+        dma16(Kb + ((int64_t)t * KV + r0) * p.ldk, koff * 2u, k_dst + stage * (TILE * 2) + r0 * 128);
+      }
     }
   };
   auto issue_v = [&](int t, int stage, bool clamp) {
-    if (clamp) {
-      int key = t * KV + d_row;
-      key = key > Lk - 1 ? Lk - 1 : key;
-      dma16(Vb + (int64_t)key * p.ldv + v_chunk * 8, v_dst + stage * (TILE * 2));
-    } else {
-      dma16(Vb + (int64_t)t * KV * p.ldv, voff * 2u, v_dst + stage * (TILE * 2));
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int r0 = i * NW * 8;
+      if (clamp) {
+        int key = t * KV + d_row + r0;
+        key = key > Lk - 1 ? Lk - 1 : key;
+        dma16(Vb + (int64_t)key * p.ldv + v_chunk * 8, v_dst + stage * (TILE * 2) + r0 * 128);
+      } else {
+        dma16(Vb + ((int64_t)t * KV + r0) * p.ldv, voff * 2u, v_dst + stage * (TILE * 2) + r0 * 128);
+      }
     }
   };
   auto dma_wait_barrier = [&]() {
@@ -370,8 +388,8 @@ __device__ __forceinline__ void kv_loop_pipelined(const AttnParams& p, const u16
   }
 }
 
-template <bool FOLD>
-__global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
+template <bool FOLD, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnParams p) {  // two waves per SIMD: 8-wave workgroup alone, or two 4-wave workgroups
   __shared__ __attribute__((aligned(16))) u16 smem[2 * KV * LDS_LD + 2 * KV * LDS_LDV];  // >= 4 * TILE, >= NW * 32 * LDS_LDO
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -406,7 +424,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
     for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
   float l_tot = -1.f;
   if (!p.exact_only) {
-    kv_loop_pipelined<FOLD>(p, Kb, Vb, smem, smem + 2 * TILE, qf, o, m_run, l_run, lane, wave, l31, lh);
+    kv_loop_pipelined<FOLD, NW>(p, Kb, Vb, smem, smem + 2 * TILE, qf, o, m_run, l_run, lane, wave, l31, lh);
     l_tot = l_run + __shfl_xor(l_run, 32);
   }
   // out of range (a later tile outgrew the first tile's max by more than 2^60) or NaN: redo with the exact loop
@@ -420,7 +438,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
     u16* Ks = smem;
     u16* Vs = smem + 2 * KV * LDS_LD;
     const u16* v_lane = Vs + (4 * (lane >> 5) + ((lane & 15) >> 2)) * LDS_LDV + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-    kv_loop<true, FOLD>(p, Kb, Vb, Ks, Vs, v_lane, qf, o, m_run, l_run, tid, l31, lh);
+    kv_loop<true, FOLD, NW>(p, Kb, Vb, Ks, Vs, v_lane, qf, o, m_run, l_run, tid, l31, lh);
     l_tot = l_run + __shfl_xor(l_run, 32);
   }
   // Both loops end with a workgroup barrier, so the K/V stages are free: O goes through a wave-private LDS tile
@@ -462,14 +480,17 @@ static int attention_launch(void* stream, const void* Q, const void* K, const vo
   static const int exact = [] { const char* e = getenv("DM4D_ATTN_EXACT"); return e ? atoi(e) : 0; }();  // tuning aid
   AttnParams p{(const u16*)Q, (const u16*)K, (const u16*)V, (u16*)O, ldq, ldk, ldv, ldo, Lq, Lk, heads, 0,
                scale * 1.4426950408889634f, exact};
-  const int rows = NW * 32;  // 32 query rows per wave (64 rows per wave measured slower)
+  // 8 waves per workgroup.  The kernels are written for NW = 4 as well (two independent 128-row workgroups per CU);
+  // measured in one call: +1..3 % on the 2-D L0 shapes, -3..-5 % on the 3-D ones (profiles/r01_attn_nw4_ab.log)
+  constexpr int nw = 8;
+  const int rows = nw * 32;  // 32 query rows per wave (64 rows per wave measured slower)
   p.nqt = (Lq + rows - 1) / rows;
   const long nwg = (long)p.nqt * heads * batch;
   if (nwg > 0x7fffffffL) return dm4d_set_error(DM4D_ERR_ARG, "attention: grid too large");
-  if (q_scaled)
-    hipLaunchKernelGGL(attn_kernel<true>, dim3((unsigned)nwg), dim3(NW * 64), 0, (hipStream_t)stream, p);
-  else
-    hipLaunchKernelGGL(attn_kernel<false>, dim3((unsigned)nwg), dim3(NW * 64), 0, (hipStream_t)stream, p);
+  const dim3 grid((unsigned)nwg), block(nw * 64);
+  hipStream_t st = (hipStream_t)stream;
+  if (q_scaled) hipLaunchKernelGGL((attn_kernel<true, nw>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((attn_kernel<false, nw>), grid, block, 0, st, p);
   return dm4d_check_launch("attn_kernel");
 }
 

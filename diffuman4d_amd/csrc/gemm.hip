@@ -55,6 +55,9 @@ struct GemmParams {
   unsigned flags;
   float out_scale;
   int tiles_n;
+  // split-K of the strip convolution over the 3 kernel rows (small images): partial sums go to ws[split][M][N] fp32
+  int splits;
+  float* ws;
 };
 
 __device__ __attribute__((aligned(16))) const uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
@@ -349,8 +352,20 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip_kernel(GemmParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
+  // split s of 3 handles kernel row ky = s only.  Column-major tile order for split launches: they exist for
+  // weight-dominated shapes (B*45 output rows against 30-60 MB of weights), where an XCD should see few weight columns.
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  int split = 0, tm, tn;
+  if (p.splits > 1) {
+    const int rows = gridDim.x / p.tiles_n;  // tile rows x splits
+    const int tms = lid % rows;
+    tn = lid / rows;
+    split = tms / (rows / p.splits);
+    tm = tms % (rows / p.splits);
+  } else {
+    tn = lid % p.tiles_n;
+    tm = lid / p.tiles_n;
+  }
   const int m0 = tm * BM, n0 = tn * BN;
   const int d_row = lane >> 3, d_pos = lane & 7;
   if (tid < 8) *reinterpret_cast<U4*>(Zs + tid * 8) = U4{0u, 0u, 0u, 0u};  // visible after the first barrier
@@ -394,8 +409,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip_kernel(GemmParams p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nci = p.Cin / BK;
-  const int nstrips = 3 * nci, nsteps = 3 * nstrips;
-  int i_ky = 0, i_cs = 0, i_kx = 0, i_step = 0, i_strip = 0;  // next step to be issued
+  const int nstrips = (p.splits > 1 ? 1 : 3) * nci, nsteps = 3 * nstrips;
+  int i_ky = p.splits > 1 ? split : 0, i_cs = 0, i_kx = 0, i_step = 0, i_strip = 0;  // next step to be issued
 
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -467,6 +482,21 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip_kernel(GemmParams p) {
       }
       __syncthreads();
     }
+  }
+  if (p.splits > 1) {  // raw fp32 partial sums; splitk_reduce_kernel adds the splits in a fixed order and applies the epilogue
+    float* wsp = p.ws + (int64_t)split * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * TN + j * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m < p.M && n < p.N) wsp[(int64_t)m * p.N + n] = acc[i][j][r];
+        }
+      }
+    return;
   }
   gemm_epilogue<MI, NI, TM, TN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
 }
@@ -780,12 +810,65 @@ int launch_pipe(hipStream_t st, GemmParams& p) {
   return dm4d_check_launch("gemm_kernel_pipe");
 }
 
+// out = epilogue(ws[0] + ws[1] + ws[2]) for the split strip convolution: 8 columns per thread, 16-byte stores
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
+  const int nv = p.N / 8;
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (int64_t)p.M * nv) return;
+  const int m = (int)(id / nv), n = (int)(id % nv) * 8;
+  const int64_t plane = (int64_t)p.M * p.N;
+  const float* w = p.ws + (int64_t)m * p.N + n;
+  float v[8];
+  {
+    const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(w), a1 = *reinterpret_cast<const f32x4_t*>(w + 4);
+    v[0] = a0[0]; v[1] = a0[1]; v[2] = a0[2]; v[3] = a0[3];
+    v[4] = a1[0]; v[5] = a1[1]; v[6] = a1[2]; v[7] = a1[3];
+  }
+  for (int s = 1; s < p.splits; ++s) {
+    const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(w + s * plane), a1 = *reinterpret_cast<const f32x4_t*>(w + s * plane + 4);
+    v[0] += a0[0]; v[1] += a0[1]; v[2] += a0[2]; v[3] += a0[3];
+    v[4] += a1[0]; v[5] += a1[1]; v[6] += a1[2]; v[7] += a1[3];
+  }
+  float t[8];
+  if (p.bias) {
+    unpack8(ldg16(p.bias + n), t);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += t[e];
+  }
+  if (p.rowbias) {
+    unpack8(ldg16(p.rowbias + (int64_t)(m / p.rows_per_rb) * p.ld_rb + n), t);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += t[e];
+  }
+  if (p.res) {
+    unpack8(ldg16(p.res + (int64_t)m * p.ld_res + n), t);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += t[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+  stg16(p.C + (int64_t)m * p.ldc + n, pack8(v));
+}
+
+// Split-K applies to stride-1 convolutions on small images (the 9x5 level of the UNet: M = B*45 rows against a
+// 11520- or 23040-deep K).  The rule looks at the per-image geometry only, never at the batch, so a frame-sharded
+// run (fewer frames per rank) sums in the same order as the unsharded one.
+__host__ inline bool strip_split_ok(const GemmParams& p) {
+  return p.H * p.W <= 64 && p.Cin >= 512 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!p.res || (p.ld_res & 7) == 0) &&
+         (!p.rowbias || (p.ld_rb & 7) == 0) && p.flags == 0;
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_strip(hipStream_t st, GemmParams& p) {
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((conv_strip_kernel<BM, BN, WM, WN>), dim3(tiles_m * p.tiles_n), dim3(WM * WN * 64), 0, st, p);
-  return dm4d_check_launch("conv_strip_kernel");
+  if (p.splits < 1) p.splits = 1;
+  hipLaunchKernelGGL((conv_strip_kernel<BM, BN, WM, WN>), dim3(tiles_m * p.tiles_n * p.splits), dim3(WM * WN * 64), 0, st, p);
+  int rc = dm4d_check_launch("conv_strip_kernel");
+  if (rc || p.splits == 1) return rc;
+  const int64_t nthreads = (int64_t)p.M * (p.N / 8);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, p);
+  return dm4d_check_launch("splitk_reduce_kernel");
 }
 
 int g_tune_cfg = 0;  // 0 = heuristic; otherwise a kernel-configuration id (tuning hook, dm4d_tune_set_gemm_config)
@@ -871,10 +954,18 @@ int choose_cfg(const GemmParams& p) {
 
 template <bool CONV>
 int launch(hipStream_t st, GemmParams& p) {
+  p.splits = 1;
   if (g_tune_cfg) {
     int rc = launch_by_id<CONV>(g_tune_cfg, st, p);
     if (rc == DM4D_ERR_ARG) return dm4d_set_error(DM4D_ERR_ARG, "gemm: forced configuration does not support this shape");
     return rc;
+  }
+  if constexpr (CONV) {
+    if (p.ws && p.stride == 1 && p.pad == 1 && !p.upsample && p.Ho == p.H && p.Wo == p.W && p.Cin % 64 == 0 &&
+        strip_split_ok(p)) {
+      p.splits = 3;
+      return launch_by_id<CONV>(31, st, p);  // 128x128 strip tiles x 3 kernel rows
+    }
   }
   return launch_by_id<CONV>(choose_cfg<CONV>(p), st, p);
 }
@@ -905,10 +996,18 @@ extern "C" int dm4d_gemm_bf16(void* stream, const void* A, int64_t lda, const vo
   return launch<false>((hipStream_t)stream, p);
 }
 
-extern "C" int dm4d_conv3x3_nhwc_bf16(void* stream, const void* X, int B, int H, int W, int Cin, const void* Wt, void* Y,
-                                      int Ho, int Wo, int Cout, int stride, int pad, int upsample, const void* bias,
-                                      const void* rowbias, int64_t ld_rowbias, const void* residual, int64_t ld_res,
-                                      float out_scale) {
+extern "C" size_t dm4d_conv3x3_ws_bytes(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int stride, int pad,
+                                        int upsample) {
+  GemmParams p{};
+  p.H = H; p.W = W; p.Cin = Cin; p.N = Cout; p.ldc = Cout;
+  const bool strip = stride == 1 && pad == 1 && !upsample && Ho == H && Wo == W && Cin % 64 == 0;
+  return strip && strip_split_ok(p) ? (size_t)3 * B * Ho * Wo * Cout * sizeof(float) : 0;
+}
+
+static int conv3x3_impl(void* stream, const void* X, int B, int H, int W, int Cin, const void* Wt, void* Y, int Ho, int Wo,
+                        int Cout, int stride, int pad, int upsample, const void* bias, const void* rowbias,
+                        int64_t ld_rowbias, const void* residual, int64_t ld_res, float out_scale, void* ws,
+                        size_t ws_bytes) {
   if (!X || !Wt || !Y || B <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0)
     return dm4d_set_error(DM4D_ERR_ARG, "conv3x3: null pointer or empty shape");
   if (Cin % 32 != 0) return dm4d_set_error(DM4D_ERR_ARG, "conv3x3: Cin must be a multiple of 32 (pad the input)");
@@ -923,5 +1022,23 @@ extern "C" int dm4d_conv3x3_nhwc_bf16(void* stream, const void* X, int B, int H,
   p.M = B * Ho * Wo; p.N = Cout; p.K = 9 * Cin;
   p.bias = (const u16*)bias; p.rowbias = (const u16*)rowbias; p.ld_rb = ld_rowbias; p.rows_per_rb = Ho * Wo;
   p.res = (const u16*)residual; p.ld_res = ld_res; p.flags = 0; p.out_scale = out_scale;
+  const size_t need = dm4d_conv3x3_ws_bytes(B, H, W, Cin, Ho, Wo, Cout, stride, pad, upsample);
+  p.ws = (ws && need && ws_bytes >= need) ? (float*)ws : nullptr;  // without a workspace the un-split kernels run
   return launch<true>((hipStream_t)stream, p);
+}
+
+extern "C" int dm4d_conv3x3_nhwc_bf16(void* stream, const void* X, int B, int H, int W, int Cin, const void* Wt, void* Y,
+                                      int Ho, int Wo, int Cout, int stride, int pad, int upsample, const void* bias,
+                                      const void* rowbias, int64_t ld_rowbias, const void* residual, int64_t ld_res,
+                                      float out_scale) {
+  return conv3x3_impl(stream, X, B, H, W, Cin, Wt, Y, Ho, Wo, Cout, stride, pad, upsample, bias, rowbias, ld_rowbias,
+                      residual, ld_res, out_scale, nullptr, 0);
+}
+
+extern "C" int dm4d_conv3x3_nhwc_bf16_ws(void* stream, const void* X, int B, int H, int W, int Cin, const void* Wt, void* Y,
+                                         int Ho, int Wo, int Cout, int stride, int pad, int upsample, const void* bias,
+                                         const void* rowbias, int64_t ld_rowbias, const void* residual, int64_t ld_res,
+                                         float out_scale, void* ws, size_t ws_bytes) {
+  return conv3x3_impl(stream, X, B, H, W, Cin, Wt, Y, Ho, Wo, Cout, stride, pad, upsample, bias, rowbias, ld_rowbias,
+                      residual, ld_res, out_scale, ws, ws_bytes);
 }

@@ -87,12 +87,15 @@ def conv3x3(x: torch.Tensor, wt: torch.Tensor, *, bias=None, rowbias=None, resid
     if rowbias is not None:
         _req(rowbias, "rowbias")
         assert rowbias.shape[0] == B
+    # small images with a deep K (the 9x5 level) run split over the three kernel rows and need an fp32 workspace
+    ws_bytes = lib.dm4d_conv3x3_ws_bytes(B, H, W, Cin, Ho, Wo, Cout, stride, pad, 1 if upsample else 0)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device) if ws_bytes else None
     with _Prof("conv3x3", 2.0 * B * Ho * Wo * 9 * Cin * Cout, "flop"):
-        rc = lib.dm4d_conv3x3_nhwc_bf16(_stream(), _p(x), B, H, W, Cin, _p(wt), _p(y), Ho, Wo, Cout, stride, pad,
-                                        1 if upsample else 0, _p(bias), _p(rowbias),
-                                        rowbias.stride(0) if rowbias is not None else 0, _p(residual),
-                                        Cout if residual is not None else 0, out_scale)
-    _l.check(rc, "dm4d_conv3x3_nhwc_bf16")
+        rc = lib.dm4d_conv3x3_nhwc_bf16_ws(_stream(), _p(x), B, H, W, Cin, _p(wt), _p(y), Ho, Wo, Cout, stride, pad,
+                                           1 if upsample else 0, _p(bias), _p(rowbias),
+                                           rowbias.stride(0) if rowbias is not None else 0, _p(residual),
+                                           Cout if residual is not None else 0, out_scale, _p(ws), ws_bytes)
+    _l.check(rc, "dm4d_conv3x3_nhwc_bf16_ws")
     return y
 
 

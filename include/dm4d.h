@@ -61,6 +61,18 @@ int dm4d_conv3x3_nhwc_bf16(void* stream, const void* X, int B, int H, int W, int
                            int Wo, int Cout, int stride, int pad, int upsample, const void* bias, const void* rowbias,
                            int64_t ld_rowbias, const void* residual, int64_t ld_res, float out_scale);
 
+/* Same convolution with a caller-owned fp32 workspace.  Stride-1 convolutions on small images with a deep K (H*W <= 64,
+ *   Cin >= 512: the 9x5 level of the UNet, unet_multiview_blocks.py:71,274,585 at the deepest resolution) are split
+ *   over the three kernel rows -- three workgroups per output tile, partial sums in ws, a second launch adds them in a
+ *   fixed order and applies the epilogue -- because B*45 output rows cannot fill 256 CUs against an 11520-deep K.
+ *   dm4d_conv3x3_ws_bytes() returns the bytes needed for a shape (0 = never split); ws == NULL or too small runs the
+ *   un-split kernel.  The split depends on the per-image geometry only, not on B.                                   */
+size_t dm4d_conv3x3_ws_bytes(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int stride, int pad, int upsample);
+int dm4d_conv3x3_nhwc_bf16_ws(void* stream, const void* X, int B, int H, int W, int Cin, const void* Wt, void* Y, int Ho,
+                              int Wo, int Cout, int stride, int pad, int upsample, const void* bias, const void* rowbias,
+                              int64_t ld_rowbias, const void* residual, int64_t ld_res, float out_scale, void* ws,
+                              size_t ws_bytes);
+
 /* Direct (fp32 FMA) convolution for thin layers, NHWC: the PoseEncoder's conv stack
  *   (pose_encoder.py:14-31: 3x3 stride 1 / 4x4 stride 2, padding 1, 3..64 input channels, SiLU after each).
  *   X [B,H,W,Cin], Wt [Cout][ksize*ksize][Cin], Y [B,Ho,Wo,Cout]; Cin, Cout multiples of 4 (zero-pad the 3-channel

@@ -95,6 +95,11 @@ def main():
         bench_attn(2, 20, 720, " 3D mid")
         bench_attn(2, 10, 65536, " 3D L1 128")
         return
+    if only == "l3":
+        for B in (32, 48):
+            bench_conv(B, 9, 5, 1280, 1280, tag=f" L3 B{B}")
+            bench_conv(B, 9, 5, 2560, 1280, tag=f" L3 up B{B}")
+        return
     if only == "gn":
         for B in (32, 48):
             bench_gn(B, 2880, 320, f" L0 B{B}")

@@ -95,6 +95,22 @@ def case_conv(B, H, W, Cin, Cout, stride=1, pad=1, pad_hi=None, upsample=False, 
     return rel_l2(out, ref), float((out.float().cpu() - ref).abs().max())
 
 
+def case_conv_batch_invariance(B, H, W, Cin, Cout, seed=0):
+    """A frame-sharded rank convolves fewer images per call: every image's result must not depend on how many
+    images share the launch (tile configuration, split-K decision), BITWISE."""
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    x = _rnd((B, H, W, Cin), g).cuda()
+    wt = _rnd((Cout, 9 * Cin), g, 1.0 / math.sqrt(9 * Cin)).cuda()
+    b = _rnd((Cout,), g, 0.5).cuda()
+    full = ops.conv3x3(x, wt, bias=b)
+    worst = 0.0
+    for n in (1, 2, B // 2):
+        part = ops.conv3x3(x[:n].contiguous(), wt, bias=b)
+        worst = max(worst, float((part.float() - full[:n].float()).abs().max()))
+    return worst, worst
+
+
 def case_conv_direct(B, H, W, Cin, Cout, k, stride, silu=True, seed=0):
     """PoseEncoder layers (pose_encoder.py:14-31): thin direct convolution, channels zero-padded to multiples of 4."""
     from diffuman4d_amd.host import ops
@@ -313,6 +329,12 @@ CASES = {
     "conv_strip_256x256": (case_conv, dict(B=16, H=36, W=20, Cin=64, Cout=1024)),
     "conv_strip_128x128": (case_conv, dict(B=11, H=36, W=20, Cin=128, Cout=640, rowbias=True, residual=True)),
     "conv_strip_w1": (case_conv, dict(B=2, H=5800, W=1, Cin=64, Cout=640)),
+    # split over the three kernel rows (small image, deep K: the 9x5 level) + reduce/epilogue launch
+    "conv_splitk": (case_conv, dict(B=5, H=9, W=5, Cin=512, Cout=320, rowbias=True, residual=True)),
+    "conv_splitk_ragged": (case_conv, dict(B=3, H=9, W=5, Cin=640, Cout=200)),
+    "conv_splitk_8x8": (case_conv, dict(B=9, H=8, W=8, Cin=512, Cout=128, residual=True)),
+    "conv_batch_invariance_l3": (case_conv_batch_invariance, dict(B=8, H=9, W=5, Cin=512, Cout=256)),
+    "conv_batch_invariance_l2": (case_conv_batch_invariance, dict(B=8, H=18, W=10, Cin=128, Cout=256)),
     # --- thin direct convs (PoseEncoder) ---------------------------------------------------------
     "convd_3to3_k3": (case_conv_direct, dict(B=2, H=40, W=24, Cin=3, Cout=3, k=3, stride=1)),
     "convd_3to16_k4s2": (case_conv_direct, dict(B=2, H=40, W=24, Cin=3, Cout=16, k=4, stride=2)),
@@ -372,7 +394,8 @@ CASES = {
     "pack_ddim_noskel": (case_pack_ddim, dict(F_=8, HW=30, use_cfg=True, vpred=False, skel=False)),
 }
 
-TOLS = {"layout": 0.0, "temb": 6e-3, "attn_kv_split": 0.0, "attn_kv_split3": 0.0, "attn_qs_kv_split": 0.0}
+TOLS = {"layout": 0.0, "temb": 6e-3, "attn_kv_split": 0.0, "attn_kv_split3": 0.0, "attn_qs_kv_split": 0.0,
+        "conv_batch_invariance_l3": 0.0, "conv_batch_invariance_l2": 0.0}
 
 
 def run_case(name):
