@@ -7,7 +7,9 @@ latent, CFG 2.0), synthetic 72x40x4 latents, SD-2.1-geometry UNet with seeded ra
 
 One "step" = one schedule unit of that run: 2 spatial window calls (F = 4 inputs + 12 targets = 16
 frames, CFG batch 32) + 1 temporal window call (F = 12 + 12 = 24 frames, CFG batch 48) -- exactly
-the 6600 : 3300 call mix of the full run.  Each call = model-input pack -> UNet ->
+the 6600 : 3300 call mix of the full run.  The K timed steps are dealt to --task-streams (default 2)
+independent tasks that are in flight at the same time, one HIP stream and worker thread each, as the runner does with the
+tasks of a round (host/runner.py: gpu_streams).  Each call = model-input pack -> UNet ->
 CFG + batched DDIM update on device-resident latents.  One unit advances 36 latent-steps = 2 fully
 denoised latents; the full run is 3300 units.  VAE encode/decode is outside the timed region
  -- inputs are resident in HBM when timing starts.
@@ -17,7 +19,7 @@ own units with no data-path collective (the only exchange of the real run, the g
 the 2 round boundaries, moves < 0.2 GB and is not part of a unit): weak scaling.
 
 Prints ONE JSON line on rank 0: the contract fields (metric, value = whole-job denoised latents/s, ...), `roofline`
-(attention kernel: HIP-event timing inside the timed region, PMC traffic from profiles/), `cpu_baseline` (N = 1 only:
+(attention kernel: HIP-event timing in a one-task-at-a-time pass of the same steps, PMC traffic from profiles/), `cpu_baseline` (N = 1 only:
 the CPU oracle on one full spatial window), `secondary` (latent-steps/s, UNet calls/s, sustained TFLOP/s) and
 `kernel_breakdown_one_step` (per kernel family, from one extra untimed instrumented step).
 Options beyond the contract: --latent HxW, --mode frame-shard, --prune-cond-rows (opt-in extension).
@@ -58,6 +60,9 @@ def parse():
     ap.add_argument("--latent", default="72x40",
                     help="latent grid HxW: 72x40 = BASELINE.json's synthetic grid (default, the judged line); 128x128 = the "
                          "1024^2 images the reference's demo configs run (SURVEY.md 8d asks for both)")
+    ap.add_argument("--task-streams", type=int, default=2,
+                    help="independent tasks in flight per GPU, each on its own HIP stream and worker thread (the runner's "
+                         "gpu_streams): the K timed steps are dealt round-robin to the streams. 1 = one task at a time")
     ap.add_argument("--prune-cond-rows", action="store_true",
                     help="opt-in extension, NOT the judged configuration: skip the per-frame tail of the UNet (after the last "
                          "3-D attention) for conditioning frames, whose noise prediction the reference discards")
@@ -188,28 +193,66 @@ def main():
         shard = FrameShard()
         if 16 % world or 24 % world:
             raise SystemExit("frame-shard mode needs a rank count dividing both window sizes (16 and 24): 1, 2, 4 or 8")
-    tasks = build_tasks(pipe, dev, shard)
+    # Tasks of a round are independent, so the runner keeps `gpu_streams` of them in flight per GPU (host/runner.py);
+    # here: S task states, S worker threads, one HIP stream each, one set of weights.  Collectives of the frame-shard
+    # mode must be issued in one order on every rank, so that mode runs one task at a time.
+    S = 1 if shard is not None else max(1, min(args.task_streams, max(1, args.steps)))
+    task_sets = [build_tasks(pipe, dev, shard) for _ in range(S)]
+    tasks = task_sets[0]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [None]
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
-        for u in range(args.warmup):
-            run_unit(pipe, tasks, u, shard)
-        barrier()
-        ops.KERNEL_TIMER = timer = []
-        t0 = time.perf_counter()
-        for u in range(args.steps):
-            run_unit(pipe, tasks, args.warmup + u, shard)
-        barrier()
-        dt = time.perf_counter() - t0
-        ops.KERNEL_TIMER = None
+    def run_units(first, count):
+        """`count` units starting at per-task unit index `first`, dealt round-robin to the S task streams."""
+        def work(si):
+            torch.cuda.set_device(dev)
+            with torch.no_grad(), torch.cuda.stream(streams[si]):
+                for j in range(si, count, S):
+                    run_unit(pipe, task_sets[si], first + j // S, shard)
+        if S == 1:
+            with torch.no_grad():
+                for j in range(count):
+                    run_unit(pipe, tasks, first + j, shard)
+            return
+        import threading
+        errs = []
+
+        def guarded(si):
+            try:
+                work(si)
+            except BaseException as e:  # noqa: BLE001
+                errs.append(e)
+        th = [threading.Thread(target=guarded, args=(si,)) for si in range(S)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        if errs:
+            raise errs[0]
+
+    run_units(0, max(args.warmup, 0) * S if args.warmup > 0 else 0)
+    barrier()
+    t0 = time.perf_counter()
+    run_units(args.warmup, args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # roofline pass: the same K steps, one task at a time, an event pair around every attention launch on the launch
+    # stream.  With several task streams the launches of different tasks overlap on the device, so per-launch intervals
+    # taken inside the timed region above would measure the mix, not the kernel.
+    with torch.no_grad():
+        ops.KERNEL_TIMER = timer = []
+        t1 = time.perf_counter()
+        for u in range(args.steps):
+            run_unit(pipe, tasks, args.warmup + args.steps + u, shard)
+        torch.cuda.synchronize()
+        dt_single = time.perf_counter() - t1
+        ops.KERNEL_TIMER = None
 
     # per-family breakdown from one extra, UNTIMED unit with an event pair around every launch (the event records
     # themselves would cost about 1 % inside the timed region)
@@ -217,7 +260,7 @@ def main():
     if rank == 0:
         with torch.no_grad():
             ops.PROFILE = prof = []
-            run_unit(pipe, tasks, args.warmup + args.steps, shard)
+            run_unit(pipe, tasks, args.warmup + 2 * args.steps, shard)
             torch.cuda.synchronize()
             ops.PROFILE = None
         fam = {}
@@ -262,6 +305,7 @@ def main():
                 "parallelism": (f"frame-shard x{world} (every window split over all ranks, RCCL K/V all-gather per 3-D "
                                 f"attention layer)" if shard is not None else
                                 f"task-parallel x{world} (independent tasks per round, no data-path collective)"),
+                "task_streams": S,
                 "finite_outputs": finite,
                 "extensions": ["prune_cond_rows"] if args.prune_cond_rows else [],
             },
@@ -272,7 +316,9 @@ def main():
                 "traffic_note": "avg HBM bytes per attn launch, PMC (2*FETCH_SIZE+WRITE_SIZE), profiles/r01_attn_traffic_pmc.json; "
                                 "algorithmic Q+K+V+O bytes average 152e6 per launch",
                 "avg_launch_ms": round(attn_ms / max(1, len(timer)), 4), "launches": len(timer),
-                "share_of_step_time": round(attn_ms * 1e-3 / dt, 4),
+                "measured_in": f"a second pass of the same {args.steps} steps with one task in flight "
+                               f"({dt_single / args.steps * 1e3:.1f} ms per step), HIP events on the launch stream",
+                "share_of_step_time": round(attn_ms * 1e-3 / dt_single, 4),
             },
         }
         # secondary figures of SURVEY.md 8d (whole job): latent-steps/s, UNet window calls/s, sustained UNet TFLOP/s

@@ -12,6 +12,7 @@ task.  Works with backend "nccl" (= RCCL over xGMI) and "gloo" (CPU tests).
 """
 from __future__ import annotations
 
+import threading
 from queue import Empty, Queue
 from threading import Thread
 from typing import Dict, List, Tuple
@@ -22,11 +23,35 @@ from .results import check_sampling_results
 from .sampler import SlidingIterativeSampler
 
 
+_tls = threading.local()
+
+
+def _denoise_on_own_stream(sampler: SlidingIterativeSampler, sample: dict, pipe_idx: int) -> dict:
+    """GPU-stage worker: every worker thread owns one HIP stream (created on first use), so the kernels of concurrently
+    denoised tasks interleave on the device."""
+    dev = sampler.pipelines[pipe_idx].device
+    if not (torch.cuda.is_available() and getattr(dev, "type", "cpu") == "cuda"):
+        return sampler.denoise(sample, pipe_idx=pipe_idx)
+    torch.cuda.set_device(dev)
+    st = getattr(_tls, "stream", None)
+    if st is None or st.device != torch.device(dev):
+        st = _tls.stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(st):
+        return sampler.denoise(sample, pipe_idx=pipe_idx)
+
+
 def run_round_pipelined(sampler: SlidingIterativeSampler, tasks: List[dict], pipe_idx: int = 0, depth: int = 1,
-                        writers: int = 1) -> None:
+                        writers: int = 1, gpu_streams: int = 1) -> None:
     """Execute the tasks of ONE alternation round on one pipeline as a 3-stage software pipeline:
 
-        loader pool: load_sample(task i+1 .. i+depth)  ||  caller: denoise(task i) on the GPU  ||  writer pool: save(task < i)
+        loader pool: load_sample(task i+1 .. i+depth)  ||  denoise(task i) on the GPU  ||  writer pool: save(task < i)
+
+    ``gpu_streams`` > 1 denoises that many tasks of the round concurrently, each on its own HIP stream (one worker
+    thread per stream, all sharing the pipeline's weights).  One task's kernels leave CUs idle -- partial last rounds
+    of workgroups, the 120-460-workgroup launches of the two deepest UNet levels, the drain/fill at every one of the
+    ~1000 kernel boundaries of a window call -- and a second task's kernels fill them: +7 % denoised latents/s with 2
+    streams, +8 % with 3 (profiles/r01_task_streams.log).  Every task computes exactly what it computes alone, so the
+    grid is bitwise the same as with one stream.
 
     The reference runs load -> denoise -> save serially per worker thread (sliding_iterative_sampler.py:201-204), so
     the GPU idles during the host-side decode/resize of 3N images and the JPEG writes (measured on
@@ -36,11 +61,12 @@ def run_round_pipelined(sampler: SlidingIterativeSampler, tasks: List[dict], pip
     written back is equivalent to the serial order; rounds are never overlapped.  Samples are denoised in task
     order whatever order the loads finish in.
     ``depth`` = tasks loaded ahead, each on its own thread (host memory: one task's tensors each); 0 = serial."""
-    if depth <= 0 or len(tasks) <= 1:
+    if (depth <= 0 and gpu_streams <= 1) or len(tasks) <= 1:
         for t in tasks:
             sampler.execute_one_task(t, pipe_idx=pipe_idx)
         return
     from concurrent.futures import ThreadPoolExecutor
+    depth = max(depth, gpu_streams)  # every GPU stream needs a loaded sample to start on
 
     pin = torch.cuda.is_available() and getattr(sampler.pipelines[pipe_idx].device, "type", "cpu") == "cuda"
 
@@ -55,19 +81,30 @@ def run_round_pipelined(sampler: SlidingIterativeSampler, tasks: List[dict], pip
     loaders = ThreadPoolExecutor(max_workers=depth, thread_name_prefix="dm4d-loader")
     savers = ThreadPoolExecutor(max_workers=max(1, writers), thread_name_prefix="dm4d-writer") \
         if sampler.result_writer is not None else None
+    gpu = ThreadPoolExecutor(max_workers=gpu_streams, thread_name_prefix="dm4d-gpu") if gpu_streams > 1 else None
     pending: List = []   # load futures, in task order
+    running: List = []   # denoise futures (gpu_streams > 1), in task order
     saves: List = []
     nxt = 0
     try:
         while nxt < len(tasks) and len(pending) < depth:
             pending.append(loaders.submit(load, **tasks[nxt]))
             nxt += 1
-        while pending:
-            sample = pending.pop(0).result()  # re-raises a loader error here, on the caller's thread
-            if nxt < len(tasks):
-                pending.append(loaders.submit(load, **tasks[nxt]))
-                nxt += 1
-            sample = sampler.denoise(sample, pipe_idx=pipe_idx)
+        while pending or running:
+            if gpu is None:
+                sample = pending.pop(0).result()  # re-raises a loader error here, on the caller's thread
+                if nxt < len(tasks):
+                    pending.append(loaders.submit(load, **tasks[nxt]))
+                    nxt += 1
+                sample = sampler.denoise(sample, pipe_idx=pipe_idx)
+            else:
+                while pending and len(running) < gpu_streams:
+                    loaded = pending.pop(0).result()
+                    if nxt < len(tasks):
+                        pending.append(loaders.submit(load, **tasks[nxt]))
+                        nxt += 1
+                    running.append(gpu.submit(_denoise_on_own_stream, sampler, loaded, pipe_idx))
+                sample = running.pop(0).result()  # task order; a worker error surfaces here
             if savers is not None:
                 saves = [f for f in saves if not (f.done() and f.exception() is None)]
                 for f in saves:
@@ -79,17 +116,19 @@ def run_round_pipelined(sampler: SlidingIterativeSampler, tasks: List[dict], pip
         for f in saves:
             f.result()
     finally:
-        for f in pending:
+        for f in pending + running:
             f.cancel()
+        if gpu is not None:
+            gpu.shutdown(wait=True)
         loaders.shutdown(wait=True)
         if savers is not None:
             savers.shutdown(wait=True)
 
 
 class SamplingRunner:
-    def __init__(self, sampler: SlidingIterativeSampler, prefetch_depth: int = 2, writers: int = 2):
+    def __init__(self, sampler: SlidingIterativeSampler, prefetch_depth: int = 2, writers: int = 2, gpu_streams: int = 2):
         self.sampler = sampler
-        self.prefetch_depth, self.writers = prefetch_depth, writers
+        self.prefetch_depth, self.writers, self.gpu_streams = prefetch_depth, writers, gpu_streams
 
     def prepare_task_queues(self):
         self.task_queues = []
@@ -132,7 +171,7 @@ class SamplingRunner:
                 raise ValueError("Sampling failed.")
         else:
             for tasks in s.all_tasks:
-                run_round_pipelined(s, tasks, 0, self.prefetch_depth, self.writers)
+                run_round_pipelined(s, tasks, 0, self.prefetch_depth, self.writers, self.gpu_streams)
             if s.result_writer is not None and not check_sampling_results(s.spa_labels, s.tem_labels, s.output_dir):
                 raise ValueError("Sampling failed.")
 
@@ -141,11 +180,12 @@ class DistributedSamplingRunner:
     """One process per GPU.  Every rank builds the same sampler (same task lists); rank r executes
     ``sampler.partition(round, r, world)`` with its single pipeline, then the grid is re-partitioned."""
 
-    def __init__(self, sampler: SlidingIterativeSampler, group=None, prefetch_depth: int = 2, writers: int = 2):
+    def __init__(self, sampler: SlidingIterativeSampler, group=None, prefetch_depth: int = 2, writers: int = 2,
+                 gpu_streams: int = 2):
         import torch.distributed as dist
         self.dist = dist
         self.sampler = sampler
-        self.prefetch_depth, self.writers = prefetch_depth, writers
+        self.prefetch_depth, self.writers, self.gpu_streams = prefetch_depth, writers, gpu_streams
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
@@ -212,7 +252,8 @@ class DistributedSamplingRunner:
     def inference(self):
         s = self.sampler
         for ri in range(len(s.all_tasks)):
-            run_round_pipelined(s, s.partition(ri, self.rank, self.world), 0, self.prefetch_depth, self.writers)
+            run_round_pipelined(s, s.partition(ri, self.rank, self.world), 0, self.prefetch_depth, self.writers,
+                                self.gpu_streams)
             self.dist.barrier(self.group)
             self.exchange(ri)
         if s.result_writer is not None and self.rank == 0:

@@ -106,6 +106,13 @@ class _RecordShard:
         self.kv.append(kv_local.clone())
         return kv_local
 
+    # split form used by the UNet (the Q projection runs between start and finish)
+    def gather_kv_start(self, kv_local):
+        return self.gather_kv(kv_local)
+
+    def gather_kv_finish(self, handle):
+        return handle
+
 
 class _ReplayShard:
     """Rank r of P, single process: the all-gather is answered from the recording of the unsharded run, after
@@ -125,6 +132,12 @@ class _ReplayShard:
         mine = full[:, self.rank * ls:(self.rank + 1) * ls]
         self.max_dev = max(self.max_dev, float((mine.float() - kv_local.float()).abs().max()))
         return full
+
+    def gather_kv_start(self, kv_local):
+        return self.gather_kv(kv_local)
+
+    def gather_kv_finish(self, handle):
+        return handle
 
 
 def case_unet_frame_shard(P=4, num_frames=8, h=16, w=8, tem=True, seed=0):

@@ -32,3 +32,19 @@ def test_bench_prints_one_contract_line():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert d["config"]["finite_outputs"] is True
+
+
+@pytest.mark.gpu
+def test_bench_with_two_task_streams():
+    """Default scheduling: the K steps are dealt to two tasks in flight (one HIP stream each); the roofline figures
+    come from the one-task-at-a-time pass that follows the timed region."""
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["steps"] == 2 and d["config"]["task_streams"] == 2 and d["config"]["finite_outputs"] is True
+    assert abs(d["value"] - 2.0 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
+    rf = d["roofline"]
+    assert rf["launches"] == 2 * 48 and 0.05 < rf["frac"] < 1.0 and "one task in flight" in rf["measured_in"]

@@ -68,3 +68,52 @@ def test_from_pretrained_equals_direct_construction(tmp_path):
               bidirectional=False, num_denoising_steps=1, alternation_rounds=1, guidance_scale=2.0, noise=noise)
     a, b = loaded.sliding_iterative_denoise(**kw), direct.sliding_iterative_denoise(**kw)
     assert torch.equal(a["latents"], b["latents"]) and torch.equal(a["images"], b["images"])
+
+
+def test_tasks_on_concurrent_streams_equal_serial(tmp_path):
+    """runner.run_round_pipelined(gpu_streams=2): two tasks denoised at the same time, each on its own HIP stream and
+    worker thread but through ONE pipeline object, must return bitwise what they return one after the other."""
+    import threading
+    from safetensors.torch import load_file
+    from diffuman4d_amd.host.pipeline import Diffuman4DPipeline
+    from diffuman4d_amd.host.scheduler import DDIMScheduler
+    from diffuman4d_amd.host.unet import UNetMultiviewConditionModel
+    from diffuman4d_amd.host.vae import AutoencoderKL
+    from diffuman4d_amd.host.weights import write_synthetic_checkpoint
+    from modelcheck import synthetic_task
+    ucfg, vcfg = _tiny_cfgs()
+    ckpt = write_synthetic_checkpoint(tmp_path / "ckpt", ucfg, vcfg, seed=7)
+    usd = load_file(f"{ckpt}/unet/diffusion_pytorch_model.safetensors")
+    vsd = load_file(f"{ckpt}/vae/diffusion_pytorch_model.safetensors")
+    pipe = Diffuman4DPipeline(AutoencoderKL(vcfg, vsd, "cuda"), UNetMultiviewConditionModel(ucfg, usd, "cuda"),
+                              DDIMScheduler(), "cuda")
+    n = 8
+    kws = []
+    for seed, domain in ((11, "spatial"), (12, "temporal"), (13, "spatial")):
+        # temporal tasks: rows 0..T-1 are the input camera's frames, rows T..2T-1 the target camera's (load_sample :112-118)
+        pv, pl, sk, cm = synthetic_task(n, 64, 64, [1, 5] if domain == "spatial" else [0, 1, 2, 3], seed)
+        g = torch.Generator().manual_seed(seed + 100)
+        noise = {k: torch.randn(n, 4, 8, 8, generator=g).to(torch.bfloat16) for k in ("pixel", "skeleton", "latents")}
+        kws.append(dict(pixel_values=pv, plucker_embeds=pl, skeletons=sk, cond_masks=cm, latents=None, domain=domain,
+                        timestep_indices=torch.zeros(n, dtype=torch.int64), window_size=4, sliding_stride=2,
+                        sliding_shift=0, bidirectional=False, num_denoising_steps=1, alternation_rounds=1,
+                        guidance_scale=2.0, noise=noise))
+    serial = [pipe.sliding_iterative_denoise(**kw) for kw in kws]
+    out, errs = [None] * len(kws), []
+
+    def work(i):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                out[i] = pipe.sliding_iterative_denoise(**kws[i])
+                out[i] = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in out[i].items()}
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+
+    for _ in range(3):  # a few rounds: interleavings differ from run to run
+        th = [threading.Thread(target=work, args=(i,)) for i in range(len(kws))]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errs, errs
+        for a, b in zip(serial, out):
+            assert torch.equal(a["latents"].cpu(), b["latents"]) and torch.equal(a["images"].cpu(), b["images"])

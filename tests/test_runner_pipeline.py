@@ -19,7 +19,7 @@ def make(writer, **kw):
     return SlidingIterativeSampler(ds, [StubPipeline()], "/tmp/unused", **args)
 
 
-def run(depth, writers=1):
+def run(depth, writers=1, gpu_streams=1):
     written, threads = [], set()
 
     def writer(sample, output_dir=None):
@@ -28,7 +28,7 @@ def run(depth, writers=1):
 
     s = make(writer)
     for tasks in s.all_tasks:
-        run_round_pipelined(s, tasks, 0, depth, writers)
+        run_round_pipelined(s, tasks, 0, depth, writers, gpu_streams)
     grid = {c: {f: (s.timestep_indices[c][f], float(s.latents[c][f].flatten()[0])) for f in s.tem_labels} for c in s.spa_labels}
     return grid, s.pipelines[0].calls, written, threads
 
@@ -44,6 +44,17 @@ def test_pipelined_rounds_equal_serial_rounds(depth, writers):
     else:
         assert sorted(w1) == sorted(w0)
     assert t0 == {"MainThread"} and all(n.startswith("dm4d-writer") for n in t1)
+
+
+@pytest.mark.parametrize("streams,depth", [(2, 1), (3, 2), (2, 0)])
+def test_concurrent_gpu_streams_leave_the_same_grid(streams, depth):
+    """Tasks of a round touch disjoint target cells: denoising several of them concurrently (one worker thread and
+    HIP stream each) must leave the grid, the set of pipeline calls and the written samples of the serial order."""
+    g0, calls0, w0, _ = run(0)
+    g1, calls1, w1, _ = run(depth, 1, streams)
+    assert g1 == g0
+    assert sorted(map(repr, calls1)) == sorted(map(repr, calls0))  # same calls; their start order is not defined
+    assert w1 == w0  # results are still collected and written in task order
 
 
 def test_runner_uses_the_pipeline_and_checks_nothing_without_a_writer():
