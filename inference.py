@@ -37,7 +37,10 @@ def inference(cfg: dict):
     pipelines = cfglib.instantiate(cfg["model"])
     log.info("Instantiating sampler <%s>", cfg["sampler"]["_target_"])
     sampler = cfglib.instantiate(cfg["sampler"], dataset=dataset, pipelines=pipelines)
-    runner = DistributedSamplingRunner(sampler) if distributed else SamplingRunner(sampler)
+    # runner.gpu_streams=N (default 2): tasks of a round in flight per GPU, one HIP stream each; 1 = the reference's
+    # one-task-at-a-time order
+    rk = {k: int(v) for k, v in (cfg.get("runner") or {}).items() if k in ("prefetch_depth", "writers", "gpu_streams")}
+    runner = DistributedSamplingRunner(sampler, **rk) if distributed else SamplingRunner(sampler, **rk)
     if cfg.get("sampling", True):
         runner.inference()
     if cfg.get("to_nerfstudio") or cfg.get("evaluating"):
