@@ -257,12 +257,13 @@ def main():
     # per-family breakdown from one extra, UNTIMED unit with an event pair around every launch (the event records
     # themselves would cost about 1 % inside the timed region)
     breakdown = None
-    if rank == 0:
+    if rank == 0 or shard is not None:  # a frame-sharded unit contains collectives: every rank has to run it
         with torch.no_grad():
             ops.PROFILE = prof = []
             run_unit(pipe, tasks, args.warmup + 2 * args.steps, shard)
             torch.cuda.synchronize()
             ops.PROFILE = None
+    if rank == 0:
         fam = {}
         for name, work, unit, e0, e1 in prof:
             f = fam.setdefault(name, {"launches": 0, "ms": 0.0, "work": 0.0, "unit": unit})

@@ -16,7 +16,7 @@ OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"
 rocprofv3 --kernel-trace --stats -d "$OUT" -o stats -- $BENCH > "$OUT.bench.log" 2> "$OUT.stats.err"
 DB=$(find "$OUT" -name "stats*results.db" | head -1)
-python tools/profile_summary.py "$DB" "rocprofv3 --kernel-trace --stats -- $BENCH ($TAG; 3 units incl. warmup + weight-init kernels)" \
+python tools/profile_summary.py "$DB" "rocprofv3 --kernel-trace --stats -- $BENCH ($TAG; 1 warm-up + 2 timed + 2 roofline-pass + 1 breakdown units, plus weight-init kernels)" \
   > gpurun_out/${TAG}_kernel_stats.txt
 tail -1 "$OUT.bench.log" > gpurun_out/${TAG}_bench_under_rocprof.json
 for C in FETCH_SIZE WRITE_SIZE; do
