@@ -209,8 +209,14 @@ class AutoencoderKL:
             for k, i in enumerate(idx):
                 fresh[i] = m[k]
         if cache is not None:
-            for i, m in fresh.items():
-                cache[keys[i]] = m.clone()
+            if fresh:
+                clones = {i: m.clone() for i, m in fresh.items()}
+                # The cache is shared by the runner's task streams (gpu_streams > 1): an entry may be read by another
+                # stream as soon as it is in the dict, so it is published only once the kernels that write it are done.
+                if self.device.type == "cuda":
+                    torch.cuda.current_stream(self.device).synchronize()
+                for i, c in clones.items():
+                    cache[keys[i]] = c
             rows = [cache[keys[i]] for i in range(n)]
         else:
             rows = [fresh[i] for i in range(n)]
