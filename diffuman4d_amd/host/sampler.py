@@ -176,10 +176,12 @@ class SlidingIterativeSampler:
                                           "timestep_indices")}
         result = pipe.sliding_iterative_denoise(domain=sample["domain"], tqdm=bar, **tensors, **asdict(self.sweep),
                                                 **self._pipeline_extensions(sample))
-        self._scatter_cells(sample["labels"], result["latents"], result["timestep_indices"])
-        sample["images"] = result["images"].float().cpu()
+        sample["images"] = result["images"].float().cpu()  # blocks until this task's stream has finished
         sample["timestep_indices"] = result["timestep_indices"].cpu()
         sample["fully_denoised"] = result["fully_denoised"].cpu()
+        # hand the cells over only now: with several task streams per GPU (runner gpu_streams) another task's thread may
+        # read the grid as soon as the cells are in it, and device tensors must be complete by then
+        self._scatter_cells(sample["labels"], result["latents"], result["timestep_indices"])
         return sample
 
     def _pipeline_extensions(self, sample: dict) -> dict:
