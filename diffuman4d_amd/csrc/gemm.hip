@@ -31,6 +31,12 @@
 #include "errors.h"
 #include <stdlib.h>
 
+// Epilogue read-back loop with shift / 32-bit-offset index arithmetic (see gemm_epilogue); 0 = the generic loop only.
+// Same floating-point operations in the same order, so results are bit-identical either way (tools/dev/fe_check.py).
+#ifndef GEMM_FAST_EPI
+#define GEMM_FAST_EPI 1
+#endif
+
 namespace {
 
 struct GemmParams {
@@ -107,6 +113,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
   const int tasks = 32 * chunks_per_row;
   const bool vec_ok = ((p.ldc & 7) == 0) && ((p.N & 7) == 0) && (!p.res || (p.ld_res & 7) == 0) &&
                       (!p.rowbias || (p.ld_rb & 7) == 0);
+#if GEMM_FAST_EPI
+  static_assert(NI == 1 || NI == 2 || NI == 4, "the fast read-back loop needs a power-of-two number of 8-column chunks per row");
+  const bool fast_ok = vec_ok && p.ldc < (1 << 24) && (!p.res || p.ld_res < (1 << 24)) && (!p.rowbias || p.rows_per_rb > 0) && NJ > 0;
+#endif
   // The staging area is private to a wave and LDS operations of one wave complete in program order, so only one
   // workgroup barrier is needed: the one that retires every wave's main-loop fragment reads before the area is reused.
   __syncthreads();
@@ -130,6 +140,55 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // compiler: keep the staging stores ahead of the row reads
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#if GEMM_FAST_EPI
+    if (fast_ok) {
+      // Row / chunk from shifts (chunks_per_row is 4, 8 or 16), 32-bit offsets from wave-uniform row-block bases, and the
+      // rowbias row (m / rows_per_rb) from one division per 32-row block: rows of a block are consecutive, so row r lies
+      // in image q0 + (r0 + r >= rows_per_rb).  The generic loop below spends ~50 VALU instructions per 8 outputs on
+      // these index computations (runtime divisions, 64-bit multiplies), more than on the outputs themselves.
+      const int m_base = m0 + wm * TM + i * 32;
+      const int cshift = 31 - __builtin_clz(chunks_per_row), cmask = chunks_per_row - 1;
+      const u16* res_base = p.res ? p.res + (int64_t)m_base * p.ld_res + ncol0 : nullptr;
+      u16* c_base = p.C + (int64_t)m_base * p.ldc + ncol0;
+      int q0 = 0, r0 = 0;
+      if (p.rowbias) {
+        q0 = m_base / p.rows_per_rb;
+        r0 = m_base - q0 * p.rows_per_rb;
+      }
+      for (int id = lane; id < tasks; id += 64) {
+        const int row = id >> cshift, cc = id & cmask;
+        if (m_base + row >= p.M || ncol0 + cc * 8 >= p.N) continue;
+        float v[8];
+        const float* s = stage + row * SLD + cc * 8;
+        f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(s);
+        f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(s + 4);
+        v[0] = s0[0]; v[1] = s0[1]; v[2] = s0[2]; v[3] = s0[3];
+        v[4] = s1[0]; v[5] = s1[1]; v[6] = s1[2]; v[7] = s1[3];
+        if (p.rowbias) {
+          int q;
+          if (p.rows_per_rb >= 32) {
+            q = q0 + ((r0 + row >= p.rows_per_rb) ? 1 : 0);
+          } else {
+            q = (m_base + row) / p.rows_per_rb;
+          }
+          float t[8];
+          unpack8(ldg16(p.rowbias + (int64_t)q * p.ld_rb + ncol0 + cc * 8), t);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += t[e];
+        }
+        if (p.res) {
+          float t[8];
+          unpack8(ldg16(res_base + (uint32_t)(row * (int)p.ld_res + cc * 8)), t);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += t[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+        stg16(c_base + (uint32_t)(row * (int)p.ldc + cc * 8), pack8(v));
+      }
+      continue;  // next 32-row block of this wave
+    }
+#endif
     for (int id = lane; id < tasks; id += 64) {
       int row = id / chunks_per_row, cc = id % chunks_per_row;
       int m = m0 + wm * TM + i * 32 + row;
