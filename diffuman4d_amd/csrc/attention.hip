@@ -45,6 +45,14 @@ constexpr int LDS_LD = 72;   // exact loop, K rows: 64 + 8 pad bf16 = 144 B  (co
 constexpr int LDS_LDV = 96;  // exact loop, V rows: 64 + 32 pad bf16 = 192 B (4 consecutive rows tile the 64 banks)
 constexpr int LDS_LDO = 72;  // O staging rows: 64 + 8 pad bf16 = 144 B
 constexpr int TILE = KV * 64;  // elements of one un-padded [64 keys][64 d] stage of the pipelined loop
+// Stages per operand ring of the pipelined loop.  2 (shipped): one DMA round and one barrier per tile.  4 (experimental,
+// NOT yet run on a GPU -- build with -DATTN_RING=4 and run `python tests/opcheck.py attn`): the main loop handles tiles
+// in pairs, one DMA round (2 K + 2 V tiles) and one barrier per pair; DMA runs two tiles ahead instead of one.
+#ifndef ATTN_RING
+#define ATTN_RING 2
+#endif
+constexpr int RING = ATTN_RING, AHEAD = RING / 2;
+static_assert(RING == 2 || RING == 4, "ATTN_RING must be 2 or 4");
 // waves per workgroup (template parameter NW): 8 = 256 query rows per workgroup, one workgroup per CU; 4 = 128 rows, two
 // independent workgroups per CU, so that a wave waiting at its workgroup's barrier shares its SIMD with a wave that is not
 constexpr float RESCALE_THR = 8.0f;  // in log2 units
@@ -323,10 +331,18 @@ __device__ __forceinline__ void kv_loop_pipelined(const AttnParams& p, const u16
       }
   };
 
-  // prologue: K(0), V(0), K(1) -> LDS (K(1) clamped when nt == 1)
-  issue_k(0, 0, true);
-  issue_v(0, 0, true);
-  issue_k(1, 1, true);
+  // prologue: K(0) .. K(AHEAD), V(0) .. V(AHEAD-1) -> LDS (clamped past the end of the sequence); tile i lives in
+  // stage i % RING of its ring
+  if (RING == 2) {
+    issue_k(0, 0, true);
+    issue_v(0, 0, true);
+    issue_k(1, 1, true);
+  } else {
+#pragma unroll
+    for (int i = 0; i <= AHEAD; ++i) issue_k(i, i % RING, true);
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i) issue_v(i, i % RING, true);
+  }
   dma_wait_barrier();
   f32x16_t s_cur[2], s_nxt[2];
   qk_block(0, 0, s_cur[0]);  // negm is still zero here
@@ -349,11 +365,11 @@ __device__ __forceinline__ void kv_loop_pipelined(const AttnParams& p, const u16
   }
   __syncthreads();  // every wave has read K(0): step 0 overwrites its stage
 
-  // one pipelined step: consumes S(t) from `sa`, produces S(t+1) into `sb`; straight-line code (no branches)
-  auto step = [&](int t, f32x16_t (&sa)[2], f32x16_t (&sb)[2], bool clamp) {
-    const int kst = (t + 1) & 1, vst = t & 1;
-    issue_k(t + 2, t & 1, clamp);        // over K(t), last read in step t-1 (clamped past the end of the sequence)
-    issue_v(t + 1, (t + 1) & 1, clamp);  // over V(t-1)
+  // One pipelined step: consumes S(t) from `sa`, produces S(t+1) into `sb`; straight-line code (no branches).
+  // Before it K(t+1 .. t+AHEAD) and V(t .. t+AHEAD-1) are resident; its DMA (issue = true) brings K(t+AHEAD+1) over
+  // K(t+AHEAD+1-RING) and V(t+AHEAD) over V(t+AHEAD-RING), both last read before the previous barrier.
+  auto compute = [&](int t, f32x16_t (&sa)[2], f32x16_t (&sb)[2]) {
+    const int kst = (t + 1) % RING, vst = t % RING;
     bf16x8_t pf[2];
     qk_block(kst, 0, sb[0]);
     softmax_block(sa[0], pf);
@@ -361,15 +377,34 @@ __device__ __forceinline__ void kv_loop_pipelined(const AttnParams& p, const u16
     qk_block(kst, 1, sb[1]);
     softmax_block(sa[1], pf);
     pv_block(vst, 1, pf);
-    asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(sb[0]), "v"(sb[1]));  // every MFMA of the step is issued before the wait
+    asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(sb[0]), "v"(sb[1]));  // every MFMA of the step is issued before what follows
+  };
+  auto step = [&](int t, f32x16_t (&sa)[2], f32x16_t (&sb)[2], bool clamp) {
+    issue_k(t + AHEAD + 1, (t + AHEAD + 1) % RING, clamp);
+    issue_v(t + AHEAD, (t + AHEAD) % RING, clamp);
+    compute(t, sa, sb);
     dma_wait_barrier();
   };
   int t = 0;
-  // main loop: every tile it loads (up to t + 3) is a full tile, so the uniform-base addressing applies
   const int n_full = Lk / KV;
-  for (; t + 3 < n_full; t += 2) {  // two steps per trip: the S register sets swap roles instead of being copied
-    step(t, s_cur, s_nxt, false);
-    step(t + 1, s_nxt, s_cur, false);
+  if (RING == 2) {
+    // main loop: every tile it loads (up to t + 3) is a full tile, so the uniform-base addressing applies
+    for (; t + 3 < n_full; t += 2) {  // two steps per trip: the S register sets swap roles instead of being copied
+      step(t, s_cur, s_nxt, false);
+      step(t + 1, s_nxt, s_cur, false);
+    }
+  } else {
+    // tiles in pairs: the DMA of both steps (K(t+3), K(t+4), V(t+2), V(t+3)) goes out at the top, one barrier at the end;
+    // the four tiles land in the four stages that do not hold K(t+1), K(t+2) / V(t), V(t+1)
+    for (; t + 4 < n_full; t += 2) {
+      issue_k(t + 3, (t + 3) % RING, false);
+      issue_k(t + 4, (t + 4) % RING, false);
+      issue_v(t + 2, (t + 2) % RING, false);
+      issue_v(t + 3, (t + 3) % RING, false);
+      compute(t, s_cur, s_nxt);
+      compute(t + 1, s_nxt, s_cur);
+      dma_wait_barrier();
+    }
   }
   for (; t < nt; ++t) {  // last tiles: clamped source rows, tail mask, no look-ahead on the final one
     if (t + 1 < nt) {
@@ -380,9 +415,9 @@ __device__ __forceinline__ void kv_loop_pipelined(const AttnParams& p, const u16
     } else {
       bf16x8_t pf[2];
       softmax_block(s_cur[0], pf);
-      pv_block(t & 1, 0, pf);
+      pv_block(t % RING, 0, pf);
       softmax_block(s_cur[1], pf);
-      pv_block(t & 1, 1, pf);
+      pv_block(t % RING, 1, pf);
       __syncthreads();
     }
   }
@@ -390,7 +425,8 @@ __device__ __forceinline__ void kv_loop_pipelined(const AttnParams& p, const u16
 
 template <bool FOLD, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnParams p) {  // two waves per SIMD: 8-wave workgroup alone, or two 4-wave workgroups
-  __shared__ __attribute__((aligned(16))) u16 smem[2 * KV * LDS_LD + 2 * KV * LDS_LDV];  // >= 4 * TILE, >= NW * 32 * LDS_LDO
+  constexpr int SMEM_EXACT = 2 * KV * LDS_LD + 2 * KV * LDS_LDV, SMEM_RINGS = 2 * RING * TILE;  // u16 elements
+  __shared__ __attribute__((aligned(16))) u16 smem[SMEM_EXACT > SMEM_RINGS ? SMEM_EXACT : SMEM_RINGS];  // >= NW * 32 * LDS_LDO
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
@@ -424,7 +460,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnParams p) {  // tw
     for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
   float l_tot = -1.f;
   if (!p.exact_only) {
-    kv_loop_pipelined<FOLD, NW>(p, Kb, Vb, smem, smem + 2 * TILE, qf, o, m_run, l_run, lane, wave, l31, lh);
+    kv_loop_pipelined<FOLD, NW>(p, Kb, Vb, smem, smem + RING * TILE, qf, o, m_run, l_run, lane, wave, l31, lh);
     l_tot = l_run + __shfl_xor(l_run, 32);
   }
   // out of range (a later tile outgrew the first tile's max by more than 2^60) or NaN: redo with the exact loop
