@@ -88,10 +88,10 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(GNParams p) {
 
 // pass 2: y = (x - mean) * rstd * gamma + beta, optional SiLU; writes the concatenated tensor
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GNParams p) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];  // scale[C], shift[C], mean[g], rstd[g]
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // reduction scratch, then mean[g], rstd[g]
   const int C = p.C1 + p.C2, CV = C / 8, CV1 = p.C1 / 8;
   float* sc = sm;  // reduction scratch
-  float* mean = sm + (2 * C > 2 * GN_THREADS ? 2 * C : 2 * GN_THREADS);  // sc/sh double as reduction scratch
+  float* mean = sm + (2 * C > 2 * GN_THREADS ? 2 * C : 2 * GN_THREADS);  // first part: reduction scratch
   float* rstd = mean + p.groups;
   const int b = blockIdx.x / p.nchunk, chunk = blockIdx.x % p.nchunk;
   const int per = (p.HW + p.nchunk - 1) / p.nchunk;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GNParams p) {
         s += w[0];
         q += w[1];
       }
-      sc[(sl * p.groups + g) * 2 + 0] = s;  // sc/sh are free until the next phase; 2*slices*groups <= 2*GN_THREADS floats
+      sc[(sl * p.groups + g) * 2 + 0] = s;  // 2*slices*groups <= 2*GN_THREADS floats
       sc[(sl * p.groups + g) * 2 + 1] = q;
     }
     __syncthreads();
