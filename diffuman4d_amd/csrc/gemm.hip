@@ -33,6 +33,7 @@
 
 // Epilogue read-back loop with shift / 32-bit-offset index arithmetic (see gemm_epilogue); 0 = the generic loop only.
 // Same floating-point operations in the same order, so results are bit-identical either way (tools/dev/fe_check.py).
+// 2 (NOT yet run on a GPU): additionally a compile-time staging row stride.
 #ifndef GEMM_FAST_EPI
 #define GEMM_FAST_EPI 1
 #endif
@@ -93,7 +94,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
   const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
   const int NJ = geglu ? NI / 2 : NI;
   const int TNO = NJ * 32;  // output columns per wave
+#if GEMM_FAST_EPI >= 2
+  constexpr int SLD = TN + 4;  // fp32 staging row stride, compile-time: staging stores get immediate offsets (ds_write2_b32)
+#else
   const int SLD = TNO + 4;  // fp32 staging row stride
+#endif
   float* stage = smem_f + wave * 32 * (TN + 4);
   const bool do_silu = (p.flags & DM4D_EPI_SILU) != 0;
   const int ncol0 = n0 + wn * TNO;
