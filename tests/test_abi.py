@@ -55,3 +55,25 @@ def test_ops_refuse_cpu_tensors():
         ops.gemm(a, a)
     with pytest.raises(L.Dm4dError, match="HIP device"):
         ops.layernorm(a, a[0], a[0])
+
+
+def test_conv_split_decision_depends_on_the_image_not_on_the_batch():
+    """dm4d_conv3x3_ws_bytes (host-only query): the split over the kernel rows applies to small images with a deep K
+    (the 9x5 level) and to stride-1 'same' convolutions only, and whether it applies never depends on B -- a
+    frame-sharded rank convolves fewer images per launch and must sum in the same order as the unsharded run."""
+    from diffuman4d_amd.host import lib as L
+    lib = L.load()
+
+    def ws(B, H, W, Cin, Cout, stride=1, pad=1, up=0, Ho=None, Wo=None):
+        Ho, Wo = (H if Ho is None else Ho), (W if Wo is None else Wo)
+        return lib.dm4d_conv3x3_ws_bytes(B, H, W, Cin, Ho, Wo, Cout, stride, pad, up)
+
+    for B in (1, 2, 3, 32, 48):
+        assert ws(B, 9, 5, 1280, 1280) == 3 * B * 45 * 1280 * 4      # three fp32 partial planes
+        assert ws(B, 9, 5, 2560, 1280) == 3 * B * 45 * 1280 * 4
+        assert ws(B, 8, 8, 512, 128) == 3 * B * 64 * 128 * 4
+        assert ws(B, 18, 10, 1280, 1280) == 0                        # 180 pixels: enough rows, never split
+        assert ws(B, 9, 5, 256, 1280) == 0                           # shallow K
+        assert ws(B, 9, 5, 1280, 1280, stride=2, Ho=5, Wo=3) == 0    # stride 2 is not a strip convolution
+        assert ws(B, 9, 5, 1280, 1280, up=1, Ho=18, Wo=10) == 0      # neither is the fused up-sampling
+        assert ws(B, 9, 5, 1280, 1284) == 0                          # N not a multiple of 8: no vector epilogue
