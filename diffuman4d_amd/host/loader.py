@@ -23,18 +23,22 @@ def load_pipelines(repo_id: str = "krahets/Diffuman4D", model_dir: str = "./mode
     if gpu_ids is None:
         gpu_ids = list(range(torch.cuda.device_count()))
         log.info("Found %d HIP devices.", len(gpu_ids))
+    # same two spellings and the same error as sampling_utils.py:28-35; both run bf16 MFMA arithmetic here, "fp16" only
+    # selects the *.fp16.safetensors files (Diffuman4DPipeline.from_pretrained)
     if torch_dtype == "fp16":
-        raise ValueError("Unsupported torch_dtype: fp16 on the MI355X path (bf16 MFMA, fp32 accumulate). Use 'bf16'.")
-    if torch_dtype != "bf16":
+        allow_patterns, dtype = ["*.json", "*model.fp16.safetensors"], torch.float16
+    elif torch_dtype == "bf16":
+        allow_patterns, dtype = ["*.json", "*model.safetensors"], torch.bfloat16
+    else:
         raise ValueError(f"Unsupported torch_dtype: {torch_dtype}. Supported types are 'bf16' and 'fp16'.")
     if not os.path.isdir(model_dir) or not os.listdir(model_dir):
         try:
             from huggingface_hub import snapshot_download
-            snapshot_download(repo_id, local_dir=model_dir, allow_patterns=["*.json", "*model.safetensors"])
+            snapshot_download(repo_id, local_dir=model_dir, allow_patterns=allow_patterns)
         except Exception as e:  # no network on the GPU boxes
             log.error("Failed to download model from %s to %s: %s. Skipping download.", repo_id, model_dir, e)
     pipelines = []
     for gpu_id in gpu_ids:
-        pipelines.append(Diffuman4DPipeline.from_pretrained(model_dir, torch_dtype=torch.bfloat16, device=f"cuda:{gpu_id}"))
-        log.info("Loaded pipeline from %s (bf16) to cuda:%d", model_dir, gpu_id)
+        pipelines.append(Diffuman4DPipeline.from_pretrained(model_dir, torch_dtype=dtype, device=f"cuda:{gpu_id}"))
+        log.info("Loaded pipeline from %s (%s files, bf16 arithmetic) to cuda:%d", model_dir, torch_dtype, gpu_id)
     return pipelines

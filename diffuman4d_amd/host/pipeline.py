@@ -63,21 +63,43 @@ class Diffuman4DPipeline:
     # ------------------------------------------------------------------------------------------
     @classmethod
     def from_pretrained(cls, model_dir, torch_dtype=BF16, device="cuda") -> "Diffuman4DPipeline":
-        """diffusers checkpoint directory (sampling_utils.py:28-46): model_index.json, unet/, vae/, scheduler/."""
+        """diffusers checkpoint directory (sampling_utils.py:28-46): model_index.json, unet/, vae/, scheduler/.
+        ``torch_dtype`` bf16 | fp16 selects the checkpoint FILES the way the reference does (``*model.safetensors`` vs
+        ``*model.fp16.safetensors``, :28-33).  The arithmetic is bf16 MFMA with fp32 accumulation in both cases: gfx950's
+        matrix pipe runs both 16-bit formats at the same rate and the kernels are written for bf16, so fp16 weights are
+        converted once at load (their 10-bit mantissas are rounded to 7; no SD-class weight leaves bf16's range)."""
         from .vae import AutoencoderKL
-        if torch_dtype not in (BF16, "bf16"):
-            raise ValueError("the MI355X path computes in bf16 (MFMA bf16, fp32 accumulate)")
+        if torch_dtype in (BF16, "bf16"):
+            variant = None
+        elif torch_dtype in (torch.float16, "fp16"):
+            variant = "fp16"
+        else:
+            raise ValueError(f"Unsupported torch_dtype: {torch_dtype}. Supported types are 'bf16' and 'fp16'.")
         model_dir = Path(model_dir)
         if (model_dir / "model_index.json").exists():
             json.loads((model_dir / "model_index.json").read_text())  # class names only; import paths are ignored
-        unet = UNetMultiviewConditionModel.from_pretrained(model_dir / "unet", device)
-        vae = AutoencoderKL.from_pretrained(model_dir / "vae", device)
+        unet = UNetMultiviewConditionModel.from_pretrained(model_dir / "unet", device, variant)
+        vae = AutoencoderKL.from_pretrained(model_dir / "vae", device, variant)
         sched = DDIMScheduler.from_pretrained(model_dir / "scheduler")
-        return cls(vae, unet, sched, device)
+        pipe = cls(vae, unet, sched, device)
+        pipe.checkpoint_variant = variant
+        pipe._source = (str(model_dir), torch_dtype)
+        return pipe
 
-    def to(self, device):  # protocol compatibility (sampling_utils.py:47); weights are placed at load time
-        if torch.device(device) != self._device:
-            raise NotImplementedError("re-create the pipeline on the target device (one pipeline per GPU)")
+    def to(self, device):
+        """Protocol compatibility (sampling_utils.py:46-47: ``from_pretrained(dir)`` then ``.to("cuda:i")``).  Weights are
+        laid out for the kernels at load time, so moving = loading the checkpoint again on the target device."""
+        dev = torch.device(device)
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        if dev == self._device:
+            return self
+        src = getattr(self, "_source", None)
+        if src is None:
+            raise NotImplementedError("this pipeline was assembled from in-memory components; build it on the target device")
+        moved = type(self).from_pretrained(src[0], torch_dtype=src[1], device=dev)
+        moved.prune_cond_rows = self.prune_cond_rows
+        self.__dict__.update(moved.__dict__)
         return self
 
     def set_progress_bar_config(self, **kw):

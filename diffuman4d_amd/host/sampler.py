@@ -99,17 +99,17 @@ class SlidingIterativeSampler:
         raise AttributeError(name)
 
     def _validate(self):
+        """Same conditions and messages as sliding_iterative_sampler.py:71-88."""
         n_tgt, n_tem, sw = len(self.target_spa_labels), len(self.tem_labels), self.sweep
-        problems = (
-            (sw.window_size > n_tgt, f"window_size = {sw.window_size} exceeds the {n_tgt} target cameras (target_spa_labels)"),
-            (n_tgt % sw.sliding_stride != 0, f"sliding_stride = {sw.sliding_stride} does not divide the {n_tgt} target cameras"),
-            (n_tem % sw.sliding_stride != 0, f"sliding_stride = {sw.sliding_stride} does not divide the {n_tem} frames (tem_labels)"),
-            (sw.alternation_rounds > 1 and sw.window_size > n_tem,
-             f"window_size = {sw.window_size} exceeds the {n_tem} frames, which temporal rounds (alternation_rounds > 1) need"),
-        )
-        for bad, message in problems:
-            if bad:
-                raise ValueError(message)
+        if sw.window_size > n_tgt:
+            raise ValueError(f"window_size(={sw.window_size}) must be <= len(target_spa_labels)(={n_tgt})")
+        if n_tgt % sw.sliding_stride != 0:
+            raise ValueError(f"len(target_spa_labels)(={n_tgt}) % sliding_stride(={sw.sliding_stride}) must be 0")
+        if n_tem % sw.sliding_stride != 0:
+            raise ValueError(f"len(tem_labels)(={n_tem}) % sliding_stride(={sw.sliding_stride}) must be 0")
+        if sw.alternation_rounds > 1 and sw.window_size > n_tem:
+            raise ValueError(f"window_size(={sw.window_size}) must be <= the number of tem_labels(={n_tem}) "
+                             "when alternation_rounds > 1")
 
     # ------------------------------------------------------------------------------------------
     def prepare_tasks(self):
@@ -164,23 +164,38 @@ class SlidingIterativeSampler:
         else:
             dev = next(lat.device for lat in cell_latents if lat is not None)
             sample["latents"] = torch.stack([lat.to(dev) for lat in cell_latents])
+            if dev.type == "cuda":
+                # this may run on a loader thread (runner.run_round_pipelined): the gather above is queued on THIS thread's
+                # current stream, the consumer is the denoise worker's own stream -> hand an event over with the sample
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                sample["_latents_ready"] = ev
         sample["timestep_indices"] = cell_indices
         return sample
 
     @torch.no_grad()
     def denoise(self, sample: dict, pipe_idx: int = 0) -> dict:
         pipe = self.pipelines[pipe_idx]
+        on_gpu = torch.cuda.is_available() and getattr(pipe.device, "type", "cpu") == "cuda"
+        ready = sample.pop("_latents_ready", None)
+        if on_gpu and ready is not None:  # the grid cells were gathered on another stream (load_sample)
+            cur = torch.cuda.current_stream(pipe.device)
+            cur.wait_event(ready)
+            sample["latents"].record_stream(cur)  # allocated in the loader stream's pool, consumed here
         axis = "spa" if sample["domain"] == "temporal" else "tem"  # the label names the FIXED axis of the task
         bar = partial(_tqdm, desc=f"Denoising alt{sample['alt']}_{axis}{sample['domain_label']} on {pipe.device}")
         tensors = {k: sample[k] for k in ("pixel_values", "plucker_embeds", "skeletons", "cond_masks", "latents",
                                           "timestep_indices")}
         result = pipe.sliding_iterative_denoise(domain=sample["domain"], tqdm=bar, **tensors, **asdict(self.sweep),
                                                 **self._pipeline_extensions(sample))
-        sample["images"] = result["images"].float().cpu()  # blocks until this task's stream has finished
+        sample["images"] = result["images"].float().cpu()
         sample["timestep_indices"] = result["timestep_indices"].cpu()
         sample["fully_denoised"] = result["fully_denoised"].cpu()
-        # hand the cells over only now: with several task streams per GPU (runner gpu_streams) another task's thread may
-        # read the grid as soon as the cells are in it, and device tensors must be complete by then
+        # hand the cells over only when they are complete: with several task streams per GPU (runner gpu_streams) another
+        # task's thread, another stream or the round-boundary exchange may read the grid as soon as the cells are in it.
+        # The copies above are not a reliable barrier (host-resident results do not synchronise), so drain explicitly.
+        if on_gpu:
+            torch.cuda.current_stream(pipe.device).synchronize()
         self._scatter_cells(sample["labels"], result["latents"], result["timestep_indices"])
         return sample
 

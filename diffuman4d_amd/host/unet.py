@@ -288,15 +288,13 @@ class UNetMultiviewConditionModel:
 
     # -- loading --------------------------------------------------------------------------------
     @classmethod
-    def from_pretrained(cls, path, device="cuda") -> "UNetMultiviewConditionModel":
-        """``path`` = the ``unet/`` folder of a diffusers checkpoint directory."""
-        from safetensors.torch import load_file
+    def from_pretrained(cls, path, device="cuda", variant: Optional[str] = None) -> "UNetMultiviewConditionModel":
+        """``path`` = the ``unet/`` folder of a diffusers checkpoint directory; ``variant="fp16"`` reads the
+        ``*.fp16.safetensors`` file (weights are converted to bf16 either way)."""
+        from .weights import load_component_state_dict
         path = Path(path)
         cfg = UNetConfig.from_dict(json.loads((path / "config.json").read_text()))
-        files = sorted(path.glob("diffusion_pytorch_model*.safetensors"))
-        if not files:
-            raise FileNotFoundError(f"no diffusion_pytorch_model*.safetensors under {path}")
-        return cls(cfg, load_file(str(files[0])), device)
+        return cls(cfg, load_component_state_dict(path, variant), device)
 
     # -- forward --------------------------------------------------------------------------------
     def _temb(self, timestep: torch.Tensor, domains: Sequence[str], num_frames: int, shard=None) -> torch.Tensor:

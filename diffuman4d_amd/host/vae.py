@@ -151,14 +151,11 @@ class AutoencoderKL:
             raise KeyError(f"unexpected keys in VAE checkpoint (strict load): {unused[:8]}")
 
     @classmethod
-    def from_pretrained(cls, path, device="cuda") -> "AutoencoderKL":
-        from safetensors.torch import load_file
+    def from_pretrained(cls, path, device="cuda", variant: Optional[str] = None) -> "AutoencoderKL":
+        from .weights import load_component_state_dict
         path = Path(path)
         cfg = VAEConfig.from_dict(json.loads((path / "config.json").read_text()))
-        files = sorted(path.glob("diffusion_pytorch_model*.safetensors"))
-        if not files:
-            raise FileNotFoundError(f"no diffusion_pytorch_model*.safetensors under {path}")
-        return cls(cfg, load_file(str(files[0])), device)
+        return cls(cfg, load_component_state_dict(path, variant), device)
 
     @property
     def scale_factor(self) -> int:

@@ -179,6 +179,35 @@ def random_state_dict(shapes: Shapes, seed: int = 0, device="cpu", dtype=torch.b
     return out
 
 
+def load_component_state_dict(path, variant: str = None) -> Dict[str, torch.Tensor]:
+    """state_dict of one diffusers component folder (``unet/`` or ``vae/``), by the file names diffusers itself uses.
+
+    ``variant=None`` (bf16 runs): ``diffusion_pytorch_model.safetensors`` -- never a ``*.fp16.*`` file that an fp16 run
+    of the reference downloaded into the same directory (sampling_utils.py:28-33 keeps both patterns in one folder).
+    ``variant="fp16"``: ``diffusion_pytorch_model.fp16.safetensors``, falling back to the un-suffixed file (what
+    ``from_pretrained(torch_dtype=float16)`` loads when no variant file exists).  A sharded checkpoint
+    (``<name>.safetensors.index.json`` with a ``weight_map``) is merged from all of its shards."""
+    import json
+    from pathlib import Path
+
+    from safetensors.torch import load_file
+    path = Path(path)
+    stems = ["diffusion_pytorch_model"]
+    if variant:
+        stems.insert(0, f"diffusion_pytorch_model.{variant}")
+    for stem in stems:
+        single, index = path / f"{stem}.safetensors", path / f"{stem}.safetensors.index.json"
+        if single.is_file():
+            return load_file(str(single))
+        if index.is_file():
+            shards = sorted(set(json.loads(index.read_text())["weight_map"].values()))
+            sd: Dict[str, torch.Tensor] = {}
+            for shard in shards:
+                sd.update(load_file(str(path / shard)))
+            return sd
+    raise FileNotFoundError(f"no {' / '.join(s_ + '.safetensors' for s_ in stems)} (or sharded index) under {path}")
+
+
 def write_synthetic_checkpoint(model_dir, unet_cfg: UNetConfig = None, vae_cfg: VAEConfig = None, seed: int = 0,
                                prediction_type: str = "epsilon", device="cpu") -> str:
     """Write a diffusers-layout checkpoint directory with seeded random weights (the layout `load_pipelines` /

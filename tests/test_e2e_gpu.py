@@ -117,3 +117,33 @@ def test_tasks_on_concurrent_streams_equal_serial(tmp_path):
         assert not errs, errs
         for a, b in zip(serial, out):
             assert torch.equal(a["latents"].cpu(), b["latents"]) and torch.equal(a["images"].cpu(), b["images"])
+
+
+def test_fp16_checkpoint_files_through_the_factory(tmp_path):
+    """`torch_dtype: fp16` (sampling_utils.py:28-30) selects the *.fp16.safetensors files; arithmetic stays bf16 MFMA.
+    The fp16 files here hold the bf16 weights re-encoded in fp16, so both loads must agree to fp16-subnormal noise; the
+    plain files are then removed to prove which ones were read; `.to()` of a loaded pipeline reloads on the target."""
+    import os
+    from safetensors.torch import load_file, save_file
+    from diffuman4d_amd.host.loader import load_pipelines
+    from diffuman4d_amd.host.weights import write_synthetic_checkpoint
+    from modelcheck import rel_l2, synthetic_task
+    ucfg, vcfg = _tiny_cfgs()
+    ckpt = write_synthetic_checkpoint(tmp_path / "ckpt", ucfg, vcfg, seed=5)
+    ref_pipe = load_pipelines(model_dir=ckpt, torch_dtype="bf16", gpu_ids=[0])[0]
+    for sub in ("unet", "vae"):
+        sd = load_file(f"{ckpt}/{sub}/diffusion_pytorch_model.safetensors")
+        save_file({k: v.to(torch.float16) for k, v in sd.items()}, f"{ckpt}/{sub}/diffusion_pytorch_model.fp16.safetensors")
+        os.remove(f"{ckpt}/{sub}/diffusion_pytorch_model.safetensors")
+    pipe = load_pipelines(model_dir=ckpt, torch_dtype="fp16", gpu_ids=[0])[0]
+    assert pipe.checkpoint_variant == "fp16" and pipe.to("cuda:0") is pipe
+    n = 8
+    pv, pl, sk, cm = synthetic_task(n, 64, 64, [1, 5], 9)
+    g = torch.Generator().manual_seed(10)
+    noise = {k: torch.randn(n, 4, 8, 8, generator=g).to(torch.bfloat16) for k in ("pixel", "skeleton", "latents")}
+    kw = dict(pixel_values=pv, plucker_embeds=pl, skeletons=sk, cond_masks=cm, latents=None, domain="spatial",
+              timestep_indices=torch.zeros(n, dtype=torch.int64), window_size=4, sliding_stride=2, sliding_shift=0,
+              bidirectional=False, num_denoising_steps=1, alternation_rounds=1, guidance_scale=2.0, noise=noise)
+    a, b = pipe.sliding_iterative_denoise(**kw), ref_pipe.sliding_iterative_denoise(**kw)
+    assert torch.equal(a["timestep_indices"], b["timestep_indices"])
+    assert rel_l2(a["latents"], b["latents"]) <= 1e-2 and rel_l2(a["images"], b["images"]) <= 1e-2

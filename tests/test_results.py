@@ -1,0 +1,115 @@
+"""Result writer vs the reference's on-disk contract (sampling_utils.py:54-129, image_utils.py:62-93). CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from diffuman4d_amd.host import results
+
+
+def _ref_restore(image: Image.Image, crop_param, background_color="white"):
+    """Literal restatement of image_utils.restore_cropped_image (:62-93): resize back to (ch, cw), drop onto a
+    2h x 2w canvas at (h/2 + ct, w/2 + cl), cut the middle h x w out."""
+    if len(crop_param) == 4:
+        ct, cl, ch, cw = crop_param
+        w, h = image.size
+    else:
+        ct, cl, ch, cw, h, w = crop_param
+    img = np.asarray(image.resize((cw, ch), Image.BICUBIC)).astype(np.float32) / 255.0
+    canvas = np.ones((h * 2, w * 2, 3), np.float32) if background_color == "white" else np.zeros((h * 2, w * 2, 3), np.float32)
+    top, left = h // 2 + ct, w // 2 + cl
+    canvas[top:top + ch, left:left + cw] = img
+    out = canvas[h // 2: h * 3 // 2, w // 2: w * 3 // 2]
+    return Image.fromarray((out * 255.0).astype(np.uint8))
+
+
+def _rand_image(w, h, seed=0):
+    rng = np.random.default_rng(seed)
+    return Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8))
+
+
+@pytest.mark.parametrize("crop", [
+    (5, 4, 30, 20),                   # 4-tuple: canvas = the image's own size
+    (10, 20, 40, 30, 96, 80),         # 6-tuple: explicit original (h, w)
+    (-7, -5, 60, 50, 64, 48),         # negative top / left: the crop window started outside the frame
+    (30, 25, 60, 40, 64, 48),         # crop runs past the bottom / right edge
+    (0, 0, 64, 48, 64, 48),           # identity geometry
+])
+def test_restore_cropped_image_matches_reference(crop):
+    img = _rand_image(32, 40, seed=sum(abs(c) for c in crop))
+    got = results.restore_cropped_image(img, crop)
+    ref = _ref_restore(img, crop)
+    assert got.size == ref.size
+    assert np.array_equal(np.asarray(got), np.asarray(ref))
+
+
+def test_restore_cropped_image_rejects_other_lengths_and_passes_none():
+    img = _rand_image(8, 8)
+    assert results.restore_cropped_image(img, None) is img
+    with pytest.raises(ValueError, match="Invalid crop_param"):
+        results.restore_cropped_image(img, (1, 2, 3))
+
+
+def _sample(n=4, H=24, W=16, crops=None, skeletons=True):
+    g = torch.Generator().manual_seed(3)
+    return {
+        "images": torch.rand(n, 3, H, W, generator=g),
+        "pixel_values": torch.rand(n, 3, H, W, generator=g) * 2 - 1,
+        "skeletons": (torch.rand(n, 3, H, W, generator=g) * 2 - 1) if skeletons else None,
+        "input_indices": torch.tensor([0]), "target_indices": torch.tensor([1, 2, 3]),
+        "fully_denoised": torch.tensor([False, True, False, True]),
+        "labels": [("scene", f"{c:02d}", "000007") for c in range(n)],
+        "crops": crops, "alt": 2, "domain": "spatial", "domain_label": "000007",
+    }
+
+
+def test_save_sampling_results_layout(tmp_path):
+    crops = [(2, 3, 30, 20, 40, 32)] * 4  # the tuples SpaTemDataset hands out (spatem_dataset.py:58,157)
+    s = _sample(crops=crops)
+    before = s["images"].clone()
+    results.save_sampling_results(s, output_dir=str(tmp_path), save_crop_param=True)
+    assert torch.equal(s["images"], before)  # the caller's tensor is left alone
+    # input view 00 and the two fully denoised targets are written; the still-noisy target 02 is not
+    names = sorted(os.path.relpath(p, tmp_path) for p in (tmp_path / "images").rglob("*.jpg"))
+    assert names == ["images/00/000007.jpg", "images/01/000007.jpg", "images/03/000007.jpg"]
+    assert Image.open(tmp_path / "images/01/000007.jpg").size == (32, 40)  # crop undone onto the (w, h) canvas
+    # spatial task -> the fixed axis is the frame: grids/alt2_tem000007.webp; 4 rows (skeletons, inputs, outputs, errors)
+    grid = Image.open(tmp_path / "grids/alt2_tem000007.webp")
+    # the reference sizes by max(H, W) = 24 but torchvision's resize(int) sets the SMALLER edge: 24x16 becomes 36x24
+    assert grid.size == (4 * (24 + 2) + 2, 4 * (36 + 2) + 2)
+    assert json.load(open(tmp_path / "crops/01/000007.json")) == [2, 3, 30, 20, 40, 32]
+    assert not (tmp_path / "crops/02/000007.json").exists()  # the reference's `continue` skips an unsaved view's crop too
+    assert not results.check_sampling_results(["00", "01", "02", "03"], ["000007"], str(tmp_path))
+    s["fully_denoised"] = torch.tensor([False, True, True, True])
+    results.save_sampling_results(s, output_dir=str(tmp_path), save_image_grid=False)
+    assert results.check_sampling_results(["00", "01", "02", "03"], ["000007"], str(tmp_path))
+
+
+def test_grid_without_skeletons_and_downscale(tmp_path):
+    s = _sample(skeletons=False, crops=None)
+    s["domain"], s["domain_label"] = "temporal", "05"
+    results.save_sampling_results(s, output_dir=str(tmp_path), max_image_size=32)  # 32 // 4 frames = 8-pixel smaller edge
+    grid = Image.open(tmp_path / "grids/alt2_spa05.webp")
+    assert grid.size == (4 * (8 + 2) + 2, 3 * (12 + 2) + 2)
+
+
+def test_make_image_grid_matches_torchvision_layout():
+    imgs = torch.arange(5 * 1 * 2 * 3, dtype=torch.float32).view(5, 1, 2, 3)
+    g = results.make_image_grid(imgs, nrow=3, padding=1, pad_value=-1.0)
+    assert g.shape == (1, 2 * 3 + 1, 3 * 4 + 1)
+    assert torch.equal(g[0, 1:3, 1:4], imgs[0, 0]) and torch.equal(g[0, 4:6, 5:8], imgs[4, 0])
+    assert float(g[0, 0, 0]) == -1.0 and float(g[0, 4, 9]) == -1.0  # padding and the empty sixth slot
+
+
+def test_nerfstudio_transforms(tmp_path):
+    src, dst = tmp_path / "data", tmp_path / "out"
+    src.mkdir()
+    frames = [{"file_path": f"images/{c}/000000.jpg", "camera_label": c} for c in ("00", "01", "13")]
+    json.dump({"fl_x": 1.0, "frames": frames}, open(src / "transforms.json", "w"))
+    results.write_nerfstudio_transforms(str(src), str(dst), input_cameras=["01", "13"])
+    full = json.load(open(dst / "transforms.json"))
+    assert [f["file_path"] for f in full["frames"]] == [f"images_alpha/{c}/000000.png" for c in ("00", "01", "13")]
+    assert [f["camera_label"] for f in json.load(open(dst / "transforms_input.json"))["frames"]] == ["01", "13"]

@@ -1,5 +1,7 @@
 """CPU: sampler task lists, label formatting, validation errors and grid hand-over between rounds
 (sliding_iterative_sampler.py:16-100,192-199) with a stub pipeline, plus the config composer."""
+import re
+
 import pytest
 import torch
 
@@ -33,16 +35,21 @@ def test_task_counts_demo_4d_and_3d():
 
 
 def test_validation_errors():
-    with pytest.raises(ValueError, match="window_size"):
+    """Conditions AND texts of sliding_iterative_sampler.py:55,63,71-88."""
+    with pytest.raises(ValueError, match=re.escape("window_size(=45) must be <= len(target_spa_labels)(=44)")):
         make(window_size=45)
-    with pytest.raises(ValueError, match="sliding_stride"):
+    with pytest.raises(ValueError, match=re.escape("len(target_spa_labels)(=44) % sliding_stride(=5) must be 0")):
         make(sliding_stride=5)
-    with pytest.raises(ValueError, match="tem_labels"):
-        make(tem_label_range=[0, 15, 1])  # README's "15 frames" is rejected with stride 2
-    with pytest.raises(ValueError, match="alternation_rounds > 1"):
+    # README's "15 frames" is rejected with stride 2 (SURVEY D5)
+    with pytest.raises(ValueError, match=re.escape("len(tem_labels)(=15) % sliding_stride(=2) must be 0")):
+        make(tem_label_range=[0, 15, 1])
+    with pytest.raises(ValueError, match=re.escape("window_size(=12) must be <= the number of tem_labels(=8) when "
+                                                   "alternation_rounds > 1")):
         make(tem_label_range=[0, 8, 1], sliding_stride=1)
-    with pytest.raises(ValueError, match="must be provided"):
+    with pytest.raises(ValueError, match="spa_labels or spa_label_range must be provided"):
         make(spa_label_range=None)
+    with pytest.raises(ValueError, match="tem_labels or tem_label_range must be provided"):
+        make(tem_label_range=None)
 
 
 def test_three_rounds_visit_every_latent_18_times_and_hand_the_grid_over():
