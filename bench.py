@@ -4,32 +4,39 @@
 Metric (BASELINE.json): denoised view-frame latents / second on the 44-target-camera x 150-frame grid
 (`demo_4d`, `sliding_fast`: window 12, stride 2, 3 alternation rounds => 18 denoising steps per
 latent, CFG 2.0), synthetic 72x40x4 latents, SD-2.1-geometry UNet with seeded random weights.
+Each window call = model-input pack -> UNet -> CFG + batched DDIM update on device-resident latents; VAE
+encode/decode is outside the timed region -- inputs are resident in HBM when timing starts.
 
-One "step" = one schedule unit of that run: 2 spatial window calls (F = 4 inputs + 12 targets = 16
-frames, CFG batch 32) + 1 temporal window call (F = 12 + 12 = 24 frames, CFG batch 48) -- exactly
-the 6600 : 3300 call mix of the full run.  The K timed steps are dealt to --task-streams (default 2)
-independent tasks that are in flight at the same time, one HIP stream and worker thread each, as the runner does with the
-tasks of a round (host/runner.py: gpu_streams).  Each call = model-input pack -> UNet ->
-CFG + batched DDIM update on device-resident latents.  One unit advances 36 latent-steps = 2 fully
-denoised latents; the full run is 3300 units.  VAE encode/decode is outside the timed region
- -- inputs are resident in HBM when timing starts.
+Modes (--mode; default `auto` = `task` at --gpus 1, `grid` at --gpus N > 1):
+  task   one "step" = one schedule unit of the run: 2 spatial window calls (F = 4 inputs + 12 targets = 16 frames,
+         CFG batch 32) + 1 temporal window call (F = 12 + 12 = 24 frames, CFG batch 48) -- exactly the 6600 : 3300 call
+         mix of the full run = 36 latent-steps = 2 fully denoised latents.  The K timed steps are dealt
+         to --task-streams (default 2) independent tasks in flight, one HIP stream and worker thread each, as the runner
+         does with the tasks of a round.  With N ranks every rank runs its own K units (weak scaling).
+  grid   the REAL round structure of the 48-camera x 150-frame job over N ranks (strong scaling): spatial round (150
+         tasks, one per frame), temporal round (44 tasks, one per target camera), spatial round, executed by the
+         product's DistributedSamplingRunner -- round-robin task partition, loader / GPU-stream pipelining per rank,
+         barrier + RCCL cell exchange at both round boundaries -- on a latents-only pipeline adapter.  Every task runs
+         the first c window calls of its sweep (spatial c_s = max(1, K // 10), temporal c_t = round(3.41 c_s): the
+         2 : 1 call mix), so wave quantisation (150 and 44 tasks over N GPUs), the exchange and host contention are
+         in the number; --steps K sets that depth and `value` counts the latent-steps actually executed / 18.
+  frame-shard  every window split over all ranks with RCCL K/V all-gathers (latency mode, BASELINE config 4).
 
-Multi-GPU (one process per GPU, torchrun): tasks of a round are independent, so ranks run their
-own units with no data-path collective (the only exchange of the real run, the grid transpose at
-the 2 round boundaries, moves < 0.2 GB and is not part of a unit): weak scaling.
-
-Prints ONE JSON line on rank 0: the contract fields (metric, value = whole-job denoised latents/s, ...), `roofline`
-(attention kernel: HIP-event timing in a one-task-at-a-time pass of the same steps, PMC traffic from profiles/), `cpu_baseline` (N = 1 only:
-the CPU oracle on one full spatial window), `secondary` (latent-steps/s, UNet calls/s, sustained TFLOP/s) and
-`kernel_breakdown_one_step` (per kernel family, from one extra untimed instrumented step).
-Options beyond the contract: --latent HxW, --mode frame-shard, --prune-cond-rows (opt-in extension).
+`python bench.py --gpus N` launches its own N ranks (torch.distributed.run on 127.0.0.1) when it is not already
+running under a launcher; rank 0 prints ONE JSON line: the contract fields, `roofline` (attention kernel: HIP-event
+timing in a one-task-at-a-time pass, PMC traffic from profiles/), `cpu_baseline` + `parity` (N = 1 only: the CPU
+oracle on one full spatial window with the SAME weights and input as the HIP UNet, timed and compared), `secondary`
+and `kernel_breakdown_one_step`.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 from pathlib import Path
 
@@ -46,6 +53,7 @@ WINDOW, STRIDE, ROUNDS, GUIDANCE = 12, 2, 3, 2.0
 STEPS_PER_LATENT = WINDOW // STRIDE * ROUNDS  # 18
 LATENTS_PER_UNIT = 3 * WINDOW / STEPS_PER_LATENT  # 2.0
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+UNIT_TFLOP = {(72, 40): (20.13, 33.06), (128, 128): (261.9, 485.8)}  # F=16 / F=24 UNet calls
 
 
 def parse():
@@ -54,27 +62,41 @@ def parse():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", choices=["task", "frame-shard"], default="task",
-                    help="multi-GPU decomposition: independent tasks per rank (default, weak scaling) or every window "
-                         "frame-sharded over all ranks with RCCL K/V all-gathers (strong scaling, BASELINE config 4)")
+    ap.add_argument("--mode", choices=["auto", "task", "grid", "frame-shard"], default="auto",
+                    help="auto: task at --gpus 1, grid at --gpus N > 1 (see the module docstring)")
     ap.add_argument("--latent", default="72x40",
                     help="latent grid HxW: 72x40 = BASELINE.json's synthetic grid (default, the judged line); 128x128 = the "
                          "1024^2 images the reference's demo configs run (SURVEY.md 8d asks for both)")
     ap.add_argument("--task-streams", type=int, default=2,
                     help="independent tasks in flight per GPU, each on its own HIP stream and worker thread (the runner's "
-                         "gpu_streams): the K timed steps are dealt round-robin to the streams. 1 = one task at a time")
+                         "gpu_streams). 1 = one task at a time")
+    ap.add_argument("--grid-frames", type=int, default=N_FRAMES, help="grid mode: frames of the (48 camera x T frame) grid")
     ap.add_argument("--prune-cond-rows", action="store_true",
                     help="opt-in extension, NOT the judged configuration: skip the per-frame tail of the UNet (after the last "
                          "3-D attention) for conditioning frames, whose noise prediction the reference discards")
     ap.add_argument("--cpu-frames", type=int, default=16,
-                    help="frames of the CPU-baseline UNet call (16 = a full spatial window); the default is the full window,"
-                         " about 20 s with 32 threads")
+                    help="frames of the CPU-baseline UNet call (16 = a full spatial window, about 20 s with 32 threads)")
     ap.add_argument("--cpu-threads", type=int, default=32,
                     help="torch threads of the CPU baseline: on the 256-thread GPU hosts 32 threads are 3x faster than 64 "
                          "and 50x faster than 256 on this model (tools/dev/cpu_baseline_probe.py)")
     return ap.parse_args()
 
 
+def self_launch(args) -> None:
+    """`python bench.py --gpus N` outside a launcher: start N ranks of this script on this node and relay rank 0's line."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# task mode: resident synthetic tasks, units of 2 spatial + 1 temporal window calls
+# ---------------------------------------------------------------------------------------------------------------------
 def build_tasks(pipe, dev, shard=None):
     """Device-resident synthetic task tensors + window plans for one spatial and one temporal task."""
     from diffuman4d_amd.host.schedule import plan_sweep
@@ -110,31 +132,156 @@ def run_unit(pipe, tasks, u, shard=None):
     run_call(pipe, tasks["temporal"], u, shard)
 
 
-def cpu_baseline(frames: int, threads: int):
-    """Time the CPU oracle (oracle/: plain PyTorch restatement of the reference) on one spatial window UNet call."""
+# ---------------------------------------------------------------------------------------------------------------------
+# grid mode: the product's sampler + distributed runner on a latents-only pipeline adapter
+# ---------------------------------------------------------------------------------------------------------------------
+class LatentGridPipeline:
+    """The pipeline protocol without the VAE, for `--mode grid`: the task's latents come from / go back to
+    the sampler's grid, the conditioning latents are resident synthetic tensors (what the VAE + resize stage would have
+    produced), and the first `depth[domain]` window calls of the task's sweep are executed; the sweep is booked as
+    complete so that the next round's plan is consistent (values of a truncated sweep mean nothing, cost does)."""
+
+    def __init__(self, pipe, depth):
+        self.pipe, self.depth = pipe, dict(depth)
+        self.calls_run = 0
+        self._cond = {}
+        self._lock = threading.Lock()
+
+    @property
+    def device(self):
+        return self.pipe.device
+
+    def clear_vae_cache(self):
+        pass
+
+    def _conditioning(self, domain, cond_flags):
+        key = (domain, len(cond_flags))
+        with self._lock:
+            if key not in self._cond:
+                dev, n, hw = self.pipe.device, len(cond_flags), LAT_H * LAT_W
+                g = torch.Generator(device=dev).manual_seed(77 + n)
+                rnd = lambda c, s: (torch.randn(n, hw, c, generator=g, device=dev) * s).to(torch.bfloat16)  # noqa: E731
+                mask = torch.tensor([0.0 if c else 1.0 for c in cond_flags], device=dev).to(torch.bfloat16)
+                self._cond[key] = (rnd(4, 0.18215 * 4), rnd(6, 0.5).clamp(-1, 1), rnd(4, 0.18215 * 4),
+                                   mask[:, None, None].expand(n, hw, 1).contiguous())
+            return self._cond[key]
+
+    @torch.no_grad()
+    def sliding_iterative_denoise(self, pixel_values=None, plucker_embeds=None, skeletons=None, cond_masks=None, latents=None,
+                                  domain="spatial", timestep_indices=None, window_size=12, sliding_stride=1, sliding_shift=0,
+                                  bidirectional=True, num_denoising_steps=1, alternation_rounds=3, guidance_scale=2.0,
+                                  tqdm=None, **_ext):
+        from diffuman4d_amd.host.schedule import plan_sweep
+        pipe, dev = self.pipe, self.pipe.device
+        on_gpu = torch.device(dev).type == "cuda"
+        if on_gpu:
+            from diffuman4d_amd.host import ops
+            torch.cuda.set_device(dev)
+            to_nhwc, to_nchw = ops.nchw_to_nhwc, ops.nhwc_to_nchw
+        else:  # CPU stand-in pipelines in tests/test_bench_grid.py (layout plumbing only; there is no CPU compute path)
+            to_nhwc, to_nchw = (lambda t: t.permute(0, 2, 3, 1).contiguous()), (lambda t: t.permute(0, 3, 1, 2).contiguous())
+        cond_flags = (cond_masks[:, 0, 0, 0] == 0.0).cpu().numpy()
+        plan = plan_sweep(cond_flags, torch.as_tensor(timestep_indices).cpu().numpy(), domain, window_size, sliding_stride,
+                          sliding_shift, bidirectional, num_denoising_steps, alternation_rounds)
+        n, hw = len(cond_flags), LAT_H * LAT_W
+        pv, pl, sk, cm = self._conditioning(domain, cond_flags)
+        if latents is None:
+            lat = torch.randn(n, hw, 4, device=dev).to(torch.bfloat16)
+        else:
+            lat = to_nhwc(latents.to(device=dev, dtype=torch.bfloat16).contiguous()).view(n, hw, 4)
+        tb = pipe.upload_plan(plan, guidance_scale)
+        k = min(self.depth[domain], tb["calls"])
+        for i in range(k):
+            pipe.window_call(lat, pv, pl, sk, cm, tb, i, LAT_H, LAT_W, [domain] * tb["cfg"], guidance_scale, tb["cfg"] == 2, False)
+        with self._lock:
+            self.calls_run += k
+        tidx = torch.from_numpy(plan.final_timestep_indices)
+        return {"images": torch.zeros(n, 3, 1, 1), "latents": to_nchw(lat.view(n, LAT_H, LAT_W, 4)),
+                "timestep_indices": tidx, "fully_denoised": tidx == plan.num_inference_steps}
+
+
+def grid_depth(steps: int):
+    """Window calls per task from --steps: spatial c_s = max(1, K // 10), temporal c_t = round(3.41 c_s) keeps the full
+    run's 6600 : 3300 call mix over 300 spatial and 44 temporal tasks (K = 20 -> 2 and 7; the full sweeps are 22 and 75)."""
+    cs = max(1, steps // 10)
+    return {"spatial": min(cs, 22), "temporal": min(max(1, round(2 * N_FRAMES * cs / (2 * 44))), 75)}
+
+
+def run_grid_pass(pipe, depth, frames, world, rank, gpu_streams):
+    """One pass over the whole (48 x frames) grid job: 3 alternation rounds through the product's runner.  Returns the
+    number of window calls THIS rank executed."""
+    from diffuman4d_amd.host.dataset import SyntheticSpaTemDataset
+    from diffuman4d_amd.host.runner import DistributedSamplingRunner, run_round_pipelined
+    from diffuman4d_amd.host.sampler import SlidingIterativeSampler
+    adapter = LatentGridPipeline(pipe, depth)
+    ds = SyntheticSpaTemDataset(height=8, width=8, num_cameras=N_CAMS)  # pixel data is never read by the adapter
+    sampler = SlidingIterativeSampler(ds, [adapter], "/tmp/dm4d_bench_unused", window_size=WINDOW, sliding_stride=STRIDE,
+                                      sliding_shift=0, bidirectional=False, num_denoising_steps=1, alternation_rounds=ROUNDS,
+                                      guidance_scale=GUIDANCE, spa_label_range=(0, N_CAMS, 1), tem_label_range=(0, frames, 1),
+                                      input_spa_labels=INPUT_CAMS)
+    sampler.result_writer = None
+    if world > 1:
+        DistributedSamplingRunner(sampler, prefetch_depth=2, writers=1, gpu_streams=gpu_streams).inference()
+    else:
+        for tasks in sampler.all_tasks:
+            run_round_pipelined(sampler, tasks, 0, 2, 1, gpu_streams)
+    done = all(sampler.timestep_indices[c][f] == STEPS_PER_LATENT
+               for t in sampler.partition(ROUNDS - 1, rank, world) for c in sampler.target_spa_labels for f in [t["domain_label"]])
+    if not done:
+        raise RuntimeError("grid pass: a target cell of this rank's last-round tasks did not reach the final timestep index")
+    return adapter.calls_run
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline + parity on the judged configuration
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline_and_parity(pipe, state_dict, task, frames: int, threads: int):
+    """The CPU oracle (oracle/: plain PyTorch restatement of the reference) on one spatial-window UNet call with the SAME
+    weights and the SAME packed input as the HIP UNet: timed (cpu_baseline) and compared (parity)."""
+    from diffuman4d_amd.host import ops
     from oracle.unet import UNetConfig, UNetMultiviewConditionModel
     torch.set_num_threads(max(1, min(threads, os.cpu_count() or 1)))
-    cfg = UNetConfig()
+    tb = task["tables"]
+    widx, cond = tb["win"][0][:frames], tb["cond"][0][:frames]
     with torch.no_grad():
-        m = UNetMultiviewConditionModel(cfg).eval()
-        for p in m.parameters():
-            p.mul_(0.5)  # default torch init, damped: values do not matter for timing
+        x = ops.pack_model_input(task["lat"].clone(), task["pv"], task["pl"], task["sk"], task["cm"], cond.contiguous(),
+                                 pipe.unet.IN_PAD, True, frame_idx=widx.contiguous())
+        t_in = torch.cat([tb["t"][0][:tb["win"].shape[1]][:frames]] * 2)
         B = 2 * frames
-        x = torch.randn(B, cfg.in_channels, LAT_H, LAT_W)
-        t = torch.randint(0, 1000, (B,))
+        out = pipe.unet(x.view(B, LAT_H, LAT_W, pipe.unet.IN_PAD), t_in, domains=["spatial"] * 2, num_frames=frames)
+        hip = ops.nhwc_to_nchw(out).float().cpu()
+        cfg = UNetConfig()
+        m = UNetMultiviewConditionModel(cfg).eval()
+        m.load_state_dict({k: v.float().cpu() for k, v in state_dict.items()}, strict=True)
+        x_cpu = ops.nhwc_to_nchw(x.view(B, LAT_H, LAT_W, pipe.unet.IN_PAD), cfg.in_channels).float().cpu()
         t0 = time.time()
-        m(x, t, domains=["spatial"] * 2, num_frames=frames)
+        ref = m(x_cpu, t_in.cpu().long(), domains=["spatial"] * 2, num_frames=frames)
         dt = time.time() - t0
-    # a window of F frames carries the same 4:12 input:target ratio as the real spatial window
-    targets = frames * (WINDOW / (WINDOW + len(INPUT_CAMS)))
-    return {
-        "value": round(targets / STEPS_PER_LATENT / dt, 5), "unit": "latents/s", "cores": torch.get_num_threads(),
-        "kind": "port",
+    err = float((hip - ref).norm() / ref.norm())
+    # a unit = 2 F=16 calls + 1 F=24 call; the F=24 call is priced by its FLOP ratio to the measured F=16 call
+    f16, f24 = UNIT_TFLOP.get((LAT_H, LAT_W), (1.0, 1.64))
+    unit_s = dt * (2 + f24 / f16) if frames >= 16 else None
+    base = {
+        "value": round(LATENTS_PER_UNIT / unit_s, 5) if unit_s else round(frames * (WINDOW / 16) / STEPS_PER_LATENT / dt, 5),
+        "unit": "latents/s", "cores": torch.get_num_threads(), "kind": "port",
         "sample": f"one spatial-window UNet forward of the CPU oracle (fp32, F={frames} of 16 frames, CFG batch {B}, "
-                  f"{LAT_H}x{LAT_W} latents) = {dt:.1f} s; {targets:.1f} latent-steps / {STEPS_PER_LATENT} steps per latent"
-                  + ("" if frames >= 16 else " (the 3-D attention share grows with F^2: the full F=16 window is slower per latent)"),
+                  f"{LAT_H}x{LAT_W} latents, the bench weights) = {dt:.1f} s measured; a unit (2 F=16 calls + 1 F=24 call = 2 latents) "
+                  f"priced as (2 + {f24 / f16:.3f}) x that call by FLOP ratio",
         "seconds": round(dt, 2),
     }
+    yard = None
+    gold = ROOT / "tests" / "golden" / "sd21_72x40.pt"
+    if gold.exists() and (LAT_H, LAT_W) == (72, 40):
+        yard = torch.load(gold).get("unet_f16_spatial", {}).get("yard_bf16")
+    parity = {
+        "case": f"UNet forward, SD-2.1 geometry, F={frames} spatial window, CFG batch {B}, {LAT_H}x{LAT_W}: HIP (bf16) vs CPU oracle (fp32), "
+                "same weights and input",
+        "rel_l2": round(err, 6), "north_star_tolerance": 1e-3, "meets_north_star": bool(err <= 1e-3),
+        "yardstick_oracle_bf16_vs_fp32": yard,
+        "note": "bf16 activations end to end: the reference's own bf16 arithmetic (the oracle run in bf16) is as far from the fp32 "
+                "oracle as this path is; 1e-3 needs fp32 activations (DESIGN.md section 3)",
+    }
+    return base, parity
 
 
 def main():
@@ -143,14 +290,16 @@ def main():
     LAT_H, LAT_W = (int(v) for v in args.latent.lower().split("x"))
     if LAT_H % 8 or LAT_W % 8:
         raise SystemExit("--latent: both sides must be multiples of 8 (three UNet down-samplings)")
+    if "RANK" not in os.environ and args.gpus > 1:
+        self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    mode = args.mode if args.mode != "auto" else ("task" if world == 1 else "grid")
     # DM4D_BENCH_SHARED_GPU=1 (testing only): all ranks share device 0 and rendezvous over gloo, so that the N > 1 code
     # paths can be exercised on a 1-GPU box; the numbers of such a run mean nothing
     shared = os.environ.get("DM4D_BENCH_SHARED_GPU") == "1"
@@ -158,6 +307,7 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         # RCCL prints a version banner on stdout when the communicator comes up; this program's stdout carries exactly
@@ -184,11 +334,15 @@ def main():
     from diffuman4d_amd.host.weights import random_state_dict, unet_param_shapes
 
     cfg = UNetConfig()
-    unet = UNetMultiviewConditionModel(cfg, random_state_dict(unet_param_shapes(cfg), 0, dev), dev)
+    state_dict = random_state_dict(unet_param_shapes(cfg), 0, dev)
+    unet = UNetMultiviewConditionModel(cfg, state_dict, dev)
+    want_cpu = (not args.no_cpu_baseline) and world == 1 and rank == 0
+    if not want_cpu:
+        state_dict = None
     pipe = Diffuman4DPipeline(None, unet, DDIMScheduler(), dev)
     pipe.prune_cond_rows = bool(args.prune_cond_rows)
     shard = None
-    if args.mode == "frame-shard" and world > 1:
+    if mode == "frame-shard" and world > 1:
         from diffuman4d_amd.host.parallel import FrameShard
         shard = FrameShard()
         if 16 % world or 24 % world:
@@ -197,7 +351,7 @@ def main():
     # here: S task states, S worker threads, one HIP stream each, one set of weights.  Collectives of the frame-shard
     # mode must be issued in one order on every rank, so that mode runs one task at a time.
     S = 1 if shard is not None else max(1, min(args.task_streams, max(1, args.steps)))
-    task_sets = [build_tasks(pipe, dev, shard) for _ in range(S)]
+    task_sets = [build_tasks(pipe, dev, shard) for _ in range(S if mode != "grid" else 1)]
     tasks = task_sets[0]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [None]
 
@@ -213,12 +367,11 @@ def main():
             with torch.no_grad(), torch.cuda.stream(streams[si]):
                 for j in range(si, count, S):
                     run_unit(pipe, task_sets[si], first + j // S, shard)
-        if S == 1:
+        if S == 1 or len(task_sets) == 1:
             with torch.no_grad():
                 for j in range(count):
                     run_unit(pipe, tasks, first + j, shard)
             return
-        import threading
         errs = []
 
         def guarded(si):
@@ -232,23 +385,50 @@ def main():
         if errs:
             raise errs[0]
 
-    run_units(0, max(args.warmup, 0) * S if args.warmup > 0 else 0)
-    barrier()
-    t0 = time.perf_counter()
-    run_units(args.warmup, args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
+    grid_info = None
+    if mode == "grid":
+        depth = grid_depth(args.steps)
+        run_units(0, 1)  # kernels / allocator warm
+        if args.warmup > 0:  # one shallow untimed pass: also brings up the RCCL point-to-point channels of the exchange
+            run_grid_pass(pipe, {"spatial": 1, "temporal": 1}, args.grid_frames, world, rank, S)
+        barrier()
+        t0 = time.perf_counter()
+        calls = run_grid_pass(pipe, depth, args.grid_frames, world, rank, S)
+        barrier()
+        dt = time.perf_counter() - t0
+        grid_info = {"calls_this_rank": calls, "depth": depth}
+        if world > 1:
+            ct = torch.tensor([float(calls)], device=dev, dtype=torch.float64)
+            gathered = [torch.zeros_like(ct) for _ in range(world)]
+            if shared:
+                gathered = [g.cpu() for g in gathered]
+                dist.all_gather(gathered, ct.cpu())
+            else:
+                dist.all_gather(gathered, ct)
+            per_rank = [int(g.item()) for g in gathered]
+        else:
+            per_rank = [calls]
+        grid_info["calls_per_rank"] = per_rank
+        total_calls = sum(per_rank)
+    else:
+        run_units(0, max(args.warmup, 0) * S if args.warmup > 0 else 0)
+        barrier()
+        t0 = time.perf_counter()
+        run_units(args.warmup, args.steps)
+        barrier()
+        dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    # roofline pass: the same K steps, one task at a time, an event pair around every attention launch on the launch
+    # roofline pass: K units, one task at a time, an event pair around every attention launch on the launch
     # stream.  With several task streams the launches of different tasks overlap on the device, so per-launch intervals
     # taken inside the timed region above would measure the mix, not the kernel.
+    k_roof = min(args.steps, 4) if mode == "grid" else args.steps
     with torch.no_grad():
         ops.KERNEL_TIMER = timer = []
         t1 = time.perf_counter()
-        for u in range(args.steps):
+        for u in range(k_roof):
             run_unit(pipe, tasks, args.warmup + args.steps + u, shard)
         torch.cuda.synchronize()
         dt_single = time.perf_counter() - t1
@@ -278,34 +458,52 @@ def main():
         dist.barrier()
     finite = bool(torch.isfinite(tasks["spatial"]["lat"].float()).all() and torch.isfinite(tasks["temporal"]["lat"].float()).all())
     # HBM traffic of the attention kernel from PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
-    # this same command, tools/… -> profiles/r01_attn_traffic_pmc.json): bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB,
-    # the factor 2 being the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md (HBM section).  Static file, not live.
-    traffic = None
-    tf = ROOT / "profiles" / "r01_attn_traffic_pmc.json"
-    if tf.exists() and (LAT_H, LAT_W) == (72, 40):
-        t = json.loads(tf.read_text())
-        traffic = int((2 * t["FETCH_SIZE"]["avg_kb"] + t["WRITE_SIZE"]["avg_kb"]) * 1024)
+    # this same command, tools/profile_bench.sh -> profiles/*attn_traffic_pmc.json): bytes per launch = (2*FETCH_SIZE +
+    # WRITE_SIZE) KiB, the factor 2 being the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md (HBM section).
+    traffic, traffic_file = None, None
+    for tf in sorted((ROOT / "profiles").glob("r*_attn_traffic_pmc.json"), reverse=True):
+        if (LAT_H, LAT_W) == (72, 40):
+            t = json.loads(tf.read_text())
+            traffic = int((2 * t["FETCH_SIZE"]["avg_kb"] + t["WRITE_SIZE"]["avg_kb"]) * 1024)
+            traffic_file = tf.name
+        break
     attn_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in timer)
     attn_fl = sum(f for _, f, _, _ in timer)
     achieved = attn_fl / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
 
     if rank == 0:
+        if mode == "grid":
+            latents_done = total_calls * WINDOW / STEPS_PER_LATENT
+            value = latents_done / dt
+            units_total = total_calls / 3.0
+        else:
+            units_total = (1 if shard is not None else world) * args.steps
+            value = units_total * LATENTS_PER_UNIT / dt
+        par = {"task": f"task-parallel x{world} (independent tasks per round, no data-path collective)",
+               "frame-shard": f"frame-shard x{world} (every window split over all ranks, RCCL K/V all-gather per 3-D attention layer)",
+               "grid": f"task-parallel x{world} over the real round structure (150 + 44 + 150 tasks dealt round-robin, barrier + "
+                       f"RCCL cell exchange at the 2 round boundaries)"}[mode]
+        workload = ("demo_4d 44cam x 150fr, sliding_fast (window 12, stride 2, 3 rounds, 18 steps/latent), "
+                    f"CFG 2.0, {LAT_H}x{LAT_W}x4 latents; ")
+        if mode == "grid":
+            workload += (f"ONE pass over the 48 x {args.grid_frames} grid job: {2 * args.grid_frames} spatial + 44 temporal tasks, "
+                         f"first {grid_info['depth']['spatial']} / {grid_info['depth']['temporal']} window calls of every task's 22 / 75; "
+                         f"value = executed latent-steps / 18 / time; VAE excluded")
+        else:
+            workload += "step = 2 spatial (F=16) + 1 temporal (F=24) window calls = 2 denoised latents; VAE excluded"
         out = {
             "metric": "denoised view-frame latents/sec (44cam x 150fr grid)",
-            "value": round((1 if shard is not None else world) * args.steps * LATENTS_PER_UNIT / dt, 4),
+            "value": round(value, 4),
             "unit": "latents/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "strong" if shard is not None else "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if mode == "task" else "strong", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {
-                "workload": "demo_4d 44cam x 150fr, sliding_fast (window 12, stride 2, 3 rounds, 18 steps/latent), "
-                            f"CFG 2.0, {LAT_H}x{LAT_W}x4 latents; step = 2 spatial (F=16) + 1 temporal (F=24) window calls "
-                            "= 2 denoised latents; VAE excluded",
+                "workload": workload,
+                "mode": mode,
                 "unet": "SD-2.1 geometry (320,640,1280,1280), 815.6M params, random init seed 0",
-                "parallelism": (f"frame-shard x{world} (every window split over all ranks, RCCL K/V all-gather per 3-D "
-                                f"attention layer)" if shard is not None else
-                                f"task-parallel x{world} (independent tasks per round, no data-path collective)"),
+                "parallelism": par,
                 "task_streams": S,
                 "finite_outputs": finite,
                 "extensions": ["prune_cond_rows"] if args.prune_cond_rows else [],
@@ -314,30 +512,28 @@ def main():
                 "kernel": "attn_kernel (2-D + 3-D view/time attention, all 48 launches of a step)",
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "traffic_note": "avg HBM bytes per attn launch, PMC (2*FETCH_SIZE+WRITE_SIZE), profiles/r01_attn_traffic_pmc.json; "
+                "traffic_note": f"avg HBM bytes per attn launch, PMC (2*FETCH_SIZE+WRITE_SIZE), profiles/{traffic_file}; "
                                 "algorithmic Q+K+V+O bytes average 152e6 per launch",
                 "avg_launch_ms": round(attn_ms / max(1, len(timer)), 4), "launches": len(timer),
-                "measured_in": f"a second pass of the same {args.steps} steps with one task in flight "
-                               f"({dt_single / args.steps * 1e3:.1f} ms per step), HIP events on the launch stream",
+                "measured_in": f"a separate pass of {k_roof} units (2 spatial + 1 temporal window calls each) with one task in flight "
+                               f"({dt_single / max(1, k_roof) * 1e3:.1f} ms per unit), HIP events on the launch stream",
                 "share_of_step_time": round(attn_ms * 1e-3 / dt_single, 4),
             },
         }
+        if grid_info is not None:
+            out["config"]["grid"] = {"calls_per_rank": grid_info["calls_per_rank"], "window_calls_per_task": grid_info["depth"],
+                                     "timed_seconds": round(dt, 3)}
         # secondary figures of SURVEY.md 8d (whole job): latent-steps/s, UNet window calls/s, sustained UNet TFLOP/s
-        ranks_units = (1 if shard is not None else world) * args.steps
-        if (LAT_H, LAT_W) == (72, 40):
-            unit_tflop = 2 * 20.13 + 33.06  # F=16 / F=24 UNet calls at 72x40
-        elif (LAT_H, LAT_W) == (128, 128):
-            unit_tflop = 2 * 261.9 + 485.8
-        else:
-            unit_tflop = None
+        ut = UNIT_TFLOP.get((LAT_H, LAT_W))
         out["kernel_breakdown_one_step"] = breakdown
         out["secondary"] = {
-            "latent_steps_per_s": round(ranks_units * 3 * WINDOW / dt, 2),
-            "unet_calls_per_s": round(ranks_units * 3 / dt, 3),
-            "unet_tflops_sustained": round(ranks_units * unit_tflop / dt, 1) if unit_tflop else None,
+            "latent_steps_per_s": round(units_total * 3 * WINDOW / dt, 2),
+            "unet_calls_per_s": round(units_total * 3 / dt, 3),
+            "unet_tflops_sustained": round(units_total * (2 * ut[0] + ut[1]) / dt, 1) if ut else None,
         }
-        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only (the CPU sample would skew multi-rank timing)
-            out["cpu_baseline"] = cpu_baseline(args.cpu_frames, args.cpu_threads)
+        if want_cpu:  # rank 0 at N = 1 only (the CPU sample would skew multi-rank timing)
+            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(pipe, state_dict, tasks["spatial"], args.cpu_frames,
+                                                                         args.cpu_threads)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

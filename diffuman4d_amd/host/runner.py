@@ -178,7 +178,13 @@ class SamplingRunner:
 
 class DistributedSamplingRunner:
     """One process per GPU.  Every rank builds the same sampler (same task lists); rank r executes
-    ``sampler.partition(round, r, world)`` with its single pipeline, then the grid is re-partitioned."""
+    ``sampler.partition(round, r, world)`` with its single pipeline, then the grid is re-partitioned.
+
+    Grid bookkeeping is replicated, data is not: every rank simulates, for ALL ranks, which round's value of which cell
+    each rank holds (``_holds``) and which rank wrote a cell last (``_written``).  That state is a pure function of the
+    task lists, so the ranks agree on every transfer without negotiating, and a rank that ran no task in a round (more
+    GPUs than frames or target cameras) still takes part in the exchange: it is sent every cell its next tasks read,
+    whoever holds them."""
 
     def __init__(self, sampler: SlidingIterativeSampler, group=None, prefetch_depth: int = 2, writers: int = 2,
                  gpu_streams: int = 2):
@@ -189,62 +195,110 @@ class DistributedSamplingRunner:
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self._written: Dict[Tuple[str, str], Tuple[int, int]] = {}  # cell -> (round of the last write, sending rank)
+        self._holds: List[Dict[Tuple[str, str], int]] = [dict() for _ in range(self.world)]  # rank -> {cell: round held}
+        self._proto = None  # (shape, dtype) of a grid cell, agreed once
+
+    def _input_camera_of(self, target_label: str) -> str:
+        ds = self.sampler.dataset
+        inputs = [int(c) for c in self.sampler.input_spa_labels]
+        near = getattr(ds, "nearest_input_camera", None)
+        return f"{near(int(target_label), inputs):02d}" if near is not None else None
 
     # cells a task reads from / writes to the grid: (spa_label, tem_label)
     def _task_cells(self, task: dict) -> List[Tuple[str, str]]:
         s = self.sampler
         if task["domain"] == "spatial":
             return [(c, task["domain_label"]) for c in s.spa_labels]
-        cams = list(s.input_spa_labels) + [task["domain_label"]]  # the nearest input camera is one of these
+        near = self._input_camera_of(task["domain_label"])
+        cams = ([near] if near is not None else list(s.input_spa_labels)) + [task["domain_label"]]
         return [(c, t) for c in cams for t in s.tem_labels]
 
     def _owned_after(self, round_index: int, rank: int) -> List[Tuple[str, str]]:
-        """Cells whose authoritative copy lives on `rank` after `round_index` (target cells only: input-camera
-        rows are re-encoded by every task that conditions on them, so their grid value is never read back
-        as data -- they only need to be non-None; owners = the lowest rank that touched them)."""
+        """TARGET cells whose authoritative copy lives on `rank` after `round_index`: the targets its tasks denoised.
+        (Input-camera rows are re-encoded by every task that conditions on them, so their grid value is never read back
+        as data -- any rank's copy will do.)"""
         s = self.sampler
         cells = []
         for t in s.partition(round_index, rank, self.world):
             if t["domain"] == "spatial":
-                cells += [(c, t["domain_label"]) for c in s.spa_labels]
+                cells += [(c, t["domain_label"]) for c in s.target_spa_labels]
             else:
                 cells += [(t["domain_label"], f) for f in s.tem_labels]
         return cells
 
+    def _record_round(self, round_index: int) -> None:
+        """Replay what every rank wrote in `round_index` into the replicated bookkeeping (lowest writer rank sends)."""
+        for r in range(self.world):
+            for t in self.sampler.partition(round_index, r, self.world):
+                for cell in self._task_cells(t):
+                    w = self._written.get(cell)
+                    if w is None or w[0] < round_index:
+                        self._written[cell] = (round_index, r)
+                    self._holds[r][cell] = round_index
+
+    def _cell_proto(self):
+        """(shape, dtype) of a grid cell.  Ranks that hold no cell yet learn it from the others (one small
+        all_gather_object, first exchange only)."""
+        if self._proto is None:
+            mine = next((l for d in self.sampler.latents.values() for l in d.values() if l is not None), None)
+            info = None if mine is None else (tuple(mine.shape), str(mine.dtype).replace("torch.", ""))
+            infos = [None] * self.world
+            self.dist.all_gather_object(infos, info, group=self.group)
+            info = next((i for i in infos if i is not None), None)
+            if info is None:
+                raise RuntimeError("grid exchange: no rank holds a latent cell")
+            self._proto = (info[0], getattr(torch, info[1]))
+        return self._proto
+
+    def _exchange_device(self) -> torch.device:
+        backend = self.dist.get_backend(self.group)
+        dev = getattr(self.sampler.pipelines[0], "device", torch.device("cpu"))
+        return torch.device(dev) if backend == "nccl" else torch.device("cpu")
+
     def exchange(self, round_index: int):
-        """After round `round_index`: send each peer the cells its round+1 tasks read, receive ours."""
+        """After round `round_index`: every rank receives, from the rank that wrote it last, each cell its round+1 tasks
+        read and whose latest value it does not hold."""
         s, dist = self.sampler, self.dist
+        self._record_round(round_index)
         if round_index + 1 >= len(s.all_tasks) or self.world == 1:
             return
-        owner: Dict[Tuple[str, str], int] = {}
-        for r in range(self.world):
-            for cell in self._owned_after(round_index, r):
-                owner.setdefault(cell, r)
-        need = {r: set() for r in range(self.world)}
-        for r in range(self.world):
-            for t in s.partition(round_index + 1, r, self.world):
-                for cell in self._task_cells(t):
-                    if cell in owner:
-                        need[r].add(cell)
-        # deterministic cell order on both sides of every pair
-        send_cells = {q: sorted(c for c in need[q] if owner[c] == self.rank and q != self.rank) for q in range(self.world)}
-        recv_cells = {q: sorted(c for c in need[self.rank] if owner[c] == q and q != self.rank) for q in range(self.world)}
-        proto = next(l for d in s.latents.values() for l in d.values() if l is not None)
+        send_cells: Dict[int, list] = {q: [] for q in range(self.world)}
+        recv_cells: Dict[int, list] = {q: [] for q in range(self.world)}
+        for q in range(self.world):
+            need = set()
+            for t in s.partition(round_index + 1, q, self.world):
+                need.update(self._task_cells(t))
+            for cell in sorted(need):  # deterministic cell order on both sides of every pair
+                w = self._written.get(cell)
+                if w is None or self._holds[q].get(cell) == w[0]:
+                    continue  # never written yet, or q already holds the latest value
+                src = w[1]
+                if src == self.rank:
+                    send_cells[q].append(cell)
+                if q == self.rank:
+                    recv_cells[src].append(cell)
+                self._holds[q][cell] = w[0]
+        shape, dtype = self._cell_proto()
+        xdev = self._exchange_device()
         ops_, recv_bufs = [], {}
         for q in range(self.world):
             if send_cells[q]:
-                buf = torch.stack([s.latents[c][t] for c, t in send_cells[q]]).contiguous()
-                idx = torch.tensor([s.timestep_indices[c][t] for c, t in send_cells[q]], dtype=torch.int64, device=buf.device)
+                buf = torch.stack([s.latents[c][t].to(xdev) for c, t in send_cells[q]]).contiguous()
+                idx = torch.tensor([s.timestep_indices[c][t] for c, t in send_cells[q]], dtype=torch.int64, device=xdev)
                 ops_ += [dist.P2POp(dist.isend, buf, q, self.group), dist.P2POp(dist.isend, idx, q, self.group)]
             if recv_cells[q]:
-                buf = torch.empty((len(recv_cells[q]),) + tuple(proto.shape), dtype=proto.dtype, device=proto.device)
-                idx = torch.empty(len(recv_cells[q]), dtype=torch.int64, device=proto.device)
+                buf = torch.empty((len(recv_cells[q]),) + tuple(shape), dtype=dtype, device=xdev)
+                idx = torch.empty(len(recv_cells[q]), dtype=torch.int64, device=xdev)
                 recv_bufs[q] = (buf, idx)
                 ops_ += [dist.P2POp(dist.irecv, buf, q, self.group), dist.P2POp(dist.irecv, idx, q, self.group)]
         if ops_:
             for req in dist.batch_isend_irecv(ops_):
                 req.wait()
+        cell_dev = getattr(s.pipelines[0], "device", xdev)
         for q, (buf, idx) in recv_bufs.items():
+            buf = buf.to(cell_dev)
+            idx = idx.cpu()
             for k, (c, t) in enumerate(recv_cells[q]):
                 s.latents[c][t] = buf[k]
                 s.timestep_indices[c][t] = int(idx[k])

@@ -1,0 +1,150 @@
+#!/usr/bin/env python
+"""Golden vectors on the JUDGED configuration (BASELINE.json configs[1..2]): the CPU oracle (oracle/: fp32 restatement
+of the reference path, see its headers) run at full SD-2.1 geometry on 72x40 latents.
+
+    python tests/golden/make_golden_sd21.py [unet16] [unet24] [vae]       (default: all three; ~10 min on 8 cores)
+
+writes tests/golden/sd21_72x40.pt:
+  * unet_f16_spatial  -- one spatial window call: F = 16 frames (4 conditioning + 12 targets), CFG batch 32, L3d = 46 080
+  * unet_f24_temporal -- one temporal window call: F = 24 frames (12 + 12), CFG batch 48, L3d = 69 120
+      each: fp32 oracle output (stored fp16), rel-L2 of the oracle run in bf16 against it (the yardstick: what the
+      reference's own bf16 arithmetic loses), input checksums
+  * vae_576x320       -- AutoencoderKL with the SD geometry (128, 256, 512, 512; mid-block attention d = 512, L = 2 880)
+      on two 576x320 images: scaled posterior sample and the decoded images, plus their bf16 yardsticks.
+
+Weights are NOT stored: both sides rebuild them with ``random_state_dict(shapes, seed, device="cpu")`` (torch's CPU
+generator is reproducible for one torch build; the fixture carries checksums that the GPU test verifies first).
+The GPU tests (tests/modelcheck.py::case_unet_sd21 / case_vae_sd) never run the oracle at this size on the GPU box.
+"""
+from __future__ import annotations
+
+import sys
+import time
+from dataclasses import asdict
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+OUT = Path(__file__).resolve().parent / "sd21_72x40.pt"
+
+BF = torch.bfloat16
+LAT_H, LAT_W = 72, 40
+UNET_SEED, VAE_SEED = 0, 1
+
+
+def rel_l2(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def unet_inputs(num_frames: int, n_cond: int, seed: int):
+    """A CFG batch shaped like pipeline_diffuman4d.py:345-395 builds it: [negative | positive] halves, channels
+    [latent 4 | Pluecker 6 | skeleton latent 4 | mask 1]; conditioning frames come first and carry t = 0."""
+    g = torch.Generator().manual_seed(seed)
+    F_, h, w = num_frames, LAT_H, LAT_W
+    lat = torch.randn(F_, 4, h, w, generator=g)
+    pv = torch.randn(F_, 4, h, w, generator=g) * (0.18215 * 4)
+    pl = (torch.randn(F_, 6, h, w, generator=g) * 0.5).clamp(-1, 1)
+    sk = torch.randn(F_, 4, h, w, generator=g) * (0.18215 * 4)
+    cond = torch.zeros(F_, dtype=torch.bool)
+    cond[:n_cond] = True
+    mask = (~cond).float()[:, None, None, None].expand(F_, 1, h, w)
+    x = torch.where(cond[:, None, None, None], pv, lat)
+    pos = torch.cat([x, pl, sk, mask], dim=1)
+    neg_x = torch.where(cond[:, None, None, None], torch.ones_like(x), x)
+    neg = torch.cat([neg_x, torch.zeros_like(pl), -torch.ones_like(sk), mask], dim=1)
+    t = torch.randint(1, 1000, (F_,), generator=g)
+    t[cond] = 0
+    sample = torch.cat([neg, pos]).to(BF)
+    return sample, torch.cat([t, t])
+
+
+def build_unet():
+    from diffuman4d_amd.host.unet import UNetConfig as HC
+    from diffuman4d_amd.host.weights import random_state_dict, unet_param_shapes
+    from oracle.unet import UNetConfig, UNetMultiviewConditionModel
+    cfg = UNetConfig()
+    sd = random_state_dict(unet_param_shapes(HC()), UNET_SEED, "cpu")
+    m = UNetMultiviewConditionModel(cfg).eval()
+    res = m.load_state_dict({k: v.float() for k, v in sd.items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    chk = float(sum(v.float().abs().sum() for v in sd.values()))
+    return cfg, m, chk
+
+
+def golden_unet(name: str, num_frames: int, n_cond: int, domain: str, seed: int):
+    cfg, m, wchk = build_unet()
+    x, t = unet_inputs(num_frames, n_cond, seed)
+    with torch.no_grad():
+        t0 = time.time()
+        ref = m(x.float(), t, domains=[domain] * 2, num_frames=num_frames)
+        t_fp32 = time.time() - t0
+        m.to(BF)
+        t0 = time.time()
+        ref_bf = m(x, t, domains=[domain] * 2, num_frames=num_frames).float()
+        t_bf = time.time() - t0
+    out = dict(out=ref.to(torch.float16), yard_bf16=rel_l2(ref_bf, ref), num_frames=num_frames, n_cond=n_cond, domain=domain,
+               seed=seed, x_checksum=float(x.float().abs().sum()), t=t, weights_checksum=wchk, oracle_seconds=(t_fp32, t_bf),
+               threads=torch.get_num_threads())
+    print(f"{name}: fp32 {t_fp32:.1f}s bf16 {t_bf:.1f}s yardstick(bf16 oracle vs fp32 oracle)={out['yard_bf16']:.3e}", flush=True)
+    return out
+
+
+def vae_inputs(n: int, seed: int):
+    g = torch.Generator().manual_seed(seed)
+    H, W = LAT_H * 8, LAT_W * 8
+    # smooth-ish images in [-1, 1]: low-frequency field + noise, white outside an ellipse (spatem_dataset.py:166)
+    base = torch.nn.functional.interpolate(torch.randn(n, 3, H // 16, W // 16, generator=g), size=(H, W), mode="bilinear")
+    img = (0.6 * base + 0.15 * torch.randn(n, 3, H, W, generator=g)).clamp(-1, 1)
+    ys, xs = torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, W), indexing="ij")
+    inside = ((xs / 0.7) ** 2 + (ys / 0.9) ** 2) < 1.0
+    img = torch.where(inside, img, torch.ones_like(img)).to(BF)
+    noise = torch.randn(n, 4, LAT_H, LAT_W, generator=g).to(BF)
+    return img, noise
+
+
+def golden_vae(n: int = 2, seed: int = 5):
+    from diffuman4d_amd.host.vae import VAEConfig as HC
+    from diffuman4d_amd.host.weights import random_state_dict, vae_param_shapes
+    from oracle.vae import AutoencoderKL, VAEConfig
+    cfg = VAEConfig()
+    sd = random_state_dict(vae_param_shapes(HC()), VAE_SEED, "cpu")
+    v = AutoencoderKL(cfg).eval()
+    res = v.load_state_dict({k: t.float() for k, t in sd.items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    img, noise = vae_inputs(n, seed)
+    with torch.no_grad():
+        t0 = time.time()
+        z = v.sample_posterior(v.moments(img.float()), noise.float()) * cfg.scaling_factor
+        dec = (v.decode(z.to(BF).float() / cfg.scaling_factor) / 2 + 0.5).clamp(0, 1)  # decoder fed the bf16-rounded latents
+        t_fp32 = time.time() - t0
+        v.to(BF)
+        z_bf = (v.sample_posterior(v.moments(img), noise) * cfg.scaling_factor).float()
+        dec_bf = (v.decode(z.to(BF) / cfg.scaling_factor) / 2 + 0.5).clamp(0, 1).float()
+    out = dict(z=z, images=dec.to(torch.float16), yard_z=rel_l2(z_bf, z), yard_images=rel_l2(dec_bf, dec), n=n, seed=seed,
+               img_checksum=float(img.float().abs().sum()), weights_checksum=float(sum(t.float().abs().sum() for t in sd.values())),
+               config=asdict(cfg), oracle_seconds=t_fp32)
+    print(f"vae_576x320: fp32 {t_fp32:.1f}s yardsticks z={out['yard_z']:.3e} images={out['yard_images']:.3e}", flush=True)
+    return out
+
+
+def main():
+    which = set(sys.argv[1:]) or {"unet16", "unet24", "vae"}
+    blob = torch.load(OUT) if OUT.exists() else {}
+    if "vae" in which:
+        blob["vae_576x320"] = golden_vae()
+        torch.save(blob, OUT)
+    if "unet16" in which:
+        blob["unet_f16_spatial"] = golden_unet("unet_f16_spatial", 16, 4, "spatial", 101)
+        torch.save(blob, OUT)
+    if "unet24" in which:
+        blob["unet_f24_temporal"] = golden_unet("unet_f24_temporal", 24, 12, "temporal", 102)
+        torch.save(blob, OUT)
+    print("wrote", OUT, {k: type(v).__name__ for k, v in blob.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -4,8 +4,15 @@ oracle on identical seeded weights, inputs and injected noise.
 `python tests/modelcheck.py` prints one line per case; tests/test_model_gpu.py wraps the same cases.
 
 Tolerances (bf16 activations end to end, fp32 accumulation; the fp32 oracle is the ground truth):
-  * a case passes when rel-L2(HIP, oracle-fp32) <= TOL[case]; we also print the error of the ORACLE
-    run in bf16 (i.e. the reference's own arithmetic) against the same fp32 truth as a yardstick;
+  * the yardstick of a case is the error of the ORACLE run in bf16 -- the reference's own arithmetic
+    (configs/model/diffuman4d.yaml: bf16) -- against the same fp32 truth, on the same weights, inputs and noise;
+  * a model-level case passes when  rel-L2(HIP, oracle-fp32) <= YARD_FACTOR x yardstick  (per compared quantity:
+    UNet output, latents, decoded RGB), i.e. when the HIP path is as close to fp32 truth as the reference's bf16 path;
+  * BASELINE.json's north_star asks for 1e-3 on decoded RGB.  No bf16 pipeline meets that against an fp32 oracle --
+    neither this one nor the reference's (yardsticks are 0.6-1.4e-2) -- so 1e-3 is reported as NOT met (NORTH_STAR);
+    it would take fp32 activations;
+  * cases with their own fixed bound (bitwise equalities, extension-vs-strict comparisons, the golden fixtures whose
+    generator did not record a yardstick) keep a TOL entry;
   * integer bookkeeping (timestep indices, fully_denoised) must be bit-exact.
 """
 from __future__ import annotations
@@ -21,6 +28,9 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 
 BF = torch.bfloat16
+YARD_FACTOR = 1.15   # HIP error may exceed the bf16-oracle yardstick by at most 15 %
+NORTH_STAR = 1e-3    # BASELINE.json: decoded RGB within 1e-3 rel-L2 -- reported, not met by any bf16 path (see above)
+GOLDEN = Path(__file__).resolve().parent / "golden"
 
 
 def rel_l2(a, b):
@@ -89,7 +99,7 @@ def case_unet(num_frames=4, cfg_batch=2, h=16, w=8, tem=False, domain="spatial",
     out = hm(xd, t.float().cuda(), skeletons=ops.nchw_to_nhwc(sk.cuda(), 4) if pose else None, domains=domains,
              num_frames=num_frames)
     out = ops.nhwc_to_nchw(out)
-    return rel_l2(out, ref), rel_l2(ref_bf, ref)
+    return {"unet_out": rel_l2(out, ref)}, {"unet_out": rel_l2(ref_bf, ref)}
 
 
 class _RecordShard:
@@ -207,17 +217,69 @@ def case_vae(h=64, w=64, seed=1):
     noise = torch.randn(3, 4, h // 8, w // 8, generator=g).to(BF)
     with torch.no_grad():
         z_ref = ov.sample_posterior(ov.moments(img.float()), noise.float()) * cfg.scaling_factor
-        img_ref = (ov.decode(z_ref / cfg.scaling_factor) / 2 + 0.5).clamp(0, 1)
+        z_in = z_ref.to(BF)  # the decoder is checked in isolation on the bf16-rounded ORACLE latents
+        img_ref = (ov.decode(z_in.float() / cfg.scaling_factor) / 2 + 0.5).clamp(0, 1)
         ov.to(BF)
         z_bf = (ov.sample_posterior(ov.moments(img), noise) * cfg.scaling_factor).float()
+        img_bf = (ov.decode(z_in / cfg.scaling_factor) / 2 + 0.5).clamp(0, 1).float()
         ov.float()
     z = hv.encode_scaled(img, noise)  # NHWC
-    e_enc = rel_l2(ops.nhwc_to_nchw(z), z_ref)
-    # decode the ORACLE latents so the decoder is checked in isolation
-    zin = ops.nchw_to_nhwc(z_ref.to(BF).contiguous().cuda())
-    out = hv.decode_to_images(zin)
-    e_dec = rel_l2(out, img_ref)
-    return max(e_enc, e_dec), rel_l2(z_bf, z_ref)
+    out = hv.decode_to_images(ops.nchw_to_nhwc(z_in.contiguous().cuda()))
+    return ({"latents": rel_l2(ops.nhwc_to_nchw(z), z_ref), "images": rel_l2(out, img_ref)},
+            {"latents": rel_l2(z_bf, z_ref), "images": rel_l2(img_bf, img_ref)})
+
+
+def _check_fixture_inputs(what, got, want):
+    if abs(got - want) > 1e-6 * abs(want):
+        raise RuntimeError(f"{what}: checksum {got!r} != fixture {want!r} -- torch's CPU generator produced different numbers "
+                           "than when tests/golden/sd21_72x40.pt was made; regenerate it (tests/golden/make_golden_sd21.py)")
+
+
+def case_unet_sd21(name):
+    """The JUDGED configuration: full SD-2.1 geometry (320, 640, 1280, 1280; heads 5/10/20/20), 72x40 latents, one spatial
+    (F = 16, CFG batch 32, 3-D attention over 46 080 / 11 520 / 2 880 / 720 tokens) or temporal (F = 24, CFG batch 48,
+    69 120 / 17 280 / 4 320 / 1 080 tokens) window call, HIP vs the fp32 CPU oracle's output recorded in
+    tests/golden/sd21_72x40.pt together with the bf16-oracle yardstick (made by tests/golden/make_golden_sd21.py)."""
+    from diffuman4d_amd.host import ops
+    from diffuman4d_amd.host.unet import UNetConfig, UNetMultiviewConditionModel
+    from diffuman4d_amd.host.weights import random_state_dict, unet_param_shapes
+    sys.path.insert(0, str(GOLDEN))
+    import make_golden_sd21 as mk
+    g = torch.load(GOLDEN / "sd21_72x40.pt")[name]
+    cfg = UNetConfig()
+    sd = random_state_dict(unet_param_shapes(cfg), mk.UNET_SEED, "cpu")
+    _check_fixture_inputs("UNet weights", float(sum(v.float().abs().sum() for v in sd.values())), g["weights_checksum"])
+    x, t = mk.unet_inputs(g["num_frames"], g["n_cond"], g["seed"])
+    _check_fixture_inputs("UNet input", float(x.float().abs().sum()), g["x_checksum"])
+    assert torch.equal(t, g["t"])
+    hm = UNetMultiviewConditionModel(cfg, sd, "cuda")
+    del sd
+    out = hm(ops.nchw_to_nhwc(x.cuda(), hm.IN_PAD), t.float().cuda(), domains=[g["domain"]] * 2, num_frames=g["num_frames"])
+    err = rel_l2(ops.nhwc_to_nchw(out), g["out"])
+    del hm
+    torch.cuda.empty_cache()
+    return {"unet_out": err}, {"unet_out": g["yard_bf16"]}
+
+
+def case_vae_sd(name="vae_576x320"):
+    """AutoencoderKL at the SD geometry (128, 256, 512, 512; mid-block attention d = 512 over 2 880 tokens) on two 576x320
+    images vs the fp32 oracle's recorded posterior sample and decoded images (tests/golden/sd21_72x40.pt)."""
+    from diffuman4d_amd.host import ops
+    from diffuman4d_amd.host.vae import AutoencoderKL, VAEConfig
+    from diffuman4d_amd.host.weights import random_state_dict, vae_param_shapes
+    sys.path.insert(0, str(GOLDEN))
+    import make_golden_sd21 as mk
+    g = torch.load(GOLDEN / "sd21_72x40.pt")[name]
+    cfg = VAEConfig.from_dict(g["config"])
+    sd = random_state_dict(vae_param_shapes(cfg), mk.VAE_SEED, "cpu")
+    _check_fixture_inputs("VAE weights", float(sum(v.float().abs().sum() for v in sd.values())), g["weights_checksum"])
+    img, noise = mk.vae_inputs(g["n"], g["seed"])
+    _check_fixture_inputs("VAE input", float(img.float().abs().sum()), g["img_checksum"])
+    hv = AutoencoderKL(cfg, sd, "cuda")
+    z = hv.encode_scaled(img, noise)
+    out = hv.decode_to_images(ops.nchw_to_nhwc(g["z"].to(BF).contiguous().cuda()))
+    return ({"latents": rel_l2(ops.nhwc_to_nchw(z), g["z"]), "images": rel_l2(out, g["images"])},
+            {"latents": g["yard_z"], "images": g["yard_images"]})
 
 
 def case_resize(seed=3):
@@ -288,10 +350,13 @@ def case_pipeline(domain="spatial", n_cams=8, T=4, window=4, stride=2, rounds=1,
     opb = OraclePipeline(ov, ou, DDIMScheduler(DDIMConfig(prediction_type=pred)), BF)
     refb = opb.sliding_iterative_denoise(pv, pl, sk, cm, None, domain, tidx, noise, **kw)
     ov.float(), ou.float()
-    yard = rel_l2(refb["images"], ref["images"])
-    print(f"    [pipeline {domain}] latents rel_l2={e_lat:.3e} images rel_l2={e_img:.3e} bookkeeping_exact={exact} "
-          f"(oracle-bf16 images rel_l2={yard:.3e})", flush=True)
-    return (max(e_lat, e_img) if exact else 1.0), yard
+    y_lat, y_img = rel_l2(refb["latents"], ref["latents"]), rel_l2(refb["images"], ref["images"])
+    print(f"    [pipeline {domain}] latents rel_l2={e_lat:.3e} (oracle-bf16 {y_lat:.3e}) images rel_l2={e_img:.3e} "
+          f"(oracle-bf16 {y_img:.3e}; north_star {NORTH_STAR:.0e}: {'met' if e_img <= NORTH_STAR else 'NOT met'}) "
+          f"bookkeeping_exact={exact}", flush=True)
+    if not exact:
+        return {"bookkeeping": 1.0}, {"bookkeeping": 0.0}
+    return {"latents": e_lat, "images": e_img}, {"latents": y_lat, "images": y_img}
 
 
 def case_pipeline_cache_lazy(seed=31):
@@ -373,8 +438,19 @@ def case_golden_pipeline(name):
     exact = torch.equal(out["timestep_indices"].cpu(), g["timestep_indices"]) and \
         torch.equal(out["fully_denoised"].cpu(), g["fully_denoised"])
     e_lat, e_img = rel_l2(out["latents"], g["latents"]), rel_l2(out["images"], g["images"])
-    print(f"    [golden {name}] latents rel_l2={e_lat:.3e} images rel_l2={e_img:.3e} bookkeeping_exact={exact}", flush=True)
-    return (max(e_lat, e_img) if exact else 1.0), 0.0
+    # yardstick: the oracle run in bf16 on the same task, measured against the same fixture (= the reference's fp32 output)
+    from oracle.ddim import DDIMConfig, DDIMScheduler
+    from oracle.pipeline import OraclePipeline
+    ov.to(BF), ou.to(BF)
+    opb = OraclePipeline(ov, ou, DDIMScheduler(DDIMConfig(prediction_type=c["pred"])), BF)
+    refb = opb.sliding_iterative_denoise(pv, pl, sk, cm, lat_in, c["domain"], g["timestep_indices_in"],
+                                         {k: v.to(BF) for k, v in g["noise"].items()}, **c["kw"])
+    y_lat, y_img = rel_l2(refb["latents"], g["latents"]), rel_l2(refb["images"], g["images"])
+    print(f"    [golden {name}] latents rel_l2={e_lat:.3e} (oracle-bf16 {y_lat:.3e}) images rel_l2={e_img:.3e} "
+          f"(oracle-bf16 {y_img:.3e}) bookkeeping_exact={exact}", flush=True)
+    if not exact:
+        return {"bookkeeping": 1.0}, {"bookkeeping": 0.0}
+    return {"latents": e_lat, "images": e_img}, {"latents": y_lat, "images": y_img}
 
 
 CASES = {
@@ -399,34 +475,56 @@ CASES = {
     "golden_bidir_nocfg": (case_golden_pipeline, dict(name="bidir_nocfg")),
     "golden_round2_shift": (case_golden_pipeline, dict(name="round2_shift")),
     "golden_pose_encoder": (case_golden_pipeline, dict(name="pose_encoder")),
+    # the judged configuration (BASELINE.json configs[1..2]): SD-2.1 geometry at 72x40, vs tests/golden/sd21_72x40.pt
+    "unet_sd21_72x40_f16": (case_unet_sd21, dict(name="unet_f16_spatial")),
+    "unet_sd21_72x40_f24": (case_unet_sd21, dict(name="unet_f24_temporal")),
+    "vae_sd_576x320": (case_vae_sd, dict()),
 }
-# multi-layer bf16 pipelines: each of ~100 ops adds ~2e-3 of rounding noise; they add in quadrature
-TOL = {"pipeline_shard_rccl_world1": 0.0, "unet_frame_shard_p4": 0.0, "unet_frame_shard_p8": 0.0, "unet_spatial": 3e-2, "unet_temporal_temb": 3e-2, "unet_2d_only": 3e-2, "unet_pose_encoder": 3e-2, "pipeline_pose_encoder": 6e-2, "pipeline_cache_lazy_decode": 0.0, "pipeline_prune_cond_rows": 5e-3, "pipeline_prune_cond_rows_temporal": 5e-3, "vae": 3e-2, "resize": 4e-3,
-       "pipeline_spatial": 6e-2, "pipeline_temporal_v": 6e-2, "pipeline_bidir_nocfg": 6e-2,
-       "golden_spatial": 6e-2, "golden_temporal_v": 6e-2, "golden_bidir_nocfg": 6e-2, "golden_round2_shift": 6e-2, "golden_pose_encoder": 6e-2}
+# Cases with a fixed bound of their own: bitwise equalities (0.0), extension-vs-strict comparisons, exact resampling.
+# Every other case is judged against its bf16-oracle yardstick (YARD_FACTOR, see the module docstring).
+TOL = {"pipeline_shard_rccl_world1": 0.0, "unet_frame_shard_p4": 0.0, "unet_frame_shard_p8": 0.0,
+       "pipeline_cache_lazy_decode": 0.0, "pipeline_prune_cond_rows": 5e-3, "pipeline_prune_cond_rows_temporal": 5e-3,
+       "resize": 4e-3}
+
+
+def judge(name, err, yard):
+    """-> (worst error, its yardstick, its bound): the compared quantity with the largest error / bound ratio."""
+    errs = err if isinstance(err, dict) else {"value": err}
+    yards = yard if isinstance(yard, dict) else {k: yard for k in errs}
+    rows = []
+    for q, e in errs.items():
+        bound = TOL[name] if name in TOL else YARD_FACTOR * yards[q]
+        rows.append((e / bound if bound > 0 else (0.0 if e == 0 else math.inf), e, yards.get(q, 0.0), bound, q))
+    rows.sort(reverse=True)
+    _, e, y, bound, q = rows[0]
+    return e, y, bound, q, errs, yards
 
 
 def run_case(name):
     fn, kw = CASES[name]
     err, yard = fn(**kw)
-    return err, yard, TOL[name]
+    e, y, bound, _, _, _ = judge(name, err, yard)
+    return e, y, bound
 
 
 def main():
     bad = 0
-    for name in CASES:
+    names = [n for n in CASES if not sys.argv[1:] or any(n.startswith(a) for a in sys.argv[1:])]
+    for name in names:
         t0 = time.time()
         try:
-            err, yard, tol = run_case(name)
-            ok = err <= tol and math.isfinite(err)
-            print(f"{'PASS' if ok else 'FAIL'} {name:24s} rel_l2={err:.3e} tol={tol:.1e} oracle_bf16_vs_fp32={yard:.3e} "
-                  f"({time.time() - t0:.1f}s)", flush=True)
+            fn, kw = CASES[name]
+            e, y, bound, q, errs, yards = judge(name, *fn(**kw))
+            ok = e <= bound and math.isfinite(e)
+            detail = " ".join(f"{k}={v:.3e}/{yards.get(k, 0.0):.3e}" for k, v in errs.items())
+            print(f"{'PASS' if ok else 'FAIL'} {name:28s} worst={q} rel_l2={e:.3e} bound={bound:.2e} "
+                  f"[err/oracle-bf16 yardstick: {detail}] ({time.time() - t0:.1f}s)", flush=True)
             bad += 0 if ok else 1
         except Exception as e:
             bad += 1
             print(f"ERROR {name}: {type(e).__name__}: {e}", flush=True)
             traceback.print_exc()
-    print(f"modelcheck: {len(CASES) - bad}/{len(CASES)} passed", flush=True)
+    print(f"modelcheck: {len(names) - bad}/{len(names)} passed", flush=True)
     return 1 if bad else 0
 
 

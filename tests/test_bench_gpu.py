@@ -31,7 +31,10 @@ def test_bench_prints_one_contract_line():
     assert rf["traffic"] is None or rf["traffic"] > 1e6
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
-    assert d["config"]["finite_outputs"] is True
+    assert d["config"]["finite_outputs"] is True and d["config"]["mode"] == "task" and d["scaling"] == "weak"
+    # the CPU-baseline forward doubles as a parity check on the SD-2.1 geometry (same weights, same input): bf16 noise floor
+    pr = d["parity"]
+    assert 0.0 < pr["rel_l2"] < 2.5e-2 and pr["north_star_tolerance"] == 1e-3 and pr["meets_north_star"] == (pr["rel_l2"] <= 1e-3)
 
 
 @pytest.mark.gpu
@@ -48,3 +51,25 @@ def test_bench_with_two_task_streams():
     assert abs(d["value"] - 2.0 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
     rf = d["roofline"]
     assert rf["launches"] == 2 * 48 and 0.05 < rf["frac"] < 1.0 and "one task in flight" in rf["measured_in"]
+
+
+@pytest.mark.gpu
+def test_bench_self_launches_grid_mode_for_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: bench starts its own ranks (torch.distributed.run on
+    127.0.0.1), defaults to the grid mode (real round structure through DistributedSamplingRunner: partition, barrier,
+    cell exchange) and rank 0 prints the one line.  Both ranks share GPU 0 over gloo here (DM4D_BENCH_SHARED_GPU, testing
+    only), on a 48 x 12 grid so that the run stays short."""
+    import os
+    env = dict(os.environ, DM4D_BENCH_SHARED_GPU="1")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--grid-frames", "12"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["mode"] == "grid" and d["scaling"] == "strong" and "cpu_baseline" not in d
+    g = d["config"]["grid"]
+    # 12 + 12 spatial tasks x 1 call, 44 temporal tasks x 3 calls (depth for K = 1), dealt round-robin to 2 ranks
+    assert g["window_calls_per_task"] == {"spatial": 1, "temporal": 3} and g["calls_per_rank"] == [6 + 66 + 6, 6 + 66 + 6]
+    assert abs(d["value"] - sum(g["calls_per_rank"]) * 12 / 18 / g["timed_seconds"]) < 1e-2 * d["value"]
+    assert d["config"]["finite_outputs"] is True

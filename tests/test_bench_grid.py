@@ -1,0 +1,84 @@
+"""CPU: bench.py's grid mode (the real round structure through the product's runner on a latents-only pipeline adapter)
+with a stand-in for the HIP pipeline: single process and gloo world 2; plus the launch plumbing that needs no device."""
+import os
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import bench  # noqa: E402
+
+
+class FakeDevicePipeline:
+    """What LatentGridPipeline needs of Diffuman4DPipeline: .device, upload_plan, window_call (adds 1 to the window's targets)."""
+    device = torch.device("cpu")
+
+    def upload_plan(self, plan, guidance_scale, shard=None):
+        return dict(win=[torch.from_numpy(w) for w in plan.windows], cond=[torch.from_numpy(c) for c in plan.is_cond],
+                    calls=len(plan.windows), cfg=2 if guidance_scale > 1 else 1)
+
+    def window_call(self, lat3, pv3, pl3, sk3, cm3, tb, i, h, w, domains, gs, use_cfg, vpred, shard=None):
+        assert lat3.shape[1:] == (h * w, 4) and pv3.shape[0] == lat3.shape[0] and len(domains) == tb["cfg"]
+        lat3[tb["win"][i][~tb["cond"][i]]] += 1.0
+
+
+@pytest.fixture()
+def small_latents(monkeypatch):
+    monkeypatch.setattr(bench, "LAT_H", 2)
+    monkeypatch.setattr(bench, "LAT_W", 2)
+
+
+def test_grid_depth_keeps_the_call_mix():
+    assert bench.grid_depth(20) == {"spatial": 2, "temporal": 7}
+    assert bench.grid_depth(4) == {"spatial": 1, "temporal": 3}
+    assert bench.grid_depth(10 ** 4) == {"spatial": 22, "temporal": 75}  # never deeper than the real sweeps
+    d = bench.grid_depth(20)
+    assert abs((300 * d["spatial"]) / (44 * d["temporal"]) - 2.0) < 0.1  # 6600 : 3300 in the full run
+
+
+def test_grid_pass_single_process(small_latents):
+    calls = bench.run_grid_pass(FakeDevicePipeline(), {"spatial": 2, "temporal": 5}, 12, 1, 0, 2)
+    assert calls == (12 + 12) * 2 + 44 * 5
+
+
+def _worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        bench.LAT_H, bench.LAT_W = 2, 2
+        calls = bench.run_grid_pass(FakeDevicePipeline(), {"spatial": 1, "temporal": 3}, 12, world, rank, 2)
+        torch.save(calls, f"{outdir}/r{rank}.pt")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_grid_pass_two_ranks_gloo():
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(2, 29400 + os.getpid() % 500, d), nprocs=2, join=True)
+        per_rank = [torch.load(f"{d}/r{r}.pt") for r in range(2)]
+    assert per_rank == [6 + 22 * 3 + 6, 6 + 22 * 3 + 6]
+
+
+def test_self_launch_command(monkeypatch):
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    with pytest.raises(SystemExit) as e:
+        bench.self_launch(bench.parse())
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

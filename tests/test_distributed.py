@@ -17,9 +17,16 @@ KW = dict(spa_label_range=[0, 20, 1], tem_label_range=[0, 12, 1], input_spa_labe
           sliding_stride=2, alternation_rounds=3, bidirectional=False)
 
 
-def make_sampler():
+# more ranks than frames: a rank idles through both spatial rounds and still has to take part in the exchanges
+KW_FEW_FRAMES = dict(spa_label_range=[0, 6, 1], tem_label_range=[0, 2, 1], input_spa_labels=[1], window_size=2,
+                     sliding_stride=1, alternation_rounds=3, bidirectional=False)
+
+
+def make_sampler(kw=None):
     ds = SyntheticSpaTemDataset(height=16, width=16, num_cameras=48)
-    return SlidingIterativeSampler(ds, [StubPipeline()], "/tmp/unused", result_writer=None, **KW)
+    s = SlidingIterativeSampler(ds, [StubPipeline()], "/tmp/unused", **(kw or KW))
+    s.result_writer = None  # (a None ctor argument selects the default JPEG writer)
+    return s
 
 
 def grid_state(s, cells=None):
@@ -32,11 +39,11 @@ def grid_state(s, cells=None):
     return out
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, kw=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        s = make_sampler()
+        s = make_sampler(kw)
         runner = DistributedSamplingRunner(s)
         runner.inference()
         last = len(s.all_tasks) - 1
@@ -47,18 +54,19 @@ def _worker(rank, world, port, outdir):
 
 
 @pytest.mark.timeout(300)
-def test_two_ranks_match_single_process():
-    ref = make_sampler()
+@pytest.mark.parametrize("world,kw,steps", [(2, KW, 9), (3, KW_FEW_FRAMES, 6)], ids=["world2", "world3_more_ranks_than_frames"])
+def test_ranks_match_single_process(world, kw, steps):
+    ref = make_sampler(kw)
     for tasks in ref.all_tasks:
         for t in tasks:
             ref.execute_one_task(t)
     ref_state = grid_state(ref)
     total_calls = sum(len(t) for t in ref.all_tasks)
     with tempfile.TemporaryDirectory() as d:
-        port = 29500 + (os.getpid() % 2000)
-        mp.spawn(_worker, args=(2, port, d), nprocs=2, join=True)
+        port = 29500 + (os.getpid() % 2000) + world
+        mp.spawn(_worker, args=(world, port, d, kw), nprocs=world, join=True)
         merged, calls = {}, 0
-        for r in range(2):
+        for r in range(world):
             blob = torch.load(f"{d}/rank{r}.pt")
             calls += blob["n_calls"]
             for k, v in blob["state"].items():
@@ -66,11 +74,11 @@ def test_two_ranks_match_single_process():
                 merged[k] = v
     assert calls == total_calls  # every task ran exactly once
     target_cells = {(c, f) for c in ref.target_spa_labels for f in ref.tem_labels}
-    assert target_cells <= set(merged)
+    assert target_cells == set(merged)
     for cell in target_cells:
         idx, lat = merged[cell]
         ridx, rlat = ref_state[cell]
-        assert idx == ridx == 9
+        assert idx == ridx == steps
         assert torch.equal(lat, rlat)
 
 
