@@ -456,10 +456,13 @@ def install():
     for name in ("torchvision", "torchvision.utils", "torchvision.transforms", "torchvision.transforms.functional",
                  "hydra", "hydra.core", "hydra.core.hydra_config", "omegaconf", "ipdb", "easyvolcap",
                  "easyvolcap.utils", "easyvolcap.utils.parallel_utils", "torchmetrics", "torchmetrics.image",
-                 "torchmetrics.image.lpip", "cv2", "lightning_utilities", "lightning_utilities.core",
-                 "lightning_utilities.core.rank_zero"):
+                 "torchmetrics.image.lpip", "torchmetrics.image.ssim", "torchmetrics.image.psnr", "cv2",
+                 "lightning_utilities", "lightning_utilities.core", "lightning_utilities.core.rank_zero",
+                 # pulled in by src/samplers/sampling_runner.py (metrics + nerfstudio export, never called here)
+                 "fire", "lpips", "scripts.preprocess", "scripts.preprocess.remove_background"):
         if name not in sys.modules:
             m = _Inert(name)
+            m.__path__ = []  # importable as a package (`import a.b.c` walks __path__)
             sys.modules[name] = m
             parent, _, child = name.rpartition(".")
             if parent in sys.modules:

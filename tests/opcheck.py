@@ -136,10 +136,13 @@ def case_conv_direct(B, H, W, Cin, Cout, k, stride, silu=True, seed=0):
     return (rel_l2(out, ref) if pad_ok else 1.0), float((out.float().cpu() - ref).abs().max())
 
 
-def case_attention(batch, heads, L, seed=0, spike=False, ramp=False, q_scaled=False):
+def case_attention(batch, heads, L, seed=0, spike=False, ramp=False, q_scaled=False, threads=None):
     """q_scaled: the kernel gets Q' = bf16(Q * scale * log2 e) (what the model's scaled to_q rows produce) through
-    dm4d_attention_qscaled_kv_bf16; the reference is SDPA on Q'/(scale * log2 e), i.e. the same numbers."""
+    dm4d_attention_qscaled_kv_bf16; the reference is SDPA on Q'/(scale * log2 e), i.e. the same numbers.
+    threads: torch CPU threads for the fp32 reference of the large shapes (the 256-thread GPU hosts are slower with all)."""
     from diffuman4d_amd.host import ops
+    if threads:
+        torch.set_num_threads(min(threads, torch.get_num_threads()))
     g = torch.Generator().manual_seed(seed)
     C = heads * 64
     qkv = _rnd((batch * L, 3 * C), g)
@@ -375,6 +378,16 @@ CASES = {
     "attn_qs_spike": (case_attention, dict(batch=1, heads=2, L=1000, spike=True, q_scaled=True)),
     "attn_qs_ramp_fallback": (case_attention, dict(batch=2, heads=2, L=1500, ramp=True, q_scaled=True)),
     "attn_qs_kv_split": (case_attention_kv_split, dict(batch=2, heads=2, L=16 * 180, parts=8, q_scaled=True)),
+    # the shapes the bench TIMES (72x40 latents, SD-2.1 heads; 3-D = CFG batch 2 over F*HW tokens, 2-D = CFG*F frames) ...
+    "attn_qs_judged_3d_l1_f16": (case_attention, dict(batch=2, heads=10, L=16 * 720, q_scaled=True, threads=32)),
+    "attn_qs_judged_3d_l1_f24": (case_attention, dict(batch=2, heads=10, L=24 * 720, q_scaled=True, threads=32)),
+    "attn_judged_3d_l1_f24": (case_attention, dict(batch=2, heads=10, L=24 * 720, threads=32)),
+    "attn_qs_judged_2d_l0": (case_attention, dict(batch=32, heads=5, L=2880, q_scaled=True, threads=32)),
+    "attn_judged_2d_l0": (case_attention, dict(batch=32, heads=5, L=2880, threads=32)),
+    "attn_qs_judged_3d_l2_f24": (case_attention, dict(batch=2, heads=20, L=24 * 180, q_scaled=True, threads=32)),
+    # ... and one sequence of the 128x128 grid (1024^2 images, level-1 3-D attention at F = 16: 16 * 64 * 64 tokens)
+    "attn_qs_128sq_L65536": (case_attention, dict(batch=1, heads=1, L=65536, q_scaled=True, threads=32)),
+    "attn_128sq_L65536": (case_attention, dict(batch=1, heads=1, L=65536, threads=32)),
     # --- norms -----------------------------------------------------------------------------------
     "gn_320": (case_groupnorm, dict(B=4, HW=720, C1=320, C2=0, groups=32, silu=True)),
     "gn_concat_1920": (case_groupnorm, dict(B=3, HW=180, C1=1280, C2=640, groups=32, silu=True)),
