@@ -29,14 +29,37 @@ def needs_build() -> bool:
     return any(d.stat().st_mtime > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> Path:
-    if not force and not needs_build():
+def _stale(obj: Path, src: Path, headers) -> bool:
+    if not obj.exists():
+        return True
+    t = obj.stat().st_mtime
+    return src.stat().st_mtime > t or any(h.stat().st_mtime > t for h in headers)
+
+
+def build(force: bool = False, verbose: bool = True, defines=()) -> Path:
+    """One object per .hip source (compiled in parallel, rebuilt only when the source or a header changed), then one
+    link.  `defines`: extra -D flags (tuning builds); they force a full rebuild."""
+    if not force and not defines and not needs_build():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-I{INCLUDE}", f"-I{CSRC}",
-           "-o", str(LIB)] + [str(CSRC / s) for s in SOURCES]
-    if verbose:
-        print("[dm4d build]", " ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = ROOT / "build"
+    objdir.mkdir(exist_ok=True)
+    headers = list(CSRC.glob("*.h")) + list(INCLUDE.glob("*.h"))
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}"] + [f"-D{d}" for d in defines]
+    hipcc = _hipcc()
+    jobs = []
+    for s in SOURCES:
+        src, obj = CSRC / s, objdir / (Path(s).stem + ".o")
+        if force or defines or _stale(obj, src, headers):
+            jobs.append([hipcc, *flags, "-c", str(src), "-o", str(obj)])
+
+    def run(cmd):
+        if verbose:
+            print("[dm4d build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1) or 1) as ex:
+        list(ex.map(run, jobs))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB)] + [str(objdir / (Path(s).stem + ".o")) for s in SOURCES])
     return LIB
 
 

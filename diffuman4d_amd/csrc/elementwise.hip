@@ -197,6 +197,66 @@ __global__ void postprocess_kernel(const u16* X, u16* Y, int B, int C, int HW, i
   Y[i] = f2bf(v);
 }
 
+// Pluecker ray maps at LATENT resolution, straight from the cameras: what calc_plucker_embeds (ray_utils.py:101-112: rays
+// through the pixel centres of the H x W image, d = normalize(R^T (K^-1 [x+.5, y+.5, 1]^T - T) - o), o = -R^T T,
+// embed = [d | o x d]) followed by F.interpolate(size=(h, w), mode="bilinear") (pipeline_diffuman4d.py:90-100) produces,
+// without ever building the [N, 6, H, W] fp32 map (25 MB per 1024^2 frame, 7.5 GB per temporal task of 300 frames) on the
+// host: a latent pixel is the bilinear blend of the 2 x 2 full-resolution pixels around its sample point, so the kernel
+// evaluates those four rays and blends them with F.interpolate's weights.  cam[n] = {invK (9, row major), R (9), T (3),
+// o (3)} fp32, prepared on the host from K and the camera-to-world pose exactly as the reference does (torch.inverse).
+// One thread per latent pixel; out [N, h*w, 6] bf16.
+struct Ray6 {
+  float v[6];
+};
+__device__ __forceinline__ Ray6 plucker_ray(const float* cam, float px, float py) {
+  const float* iK = cam;
+  const float* R = cam + 9;
+  const float* T = cam + 18;
+  const float* o = cam + 21;
+  // pixel_camera = invK @ [x, y, 1]
+  const float c0 = iK[0] * px + iK[1] * py + iK[2], c1 = iK[3] * px + iK[4] * py + iK[5], c2 = iK[6] * px + iK[7] * py + iK[8];
+  const float t0 = c0 - T[0], t1 = c1 - T[1], t2 = c2 - T[2];
+  // pixel_world = R^T @ (pixel_camera - T);  ray_d = pixel_world - ray_o
+  float d0 = (R[0] * t0 + R[3] * t1 + R[6] * t2) - o[0];
+  float d1 = (R[1] * t0 + R[4] * t1 + R[7] * t2) - o[1];
+  float d2 = (R[2] * t0 + R[5] * t1 + R[8] * t2) - o[2];
+  const float inv = 1.0f / (sqrtf(d0 * d0 + d1 * d1 + d2 * d2) + 1e-8f);  // normalize(): x / (|x| + eps)
+  d0 *= inv;
+  d1 *= inv;
+  d2 *= inv;
+  Ray6 r;
+  r.v[0] = d0;
+  r.v[1] = d1;
+  r.v[2] = d2;
+  r.v[3] = o[1] * d2 - o[2] * d1;  // o x d
+  r.v[4] = o[2] * d0 - o[0] * d2;
+  r.v[5] = o[0] * d1 - o[1] * d0;
+  return r;
+}
+
+__global__ void plucker_latent_kernel(const float* cams, u16* Y, int N, int H, int W, int h, int w) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over N*h*w
+  if (i >= (int64_t)N * h * w) return;
+  const int ox = (int)(i % w);
+  const int64_t r = i / w;
+  const int oy = (int)(r % h), n = (int)(r / h);
+  const float* cam = cams + (int64_t)n * 24;
+  const float sy = (float)H / (float)h, sx = (float)W / (float)w;
+  float fy = ((float)oy + 0.5f) * sy - 0.5f, fx = ((float)ox + 0.5f) * sx - 0.5f;
+  fy = fy < 0.f ? 0.f : fy;
+  fx = fx < 0.f ? 0.f : fx;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  // pixel centres (correct_pix): column x + 0.5, row y + 0.5
+  const Ray6 a = plucker_ray(cam, (float)x0 + 0.5f, (float)y0 + 0.5f), b = plucker_ray(cam, (float)x1 + 0.5f, (float)y0 + 0.5f);
+  const Ray6 c = plucker_ray(cam, (float)x0 + 0.5f, (float)y1 + 0.5f), d = plucker_ray(cam, (float)x1 + 0.5f, (float)y1 + 0.5f);
+  u16* y = Y + i * 6;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) y[k] = f2bf(hy * (hx * a.v[k] + lx * b.v[k]) + ly * (hx * c.v[k] + lx * d.v[k]));
+}
+
 inline dim3 grid1d(int64_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
 
 }  // namespace
@@ -283,4 +343,11 @@ extern "C" int dm4d_postprocess_images_bf16(void* stream, const void* X, void* Y
   hipLaunchKernelGGL(postprocess_kernel, grid1d((int64_t)B * C * HW, 256), dim3(256), 0, (hipStream_t)stream,
                      (const u16*)X, (u16*)Y, B, C, HW, ldx);
   return dm4d_check_launch("postprocess_kernel");
+}
+
+extern "C" int dm4d_plucker_latent_bf16(void* stream, const float* cams, void* Y, int N, int H, int W, int h, int w) {
+  if (!cams || !Y || N <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0) return dm4d_set_error(DM4D_ERR_ARG, "plucker: bad arguments");
+  hipLaunchKernelGGL(plucker_latent_kernel, grid1d((int64_t)N * h * w, 256), dim3(256), 0, (hipStream_t)stream, cams, (u16*)Y, N,
+                     H, W, h, w);
+  return dm4d_check_launch("plucker_latent_kernel");
 }

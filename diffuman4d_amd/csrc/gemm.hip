@@ -120,8 +120,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
                       (!p.rowbias || (p.ld_rb & 7) == 0);
 #if GEMM_FAST_EPI
   static_assert(NI == 1 || NI == 2 || NI == 4, "the fast read-back loop needs a power-of-two number of 8-column chunks per row");
-  const bool fast_ok = vec_ok && p.ldc < (1 << 24) && (!p.res || p.ld_res < (1 << 24)) && (!p.rowbias || p.rows_per_rb > 0) && NJ > 0;
+  const bool fast_ok = vec_ok && p.ldc < (1 << 24) && (!p.res || p.ld_res < (1 << 24)) && (!p.rowbias || p.rows_per_rb > 0) && NJ > 0 &&
+                       !(p.flags & DM4D_EPI_F32OUT);
 #endif
+  const bool f32out = (p.flags & DM4D_EPI_F32OUT) != 0;  // C is float* (fp32 logits of the VAE mid-block attention)
   // The staging area is private to a wave and LDS operations of one wave complete in program order, so only one
   // workgroup barrier is needed: the one that retires every wave's main-loop fragment reads before the area is reused.
   __syncthreads();
@@ -220,13 +222,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
-        stg16(p.C + (int64_t)m * p.ldc + n, pack8(v));
+        if (f32out) {
+          float* cf = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
+          f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+          *reinterpret_cast<f32x4_t*>(cf) = o0;
+          *reinterpret_cast<f32x4_t*>(cf + 4) = o1;
+        } else {
+          stg16(p.C + (int64_t)m * p.ldc + n, pack8(v));
+        }
       } else {
         for (int e = 0; e < 8 && n + e < p.N; ++e) {
           float x = v[e];
           if (p.rowbias) x += bf2f(p.rowbias[(int64_t)(m / p.rows_per_rb) * p.ld_rb + n + e]);
           if (p.res) x += bf2f(p.res[(int64_t)m * p.ld_res + n + e]);
-          p.C[(int64_t)m * p.ldc + n + e] = f2bf(x * p.out_scale);
+          if (f32out) reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + n + e] = x * p.out_scale;
+          else p.C[(int64_t)m * p.ldc + n + e] = f2bf(x * p.out_scale);
         }
       }
     }

@@ -252,6 +252,49 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const u16* S, int64_t
   for (int i = tid; i < N; i += 256) o[i] = f2bf(__builtin_amdgcn_exp2f((bf2f(s[i]) - mx) * c) * inv);
 }
 
+// the same for fp32 logits (VAE mid-block attention, d = 512: SDPA keeps its logits in fp32; rounding them to bf16 first
+// costs up to 2^-9 * |logit| in the exponent).  Rows are read as float4 (N % 4 == 0, 16-byte aligned rows); the second
+// and third pass of a row hit L2.
+__global__ __launch_bounds__(256) void softmax_rows_f32_kernel(const float* S, int64_t lds, u16* P, int64_t ldp, int N,
+                                                               float scale) {
+  __shared__ float red[8];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const f32x4_t* s = reinterpret_cast<const f32x4_t*>(S + (int64_t)row * lds);
+  uint2* o = reinterpret_cast<uint2*>(P + (int64_t)row * ldp);
+  const int n4 = N >> 2;
+  float mx = -3.0e38f;
+  for (int i = tid; i < n4; i += 256) {
+    const f32x4_t v = s[i];
+    mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float c = scale * 1.4426950408889634f;
+  const float mc = mx * c;
+  float sum = 0.f;
+  for (int i = tid; i < n4; i += 256) {
+    const f32x4_t v = s[i];
+    sum += (__builtin_amdgcn_exp2f(fmaf(v[0], c, -mc)) + __builtin_amdgcn_exp2f(fmaf(v[1], c, -mc))) +
+           (__builtin_amdgcn_exp2f(fmaf(v[2], c, -mc)) + __builtin_amdgcn_exp2f(fmaf(v[3], c, -mc)));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  sum = (red[4] + red[5]) + (red[6] + red[7]);
+  const float inv = 1.0f / sum;
+  for (int i = tid; i < n4; i += 256) {
+    const f32x4_t v = s[i];
+    uint2 w;
+    w.x = pack_bf2(__builtin_amdgcn_exp2f(fmaf(v[0], c, -mc)) * inv, __builtin_amdgcn_exp2f(fmaf(v[1], c, -mc)) * inv);
+    w.y = pack_bf2(__builtin_amdgcn_exp2f(fmaf(v[2], c, -mc)) * inv, __builtin_amdgcn_exp2f(fmaf(v[3], c, -mc)) * inv);
+    o[i] = w;
+  }
+}
+
 }  // namespace
 
 extern "C" size_t dm4d_groupnorm_ws_bytes(int B, int HW, int groups) {
@@ -307,4 +350,13 @@ extern "C" int dm4d_softmax_rows_bf16(void* stream, const void* S, int64_t lds, 
   hipLaunchKernelGGL(softmax_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const u16*)S, lds, (u16*)P, ldp,
                      N, scale);
   return dm4d_check_launch("softmax_rows_kernel");
+}
+
+extern "C" int dm4d_softmax_rows_f32in_bf16(void* stream, const float* S, int64_t lds, void* P, int64_t ldp, int M, int N,
+                                            float scale) {
+  if (!S || !P || M <= 0 || N <= 0) return dm4d_set_error(DM4D_ERR_ARG, "softmax: null pointer or empty shape");
+  if ((N & 3) || (lds & 3) || (ldp & 3) || (((uintptr_t)S) & 15) || (((uintptr_t)P) & 7))
+    return dm4d_set_error(DM4D_ERR_ARG, "softmax (fp32 logits): N and the row strides must be multiples of 4, rows 16-byte aligned");
+  hipLaunchKernelGGL(softmax_rows_f32_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, S, lds, (u16*)P, ldp, N, scale);
+  return dm4d_check_launch("softmax_rows_f32_kernel");
 }

@@ -32,6 +32,7 @@ SIGNATURES = {
     "dm4d_attention_kv_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _f]),
     "dm4d_attention_qscaled_kv_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i]),
     "dm4d_softmax_rows_bf16": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _f]),
+    "dm4d_softmax_rows_f32in_bf16": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _f]),
     "dm4d_timestep_embedding_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _f]),
     "dm4d_silu_bf16": (_i, [_vp, _vp, _vp, _i64]),
     "dm4d_pack_model_input_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
@@ -39,6 +40,7 @@ SIGNATURES = {
     "dm4d_vae_sample_bf16": (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _i, _f]),
     "dm4d_scale_pad_bf16": (_i, [_vp, _vp, _i64, _vp, _i, _i64, _i, _f]),
     "dm4d_resize_nchw_f32_to_nhwc_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
+    "dm4d_plucker_latent_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "dm4d_postprocess_images_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),
     "dm4d_tune_set_gemm_config": (_i, [_i]),
     "dm4d_nchw_to_nhwc_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),
@@ -47,6 +49,7 @@ SIGNATURES = {
 
 EPI_GEGLU = 1
 EPI_SILU = 2
+EPI_F32OUT = 4
 
 
 class Dm4dError(RuntimeError):

@@ -34,8 +34,9 @@ def _p(t: Optional[torch.Tensor]):
 
 def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None, bias=None, rowbias=None,
          rows_per_rowbias: int = 1, residual=None, geglu: bool = False, silu: bool = False, out_scale: float = 1.0,
-         out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[M,N] = epi([a | a2] @ w^T); a [M,K1], a2 [M,K-K1], w [N,K] (GEGLU: [2N,K])."""
+         out: Optional[torch.Tensor] = None, out_f32: bool = False) -> torch.Tensor:
+    """out[M,N] = epi([a | a2] @ w^T); a [M,K1], a2 [M,K-K1], w [N,K] (GEGLU: [2N,K]).
+    out_f32: the result is stored unrounded in an fp32 tensor (attention logits of the VAE mid block)."""
     lib = _l.load()
     _req(a, "a"), _req(w, "w")
     M, K1 = a.shape
@@ -50,9 +51,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
         if t is not None:
             _req(t, n)
     if out is None:
-        out = torch.empty((M, N), dtype=BF16, device=a.device)
-    _req(out, "out")
-    flags = (_l.EPI_GEGLU if geglu else 0) | (_l.EPI_SILU if silu else 0)
+        out = torch.empty((M, N), dtype=torch.float32 if out_f32 else BF16, device=a.device)
+    _req(out, "out", torch.float32 if out_f32 else BF16)
+    flags = (_l.EPI_GEGLU if geglu else 0) | (_l.EPI_SILU if silu else 0) | (_l.EPI_F32OUT if out_f32 else 0)
     with _Prof("linear", 2.0 * M * w.shape[0] * K, "flop"):
         rc = lib.dm4d_gemm_bf16(_stream(), _p(a), a.stride(0), _p(a2), a2.stride(0) if a2 is not None else 0,
                                 K1 if a2 is not None else 0, _p(w), w.stride(0), _p(out), out.stride(0), M, N, K,
@@ -215,11 +216,14 @@ class _Prof:
 
 
 def softmax_rows(s: torch.Tensor, scale: float) -> torch.Tensor:
+    """P = softmax(s * scale) per row, bf16; s bf16 or fp32 (logits from gemm(out_f32=True))."""
     lib = _l.load()
-    _req(s, "s")
-    p = torch.empty_like(s)
-    rc = lib.dm4d_softmax_rows_bf16(_stream(), _p(s), s.stride(0), _p(p), p.stride(0), s.shape[0], s.shape[1], scale)
-    _l.check(rc, "dm4d_softmax_rows_bf16")
+    f32 = s.dtype == torch.float32
+    _req(s, "s", torch.float32 if f32 else BF16)
+    p = torch.empty(s.shape, dtype=BF16, device=s.device)
+    fn = lib.dm4d_softmax_rows_f32in_bf16 if f32 else lib.dm4d_softmax_rows_bf16
+    rc = fn(_stream(), _p(s), s.stride(0), _p(p), p.stride(0), s.shape[0], s.shape[1], scale)
+    _l.check(rc, "dm4d_softmax_rows_f32in_bf16" if f32 else "dm4d_softmax_rows_bf16")
     return p
 
 
@@ -337,6 +341,28 @@ def resize_to_nhwc(x: torch.Tensor, size: Tuple[int, int], mode: str) -> torch.T
     y = torch.empty((B, h, w, C), dtype=BF16, device=x.device)
     rc = lib.dm4d_resize_nchw_f32_to_nhwc_bf16(_stream(), _p(x), _p(y), B, C, H, W, h, w, 1 if mode == "bilinear" else 0)
     _l.check(rc, "dm4d_resize_nchw_f32_to_nhwc_bf16")
+    return y
+
+
+def camera_rows(Ks: torch.Tensor, poses: torch.Tensor) -> torch.Tensor:
+    """Per-frame camera constants of dm4d_plucker_latent_bf16, on the host in fp32 as the reference prepares them
+    (ray_utils.py:56-59,101-105): [K^-1 | R | T | -R^T T] with [R | T] = inverse(pose)[:3].  -> [N, 24] fp32 (CPU)."""
+    Ks, poses = Ks.detach().float().cpu(), poses.detach().float().cpu()
+    ext = torch.inverse(poses)
+    R, T = ext[:, :3, :3], ext[:, :3, 3:]
+    o = -R.mT @ T
+    return torch.cat([torch.inverse(Ks).reshape(-1, 9), R.reshape(-1, 9), T.reshape(-1, 3), o.reshape(-1, 3)], dim=1).contiguous()
+
+
+def plucker_latents(Ks: torch.Tensor, poses: torch.Tensor, image_size: Tuple[int, int], latent_size: Tuple[int, int],
+                    device) -> torch.Tensor:
+    """Pluecker maps at latent resolution from the cameras -> bf16 NHWC [N, h, w, 6] on `device` (see dm4d.h)."""
+    lib = _l.load()
+    cams = camera_rows(Ks, poses).to(device)
+    (H, W), (h, w) = image_size, latent_size
+    y = torch.empty((cams.shape[0], h, w, 6), dtype=BF16, device=device)
+    rc = lib.dm4d_plucker_latent_bf16(_stream(), _p(cams), _p(y), cams.shape[0], H, W, h, w)
+    _l.check(rc, "dm4d_plucker_latent_bf16")
     return y
 
 

@@ -112,16 +112,24 @@ class Diffuman4DPipeline:
         return ops.nchw_to_nhwc(x, cpad)
 
     def prepare_all_latents(self, pixel_values, plucker_embeds, skeletons, cond_masks, latents, noise: Optional[Dict],
-                            cache_keys=None):
+                            cache_keys=None, cameras: Optional[Dict] = None):
         """pipeline_diffuman4d.py:193-263 (sliding entry).  Returns NHWC bf16 device tensors.
         cache_keys: one hashable key per frame (e.g. (camera, frame) labels) -> VAE encoder moments are reused
-        across tasks and alternation rounds (see AutoencoderKL.encode_scaled)."""
+        across tasks and alternation rounds (see AutoencoderKL.encode_scaled).
+        cameras (with plucker_embeds=None): {"Ks": [N,3,3], "poses": [N,4,4] camera-to-world, "image_size": (H, W)} -> the
+        Pluecker maps are evaluated on the device at latent resolution (ops.plucker_latents) instead of being built at
+        image resolution on the host, shipped and resized (spatem_dataset.py:169-176 + :90-100)."""
         noise = noise or {}
         n = pixel_values.shape[0]
         ck = dict(cache=self._vae_cache["pixel"], keys=cache_keys) if cache_keys is not None else {}
         pv_lat = self.vae.encode_scaled(pixel_values, noise.get("pixel"), **ck)  # [N,h,w,4], x scaling_factor
         h, w = pv_lat.shape[1:3]
-        pl_lat = self.vae.resize_to_nhwc(plucker_embeds, (h, w), "bilinear")
+        if plucker_embeds is not None:
+            pl_lat = self.vae.resize_to_nhwc(plucker_embeds, (h, w), "bilinear")
+        elif cameras is not None:
+            pl_lat = ops.plucker_latents(cameras["Ks"], cameras["poses"], tuple(cameras["image_size"]), (h, w), self._device)
+        else:
+            raise ValueError("plucker_embeds is None and no cameras were given")
         if self.unet.config.enable_pose_encoder:
             # the reference hands the raw skeleton images to the UNet, which re-encodes them on every call
             # (:229-231; unet_multiview_condition.py:551-552); they do not change, so encode once per task
@@ -221,12 +229,13 @@ class Diffuman4DPipeline:
                                   sliding_stride: int = 1, sliding_shift: int = 0, bidirectional: bool = True,
                                   num_denoising_steps: int = 1, alternation_rounds: int = 3, guidance_scale: float = 2.0,
                                   tqdm: Callable = _identity_tqdm, noise: Optional[Dict] = None, cache_keys=None,
-                                  decode: str = "all"):
+                                  decode: str = "all", cameras: Optional[Dict] = None):
         """Same contract as pipeline_diffuman4d.py:439-559 (inputs are not mutated).
         Extensions, off by default (= the reference's behaviour): `noise` injects the random draws; `cache_keys`
         (one hashable per frame) reuses VAE encoder moments across calls; `decode="denoised"` runs the VAE decoder
         only for fully denoised rows -- the only ones the sampler saves (sampling_utils.py:103-104) -- and returns
-        zero images for the rest."""
+        zero images for the rest; `cameras` (with plucker_embeds=None) evaluates the Pluecker maps on the device at latent
+        resolution (see prepare_all_latents)."""
         if decode not in ("all", "denoised"):
             raise ValueError("decode must be 'all' or 'denoised'")
         if self.vae is None:
@@ -236,7 +245,7 @@ class Diffuman4DPipeline:
         plan = plan_sweep(cond_flags, torch.as_tensor(timestep_indices).cpu().numpy(), domain, window_size,
                           sliding_stride, sliding_shift, bidirectional, num_denoising_steps, alternation_rounds)
         pv_lat, pl_lat, sk_lat, cm_lat, lat = self.prepare_all_latents(pixel_values, plucker_embeds, skeletons,
-                                                                       cond_masks, latents, noise, cache_keys)
+                                                                       cond_masks, latents, noise, cache_keys, cameras)
         self.denoise_latents(pv_lat, pl_lat, sk_lat, cm_lat, lat, plan, domain, guidance_scale, tqdm)
         tidx = torch.from_numpy(plan.final_timestep_indices)
         rows = (tidx == plan.num_inference_steps) if decode == "denoised" else None

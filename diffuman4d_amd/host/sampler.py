@@ -11,7 +11,8 @@ What is organised differently here:
     a task's cells are two small methods under one lock;
   * ``result_writer`` is injectable (the reference hard-wires ``save_sampling_results``);
   * ``partition(round, rank, world)`` exposes the per-round task sharding used by the one-process-per-GPU runner;
-  * optional pipeline extensions (``vae_cache``, ``decode_policy``, ``prune_cond_rows``), off by default.
+  * optional pipeline extensions (``vae_cache``, ``decode_policy``, ``prune_cond_rows``, ``plucker_on_device``), off by
+    default.
 """
 from __future__ import annotations
 
@@ -61,7 +62,8 @@ class SlidingIterativeSampler:
                  spa_label_range: Optional[Sequence[int]] = (0, 48, 1), tem_label_range: Optional[Sequence[int]] = (0, 150, 1),
                  spa_labels: Optional[Sequence[int]] = None, tem_labels: Optional[Sequence[int]] = None,
                  input_spa_labels: Sequence[int] = (1, 13, 25, 37), result_writer: Optional[Callable] = None,
-                 vae_cache: bool = False, decode_policy: str = "all", prune_cond_rows: bool = False):
+                 vae_cache: bool = False, decode_policy: str = "all", prune_cond_rows: bool = False,
+                 plucker_on_device: bool = False):
         self.dataset, self.pipelines, self.output_dir = dataset, pipelines, output_dir
         self.sweep = SweepConfig(window_size, sliding_stride, sliding_shift, bidirectional, num_denoising_steps,
                                  alternation_rounds, guidance_scale)
@@ -71,6 +73,7 @@ class SlidingIterativeSampler:
         if decode_policy not in ("all", "denoised"):
             raise ValueError("decode_policy must be 'all' or 'denoised'")
         self.vae_cache, self.decode_policy = bool(vae_cache), decode_policy
+        self.plucker_on_device = bool(plucker_on_device)
         if self.vae_cache:  # the cache is keyed by (camera, frame) of ONE scene
             for pipe in pipelines:
                 pipe.clear_vae_cache()
@@ -186,6 +189,8 @@ class SlidingIterativeSampler:
         bar = partial(_tqdm, desc=f"Denoising alt{sample['alt']}_{axis}{sample['domain_label']} on {pipe.device}")
         tensors = {k: sample[k] for k in ("pixel_values", "plucker_embeds", "skeletons", "cond_masks", "latents",
                                           "timestep_indices")}
+        if self.plucker_on_device:
+            tensors["plucker_embeds"] = None
         result = pipe.sliding_iterative_denoise(domain=sample["domain"], tqdm=bar, **tensors, **asdict(self.sweep),
                                                 **self._pipeline_extensions(sample))
         sample["images"] = result["images"].float().cpu()
@@ -204,6 +209,10 @@ class SlidingIterativeSampler:
         image is otherwise re-encoded by each task that touches it, in every round (pipeline_diffuman4d.py:208-239) --
         and decoding only the rows that are saved (sampling_utils.py:103-104)."""
         kw = {}
+        if self.plucker_on_device:  # cameras instead of full-resolution ray maps (SURVEY 8f-2)
+            if sample.get("Ks") is None or sample.get("poses") is None:
+                raise ValueError("plucker_on_device needs the dataset's 'Ks' and 'poses' (spatem_dataset.py:178-189)")
+            kw["cameras"] = {"Ks": sample["Ks"], "poses": sample["poses"], "image_size": tuple(sample["pixel_values"].shape[-2:])}
         if self.vae_cache:
             kw["cache_keys"] = [(spa, tem) for _, spa, tem in sample["labels"]]
         if self.decode_policy != "all":

@@ -64,6 +64,8 @@ class _Res:
 class _MidAttn:
     """Single-head attention, GroupNorm on the input, q/k/v with bias, residual connection."""
 
+    QBLOCK_BYTES = 128 << 20  # fp32 logits of one query block
+
     def __init__(self, W: _Weights, pfx: str, groups: int):
         self.g = groups
         self.nw, self.nb = W.vec(pfx + "group_norm.weight"), W.vec(pfx + "group_norm.bias")
@@ -83,13 +85,18 @@ class _MidAttn:
         qkv = ops.gemm(n.view(B * L, C), self.qkv_w, bias=self.qkv_b)  # [B*L, 3C]
         o = torch.empty((B * L, C), dtype=BF16, device=x.device)
         scale = float(C) ** -0.5
+        # S = q k^T stays in fp32 from the MFMA accumulator to the softmax (SDPA's logits are fp32; a bf16 round trip would
+        # cost 2^-9 |logit| in the exponent at d = 512).  Query rows go in blocks so that the fp32 logits of a block stay
+        # below QBLOCK_BYTES whatever the image size: 1024^2 images have L = 16 384, i.e. 1 GB per image unblocked.
+        qb = max(32, min(L, (self.QBLOCK_BYTES // (4 * L)) // 32 * 32))
         for b in range(B):
             rows = slice(b * L, (b + 1) * L)
-            q, k, v = qkv[rows, :C], qkv[rows, C:2 * C], qkv[rows, 2 * C:]
-            s = ops.gemm(q, k)  # [L, L] = q k^T
-            p = ops.softmax_rows(s, scale)
+            k, v = qkv[rows, C:2 * C], qkv[rows, 2 * C:]
             vt = _transpose(v, C)  # [C, L]
-            ops.gemm(p, vt, out=o[rows])
+            for q0 in range(0, L, qb):
+                q1 = min(L, q0 + qb)
+                s = ops.gemm(qkv[b * L + q0: b * L + q1, :C], k, out_f32=True)  # [q1 - q0, L] fp32
+                ops.gemm(ops.softmax_rows(s, scale), vt, out=o[b * L + q0: b * L + q1])
         return ops.gemm(o, self.ow, bias=self.ob, residual=x.view(B * L, C)).view(B, H, Wd, C)
 
 

@@ -32,6 +32,7 @@ extern "C" {
 /* gemm / conv epilogue flags */
 #define DM4D_EPI_GEGLU 1u /* W holds [2*N, K]: out = (x W_h^T + b_h) * gelu(x W_g^T + b_g)   */
 #define DM4D_EPI_SILU 2u  /* out = silu(acc + bias ...) (time embedding MLP)                 */
+#define DM4D_EPI_F32OUT 4u /* dm4d_gemm_bf16 only: C is float* [M, ldc] (ldc in floats): the result is stored unrounded */
 
 int dm4d_version(void);
 const char* dm4d_last_error(void);
@@ -117,8 +118,12 @@ int dm4d_attention_kv_bf16(void* stream, const void* Q, const void* K, const voi
 int dm4d_attention_qscaled_kv_bf16(void* stream, const void* Q, const void* K, const void* V, void* O, int64_t ldq,
                                    int64_t ldk, int64_t ldv, int64_t ldo, int batch, int heads, int Lq, int Lk);
 
-/* Generic-head-dim attention pieces for the VAE mid block (single head, d = 512): row softmax.   */
+/* Generic-head-dim attention pieces for the VAE mid block (AutoencoderKL mid_block.attentions.0: single head, d = 512,
+ *   reached from pipeline_diffuman4d.py:52,65): P = softmax(S * scale) per row, P in bf16.  The f32in form takes the
+ *   logits as dm4d_gemm_bf16(..., DM4D_EPI_F32OUT) leaves them (SDPA keeps its logits in fp32);
+ *   N, lds, ldp multiples of 4 there.                                                                              */
 int dm4d_softmax_rows_bf16(void* stream, const void* S, int64_t lds, void* P, int64_t ldp, int M, int N, float scale);
+int dm4d_softmax_rows_f32in_bf16(void* stream, const float* S, int64_t lds, void* P, int64_t ldp, int M, int N, float scale);
 
 /* sinusoidal timestep embedding, diffusers get_timestep_embedding (unet_multiview_condition.py:494):
  *   out[b, :] = [cos(t*f) | sin(t*f)] (flip_sin_to_cos) in bf16, t given as fp32                  */
@@ -159,6 +164,13 @@ int dm4d_scale_pad_bf16(void* stream, const void* X, int64_t ldx, void* Y, int c
  *   (encode_image_resizing, pipeline_diffuman4d.py:90-100: Pluecker maps and condition masks)        */
 int dm4d_resize_nchw_f32_to_nhwc_bf16(void* stream, const float* X, void* Y, int B, int C, int H, int W, int h, int w,
                                       int bilinear);
+
+/* Pluecker ray maps at latent resolution, from the cameras: calc_plucker_embeds(H, W, K, pose) (data/utils/ray_utils.py:101-112,
+ *   called at spatem_dataset.py:169-176) followed by F.interpolate(size=(h, w), mode="bilinear") and the cast to bf16
+ *   (encode_image_resizing, pipeline_diffuman4d.py:90-100, 218-222) in one launch: no [N, 6, H, W] fp32 map on the host, no
+ *   H2D copy of it.  cams [N, 24] fp32 = per frame {K^-1 (9, row major) | R (9) | T (3) | o = -R^T T (3)} with [R | T] =
+ *   inverse(camera-to-world pose)[:3]; Y [N, h*w, 6] bf16 = [ray direction | o x direction].                        */
+int dm4d_plucker_latent_bf16(void* stream, const float* cams, void* Y, int N, int H, int W, int h, int w);
 
 /* VaeImageProcessor.postprocess(do_denormalize): (x/2 + 0.5).clamp(0,1), NHWC(ldx) -> NCHW (:282-284)  */
 int dm4d_postprocess_images_bf16(void* stream, const void* X, void* Y, int B, int C, int HW, int ldx);

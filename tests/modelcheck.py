@@ -419,6 +419,34 @@ def case_pipeline_prune(domain="spatial", seed=41):
     return (err if exact else 1.0), 0.0
 
 
+def case_pipeline_plucker_on_device(seed=51):
+    """the Pluecker conditioning evaluated on the device at latent resolution from the cameras vs the
+    reference route (full-resolution fp32 maps built on the host, shipped, resized on the device) -- same task, same
+    noise.  The two maps differ by isolated bf16 ulps (tests/opcheck.py::plucker_*), so the results agree to noise."""
+    from diffuman4d_amd.host.pipeline import Diffuman4DPipeline
+    from diffuman4d_amd.host.scheduler import DDIMConfig as HC, DDIMScheduler as HS
+    from oracle import plucker as op
+    from test_plucker import cameras
+    cfg_u, ou = make_unet(seed)
+    cfg_v, ov = make_vae(seed + 1)
+    n, inputs, H, W = 8, [1, 5], 64, 64
+    pv, _, sk, cm = synthetic_task(n, H, W, inputs, seed)
+    Ks, poses = cameras(n, H, W, seed)
+    poses = op.calc_relative_poses(poses)
+    pl = op.calc_plucker_embeds(H, W, Ks, poses)
+    g = torch.Generator().manual_seed(seed + 2)
+    noise = {k: torch.randn(n, 4, 8, 8, generator=g).to(BF) for k in ("pixel", "skeleton", "latents")}
+    kw = dict(pixel_values=pv, skeletons=sk, cond_masks=cm, latents=None, domain="spatial",
+              timestep_indices=torch.zeros(n, dtype=torch.int64), window_size=4, sliding_stride=2, sliding_shift=0,
+              bidirectional=False, num_denoising_steps=1, alternation_rounds=1, guidance_scale=2.0, noise=noise)
+    hp = Diffuman4DPipeline(hip_vae(cfg_v, ov), hip_unet(cfg_u, ou), HS(HC()), "cuda")
+    ref = hp.sliding_iterative_denoise(plucker_embeds=pl, **kw)
+    out = hp.sliding_iterative_denoise(plucker_embeds=None, cameras={"Ks": Ks, "poses": poses, "image_size": (H, W)}, **kw)
+    exact = torch.equal(out["timestep_indices"], ref["timestep_indices"]) and torch.equal(out["fully_denoised"], ref["fully_denoised"])
+    err = max(rel_l2(out["latents"], ref["latents"]), rel_l2(out["images"], ref["images"]))
+    return (err if exact else 1.0), 0.0
+
+
 def case_golden_pipeline(name):
     """HIP sliding_iterative_denoise vs the output of the REFERENCE's own pipeline code (committed
     fixture tests/golden/pipeline_sliding.pt, fp32): same seeded weights, task tensors and noise."""
@@ -465,6 +493,7 @@ CASES = {
     "pipeline_cache_lazy_decode": (case_pipeline_cache_lazy, dict()),
     "pipeline_prune_cond_rows": (case_pipeline_prune, dict(domain="spatial")),
     "pipeline_prune_cond_rows_temporal": (case_pipeline_prune, dict(domain="temporal")),
+    "pipeline_plucker_on_device": (case_pipeline_plucker_on_device, dict()),
     "vae": (case_vae, dict()),
     "resize": (case_resize, dict()),
     "pipeline_spatial": (case_pipeline, dict(domain="spatial")),
@@ -484,7 +513,7 @@ CASES = {
 # Every other case is judged against its bf16-oracle yardstick (YARD_FACTOR, see the module docstring).
 TOL = {"pipeline_shard_rccl_world1": 0.0, "unet_frame_shard_p4": 0.0, "unet_frame_shard_p8": 0.0,
        "pipeline_cache_lazy_decode": 0.0, "pipeline_prune_cond_rows": 5e-3, "pipeline_prune_cond_rows_temporal": 5e-3,
-       "resize": 4e-3}
+       "pipeline_plucker_on_device": 5e-3, "resize": 4e-3}
 
 
 def judge(name, err, yard):

@@ -220,6 +220,40 @@ def case_softmax(M, N, seed=0):
     return rel_l2(out, ref), float((out.float().cpu() - ref).abs().max())
 
 
+def case_logits_softmax_f32(M, N, K, seed=0):
+    """VAE mid-block attention pieces: fp32 logits straight from the GEMM (DM4D_EPI_F32OUT) and the softmax that reads
+    them.  The logits must equal an fp32 matmul of the bf16 operands to accumulation order (no bf16 rounding)."""
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    q, k = _rnd((M, K), g), _rnd((N, K), g)
+    ref_s = q.float() @ k.float().t()
+    s = ops.gemm(q.cuda(), k.cuda(), out_f32=True)
+    assert s.dtype == torch.float32
+    e_logits = rel_l2(s, ref_s)
+    scale = K ** -0.5
+    p = ops.softmax_rows(s, scale)
+    e_p = rel_l2(p, torch.softmax(ref_s * scale, dim=-1))
+    return (e_p if e_logits <= 2e-6 else 1.0), e_logits
+
+
+def case_plucker(n, H, W, h, w, seed=0):
+    """Pluecker maps at latent resolution from the cameras (one launch) vs the reference path restated in
+    oracle/plucker.py: full-resolution fp32 maps on the CPU -> F.interpolate(bilinear) -> bf16.  Both round the same
+    fp32 values (to a few ulp) to bf16, so they may differ by one bf16 ulp on isolated elements."""
+    from diffuman4d_amd.host import ops
+    from oracle import plucker as op
+    from test_plucker import cameras
+    Ks, poses = cameras(n, H, W, seed)
+    poses = op.calc_relative_poses(poses)
+    ref = op.plucker_latents(H, W, Ks, poses, (h, w)).permute(0, 2, 3, 1)  # NHWC bf16
+    out = ops.plucker_latents(Ks, poses, (H, W), (h, w), "cuda")
+    assert tuple(out.shape) == (n, h, w, 6)
+    diff = (out.float().cpu() - ref.float()).abs()
+    ulp_ok = bool((diff <= 2.0 ** -7 * ref.float().abs().clamp(min=0.5)).all())  # <= 1 bf16 ulp at the element's magnitude
+    frac_exact = float((diff == 0).float().mean())
+    return (rel_l2(out, ref) if ulp_ok and frac_exact > 0.97 else 1.0), float(diff.max())
+
+
 def case_temb(B, dim, seed=0):
     from diffuman4d_amd.host import ops
     from oracle.unet import timestep_embedding
@@ -398,6 +432,12 @@ CASES = {
     "ln_1280": (case_layernorm, dict(M=77, C=1280)),
     "ln_64": (case_layernorm, dict(M=130, C=64)),
     "softmax": (case_softmax, dict(M=50, N=2880)),
+    "logits_softmax_f32": (case_logits_softmax_f32, dict(M=320, N=2880, K=512)),
+    "logits_softmax_f32_ragged": (case_logits_softmax_f32, dict(M=77, N=200, K=64)),
+    # --- conditioning prep on the device ---------------------------------------------
+    "plucker_576x320": (case_plucker, dict(n=6, H=576, W=320, h=72, w=40)),
+    "plucker_odd_ratio": (case_plucker, dict(n=3, H=100, W=60, h=7, w=5, seed=2)),
+    "plucker_identity_size": (case_plucker, dict(n=2, H=16, W=24, h=16, w=24, seed=3)),
     # --- small kernels ---------------------------------------------------------------------------
     "temb": (case_temb, dict(B=8, dim=320)),
     "silu": (case_silu, dict(n=32 * 1280 + 3)),
@@ -407,7 +447,7 @@ CASES = {
     "pack_ddim_noskel": (case_pack_ddim, dict(F_=8, HW=30, use_cfg=True, vpred=False, skel=False)),
 }
 
-TOLS = {"layout": 0.0, "temb": 6e-3, "attn_kv_split": 0.0, "attn_kv_split3": 0.0, "attn_qs_kv_split": 0.0,
+TOLS = {"plucker_576x320": 2e-3, "plucker_odd_ratio": 2e-3, "plucker_identity_size": 2e-3, "layout": 0.0, "temb": 6e-3, "attn_kv_split": 0.0, "attn_kv_split3": 0.0, "attn_qs_kv_split": 0.0,
         "conv_batch_invariance_l3": 0.0, "conv_batch_invariance_l2": 0.0}
 
 

@@ -28,8 +28,8 @@ def test_cli_path_on_synthetic_checkpoint(tmp_path, fast):
           "data.height=64", "data.width=64", "data.num_cameras=8", f"result_dir={tmp_path / 'results'}",
           "sampler.spa_label_range=[0,8,1]", "sampler.tem_label_range=[0,4,1]", "sampler.input_spa_labels=[1,5]",
           "sampler.window_size=4", "sampler.sliding_stride=2"]
-    if fast:
-        ov += ["sampler.vae_cache=true", "sampler.decode_policy=denoised"]
+    if fast:  # every opt-in extension at once: VAE moment cache, decode-on-demand, Pluecker maps from the cameras on the device
+        ov += ["sampler.vae_cache=true", "sampler.decode_policy=denoised", "sampler.plucker_on_device=true", "data.plucker=cameras"]
     cfg = cfglib.compose(ov)
     pipelines = cfglib.instantiate(cfg["model"])
     assert len(pipelines) == 1 and pipelines[0].device.type == "cuda"
