@@ -967,6 +967,10 @@ int launch_by_id(int id, hipStream_t st, GemmParams& p) {
     case 16: return launch_pipe<256, 256, 2, 4, 3, CONV>(st, p);
     case 17: return launch_pipe<256, 64, 4, 1, 4, CONV>(st, p);
     case 18: return launch_pipe<128, 64, 4, 1, 4, CONV>(st, p);
+    // 16 waves (one 1024-thread workgroup per CU, four waves per SIMD like two 8-wave workgroups) on a 256x256 tile: the
+    // per-wave work of id 14 (64x64) with 2/3 of its L2->LDS bytes per flop -- these kernels run at the CU's fill rate
+    case 19: return launch_pipe<256, 256, 4, 4, 3, CONV>(st, p);
+    case 20: return launch_pipe<256, 256, 4, 4, 4, CONV>(st, p);
     case 31: case 32: case 33: case 34:
       if constexpr (CONV) {
         if (!(k64 && p.stride == 1 && p.pad == 1 && !p.upsample && p.Ho == p.H && p.Wo == p.W)) return DM4D_ERR_ARG;
