@@ -48,6 +48,9 @@ KERNELS = {
     'gemm_ff1_l1': lambda: gemm(M1, 2560, 640, geglu=True, res=False), 'gemm_ff2_l1': lambda: gemm(M1, 640, 2560),
     'gn_l0': lambda: gn(32, 2880, 320), 'gn_l2': lambda: gn(32, 180, 1280),
 }
+if len(sys.argv) > 2:  # force one GEMM / conv kernel configuration id (tuning hook)
+    from diffuman4d_amd.host import lib as _l
+    _l.load().dm4d_tune_set_gemm_config(int(sys.argv[2]))
 f = KERNELS[sys.argv[1]]()
 for _ in range(5):
     f()
