@@ -23,10 +23,10 @@ rocprofv3 -L > $O/counters.txt 2>&1
 cd /tmp; cd "$GRAFT_REPO_ROOT"
 for k in "gemm_qkv_l0" "gemm_qkv_l0 19" "gemm_ff1_l0" "gemm_ff1_l0 19" "conv_l1"; do
   tag=$(echo $k | tr ' ' '_')
-  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU -d $O/pmc -o ${tag}_a -- python tools/dev/one.py $k > /dev/null 2>$O/pmc_${tag}_a.err
-  rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum -d $O/pmc -o ${tag}_c -- python tools/dev/one.py $k > /dev/null 2>$O/pmc_${tag}_c.err
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc -o ${tag}_d -- python tools/dev/one.py $k > /dev/null 2>$O/pmc_${tag}_d.err
-  python tools/dev/pmc_report.py $O/pmc $tag gemm_kernel conv_strip > $O/pmc_$tag.txt 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU -d /tmp/pmc -o ${tag}_a -- python tools/dev/one.py $k > /dev/null 2>$O/pmc_${tag}_a.err
+  rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum -d /tmp/pmc -o ${tag}_c -- python tools/dev/one.py $k > /dev/null 2>$O/pmc_${tag}_c.err
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc -o ${tag}_d -- python tools/dev/one.py $k > /dev/null 2>$O/pmc_${tag}_d.err
+  python tools/dev/pmc_report.py /tmp/pmc $tag gemm_kernel conv_strip > $O/pmc_$tag.txt 2>&1
 done
-rm -rf $O/pmc/*/*.db 2>/dev/null; du -sh $O
+du -sh $O
 tail -5 $O/fill_probe.log; tail -3 $O/gemm_tune.log; tail -3 $O/pytest_fp16.log

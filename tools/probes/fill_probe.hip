@@ -63,11 +63,14 @@ __global__ __launch_bounds__(NW * 64) void fill_kernel(Args a) {
   if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u) a.sink[threadIdx.x] = acc.x;
 }
 
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); fflush(stdout); exit(1); } } while (0)
+
 template <int NW, int DEPTH, bool TO_LDS>
 double run(Args a, int wgs_per_cu, double clock_mhz) {
   const int grid = 256 * wgs_per_cu;
   hipLaunchKernelGGL((fill_kernel<NW, DEPTH, TO_LDS>), dim3(grid), dim3(NW * 64), 0, 0, a);
-  hipDeviceSynchronize();
+  CHECK(hipGetLastError());
+  CHECK(hipDeviceSynchronize());
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
@@ -84,11 +87,14 @@ double run(Args a, int wgs_per_cu, double clock_mhz) {
 
 int main() {
   const uint64_t cap = 1ull << 30;
-  char* buf;
-  hipMalloc(&buf, cap);
-  hipMemset(buf, 1, cap);
-  unsigned* sink;
-  hipMalloc(&sink, 4096);
+  char* buf = nullptr;
+  CHECK(hipMalloc((void**)&buf, cap));
+  CHECK(hipMemset(buf, 1, cap));
+  unsigned* sink = nullptr;
+  CHECK(hipMalloc((void**)&sink, 4096));
+  CHECK(hipDeviceSynchronize());
+  printf("buffer %p, sink %p\n", (void*)buf, (void*)sink);
+  fflush(stdout);
   const double clk = 2400.0;  // nominal; B/cycle figures scale with the real clock (DVFS), TB/s printed beside
   printf("bytes/cycle/CU at a nominal 2.4 GHz  (x 256 CUs x 2.4e9 = chip bytes/s; 10 B/cycle/CU = 6.1 TB/s)\n");
   struct Shape { const char* name; int rows, rowbytes, stride; } shapes[] = {
@@ -103,7 +109,7 @@ int main() {
     printf("--- %s\n", f.name);
     for (auto& s : shapes) {
       Args a{buf, f.region, 4096, s.rows, s.rowbytes, s.stride, f.shared, sink};
-#define ROW(NW, D, L, W) { double b = run<NW, D, L>(a, W, clk); printf("   %-28s %s waves/CU=%2d in-flight/wave=%d : %6.2f B/cyc/CU  (%5.2f TB/s)\n", s.name, L ? "->LDS" : "->VGPR", NW * W, D, b, b * 256 * 2.4e-3); }
+#define ROW(NW, D, L, W) { double b = run<NW, D, L>(a, W, clk); printf("   %-28s %s waves/CU=%2d in-flight/wave=%d : %6.2f B/cyc/CU  (%5.2f TB/s)\n", s.name, L ? "->LDS" : "->VGPR", NW * W, D, b, b * 256 * 2.4e-3); fflush(stdout); }
       ROW(4, 4, true, 1) ROW(8, 4, true, 1) ROW(16, 4, true, 1) ROW(8, 4, true, 2) ROW(16, 4, true, 2)
       ROW(8, 2, true, 1) ROW(8, 8, true, 1) ROW(16, 8, true, 1) ROW(16, 2, true, 1)
       ROW(8, 4, false, 1) ROW(16, 4, false, 1) ROW(16, 8, false, 1)
