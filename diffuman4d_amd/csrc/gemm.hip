@@ -37,6 +37,12 @@
 #ifndef GEMM_FAST_EPI
 #define GEMM_FAST_EPI 1
 #endif
+// Ablation builds for profiling only (tools/dev/build_variant.sh ... -DGEMM_ABLATE=n; results are WRONG by construction):
+// 1 = no global stores in the epilogue, 2 = no epilogue at all, 3 = gemm_kernel_pipe without its in-loop DMA (MFMA + LDS
+// reads + barriers only), 4 = gemm_kernel_pipe without its MFMAs (DMA + LDS reads + barriers only).
+#ifndef GEMM_ABLATE
+#define GEMM_ABLATE 0
+#endif
 
 namespace {
 
@@ -91,6 +97,16 @@ template <int MI, int NI, int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[MI][NI], float* smem_f, int m0, int n0,
                                               int wm, int wn, int wave, int lane) {
   const int l31 = lane & 31, lh = lane >> 5;
+#if GEMM_ABLATE == 2
+  float keep = 0.f;  // keep the accumulators (and with them the main loop) alive without an epilogue
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) keep += acc[i][j][r];
+  if (p.out_scale == 12345.678f) p.C[l31 + lh] = f2bf(keep);
+#else
   const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
   const int NJ = geglu ? NI / 2 : NI;
   const int TNO = NJ * 32;  // output columns per wave
@@ -191,7 +207,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+#if GEMM_ABLATE == 1
+        { U4 pk = pack8(v); asm volatile("" ::"v"(pk.x), "v"(pk.y), "v"(pk.z), "v"(pk.w)); }
+#else
         stg16(c_base + (uint32_t)(row * (int)p.ldc + cc * 8), pack8(v));
+#endif
       }
       continue;  // next 32-row block of this wave
     }
@@ -241,6 +261,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
       }
     }
   }
+#endif  // GEMM_ABLATE == 2
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -525,7 +546,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip_kernel(GemmParams p) {
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       const int bbuf = (g + kx) & 1;  // == (3 g + kx) & 1
+#if GEMM_ABLATE != 3
       if (g * 3 + kx + 1 < nsteps) issue_step();
+#endif
       const int swa = ((l31 + kx) >> 1) & 7;
       bf16x8_t af[2][MI], bfr[2][NI];
       const u16* arow[MI];
@@ -548,11 +571,18 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip_kernel(GemmParams p) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         if (ks + 1 < 4) read_frags(ks + 1, (ks + 1) & 1);
+#if GEMM_ABLATE == 4
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[i][0][0] += (float)af[ks & 1][i][0];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[0][j][1] += (float)bfr[ks & 1][j][0];
+#else
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NI; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
+#endif
       }
       __syncthreads();
     }
@@ -712,7 +742,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_pipe(GemmParams p) {
     }
     __builtin_amdgcn_s_barrier();  // every wave's part of slab kt is in LDS; everyone is done reading slab kt-1
     asm volatile("" ::: "memory");
+#if GEMM_ABLATE != 3
     if (kt + NST - 1 < nk) issue_slab(kt + NST - 1, st_issue);  // overwrites the stage slab kt-1 lived in
+#endif
     const u16* As = smem + st * STAGE;
     const u16* Bs = As + BM * BK;
 #pragma unroll
@@ -723,10 +755,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_pipe(GemmParams p) {
       for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(As + (wm * TM + i * 32 + l31) * BK + pos);
 #pragma unroll
       for (int j = 0; j < NI; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(Bs + (wn * TN + j * 32 + l31) * BK + pos);
+#if GEMM_ABLATE == 4
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[i][0][0] += (float)af[i][0];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[0][j][1] += (float)bfr[j][0];
+#else
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+#endif
     }
     st = (st + 1 == NST) ? 0 : st + 1;
     st_issue = (st_issue + 1 == NST) ? 0 : st_issue + 1;
