@@ -33,7 +33,7 @@
 
 // Epilogue read-back loop with shift / 32-bit-offset index arithmetic (see gemm_epilogue); 0 = the generic loop only.
 // Same floating-point operations in the same order, so results are bit-identical either way (tools/dev/fe_check.py).
-// 2 (NOT yet run on a GPU): additionally a compile-time staging row stride.
+// (The compile-time staging stride that used to be GEMM_FAST_EPI=2 is now part of the MODE-specialised epilogue.)
 #ifndef GEMM_FAST_EPI
 #define GEMM_FAST_EPI 1
 #endif
@@ -93,84 +93,79 @@ __device__ __forceinline__ int weight_row(const GemmParams& p, int n0, int r, bo
 }
 
 // D fragment layout (32x32): lane holds column (lane & 31), rows (r&3) + 8*(r>>2) + 4*(lane>>5).
-template <int MI, int NI, int TM, int TN>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[MI][NI], float* smem_f, int m0, int n0,
-                                              int wm, int wn, int wave, int lane) {
+//
+// The epilogue is specialised at compile time on what it has to apply (MODE: 0 = bias only, 1 = + SiLU, 2 = GEGLU): the
+// flags are wave-uniform, but with a runtime `if (do_silu)` inside the 16-element loops hipcc if-converts the branch --
+// every output element of every Linear layer and convolution then pays v_exp + v_rcp + a select for a SiLU only the
+// two time-embedding GEMMs use, plus one scalar branch per element for GEGLU and per-element staging address arithmetic
+// (runtime row stride).  Ablation (profiles/r02_gemm_ablation.log): the epilogue was 39 % of the K = 320 Linear layers'
+// time, the stores only 8 %.  With MODE a template parameter the staging stride, the chunk geometry and the trip counts
+// are constants: the staging stores take immediate offsets and the read-back loop unrolls.  Same floating-point
+// operations in the same order as before: results are bit-identical.
+template <int MI, int NI, int TM, int TN, int MODE>
+__device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t (&acc)[MI][NI], float* smem_f, int m0, int n0,
+                                                   int wm, int wn, int wave, int lane) {
   const int l31 = lane & 31, lh = lane >> 5;
-#if GEMM_ABLATE == 2
-  float keep = 0.f;  // keep the accumulators (and with them the main loop) alive without an epilogue
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) keep += acc[i][j][r];
-  if (p.out_scale == 12345.678f) p.C[l31 + lh] = f2bf(keep);
-#else
-  const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
-  const int NJ = geglu ? NI / 2 : NI;
-  const int TNO = NJ * 32;  // output columns per wave
-#if GEMM_FAST_EPI >= 2
-  constexpr int SLD = TN + 4;  // fp32 staging row stride, compile-time: staging stores get immediate offsets (ds_write2_b32)
-#else
-  const int SLD = TNO + 4;  // fp32 staging row stride
-#endif
+  constexpr bool geglu = MODE == 2;
+  constexpr int NJ = geglu ? NI / 2 : NI;
+  constexpr int TNO = NJ * 32;   // output columns per wave
+  constexpr int SLD = TNO + 4;   // fp32 staging row stride
+  constexpr int CPR = TNO / 8;   // 8-column chunks per row
+  constexpr int TASKS = 32 * CPR;
   float* stage = smem_f + wave * 32 * (TN + 4);
-  const bool do_silu = (p.flags & DM4D_EPI_SILU) != 0;
   const int ncol0 = n0 + wn * TNO;
 
-  float bias_h[NI], bias_g[NI];
+  float bias_h[NJ], bias_g[NJ];
 #pragma unroll
-  for (int j = 0; j < NI; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     bias_h[j] = 0.f;
     bias_g[j] = 0.f;
-    int n = ncol0 + j * 32 + l31;
-    if (p.bias && j < NJ && n < p.N) {
+    const int n = ncol0 + j * 32 + l31;
+    if (p.bias && n < p.N) {
       bias_h[j] = bf2f(p.bias[n]);
       if (geglu) bias_g[j] = bf2f(p.bias[p.N + n]);
     }
   }
-  const int chunks_per_row = TNO / 8;
-  const int tasks = 32 * chunks_per_row;
   const bool vec_ok = ((p.ldc & 7) == 0) && ((p.N & 7) == 0) && (!p.res || (p.ld_res & 7) == 0) &&
                       (!p.rowbias || (p.ld_rb & 7) == 0);
-#if GEMM_FAST_EPI
-  static_assert(NI == 1 || NI == 2 || NI == 4, "the fast read-back loop needs a power-of-two number of 8-column chunks per row");
-  const bool fast_ok = vec_ok && p.ldc < (1 << 24) && (!p.res || p.ld_res < (1 << 24)) && (!p.rowbias || p.rows_per_rb > 0) && NJ > 0 &&
-                       !(p.flags & DM4D_EPI_F32OUT);
-#endif
   const bool f32out = (p.flags & DM4D_EPI_F32OUT) != 0;  // C is float* (fp32 logits of the VAE mid-block attention)
+#if GEMM_FAST_EPI
+  // the fast read-back loop takes row / chunk of a task from shifts: it needs a power-of-two number of chunks per row
+  constexpr bool CPR_POW2 = (CPR & (CPR - 1)) == 0;
+  const bool fast_ok = CPR_POW2 && vec_ok && p.ldc < (1 << 24) && (!p.res || p.ld_res < (1 << 24)) &&
+                       (!p.rowbias || p.rows_per_rb > 0) && !f32out;
+#endif
   // The staging area is private to a wave and LDS operations of one wave complete in program order, so only one
   // workgroup barrier is needed: the one that retires every wave's main-loop fragment reads before the area is reused.
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
+    float* srow = stage + (4 * lh) * SLD + l31;  // this lane's first staging row; the other 15 are compile-time offsets away
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      if (j < NJ) {
+    for (int j = 0; j < NJ; ++j) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          float v = acc[i][j][r] + bias_h[j];
-          if (geglu) {
-            float g = acc[i][(j + NI / 2) % NI][r] + bias_g[j];
-            v = v * gelu_erf_f(g);
-          }
-          if (do_silu) v = silu_f(v);
-          stage[row * SLD + j * 32 + l31] = v;
+      for (int r = 0; r < 16; ++r) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int row = (r & 3) + 8 * (r >> 2);  // + 4 * lh, folded into srow
+        float v = acc[i][j][r] + bias_h[j];
+        if constexpr (geglu) {
+          const float g = acc[i][j + NI / 2][r] + bias_g[j];
+          v = v * gelu_erf_f(g);
         }
+        if constexpr (MODE == 1) v = silu_f(v);
+        srow[row * SLD + j * 32] = v;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // compiler: keep the staging stores ahead of the row reads
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #if GEMM_FAST_EPI
     if (fast_ok) {
-      // Row / chunk from shifts (chunks_per_row is 4, 8 or 16), 32-bit offsets from wave-uniform row-block bases, and the
-      // rowbias row (m / rows_per_rb) from one division per 32-row block: rows of a block are consecutive, so row r lies
-      // in image q0 + (r0 + r >= rows_per_rb).  The generic loop below spends ~50 VALU instructions per 8 outputs on
-      // these index computations (runtime divisions, 64-bit multiplies), more than on the outputs themselves.
+      // 32-bit offsets from wave-uniform row-block bases, and the rowbias row (m / rows_per_rb) from one division per
+      // 32-row block: rows of a block are consecutive, so row r lies in image q0 + (r0 + r >= rows_per_rb).
       const int m_base = m0 + wm * TM + i * 32;
-      const int cshift = 31 - __builtin_clz(chunks_per_row), cmask = chunks_per_row - 1;
+      constexpr int cshift = CPR >= 16 ? 4 : (CPR >= 8 ? 3 : (CPR >= 4 ? 2 : (CPR >= 2 ? 1 : 0)));
+      constexpr int cmask = CPR - 1;
       const u16* res_base = p.res ? p.res + (int64_t)m_base * p.ld_res + ncol0 : nullptr;
       u16* c_base = p.C + (int64_t)m_base * p.ldc + ncol0;
       int q0 = 0, r0 = 0;
@@ -178,7 +173,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
         q0 = m_base / p.rows_per_rb;
         r0 = m_base - q0 * p.rows_per_rb;
       }
-      for (int id = lane; id < tasks; id += 64) {
+#pragma unroll
+      for (int it = 0; it < (TASKS + 63) / 64; ++it) {
+        const int id = lane + it * 64;
+        if (TASKS % 64 != 0 && id >= TASKS) continue;
         const int row = id >> cshift, cc = id & cmask;
         if (m_base + row >= p.M || ncol0 + cc * 8 >= p.N) continue;
         float v[8];
@@ -208,7 +206,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
 #if GEMM_ABLATE == 1
-        { U4 pk = pack8(v); asm volatile("" ::"v"(pk.x), "v"(pk.y), "v"(pk.z), "v"(pk.w)); }
+        {
+          U4 pk = pack8(v);
+          if (pk.x == 0x12345678u && pk.y == 0x9abcdef0u && pk.z == pk.w) c_base[0] = 0;
+        }
 #else
         stg16(c_base + (uint32_t)(row * (int)p.ldc + cc * 8), pack8(v));
 #endif
@@ -216,8 +217,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
       continue;  // next 32-row block of this wave
     }
 #endif
-    for (int id = lane; id < tasks; id += 64) {
-      int row = id / chunks_per_row, cc = id % chunks_per_row;
+    for (int id = lane; id < TASKS; id += 64) {
+      int row = id / CPR, cc = id % CPR;
       int m = m0 + wm * TM + i * 32 + row;
       int n = ncol0 + cc * 8;
       if (m >= p.M || n >= p.N) continue;
@@ -261,7 +262,31 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
       }
     }
   }
-#endif  // GEMM_ABLATE == 2
+}
+
+template <int MI, int NI, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[MI][NI], float* smem_f, int m0, int n0,
+                                              int wm, int wn, int wave, int lane) {
+#if GEMM_ABLATE == 2
+  float keep = 0.f;  // keep the accumulators (and with them the main loop) alive without an epilogue
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) keep += acc[i][j][r];
+  if (p.out_scale == 12345.678f) p.C[lane] = f2bf(keep);
+#else
+  // wave-uniform dispatch; GEGLU pairs hidden block j with gate block j + NI/2 inside the wave, so it needs NI >= 2
+  if constexpr (NI >= 2) {
+    if (p.flags & DM4D_EPI_GEGLU) {
+      gemm_epilogue_impl<MI, NI, TM, TN, 2>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
+      return;
+    }
+  }
+  if (p.flags & DM4D_EPI_SILU) gemm_epilogue_impl<MI, NI, TM, TN, 1>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
+  else gemm_epilogue_impl<MI, NI, TM, TN, 0>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
