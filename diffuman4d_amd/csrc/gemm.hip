@@ -637,11 +637,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip_kernel(GemmParams p) {
 // prefetch cannot cover the L2->LDS latency, and a 128x128 tile needs the CU's whole L1 bandwidth at
 // MFMA peak); larger tiles halve the bytes per flop, more stages cover the latency.
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int NST, bool CONV>
+template <int BM, int BN, int WM, int WN, int NST, bool CONV, int BK = 32>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_pipe(GemmParams p) {
-  constexpr int NW = WM * WN, BK = 32;
+  constexpr int NW = WM * WN;
+  static_assert(BK == 32 || BK == 64, "K-slab of 32 (64-byte row pieces) or 64 (whole 128-byte lines)");
+  constexpr int RPI = 1024 / (BK * 2);  // tile rows per 1-KiB DMA instruction: 16 (BK 32) or 8 (BK 64)
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
-  constexpr int AW = BM / 16 / NW, BW = BN / 16 / NW;  // 1-KiB DMA instructions (16 rows x 64 B) per wave per slab
+  constexpr int AW = BM / RPI / NW, BW = BN / RPI / NW;  // 1-KiB DMA instructions (RPI rows of BK bf16) per wave per slab
   static_assert(AW >= 1 && BW >= 1 && NST >= 2 && NST <= 4, "tile/wave/stage combination");
   constexpr int LD = AW + BW;
   constexpr int STAGE = (BM + BN) * BK;  // elements per stage
@@ -660,16 +662,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_pipe(GemmParams p) {
   const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
   const int n0 = tn * (geglu ? BN / 2 : BN);
 
-  // DMA lane mapping: 16 rows x 4 chunks per instruction; LDS position (row, pos) holds chunk pos ^ ((row>>2)&3)
-  const int d_row = lane >> 2, d_pos = lane & 3;
-  const int d_chunk = d_pos ^ ((d_row >> 2) & 3);
+  // DMA lane mapping.  BK 32: 16 rows x 4 chunks per instruction, LDS position (row, pos) holds chunk pos ^ ((row>>2)&3).
+  // BK 64: 8 rows x 8 chunks (whole 128-byte lines: a 64-byte piece costs a full line of fabric bandwidth when the row
+  // comes from HBM / Infinity Cache -- tools/probes/fill_probe.hip: 6 vs 12 B/cycle/CU), position holds chunk pos ^ ((row>>1)&7).
+  constexpr int CPRW = BK / 8;  // 16-byte chunks per tile row
+  const int d_row = lane / CPRW, d_pos = lane % CPRW;
+  // source chunk of tile row `row` for this lane's LDS position (BK 32: instructions start at multiples of 16 rows, so
+  // the key depends on d_row only; BK 64: they start at multiples of 8, bit 2 of the key comes from the instruction)
+  auto src_chunk = [&](int row) { return BK == 32 ? (d_pos ^ ((row >> 2) & 3)) : (d_pos ^ ((row >> 1) & 7)); };
   const u16* a_src[AW];
   const u16* a2_src[AW];
   int iy0[AW], ix0[AW], img_off[AW], tap_off[AW];  // tap_off: element offset of the current tap's pixel, -1 = padding
 #pragma unroll
   for (int i = 0; i < AW; ++i) {
     img_off[i] = tap_off[i] = 0;
-    int m = m0 + (wave + NW * i) * 16 + d_row;
+    const int d_chunk = src_chunk((wave + NW * i) * RPI + d_row);
+    int m = m0 + (wave + NW * i) * RPI + d_row;
     if (m > p.M - 1) m = p.M - 1;
     if constexpr (CONV) {
       int ox = m % p.Wo;
@@ -690,7 +698,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_pipe(GemmParams p) {
   const u16* w_src[BW];
 #pragma unroll
   for (int i = 0; i < BW; ++i)
-    w_src[i] = p.Wt + (int64_t)weight_row<TN>(p, n0, (wave + NW * i) * 16 + d_row, geglu) * p.ldw + d_chunk * 8;
+    w_src[i] = p.Wt + (int64_t)weight_row<TN>(p, n0, (wave + NW * i) * RPI + d_row, geglu) * p.ldw +
+               src_chunk((wave + NW * i) * RPI + d_row) * 8;
 
   f32x16_t acc[MI][NI];
 #pragma unroll
@@ -733,7 +742,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_pipe(GemmParams p) {
       } else {
         src = a_src[i] + kt * BK;
       }
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (wave + NW * i) * 16 * BK), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (wave + NW * i) * RPI * BK), 16, 0, 0);
     }
     if constexpr (CONV) {
       ci0 += BK;
@@ -747,10 +756,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_pipe(GemmParams p) {
     }
 #pragma unroll
     for (int i = 0; i < BW; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + kt * BK), (lptr_t)(Bs + (wave + NW * i) * 16 * BK), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + kt * BK), (lptr_t)(Bs + (wave + NW * i) * RPI * BK), 16, 0, 0);
   };
 
-  const int sw = (l31 >> 2) & 3;
+  const int sw = BK == 32 ? ((l31 >> 2) & 3) : ((l31 >> 1) & 7);
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
     if (s < nk) issue_slab(s, s);
@@ -773,7 +782,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_pipe(GemmParams p) {
     const u16* As = smem + st * STAGE;
     const u16* Bs = As + BM * BK;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < BK / 16; ++ks) {
       const int pos = ((ks * 2 + lh) ^ sw) * 8;
       bf16x8_t af[MI], bfr[NI];
 #pragma unroll
@@ -938,13 +947,13 @@ int launch_cfg(hipStream_t st, GemmParams& p) {
   return dm4d_check_launch("gemm_kernel");
 }
 
-template <int BM, int BN, int WM, int WN, int NST, bool CONV>
+template <int BM, int BN, int WM, int WN, int NST, bool CONV, int BK = 32>
 int launch_pipe(hipStream_t st, GemmParams& p) {
   const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
   const int bn_out = geglu ? BN / 2 : BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + bn_out - 1) / bn_out;
-  hipLaunchKernelGGL((gemm_kernel_pipe<BM, BN, WM, WN, NST, CONV>), dim3(tiles_m * p.tiles_n), dim3(WM * WN * 64), 0, st, p);
+  hipLaunchKernelGGL((gemm_kernel_pipe<BM, BN, WM, WN, NST, CONV, BK>), dim3(tiles_m * p.tiles_n), dim3(WM * WN * 64), 0, st, p);
   return dm4d_check_launch("gemm_kernel_pipe");
 }
 
@@ -1035,6 +1044,12 @@ int launch_by_id(int id, hipStream_t st, GemmParams& p) {
     // per-wave work of id 14 (64x64) with 2/3 of its L2->LDS bytes per flop -- these kernels run at the CU's fill rate
     case 19: return launch_pipe<256, 256, 4, 4, 3, CONV>(st, p);
     case 20: return launch_pipe<256, 256, 4, 4, 4, CONV>(st, p);
+    // K-slab 64 (whole 128-byte lines per DMA row) on the counted-vmcnt pipeline; need K (conv: Cin) % 64 == 0
+    case 41: return k64 ? launch_pipe<256, 128, 4, 2, 2, CONV, 64>(st, p) : DM4D_ERR_ARG;  // 98 KB, 1 workgroup / CU
+    case 42: return k64 ? launch_pipe<128, 128, 4, 2, 2, CONV, 64>(st, p) : DM4D_ERR_ARG;  // 64 KB, 2 workgroups / CU
+    case 43: return k64 ? launch_pipe<128, 128, 4, 2, 3, CONV, 64>(st, p) : DM4D_ERR_ARG;  // 96 KB, 1 workgroup / CU
+    case 44: return k64 ? launch_pipe<256, 128, 4, 2, 3, CONV, 64>(st, p) : DM4D_ERR_ARG;  // 144 KB, 1 workgroup / CU
+    case 45: return k64 ? launch_pipe<256, 64, 8, 1, 3, CONV, 64>(st, p) : DM4D_ERR_ARG;   // 120 KB... (256+64)*128*3
     case 31: case 32: case 33: case 34:
       if constexpr (CONV) {
         if (!(k64 && p.stride == 1 && p.pad == 1 && !p.upsample && p.Ho == p.H && p.Wo == p.W)) return DM4D_ERR_ARG;
