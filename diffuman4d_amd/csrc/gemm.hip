@@ -102,22 +102,25 @@ __device__ __forceinline__ int weight_row(const GemmParams& p, int n0, int r, bo
 // time, the stores only 8 %.  With MODE a template parameter the staging stride, the chunk geometry and the trip counts
 // are constants: the staging stores take immediate offsets and the read-back loop unrolls.  Same floating-point
 // operations in the same order as before: results are bit-identical.
-template <int MI, int NI, int TM, int TN, int MODE>
+template <int MI, int NI, int TM, int TN, int MODE, int EPW, int J0, int JN, bool SYNC>
 __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t (&acc)[MI][NI], float* smem_f, int m0, int n0,
                                                    int wm, int wn, int wave, int lane) {
+  // This instance handles output blocks [J0, J0 + JN) of the wave's NJ 32-column blocks (a "column group"): wide per-wave
+  // tiles (TN = 160) are staged in groups that fit the LDS (EPW = columns of staging space per wave).
   const int l31 = lane & 31, lh = lane >> 5;
   constexpr bool geglu = MODE == 2;
   constexpr int NJ = geglu ? NI / 2 : NI;
-  constexpr int TNO = NJ * 32;   // output columns per wave
+  static_assert(J0 + JN <= NJ && JN * 32 <= EPW, "column group outside the wave's tile or wider than its staging area");
+  constexpr int TNO = JN * 32;   // output columns of this group
   constexpr int SLD = TNO + 4;   // fp32 staging row stride
   constexpr int CPR = TNO / 8;   // 8-column chunks per row
   constexpr int TASKS = 32 * CPR;
-  float* stage = smem_f + wave * 32 * (TN + 4);
-  const int ncol0 = n0 + wn * TNO;
+  float* stage = smem_f + wave * 32 * (EPW + 4);
+  const int ncol0 = n0 + wn * (NJ * 32) + J0 * 32;
 
-  float bias_h[NJ], bias_g[NJ];
+  float bias_h[JN], bias_g[JN];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
+  for (int j = 0; j < JN; ++j) {
     bias_h[j] = 0.f;
     bias_g[j] = 0.f;
     const int n = ncol0 + j * 32 + l31;
@@ -136,21 +139,20 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t
                        (!p.rowbias || p.rows_per_rb > 0) && !f32out;
 #endif
   // The staging area is private to a wave and LDS operations of one wave complete in program order, so only one
-  // workgroup barrier is needed: the one that retires every wave's main-loop fragment reads before the area is reused.
-  __syncthreads();
+  // workgroup barrier is needed: the one that retires every wave's main-loop fragment reads before the area is reused
+  // (SYNC: the first column group of the tile issues it).
+  if constexpr (SYNC) __syncthreads();
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     float* srow = stage + (4 * lh) * SLD + l31;  // this lane's first staging row; the other 15 are compile-time offsets away
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
+    for (int j = 0; j < JN; ++j) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        constexpr int dummy = 0;
-        (void)dummy;
         const int row = (r & 3) + 8 * (r >> 2);  // + 4 * lh, folded into srow
-        float v = acc[i][j][r] + bias_h[j];
+        float v = acc[i][J0 + j][r] + bias_h[j];
         if constexpr (geglu) {
-          const float g = acc[i][j + NI / 2][r] + bias_g[j];
+          const float g = acc[i][J0 + j + NI / 2][r] + bias_g[j];
           v = v * gelu_erf_f(g);
         }
         if constexpr (MODE == 1) v = silu_f(v);
@@ -264,6 +266,27 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t
   }
 }
 
+// Staging columns per wave: the whole per-wave tile up to 128 columns; wider tiles (TN = 160) go in column groups.
+template <int TN>
+struct EpiGeom {
+  static constexpr int EPW = TN <= 128 ? TN : 128;
+};
+
+template <int MI, int NI, int TM, int TN, int MODE>
+__device__ __forceinline__ void gemm_epilogue_mode(const GemmParams& p, f32x16_t (&acc)[MI][NI], float* smem_f, int m0, int n0,
+                                                   int wm, int wn, int wave, int lane) {
+  constexpr int NJ = MODE == 2 ? NI / 2 : NI;
+  constexpr int EPW = EpiGeom<TN>::EPW;
+  constexpr int G = EPW / 32;  // blocks per full column group
+  if constexpr (NJ <= G) {
+    gemm_epilogue_impl<MI, NI, TM, TN, MODE, EPW, 0, NJ, true>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
+  } else {
+    static_assert(NJ <= 2 * G, "at most two column groups");
+    gemm_epilogue_impl<MI, NI, TM, TN, MODE, EPW, 0, G, true>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
+    gemm_epilogue_impl<MI, NI, TM, TN, MODE, EPW, G, NJ - G, false>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
+  }
+}
+
 template <int MI, int NI, int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[MI][NI], float* smem_f, int m0, int n0,
                                               int wm, int wn, int wave, int lane) {
@@ -277,15 +300,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
       for (int r = 0; r < 16; ++r) keep += acc[i][j][r];
   if (p.out_scale == 12345.678f) p.C[lane] = f2bf(keep);
 #else
-  // wave-uniform dispatch; GEGLU pairs hidden block j with gate block j + NI/2 inside the wave, so it needs NI >= 2
-  if constexpr (NI >= 2) {
+  // wave-uniform dispatch; GEGLU pairs hidden block j with gate block j + NI/2 inside the wave, so it needs an even NI
+  if constexpr (NI >= 2 && NI % 2 == 0) {
     if (p.flags & DM4D_EPI_GEGLU) {
-      gemm_epilogue_impl<MI, NI, TM, TN, 2>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
+      gemm_epilogue_mode<MI, NI, TM, TN, 2>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
       return;
     }
   }
-  if (p.flags & DM4D_EPI_SILU) gemm_epilogue_impl<MI, NI, TM, TN, 1>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
-  else gemm_epilogue_impl<MI, NI, TM, TN, 0>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
+  if (p.flags & DM4D_EPI_SILU) gemm_epilogue_mode<MI, NI, TM, TN, 1>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
+  else gemm_epilogue_mode<MI, NI, TM, TN, 0>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
 #endif
 }
 
@@ -299,7 +322,7 @@ __global__ __launch_bounds__(256) void gemm_kernel_glds(GemmParams p) {
   constexpr int AW = BM / 32, BW = BN / 32;  // 1-KiB DMA instructions per wave per slab (8 rows each)
   static_assert(WM * WN == 4, "4 waves");
   constexpr int SMEM_MAIN = 2 * (BM + BN) * BK * 2;
-  constexpr int SMEM_EPI = 4 * 32 * (TN + 4) * 4;
+  constexpr int SMEM_EPI = 4 * 32 * (EpiGeom<TN>::EPW + 4) * 4;
   constexpr int SMEM_BYTES = SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI;
   __shared__ __attribute__((aligned(16))) u16 smem[SMEM_BYTES / 2];
   u16* As = smem;                // [2][BM][64]
@@ -461,7 +484,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip_kernel(GemmParams p) {
   constexpr int NA = SR / 8;  // 1-KiB DMA instructions per strip
   constexpr int AW = (NA + NW - 1) / NW, BW = BN / (8 * NW);
   constexpr int SMEM_MAIN = 2 * (SR + BN) * BK * 2 + BK * 2;  // + one zero row
-  constexpr int SMEM_EPI = NW * 32 * (TN + 4) * 4;
+  constexpr int SMEM_EPI = NW * 32 * (EpiGeom<TN>::EPW + 4) * 4;
   constexpr int SMEM_BYTES = SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI;
   __shared__ __attribute__((aligned(16))) u16 smem[SMEM_BYTES / 2];
   u16* As = smem;                       // [2][SR][64]
@@ -648,7 +671,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_pipe(GemmParams p) {
   constexpr int LD = AW + BW;
   constexpr int STAGE = (BM + BN) * BK;  // elements per stage
   constexpr int SMEM_MAIN = NST * STAGE * 2;
-  constexpr int SMEM_EPI = NW * 32 * (TN + 4) * 4;
+  constexpr int SMEM_EPI = NW * 32 * (EpiGeom<TN>::EPW + 4) * 4;
   constexpr int SMEM_BYTES = SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI;
   __shared__ __attribute__((aligned(16))) u16 smem[SMEM_BYTES / 2];
 
@@ -817,7 +840,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   constexpr int AI = BM / 64, BI = BN / 64;
   static_assert(WM * WN == 4, "4 waves");
   constexpr int SMEM_MAIN = 2 * (BM + BN) * LDK * 2;
-  constexpr int SMEM_EPI = 4 * 32 * (TN + 4) * 4;
+  constexpr int SMEM_EPI = 4 * 32 * (EpiGeom<TN>::EPW + 4) * 4;
   constexpr int SMEM_BYTES = SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI;
   __shared__ __attribute__((aligned(16))) u16 smem[SMEM_BYTES / 2];
   u16* As = smem;
@@ -1049,13 +1072,18 @@ int launch_by_id(int id, hipStream_t st, GemmParams& p) {
     case 42: return k64 ? launch_pipe<128, 128, 4, 2, 2, CONV, 64>(st, p) : DM4D_ERR_ARG;  // 64 KB, 2 workgroups / CU
     case 43: return k64 ? launch_pipe<128, 128, 4, 2, 3, CONV, 64>(st, p) : DM4D_ERR_ARG;  // 96 KB, 1 workgroup / CU
     case 44: return k64 ? launch_pipe<256, 128, 4, 2, 3, CONV, 64>(st, p) : DM4D_ERR_ARG;  // 144 KB, 1 workgroup / CU
-    case 45: return k64 ? launch_pipe<256, 64, 8, 1, 3, CONV, 64>(st, p) : DM4D_ERR_ARG;   // 120 KB... (256+64)*128*3
-    case 31: case 32: case 33: case 34:
+    case 45: return k64 ? launch_pipe<256, 64, 8, 1, 3, CONV, 64>(st, p) : DM4D_ERR_ARG;   // 120 KB
+    // 320-wide tile (see id 35), K-slab 64, 2 stages = 144 KB; per-wave tile 64 x 160 = 5 column blocks: no GEGLU pairing
+    case 46: return (k64 && !geglu) ? launch_pipe<256, 320, 4, 2, 2, CONV, 64>(st, p) : DM4D_ERR_ARG;
+    case 31: case 32: case 33: case 34: case 35:
       if constexpr (CONV) {
         if (!(k64 && p.stride == 1 && p.pad == 1 && !p.upsample && p.Ho == p.H && p.Wo == p.W)) return DM4D_ERR_ARG;
         if (id == 31) return launch_strip<128, 128, 2, 2>(st, p);
         if (id == 32) return launch_strip<256, 128, 4, 2>(st, p);
         if (id == 33) return launch_strip<128, 64, 4, 1>(st, p);
+        // every channel count of an SD-class UNet is a multiple of 320: a 320-wide tile reads the A strip once per
+        // kernel row for N = 320 (level 0) and feeds 40 MFMAs per wave between two barriers
+        if (id == 35) return launch_strip<256, 320, 4, 2>(st, p);
         return launch_strip<256, 256, 2, 4>(st, p);
       } else {
         return DM4D_ERR_ARG;
