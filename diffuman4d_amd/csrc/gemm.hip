@@ -1110,6 +1110,9 @@ int choose_cfg(const GemmParams& p) {
   const int bn = geglu ? 64 : 128;  // output columns of a 128-wide B tile
   const long tm256 = (p.M + 255) / 256, tm128 = (p.M + 127) / 128, tn = (p.N + bn - 1) / bn;
   if (!CONV) {
+    // N = 320 with a deep K (the level-0 feed-forward output projection): one 320-wide tile reads A once instead of three
+    // times (profiles/r02_gemm_tune_wide.log: 130 vs 146 us at CFG batch 32, 190 vs 207 at 48)
+    if (!geglu && p.N == 320 && p.K >= 1024 && tm256 >= 256) return 46;
     // Linear layers stream A once with little reuse (K = C or 4C): they are bound by L2->LDS bytes and DMA latency,
     // so the 8-wave 256x128 tile with 2 slabs of DMA in flight wins whenever it still fills the chip (1.2-1.35x)
     const long t = tm256 * tn;  // one 8-wave workgroup per CU => 256 slots per round; avoid a mostly empty last round
@@ -1118,6 +1121,9 @@ int choose_cfg(const GemmParams& p) {
     // stride-1 convs: the strip kernels stage A once per kernel row (profiles/r01_conv_strip.log)
     if (p.stride == 1 && p.pad == 1 && !p.upsample && p.Ho == p.H && p.Wo == p.W) {
       if (!n128) {
+        // N = 320 (level 0) with Cin >= 640 (the up path's concatenated inputs): the 320-wide strip tile (-5..-6 % at CFG
+        // batch 32, even at 48); same K order as every strip kernel, so the choice never changes a result
+        if (p.N == 320 && p.Cin >= 640 && tm256 >= 256) return 35;
         if (tm128 * ((p.N + 63) / 64) >= 256) return 33;
       } else {
         const long t = tm256 * tn;
@@ -1125,6 +1131,13 @@ int choose_cfg(const GemmParams& p) {
         if (t >= 200 && 5 * t >= 4 * ((t + 255) / 256) * 256) return 32;
         if (tm128 * tn >= 256) return 31;
       }
+    }
+    // upsample-fused convs (Upsample2D): the gather reads every input pixel four times, so tiles that cut the A traffic
+    // win: 320-wide for N = 640 (578 vs 698-760 us), 16-wave 256x256 for N = 1280 (634 vs 685-740 us); all of these walk K
+    // in the same (ky, kx, ci) order as the other gather kernels
+    if (p.upsample && k64) {
+      if (p.N % 320 == 0 && p.N <= 640 && tm256 >= 64) return 46;
+      if (p.N % 256 == 0 && tm256 * (p.N / 256) >= 256) return 20;
     }
     // other convs: 128x128 / 2 workgroups per CU is best except for wide, tall problems
     if (!geglu && p.N % 256 == 0 && tm256 * (p.N / 256) >= 384) return 13;
