@@ -54,6 +54,18 @@ constexpr int TILE = KV * 64;  // elements of one un-padded [64 keys][64 d] stag
 #ifndef ATTN_PRIO_YOUNG
 #define ATTN_PRIO_YOUNG 0  // experimental: see attn_kernel
 #endif
+// Software-pipelined softmax (see compute_swp): the exponentials of a tile are spread over the MFMA shadows of TWO steps so
+// that every one of a step's 16 MFMAs has two v_exp behind it; 0 = the straight-line body (compute).
+#ifndef ATTN_SWP
+#define ATTN_SWP 1
+#endif
+// sched_group_barrier pattern for compute_swp: 0 = leave the order to the compiler
+#ifndef ATTN_SWP_SGB
+#define ATTN_SWP_SGB 1
+#endif
+#ifndef ATTN_SWP_LEAD
+#define ATTN_SWP_LEAD 4  // fragment reads issued ahead of the first MFMA of a step
+#endif
 constexpr int RING = ATTN_RING, AHEAD = RING / 2;
 static_assert(RING == 2 || RING == 4, "ATTN_RING must be 2 or 4");
 // waves per workgroup (template parameter NW): 8 = 256 query rows per workgroup, one workgroup per CU; 4 = 128 rows, two
@@ -388,14 +400,110 @@ __device__ __forceinline__ void kv_loop_pipelined(const AttnParams& p, const u16
     compute(t, sa, sb);
     dma_wait_barrier();
   };
+#if ATTN_SWP
+  // The same step with the softmax spread over the MFMA shadows.  On this chip a wave's VALU work hides only behind its
+  // OWN MFMAs, about two v_exp (or four plain VALU) per 32-cycle MFMA (tools/probes/issue_probe.hip: 1 MFMA + 2 v_exp = 39
+  // cycles, + 4 = 48, + 8 = 78), and `compute` gives the scheduler 7 exponentials per gap in places and none in others.
+  // A step has 16 MFMAs and 32 exponentials, but their deadlines do not line up inside one step: P of key block 0 must
+  // be complete before PV0 and P of block 1 before PV1, which leaves nothing for PV1's four shadows.  So the first half of
+  // block 0's exponentials is taken one step early, in the PV1 shadows of the PREVIOUS step (S(t+1) block 0 is ready by
+  // then: its QK^T MFMAs open this step), and carried in `pc`:
+  //   QK0 x4 | exp S(t).0[8..16]    QK1 x4 | exp S(t).1[0..8]    PV0 x4 | exp S(t).1[8..16]    PV1 x4 | exp S(t+1).0[0..8] -> pc
+  // Row sums go as two 8-term trees per block next to the exponentials they consume.  PV MFMAs run (d0,k0) (d1,k0) (d0,k1)
+  // (d1,k1) so that the second k-slot half of P is needed two MFMAs later; each accumulator still sees its k-slots in
+  // the same order as in `compute`.
+  auto exp8 = [&](const f32x16_t& sv, int r0, float (&pv)[8]) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) pv[r] = FOLD ? __builtin_amdgcn_exp2f(sv[r0 + r]) : __builtin_amdgcn_exp2f(sv[r0 + r] * cs - mc);
+  };
+  auto sum8 = [&](const float (&pv)[8]) { return ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7])); };
+  auto pack8p = [&](const float (&pv)[8]) {
+    U4 w;
+    w.x = cvt_pk_bf16(pv[0], pv[1]);
+    w.y = cvt_pk_bf16(pv[2], pv[3]);
+    w.z = cvt_pk_bf16(pv[4], pv[5]);
+    w.w = cvt_pk_bf16(pv[6], pv[7]);
+    return *reinterpret_cast<bf16x8_t*>(&w);
+  };
+  auto v_frag = [&](int stage, int kb, int db, int jj) {
+    const u16* vp = Vs + stage * TILE + (kb * 32 + jj * 16) * 64 + v_lane[db];
+    s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)vp);
+    s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vp + 8 * 64));
+    s16x8_t v01 = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+    return *reinterpret_cast<bf16x8_t*>(&v01);
+  };
+  auto compute_swp = [&](int t, f32x16_t (&sa)[2], f32x16_t (&sb)[2], float (&pc)[8]) {
+    const int kst = (t + 1) % RING, vst = t % RING;
+    float pa[8], pb[8], pn[8];
+    bf16x8_t f0lo = pack8p(pc), f0hi, f1lo, f1hi;
+    // QK0 (S(t+1) block 0)  ||  second half of block 0's exponentials
+    qk_block(kst, 0, sb[0]);
+    exp8(sa[0], 8, pa);
+    l_run += sum8(pc) + sum8(pa);
+    f0hi = pack8p(pa);
+    // QK1  ||  first half of block 1
+    qk_block(kst, 1, sb[1]);
+    exp8(sa[1], 0, pb);
+    f1lo = pack8p(pb);
+    // PV0  ||  second half of block 1
+    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_frag(vst, 0, 0, 0), f0lo, o[0], 0, 0, 0);
+    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_frag(vst, 0, 1, 0), f0lo, o[1], 0, 0, 0);
+    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_frag(vst, 0, 0, 1), f0hi, o[0], 0, 0, 0);
+    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_frag(vst, 0, 1, 1), f0hi, o[1], 0, 0, 0);
+    exp8(sa[1], 8, pa);
+    l_run += sum8(pb) + sum8(pa);
+    f1hi = pack8p(pa);
+    // PV1  ||  first half of the NEXT tile's block 0 (carried)
+    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_frag(vst, 1, 0, 0), f1lo, o[0], 0, 0, 0);
+    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_frag(vst, 1, 1, 0), f1lo, o[1], 0, 0, 0);
+    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_frag(vst, 1, 0, 1), f1hi, o[0], 0, 0, 0);
+    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_frag(vst, 1, 1, 1), f1hi, o[1], 0, 0, 0);
+    exp8(sb[0], 0, pn);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) pc[r] = pn[r];
+#if ATTN_SWP_SGB
+    // 16 x { 1 MFMA, 2 transcendentals, up to 3 other VALU (adds, packs), LDS reads }.  Fragment reads lead their MFMA by
+    // about three slots: four K fragments up front, then one read per QK^T slot and two per PV slot (a PV fragment is two
+    // transposing reads).
+    __builtin_amdgcn_sched_group_barrier(0x100, ATTN_SWP_LEAD, 0);
+#define DM4D_SGB_SLOT(NDS)                                                                                  \
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   /* MFMA */                                           \
+  __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);   /* TRANS */                                          \
+  __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   /* VALU */                                           \
+  __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0); /* DS read */
+    DM4D_SGB_SLOT(1) DM4D_SGB_SLOT(1) DM4D_SGB_SLOT(1) DM4D_SGB_SLOT(1) DM4D_SGB_SLOT(1) DM4D_SGB_SLOT(1) DM4D_SGB_SLOT(1) DM4D_SGB_SLOT(1)
+    DM4D_SGB_SLOT(2) DM4D_SGB_SLOT(2) DM4D_SGB_SLOT(2) DM4D_SGB_SLOT(2) DM4D_SGB_SLOT(2) DM4D_SGB_SLOT(2) DM4D_SGB_SLOT(2) DM4D_SGB_SLOT(2)
+#undef DM4D_SGB_SLOT
+#endif
+    asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(sb[0]), "v"(sb[1]));  // every MFMA of the step is issued before what follows
+  };
+  auto step_swp = [&](int t, f32x16_t (&sa)[2], f32x16_t (&sb)[2], float (&pc)[8]) {
+    issue_k(t + AHEAD + 1, (t + AHEAD + 1) % RING, false);
+    issue_v(t + AHEAD, (t + AHEAD) % RING, false);
+    compute_swp(t, sa, sb, pc);
+    dma_wait_barrier();
+  };
+#endif
   int t = 0;
   const int n_full = Lk / KV;
   if (RING == 2) {
     // main loop: every tile it loads (up to t + 3) is a full tile, so the uniform-base addressing applies
+#if ATTN_SWP
+    if (t + 3 < n_full) {
+      float pc[8];  // exponentials of S(t) block 0, first half: produced one step ahead (see compute_swp)
+      exp8(s_cur[0], 0, pc);
+      for (; t + 3 < n_full; t += 2) {
+        step_swp(t, s_cur, s_nxt, pc);
+        step_swp(t + 1, s_nxt, s_cur, pc);
+      }
+      // the carry of the first tile of the tail is dropped: the tail recomputes those eight exponentials
+    }
+#else
     for (; t + 3 < n_full; t += 2) {  // two steps per trip: the S register sets swap roles instead of being copied
       step(t, s_cur, s_nxt, false);
       step(t + 1, s_nxt, s_cur, false);
     }
+#endif
   } else {
     // tiles in pairs: the DMA of both steps (K(t+3), K(t+4), V(t+2), V(t+3)) goes out at the top, one barrier at the end;
     // the four tiles land in the four stages that do not hold K(t+1), K(t+2) / V(t), V(t+1)
