@@ -55,9 +55,12 @@ constexpr int TILE = KV * 64;  // elements of one un-padded [64 keys][64 d] stag
 #define ATTN_PRIO_YOUNG 0  // experimental: see attn_kernel
 #endif
 // Software-pipelined softmax (see compute_swp): the exponentials of a tile are spread over the MFMA shadows of TWO steps so
-// that every one of a step's 16 MFMAs has two v_exp behind it; 0 = the straight-line body (compute).
+// that every one of a step's 16 MFMAs has two v_exp behind it; 0 = the straight-line body (compute), which is what ships:
+// measured on MI355X the regular schedule is SLOWER than the compiler's own irregular one (-6 % with the
+// sched_group_barrier slots, -2.5 % without them, -4..-10 % with other fragment-read leads; 38/38 parity cases pass either
+// way; profiles/r02_attn_swp_ab.log) -- the same sign as round 1's attempts at steering this loop.
 #ifndef ATTN_SWP
-#define ATTN_SWP 1
+#define ATTN_SWP 0
 #endif
 // sched_group_barrier pattern for compute_swp: 0 = leave the order to the compiler
 #ifndef ATTN_SWP_SGB
