@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vae", action="store_true", help="skip the (untimed, secondary) VAE encode / decode measurement")
     ap.add_argument("--mode", choices=["auto", "task", "grid", "frame-shard"], default="auto",
                     help="auto: task at --gpus 1, grid at --gpus N > 1 (see the module docstring)")
     ap.add_argument("--latent", default="72x40",
@@ -282,6 +283,36 @@ def cpu_baseline_and_parity(pipe, state_dict, task, frames: int, threads: int):
                 "oracle as this path is; 1e-3 needs fp32 activations (DESIGN.md section 3)",
     }
     return base, parity
+
+
+def vae_secondary(dev):
+    """SD-geometry AutoencoderKL on 8 images of the bench's pixel size: encode and decode time per image (outside the
+    timed region: SURVEY.md 8d reports the VAE separately).  FLOPs scale with the pixel count from SURVEY's per-image
+    figures at 576x320 (0.78 TF encode, 1.76 TF decode)."""
+    from diffuman4d_amd.host.vae import AutoencoderKL, VAEConfig
+    from diffuman4d_amd.host.weights import random_state_dict, vae_param_shapes
+    cfg = VAEConfig()
+    vae = AutoencoderKL(cfg, random_state_dict(vae_param_shapes(cfg), 1, dev), dev)
+    H, W, n = 8 * LAT_H, 8 * LAT_W, 8
+    g = torch.Generator(device=dev).manual_seed(5)
+    img = (torch.rand(n, 3, H, W, generator=g, device=dev) * 2 - 1).to(torch.bfloat16)
+    noise = torch.randn(n, 4, LAT_H, LAT_W, generator=g, device=dev).to(torch.bfloat16)
+    out = {}
+    with torch.no_grad():
+        z = vae.encode_scaled(img, noise)
+        vae.decode_to_images(z)
+        for name, fn, tf in (("encode", lambda: vae.encode_scaled(img, noise), 0.78), ("decode", lambda: vae.decode_to_images(z), 1.76)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 3 / n
+            flops = tf * 1e12 * (H * W) / (576 * 320)
+            out[name] = {"ms_per_image": round(ms, 3), "tflops": round(flops / (ms * 1e-3) / 1e12, 1)}
+    out["images"] = f"{n} x {H}x{W}, SD geometry (128,256,512,512), random init"
+    return out
 
 
 def main():
@@ -531,6 +562,8 @@ def main():
             "unet_calls_per_s": round(units_total * 3 / dt, 3),
             "unet_tflops_sustained": round(units_total * (2 * ut[0] + ut[1]) / dt, 1) if ut else None,
         }
+        if world == 1 and not args.no_vae and LAT_H * LAT_W <= 128 * 128:
+            out["secondary"]["vae"] = vae_secondary(dev)
         if want_cpu:  # rank 0 at N = 1 only (the CPU sample would skew multi-rank timing)
             out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(pipe, state_dict, tasks["spatial"], args.cpu_frames,
                                                                          args.cpu_threads)
