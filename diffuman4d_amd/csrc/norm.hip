@@ -172,6 +172,147 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GNParams p) {
   }
 }
 
+// Single-launch GroupNorm for feature maps small enough to stay in registers between the statistics and the apply step
+// (levels 1-3 of the UNet at 72x40 latents): one workgroup owns (sample, slab of `gps` whole groups), every thread
+// keeps one 16-byte channel vector of up to NV pixels in VGPRs, so X is read from HBM exactly once and the second
+// launch (with its dependent-launch gap) disappears.  Same fp32 sum / sum-of-squares formulas as the two-pass kernels;
+// the summation order is fixed by (HW, C, groups) only, never by the batch.
+constexpr int GN_RES_MAXGPS = 8;
+
+template <int NV>
+__global__ __launch_bounds__(GN_THREADS) void gn_resident_kernel(GNParams p, int gps, int SV, int PPB, int NS, int xcd_map) {
+  __shared__ float sm[2 * 8 * GN_THREADS];  // [PPB][SC][2]
+  __shared__ float sm2[2 * GN_THREADS];     // [PARTS][SC][2]
+  __shared__ float stat[2 * GN_RES_MAXGPS];
+  const int C = p.C1 + p.C2, CV1 = p.C1 / 8, gs = C / p.groups, SC = SV * 8;
+  int b, slab;
+  if (xcd_map) {  // workgroup i runs on XCD i % 8: keep all slabs of a sample on one XCD so that the 128-byte lines
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;  // two slabs share are fetched into ONE L2
+    b = x + 8 * (j / NS);
+    slab = j % NS;
+  } else {
+    b = blockIdx.x / NS;
+    slab = blockIdx.x % NS;
+  }
+  const int tid = threadIdx.x, sv = tid % SV, prow = tid / SV;
+  const bool active = prow < PPB;
+  const int cv = slab * gps * gs / 8 + sv;  // vector index in the concatenated channel axis
+  const u16* src;
+  int ld;
+  if (cv < CV1) {
+    src = p.X1 + (int64_t)b * p.HW * p.C1 + cv * 8;
+    ld = p.C1;
+  } else {
+    src = p.X2 + (int64_t)b * p.HW * p.C2 + (cv - CV1) * 8;
+    ld = p.C2;
+  }
+  U4 r[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int px = prow + k * PPB;
+    if (active && px < p.HW) r[k] = ldg16(src + (int64_t)px * ld);
+  }
+  {
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int px = prow + k * PPB;
+      if (active && px < p.HW) {
+        float v[8];
+        unpack8(r[k], v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          s[e] += v[e];
+          q[e] += v[e] * v[e];
+        }
+      }
+    }
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        sm[(prow * SC + sv * 8 + e) * 2 + 0] = s[e];
+        sm[(prow * SC + sv * 8 + e) * 2 + 1] = q[e];
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const int PARTS = GN_THREADS / SC, c = tid % SC, part = tid / SC;
+    if (part < PARTS) {
+      float s = 0.f, q = 0.f;
+      for (int rr = part; rr < PPB; rr += PARTS) {
+        s += sm[(rr * SC + c) * 2 + 0];
+        q += sm[(rr * SC + c) * 2 + 1];
+      }
+      sm2[(part * SC + c) * 2 + 0] = s;
+      sm2[(part * SC + c) * 2 + 1] = q;
+    }
+    __syncthreads();
+    if (tid < gps) {
+      float s = 0.f, q = 0.f;
+      for (int pt = 0; pt < PARTS; ++pt)
+        for (int cc = tid * gs; cc < (tid + 1) * gs; ++cc) {
+          s += sm2[(pt * SC + cc) * 2 + 0];
+          q += sm2[(pt * SC + cc) * 2 + 1];
+        }
+      const float n = (float)gs * (float)p.HW;
+      const float mu = s / n;
+      float var = q / n - mu * mu;
+      var = var < 0.f ? 0.f : var;
+      stat[tid * 2 + 0] = mu;
+      stat[tid * 2 + 1] = rsqrtf(var + p.eps);
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+  float a[8], sft[8];
+  {
+    float gm[8], bt[8];
+    unpack8(ldg16(p.gamma + cv * 8), gm);
+    unpack8(ldg16(p.beta + cv * 8), bt);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = (sv * 8 + e) / gs;
+      a[e] = gm[e] * stat[g * 2 + 1];
+      sft[e] = bt[e] - stat[g * 2 + 0] * a[e];
+    }
+  }
+  u16* dst = p.Y + (int64_t)b * p.HW * C + cv * 8;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int px = prow + k * PPB;
+    if (px < p.HW) {
+      float v[8];
+      unpack8(r[k], v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float y = v[e] * a[e] + sft[e];
+        v[e] = p.silu ? silu_f(y) : y;
+      }
+      stg16(dst + (int64_t)px * C, pack8(v));
+    }
+  }
+}
+
+int g_gn_resident = 1;  // tuning hook (dm4d_tune_set_groupnorm_resident)
+
+// slab geometry of the single-launch kernel, or false when the map does not fit in registers (two-pass path then)
+bool gn_resident_plan(int C, int HW, int groups, int* gps, int* SV, int* PPB, int* NV) {
+  const int gs = C / groups;
+  for (int g = 1; g <= GN_RES_MAXGPS && g <= groups; g *= 2) {
+    if (groups % g || (g * gs) % 8 || g * gs * 2 < 64) continue;
+    const int sv = g * gs / 8;
+    if (sv > 32) return false;
+    const int ppb = GN_THREADS / sv, nv = (HW + ppb - 1) / ppb;
+    if (nv > 16) return false;
+    *gps = g, *SV = sv, *PPB = ppb, *NV = nv;
+    return true;
+  }
+  return false;
+}
+
 // LayerNorm: one wave per row, row kept in registers (two-pass mean / variance)
 template <int NV>  // 16-byte vectors per lane
 __global__ __launch_bounds__(256) void ln_kernel(const u16* X, int64_t ldx, const u16* gamma, const u16* beta, u16* Y,
@@ -313,6 +454,18 @@ extern "C" int dm4d_groupnorm_nhwc_bf16(void* stream, const void* X1, int C1, co
   GNParams p{(const u16*)X1, (const u16*)X2, C1, C2, B, HW, groups, gn_nchunk(B, HW), eps,
              (const u16*)gamma, (const u16*)beta, (u16*)Y, apply_silu, (float*)ws};
   hipStream_t st = (hipStream_t)stream;
+  {
+    int gps, SV, RPB, NV;
+    if (g_gn_resident && gn_resident_plan(C, HW, groups, &gps, &SV, &RPB, &NV)) {
+      const int NS = groups / gps, xcd = (B % 8 == 0);
+      const dim3 grid(B * NS), blk(GN_THREADS);
+      if (NV <= 2) hipLaunchKernelGGL(gn_resident_kernel<2>, grid, blk, 0, st, p, gps, SV, RPB, NS, xcd);
+      else if (NV <= 4) hipLaunchKernelGGL(gn_resident_kernel<4>, grid, blk, 0, st, p, gps, SV, RPB, NS, xcd);
+      else if (NV <= 8) hipLaunchKernelGGL(gn_resident_kernel<8>, grid, blk, 0, st, p, gps, SV, RPB, NS, xcd);
+      else hipLaunchKernelGGL(gn_resident_kernel<16>, grid, blk, 0, st, p, gps, SV, RPB, NS, xcd);
+      return dm4d_check_launch("gn_resident_kernel");
+    }
+  }
   const int CV = C / 8;
   const int PPB = CV >= GN_THREADS ? 1 : GN_THREADS / CV;
   const size_t sm1 = (size_t)PPB * C * 2 * sizeof(float);
@@ -359,4 +512,9 @@ extern "C" int dm4d_softmax_rows_f32in_bf16(void* stream, const float* S, int64_
     return dm4d_set_error(DM4D_ERR_ARG, "softmax (fp32 logits): N and the row strides must be multiples of 4, rows 16-byte aligned");
   hipLaunchKernelGGL(softmax_rows_f32_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, S, lds, (u16*)P, ldp, N, scale);
   return dm4d_check_launch("softmax_rows_f32_kernel");
+}
+
+extern "C" int dm4d_tune_set_groupnorm_resident(int on) {
+  g_gn_resident = on;
+  return DM4D_OK;
 }

@@ -71,7 +71,12 @@ def bench_gn(B, HW, C, tag=""):
     g, bt = rnd(C), rnd(C)
     t = timeit(lambda: ops.groupnorm(x, g, bt, 32, 1e-5, silu=True))
     by = 2.0 * B * HW * C * 2  # algorithmic: read once + write once, bf16
-    print(f"gn  {tag:10s} B={B:3d} HW={HW:6d} C={C:5d}  {t*1e6:9.1f} us  {by/t/1e9:7.1f} GB/s(alg)", flush=True)
+    from diffuman4d_amd.host import lib
+    lib.load().dm4d_tune_set_groupnorm_resident(0)  # A/B: the statistics + apply kernel pair on the same shape
+    t2 = timeit(lambda: ops.groupnorm(x, g, bt, 32, 1e-5, silu=True))
+    lib.load().dm4d_tune_set_groupnorm_resident(1)
+    print(f"gn  {tag:10s} B={B:3d} HW={HW:6d} C={C:5d}  {t*1e6:9.1f} us  {by/t/1e9:7.1f} GB/s(alg)   two-launch {t2*1e6:7.1f} us",
+          flush=True)
 
 
 def bench_ln(M, C, tag=""):
@@ -105,11 +110,15 @@ def main():
             bench_gn(B, 2880, 320, f" L0 B{B}")
             bench_gn(B, 2880, 640, f" L0c B{B}")
             bench_gn(B, 2880, 960, f" L0cc B{B}")
+            bench_gn(B, 720, 320, f" L1in B{B}")
             bench_gn(B, 720, 640, f" L1 B{B}")
+            bench_gn(B, 720, 1280, f" L1c B{B}")
             bench_gn(B, 720, 1920, f" L1cc B{B}")
             bench_gn(B, 180, 1280, f" L2 B{B}")
+            bench_gn(B, 180, 1920, f" L2c B{B}")
             bench_gn(B, 180, 2560, f" L2cc B{B}")
             bench_gn(B, 45, 1280, f" L3 B{B}")
+            bench_gn(B, 45, 2560, f" L3c B{B}")
         return
     print("device:", torch.cuda.get_device_name(0), "attn q_scaled:", QS, flush=True)
     B = 32  # F=16, CFG

@@ -185,8 +185,41 @@ def case_attention_kv_split(batch, heads, L, parts, seed=0, q_scaled=False):
     return worst, worst
 
 
-def case_groupnorm(B, HW, C1, C2, groups, silu, eps=1e-5, seed=0):
-    from diffuman4d_amd.host import ops
+def case_groupnorm(B, HW, C1, C2, groups, silu, eps=1e-5, seed=0, two_launch=False):
+    """two_launch=True forces the statistics + apply kernel pair for a shape the single-launch kernel would take."""
+    from diffuman4d_amd.host import lib, ops
+    if two_launch:
+        lib.load().dm4d_tune_set_groupnorm_resident(0)
+    try:
+        return _groupnorm(ops, B, HW, C1, C2, groups, silu, eps, seed)
+    finally:
+        lib.load().dm4d_tune_set_groupnorm_resident(1)
+
+
+def case_groupnorm_batch_invariant(B, HW, C1, C2, groups, seed=0):
+    """Sample k of a batch-B call == the same sample normalised alone, bit for bit (both kernels); the single-launch
+    and the two-launch kernels agree to rounding (different fp32 summation order of the statistics)."""
+    from diffuman4d_amd.host import lib, ops
+    g = torch.Generator().manual_seed(seed)
+    x1 = (_rnd((B, HW, C1), g) + 0.5).cuda()
+    x2 = (_rnd((B, HW, C2), g) * 2.0 - 0.25).cuda() if C2 else None
+    gamma, beta = (_rnd((C1 + C2,), g) + 1.0).cuda(), _rnd((C1 + C2,), g, 0.3).cuda()
+    outs = []
+    try:
+        for resident in (1, 0):
+            lib.load().dm4d_tune_set_groupnorm_resident(resident)
+            full = ops.groupnorm(x1, gamma, beta, groups, 1e-5, x2=x2, silu=True)
+            for k in (0, B - 1):
+                one = ops.groupnorm(x1[k:k + 1].contiguous(), gamma, beta, groups, 1e-5,
+                                    x2=x2[k:k + 1].contiguous() if C2 else None, silu=True)
+                assert torch.equal(one[0], full[k]), f"groupnorm depends on the batch (resident={resident}, sample {k})"
+            outs.append(full.float())
+    finally:
+        lib.load().dm4d_tune_set_groupnorm_resident(1)
+    return rel_l2(outs[0], outs[1].cpu()), float((outs[0] - outs[1]).abs().max())
+
+
+def _groupnorm(ops, B, HW, C1, C2, groups, silu, eps, seed):
     g = torch.Generator().manual_seed(seed)
     x1 = _rnd((B, HW, C1), g) + 0.5
     x2 = (_rnd((B, HW, C2), g) * 2.0 - 0.25) if C2 else None
@@ -426,6 +459,15 @@ CASES = {
     "gn_320": (case_groupnorm, dict(B=4, HW=720, C1=320, C2=0, groups=32, silu=True)),
     "gn_concat_1920": (case_groupnorm, dict(B=3, HW=180, C1=1280, C2=640, groups=32, silu=True)),
     "gn_concat_2560": (case_groupnorm, dict(B=2, HW=45, C1=1280, C2=1280, groups=32, silu=False, eps=1e-6)),
+    "gn_320_two_launch": (case_groupnorm, dict(B=4, HW=720, C1=320, C2=0, groups=32, silu=True, two_launch=True)),
+    "gn_concat_1920_two_launch": (case_groupnorm, dict(B=3, HW=180, C1=1280, C2=640, groups=32, silu=True, two_launch=True)),
+    "gn_l0_2880": (case_groupnorm, dict(B=2, HW=2880, C1=320, C2=0, groups=32, silu=True)),  # too big for registers
+    "gn_l1_640_b16": (case_groupnorm, dict(B=16, HW=720, C1=640, C2=0, groups=32, silu=True)),  # XCD-grouped grid
+    "gn_l1_concat_1280_b8": (case_groupnorm, dict(B=8, HW=720, C1=640, C2=640, groups=32, silu=False)),
+    "gn_l1_concat_960": (case_groupnorm, dict(B=2, HW=720, C1=640, C2=320, groups=32, silu=True)),  # 60-B groups: two-launch
+    "gn_l3_1280_b32": (case_groupnorm, dict(B=32, HW=45, C1=1280, C2=0, groups=32, silu=True)),
+    "gn_batch_invariant_l1": (case_groupnorm_batch_invariant, dict(B=9, HW=720, C1=640, C2=0, groups=32)),
+    "gn_batch_invariant_l2_concat": (case_groupnorm_batch_invariant, dict(B=16, HW=180, C1=1280, C2=640, groups=32)),
     "gn_tiny64": (case_groupnorm, dict(B=5, HW=100, C1=64, C2=0, groups=32, silu=True)),
     "gn_tiny_concat": (case_groupnorm, dict(B=2, HW=50, C1=128, C2=64, groups=32, silu=True)),
     "ln_320": (case_layernorm, dict(M=1000, C=320)),
