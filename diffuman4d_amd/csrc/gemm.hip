@@ -30,6 +30,7 @@
 #include "dm4d.h"
 #include "errors.h"
 #include <stdlib.h>
+#include <type_traits>
 
 // Epilogue read-back loop with shift / 32-bit-offset index arithmetic (see gemm_epilogue); 0 = the generic loop only.
 // Same floating-point operations in the same order, so results are bit-identical either way (tools/dev/fe_check.py).
@@ -42,6 +43,13 @@
 // reads + barriers only), 4 = gemm_kernel_pipe without its MFMAs (DMA + LDS reads + barriers only).
 #ifndef GEMM_ABLATE
 #define GEMM_ABLATE 0
+#endif
+// conv_strip2_kernel: 1 = sched_group_barrier directives put the fragment reads of k step s+1 behind the MFMAs of step s
+#ifndef STRIP2_SCHED
+#define STRIP2_SCHED 1
+#endif
+#ifndef STRIP2_NOWAIT
+#define STRIP2_NOWAIT 0
 #endif
 
 namespace {
@@ -654,6 +662,312 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip_kernel(GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Strip convolution, second form: the SAME tiling, LDS layout, K order and MFMA accumulation order as conv_strip_kernel
+// (results are bit-identical), with a main loop that issues nothing but MFMAs, LDS reads, DMA instructions and scalar
+// bookkeeping.  The ISA of conv_strip_kernel<256,128,4,2> spends about six VALU instructions per MFMA in its loop:
+// 64-bit source pointers rebuilt per DMA instruction (plus a select against a zero page for rows outside the image and a
+// PC-relative address of that page), fragment addresses rebuilt per read (swizzle XOR, buffer parity, edge selects); and
+// it waits for lgkmcnt(0) in front of every pair of MFMAs.  On this chip a wave's VALU instructions are not hidden
+// behind the MFMAs of the wave it shares a SIMD with (issue probe), so all of that is paid in MFMA
+// time.  Here:
+//   * DMA sources are `uniform 64-bit base (SGPRs) + loop-invariant 32-bit lane offset`: rows outside the image are NOT
+//     zero-filled on the way in (their source pixel is clamped to a valid one) ...
+//   * ... instead the fragment READS of taps that fall outside the image -- left / right edge as before, now also the
+//     rows above / below it -- point at a zero row kept in each A buffer behind the strip (rows BM+8..: never DMA'd);
+//   * every fragment read address is a precomputed VGPR (per tap column kx, fragment row block and 16-wide k step; they
+//     change only with the kernel row ky, i.e. three times per launch); the buffer parity is added once per step;
+//   * the DMA issue is laid out statically per tap column: no per-step branches on the step counters.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dma16_sv(const void* uniform_base, uint32_t lane_byte_off, uint32_t lds_dst) {
+  // global_load_lds_dwordx4 vaddr(32-bit offset), saddr: lane i's 16 bytes land at lds_dst + 16 i.  Volatile asm: no VGPR
+  // destination, completion awaited by hand (s_waitcnt vmcnt(0) before the step's barrier).
+  // M0 (the LDS destination) is a reserved register the compiler sets right before each of its own uses, so it is written
+  // here without being saved; the statement is atomic as far as the compiler is concerned.
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               :
+               : "v"(lane_byte_off), "s"(uniform_base), "s"(lds_dst)
+               : "memory");
+}
+
+// Scheduling directive for one 16-wide k step: Q MFMAs with the R fragment reads of the NEXT k step spread behind the
+// first of them (one basic block; the reads then land in the second fragment register set while the MFMAs run).
+template <int Q, int R, int q = 0>
+__device__ __forceinline__ void sched_mfma_with_reads() {
+  if constexpr (q < Q) {
+    constexpr int lo = (q * R) / Q, hi = ((q + 1) * R) / Q;
+    if constexpr (hi > lo) __builtin_amdgcn_sched_group_barrier(0x100, hi - lo, 0);  // DS reads (ahead of the MFMA: the
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                               // last read is not the last issue)
+    sched_mfma_with_reads<Q, R, q + 1>();
+  }
+}
+
+// The same for the single-register-set order: MFMA (i, j) is followed by the reload of A fragment i when j is the last
+// column block, and of B fragment j when i is the last row block.
+template <int MI, int NI, bool RELOAD, int q = 0>
+__device__ __forceinline__ void sched_mfma_reload() {
+  if constexpr (q < MI * NI) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    constexpr int i = q / NI, j = q % NI;
+    constexpr int n = RELOAD ? ((j == NI - 1 ? 1 : 0) + (i == MI - 1 ? 1 : 0)) : 0;
+    if constexpr (n > 0) __builtin_amdgcn_sched_group_barrier(0x100, n, 0);
+    sched_mfma_reload<MI, NI, RELOAD, q + 1>();
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void conv_strip2_kernel(GemmParams p) {
+  constexpr int BK = 64, ROWB = BK * 2;  // bytes per LDS row
+  constexpr int NW = WM * WN;
+  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
+  constexpr int NA = (BM + 8) / 8;  // 1-KiB DMA instructions per strip (BM + 2 rows needed, 8 rows per instruction)
+  constexpr int SR = BM + 16;       // rows per A buffer: the strip, then the zero row at BM + 8
+  constexpr int ZROW = BM + 8;
+  constexpr int AW = (NA + NW - 1) / NW, BW = BN / (8 * NW);
+  constexpr int A_BYTES = SR * ROWB, B_BYTES = BN * ROWB;
+  constexpr int SMEM_MAIN = 2 * (A_BYTES + B_BYTES);
+  constexpr int SMEM_EPI = NW * 32 * (EpiGeom<TN>::EPW + 4) * 4;
+  constexpr int SMEM_BYTES = SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI;
+  static_assert(SMEM_BYTES <= 160 * 1024, "tile does not fit the LDS");
+  static_assert(2 * A_BYTES + 2 * B_BYTES - 1 + 0 < (1 << 20), "LDS offsets");
+  __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+  constexpr int BS0 = 2 * A_BYTES;  // byte offset of the B buffers
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  int split = 0, tm, tn;
+  if (p.splits > 1) {
+    const int rows = gridDim.x / p.tiles_n;  // tile rows x splits
+    const int tms = lid % rows;
+    tn = lid / rows;
+    split = tms / (rows / p.splits);
+    tm = tms % (rows / p.splits);
+  } else {
+    tn = lid % p.tiles_n;
+    tm = lid / p.tiles_n;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int d_row = lane >> 3, d_pos = lane & 7;
+  if (tid < 16) *reinterpret_cast<U4*>(smem + (tid >> 3) * A_BYTES + ZROW * ROWB + (tid & 7) * 16) = U4{0u, 0u, 0u, 0u};
+
+  // ---- DMA lane offsets (bytes): A per kernel row (three times per launch), W fixed ---------------------------------
+  uint32_t a_voff[AW];  // the strip row's source pixel for the kernel row being ISSUED, clamped into the tensor
+  auto set_a_voff = [&](int ky) {
+#pragma unroll
+    for (int i = 0; i < AW; ++i) {
+      const int row = (wave + NW * i) * 8 + d_row;
+      int px = m0 - 1 + row + (ky - 1) * p.W;  // m0 - 1 + row: centre output pixel served by this strip row
+      px = px < 0 ? 0 : (px > p.M - 1 ? p.M - 1 : px);
+      a_voff[i] = (uint32_t)px * (uint32_t)(p.Cin * 2) + (uint32_t)((d_pos ^ ((row >> 1) & 7)) * 16);
+    }
+  };
+  uint32_t w_voff[BW];
+#pragma unroll
+  for (int i = 0; i < BW; ++i) {
+    const int row = (wave + NW * i) * 8 + d_row;
+    const int chunk = d_pos ^ ((row >> 1) & 7);
+    int n = n0 + row;
+    if (n > p.N - 1) n = p.N - 1;
+    w_voff[i] = ((uint32_t)n * (uint32_t)p.ldw + (uint32_t)chunk * 8u) * 2u;
+  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+
+  // ---- fragment read addresses (LDS byte offsets) ------------------------------------------------------------------
+  unsigned edge[MI];  // bit 0: x == 0, 1: x == W-1, 2: y == 0, 3: y == H-1 of this lane's output pixel in row block i
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    int m = m0 + wm * TM + i * 32 + l31;
+    if (m > p.M - 1) m = p.M - 1;
+    const int x = m % p.W, y = (m / p.W) % p.H;
+    edge[i] = (x == 0 ? 1u : 0u) | (x == p.W - 1 ? 2u : 0u) | (y == 0 ? 4u : 0u) | (y == p.H - 1 ? 8u : 0u);
+  }
+  // address of a fragment = a_row (row block i of tap column kx: the strip row, or the zero row) + a_swz (k step ks under
+  // the strip row's swizzle key) + an immediate for the buffer parity
+  int a_row[3][MI], a_swz[3][4];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    const int swa = ((l31 + kx) >> 1) & 7;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) a_swz[kx][ks] = ((ks * 2 + lh) ^ swa) * 16;
+  }
+  auto set_a_addrs = [&](int ky) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const unsigned e = edge[i];
+        const bool zero = (kx == 0 && (e & 1u)) || (kx == 2 && (e & 2u)) || (ky == 0 && (e & 4u)) || (ky == 2 && (e & 8u));
+        a_row[kx][i] = zero ? ZROW * ROWB : (wm * TM + i * 32 + l31 + kx) * ROWB;
+      }
+  };
+  int b_rd[4];  // [k step]; column block and buffer parity come as immediates
+  {
+    const int swb = (l31 >> 1) & 7;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) b_rd[ks] = BS0 + (wn * TN + l31) * ROWB + (((ks * 2 + lh) ^ swb) * 16);
+  }
+
+  f32x16_t acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- the K walk: ky (kernel row) > cs (64-channel slab) > kx (tap column); one DMA'd step ahead -------------------
+  const int nci = p.Cin / BK;
+  const int ky0 = p.splits > 1 ? split : 0, ky1 = p.splits > 1 ? split + 1 : 3;
+  const int nstrips = (ky1 - ky0) * nci;
+  // DMA issue, statically laid out per tap column (no per-step bookkeeping branches): a weight slab is 8 * NW rows per
+  // instruction round, the A strip NA pieces of 8 rows of which the last round is partial
+  const uint32_t a_dst0 = lds0 + wave * 1024, b_dst0 = lds0 + BS0 + wave * 1024;
+  auto issue_b = [&](const u16* wbase, int par) {  // slab at wbase -> B buffer `par`
+    const uint32_t dst = b_dst0 + (par ? B_BYTES : 0);
+#pragma unroll
+    for (int i = 0; i < BW; ++i) dma16_sv(wbase, w_voff[i], dst + NW * i * 1024);
+  };
+  auto issue_a = [&](const u16* abase, int par) {  // strip at abase (+ a_voff) -> A buffer `par`
+    const uint32_t dst = a_dst0 + (par ? A_BYTES : 0);
+#pragma unroll
+    for (int i = 0; i < AW; ++i) {
+      if (NW * (i + 1) <= NA) {
+        dma16_sv(abase, a_voff[i], dst + NW * i * 1024);
+      } else if (wave < NA - NW * i) {
+        dma16_sv(abase, a_voff[i], dst + NW * i * 1024);
+      }
+    }
+  };
+  auto dma_wait_barrier = [&]() {
+    // lgkmcnt: the fragment reads of this step must have executed before any wave's next DMA (or the epilogue's staging
+    // stores) may overwrite the buffers they read
+#if !STRIP2_NOWAIT  // profiling only: without the wait results are WRONG; bounds what hiding the DMA latency could buy
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  // One step (64 K elements of one tap).  Small wave tiles keep two fragment register sets and read k step ks+1 while
+  // the MFMAs of ks run; the 64x160 tile (160 accumulators) keeps one set and reloads each fragment right behind the
+  // MFMA that used it last in this k step -- at least four MFMAs (128 cycles) before its next use.
+  constexpr bool TWO_SETS = MI * NI <= 8;
+  auto compute = [&](int abuf, auto kx_c) {  // abuf: strip parity (uniform)
+    constexpr int KX = decltype(kx_c)::value;
+    const int a_par = abuf ? A_BYTES : 0;
+    const int b_par = (abuf ^ (KX & 1)) ? B_BYTES : 0;  // B buffer parity: (3 strip + kx) & 1
+    int arow[MI], brow[4];  // the step's own base addresses: MI + 4 adds per step, every read is base + immediate
+#pragma unroll
+    for (int i = 0; i < MI; ++i) arow[i] = a_row[KX][i] + a_par;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) brow[ks] = b_rd[ks] + b_par;
+    auto read_a = [&](int ks, int i) { return *reinterpret_cast<const bf16x8_t*>(smem + arow[i] + a_swz[KX][ks]); };
+    auto read_b = [&](int ks, int j) { return *reinterpret_cast<const bf16x8_t*>(smem + brow[ks] + j * 32 * ROWB); };
+    if constexpr (TWO_SETS) {
+      bf16x8_t af[2][MI], bfr[2][NI];
+      auto read_frags = [&](int ks, int slot) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[slot][i] = read_a(ks, i);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bfr[slot][j] = read_b(ks, j);
+      };
+      read_frags(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks + 1 < 4) read_frags(ks + 1, (ks + 1) & 1);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
+      }
+#if STRIP2_SCHED
+      __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);  // fragments of k step 0
+      sched_mfma_with_reads<MI * NI, MI + NI>();
+      sched_mfma_with_reads<MI * NI, MI + NI>();
+      sched_mfma_with_reads<MI * NI, MI + NI>();
+      sched_mfma_with_reads<MI * NI, 0>();
+#endif
+    } else {
+      bf16x8_t af[MI], bfr[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = read_a(0, i);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bfr[j] = read_b(0, j);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            if (ks + 1 < 4) {
+              if (j == NI - 1) af[i] = read_a(ks + 1, i);
+              if (i == MI - 1) bfr[j] = read_b(ks + 1, j);
+            }
+          }
+#if STRIP2_SCHED
+      __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
+      sched_mfma_reload<MI, NI, true>();
+      sched_mfma_reload<MI, NI, true>();
+      sched_mfma_reload<MI, NI, true>();
+      sched_mfma_reload<MI, NI, false>();
+#endif
+    }
+  };
+  // weights of (ky, cs, kx): Wt + (ky * 3 + kx) * Cin + cs * 64; strip of (ky, cs): A + cs * 64 (+ a_voff of ky)
+  const int cin = p.Cin;
+  int c_ky = ky0, c_cs = 0;
+  const u16* wp = p.Wt + ky0 * 3 * cin;
+  set_a_voff(ky0);
+  issue_a(p.A, 0);
+  issue_b(wp, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // also publishes the zero rows
+  for (int g = 0; g < nstrips; ++g) {
+    if (c_cs == 0) set_a_addrs(c_ky);
+    const int abuf = g & 1;
+    issue_b(wp + cin, abuf ^ 1);  // (g, kx = 1)
+    compute(abuf, std::integral_constant<int, 0>{});
+    dma_wait_barrier();
+    issue_b(wp + 2 * cin, abuf);  // (g, kx = 2)
+    compute(abuf, std::integral_constant<int, 1>{});
+    dma_wait_barrier();
+    if (++c_cs == nci) {
+      c_cs = 0;
+      ++c_ky;
+    }
+    if (g + 1 < nstrips) {  // the next strip's A rows and its first weight slab
+      if (c_cs == 0) set_a_voff(c_ky);
+      wp = p.Wt + (c_ky * 3 * cin + c_cs * BK);
+      issue_a(p.A + c_cs * BK, abuf ^ 1);
+      issue_b(wp, abuf ^ 1);
+    }
+    compute(abuf, std::integral_constant<int, 2>{});
+    dma_wait_barrier();
+  }
+  if (p.splits > 1) {  // raw fp32 partial sums; splitk_reduce_kernel adds the splits in a fixed order and applies the epilogue
+    float* wsp = p.ws + (int64_t)split * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * TN + j * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m < p.M && n < p.N) wsp[(int64_t)m * p.N + n] = acc[i][j][r];
+        }
+      }
+    return;
+  }
+  gemm_epilogue<MI, NI, TM, TN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
 // deep pipeline: K-slab 32, NST LDS stages, NST-1 slabs of DMA in flight across barriers
 // (counted s_waitcnt vmcnt + raw s_barrier: a __syncthreads() would drain the DMA queue), 4 or 8
 // waves.  Ablation of the 2-stage kernel showed the DMA side, not the MFMAs, bounds it (one slab of
@@ -831,6 +1145,184 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_pipe(GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Linear layers, second form (the counterpart of conv_strip2_kernel for dense A): K-slab 64 (whole 128-byte DMA rows),
+// NST-stage ring with NST-1 slabs in flight under a counted vmcnt, DMA sources as `uniform base + loop-invariant 32-bit
+// lane offset`, fragment reads at `per-step base + immediate`, reads of k step s+1 (or single-set reloads) placed among
+// the MFMAs of step s by scheduling directives.  Same K order as every other kernel of this file (ascending 16-wide k
+// steps into each accumulator), so results are bit-identical to gemm_kernel_pipe / gemm_kernel_glds.
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int NST>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_lin2_kernel(GemmParams p) {
+  constexpr int BK = 64, ROWB = BK * 2;
+  constexpr int NW = WM * WN;
+  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
+  constexpr int AW = BM / 8 / NW, BW = BN / 8 / NW;  // 1-KiB DMA instructions (8 rows of 128 B) per wave per slab
+  static_assert(AW >= 1 && BW >= 1 && NST >= 2 && NST <= 3, "tile/wave/stage combination");
+  constexpr int LD = AW + BW;
+  constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+  constexpr int SMEM_MAIN = NST * STAGE_BYTES;
+  constexpr int SMEM_EPI = NW * 32 * (EpiGeom<TN>::EPW + 4) * 4;
+  constexpr int SMEM_BYTES = SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI;
+  static_assert(SMEM_BYTES <= 160 * 1024, "tile does not fit the LDS");
+  __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
+  const int m0 = tm * BM;
+  const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
+  const int n0 = tn * (geglu ? BN / 2 : BN);
+  const int d_row = lane >> 3, d_pos = lane & 7;
+
+  uint32_t a_voff[AW], a2_voff[AW], w_voff[BW];
+#pragma unroll
+  for (int i = 0; i < AW; ++i) {
+    const int row = (wave + NW * i) * 8 + d_row;
+    const uint32_t chunk = (uint32_t)(d_pos ^ ((row >> 1) & 7)) * 16u;
+    int m = m0 + row;
+    if (m > p.M - 1) m = p.M - 1;
+    a_voff[i] = (uint32_t)m * (uint32_t)(p.lda * 2) + chunk;
+    a2_voff[i] = (uint32_t)m * (uint32_t)(p.lda2 * 2) + chunk;
+  }
+#pragma unroll
+  for (int i = 0; i < BW; ++i) {
+    const int row = (wave + NW * i) * 8 + d_row;
+    w_voff[i] = (uint32_t)weight_row<TN>(p, n0, row, geglu) * (uint32_t)(p.ldw * 2) + (uint32_t)(d_pos ^ ((row >> 1) & 7)) * 16u;
+  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+  const uint32_t a_dst0 = lds0 + wave * 1024, b_dst0 = lds0 + BM * ROWB + wave * 1024;
+  const int k1 = p.A2 ? p.K1 : p.K;  // slabs below k1 come from A, the others from A2 (split A: K1 % 64 == 0)
+  auto issue_slab = [&](int kt, int st) {
+    const int k = kt * BK;
+    const uint32_t so = st * STAGE_BYTES;
+    if (k < k1) {
+      const u16* ab = p.A + k;
+#pragma unroll
+      for (int i = 0; i < AW; ++i) dma16_sv(ab, a_voff[i], a_dst0 + so + NW * i * 1024);
+    } else {
+      const u16* ab = p.A2 + (k - k1);
+#pragma unroll
+      for (int i = 0; i < AW; ++i) dma16_sv(ab, a2_voff[i], a_dst0 + so + NW * i * 1024);
+    }
+    const u16* wb = p.Wt + k;
+#pragma unroll
+    for (int i = 0; i < BW; ++i) dma16_sv(wb, w_voff[i], b_dst0 + so + NW * i * 1024);
+  };
+
+  // fragment read addresses: row base + k-step swizzle (A and B rows share the key: both are l31 + a multiple of 32)
+  int a_rd[4], b_rd[4];
+  {
+    const int sw = (l31 >> 1) & 7;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int z = ((ks * 2 + lh) ^ sw) * 16;
+      a_rd[ks] = (wm * TM + l31) * ROWB + z;
+      b_rd[ks] = BM * ROWB + (wn * TN + l31) * ROWB + z;
+    }
+  }
+
+  f32x16_t acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  constexpr bool TWO_SETS = MI * NI <= 8;
+  auto compute = [&](int st) {
+    const int so = st * STAGE_BYTES;
+    int ar[4], br[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      ar[ks] = a_rd[ks] + so;
+      br[ks] = b_rd[ks] + so;
+    }
+    auto read_a = [&](int ks, int i) { return *reinterpret_cast<const bf16x8_t*>(smem + ar[ks] + i * 32 * ROWB); };
+    auto read_b = [&](int ks, int j) { return *reinterpret_cast<const bf16x8_t*>(smem + br[ks] + j * 32 * ROWB); };
+    if constexpr (TWO_SETS) {
+      bf16x8_t af[2][MI], bfr[2][NI];
+      auto read_frags = [&](int ks, int slot) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[slot][i] = read_a(ks, i);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bfr[slot][j] = read_b(ks, j);
+      };
+      read_frags(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks + 1 < 4) read_frags(ks + 1, (ks + 1) & 1);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
+      }
+#if STRIP2_SCHED
+      __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
+      sched_mfma_with_reads<MI * NI, MI + NI>();
+      sched_mfma_with_reads<MI * NI, MI + NI>();
+      sched_mfma_with_reads<MI * NI, MI + NI>();
+      sched_mfma_with_reads<MI * NI, 0>();
+#endif
+    } else {
+      bf16x8_t af[MI], bfr[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = read_a(0, i);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bfr[j] = read_b(0, j);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            if (ks + 1 < 4) {
+              if (j == NI - 1) af[i] = read_a(ks + 1, i);
+              if (i == MI - 1) bfr[j] = read_b(ks + 1, j);
+            }
+          }
+#if STRIP2_SCHED
+      __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
+      sched_mfma_reload<MI, NI, true>();
+      sched_mfma_reload<MI, NI, true>();
+      sched_mfma_reload<MI, NI, true>();
+      sched_mfma_reload<MI, NI, false>();
+#endif
+    }
+  };
+
+  const int nk = p.K / BK;
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nk) issue_slab(s, s);
+  int st = 0, st_issue = NST - 1;  // stage holding slab kt / stage receiving slab kt + NST - 1
+  for (int kt = 0; kt < nk; ++kt) {
+    // slab kt has landed once at most min(NST-2, nk-1-kt) younger slabs of THIS wave are outstanding; lgkmcnt(0): this
+    // wave's fragment reads of slab kt-1 are done before anyone overwrites its stage
+    if (NST >= 3 && nk - 1 - kt >= 1) {
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LD) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + NST - 1 < nk) issue_slab(kt + NST - 1, st_issue);  // overwrites the stage slab kt-1 lived in
+    compute(st);
+    st = (st + 1 == NST) ? 0 : st + 1;
+    st_issue = (st_issue + 1 == NST) ? 0 : st_issue + 1;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // all fragment reads done: the epilogue stages through the same LDS
+  asm volatile("" ::: "memory");
+  gemm_epilogue<MI, NI, TM, TN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
 // fallback: K-slab 32, register staged, padded LDS rows (80 B stride => conflict-free fragment reads)
 // ------------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, bool CONV>
@@ -980,6 +1472,23 @@ int launch_pipe(hipStream_t st, GemmParams& p) {
   return dm4d_check_launch("gemm_kernel_pipe");
 }
 
+// the second form addresses A, A2 and W with 32-bit byte offsets from a uniform base and walks K in slabs of 64
+__host__ inline bool lin2_ok(const GemmParams& p) {
+  return p.K % 64 == 0 && (!p.A2 || p.K1 % 64 == 0) && (uint64_t)p.M * (uint64_t)p.lda * 2u < (1ull << 32) &&
+         (!p.A2 || (uint64_t)p.M * (uint64_t)p.lda2 * 2u < (1ull << 32)) &&
+         (uint64_t)(2 * (uint64_t)p.N) * (uint64_t)p.ldw * 2u < (1ull << 32);
+}
+
+template <int BM, int BN, int WM, int WN, int NST>
+int launch_lin2(hipStream_t st, GemmParams& p) {
+  const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
+  const int bn_out = geglu ? BN / 2 : BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + bn_out - 1) / bn_out;
+  hipLaunchKernelGGL((gemm_lin2_kernel<BM, BN, WM, WN, NST>), dim3(tiles_m * p.tiles_n), dim3(WM * WN * 64), 0, st, p);
+  return dm4d_check_launch("gemm_lin2_kernel");
+}
+
 // out = epilogue(ws[0] + ws[1] + ws[2]) for the split strip convolution: 8 columns per thread, 16-byte stores
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   const int nv = p.N / 8;
@@ -1041,6 +1550,26 @@ int launch_strip(hipStream_t st, GemmParams& p) {
   return dm4d_check_launch("splitk_reduce_kernel");
 }
 
+// the second form addresses A and W with 32-bit byte offsets from a uniform base
+__host__ inline bool strip2_ok(const GemmParams& p) {
+  return (uint64_t)p.M * (uint64_t)p.Cin * 2u < (1ull << 32) && (uint64_t)p.N * (uint64_t)p.ldw * 2u < (1ull << 32);
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_strip2(hipStream_t st, GemmParams& p) {
+  if (!strip2_ok(p)) return launch_strip<BM, BN, WM, WN>(st, p);
+  const int tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  if (p.splits < 1) p.splits = 1;
+  hipLaunchKernelGGL((conv_strip2_kernel<BM, BN, WM, WN>), dim3(tiles_m * p.tiles_n * p.splits), dim3(WM * WN * 64), 0, st, p);
+  int rc = dm4d_check_launch("conv_strip2_kernel");
+  if (rc || p.splits == 1) return rc;
+  const int64_t nthreads = (int64_t)p.M * (p.N / 8);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, p);
+  return dm4d_check_launch("splitk_reduce_kernel");
+}
+
+int g_strip_form = 2;  // 2 = conv_strip2_kernel serves ids 31-35 (bit-identical results), 1 = conv_strip_kernel (tuning hook)
 int g_tune_cfg = 0;  // 0 = heuristic; otherwise a kernel-configuration id (tuning hook, dm4d_tune_set_gemm_config)
 
 // Kernel configurations.  glds: K-slab 64, 2 LDS stages, 4 waves.  pipe: K-slab 32, 3-4 stages, 4 or 8 waves.
@@ -1049,6 +1578,7 @@ int launch_by_id(int id, hipStream_t st, GemmParams& p) {
   const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
   const bool k64 = CONV ? (p.Cin % 64 == 0) : (p.K % 64 == 0 && (!p.A2 || p.K1 % 64 == 0));
   if (id >= 1 && id <= 5 && !k64) return DM4D_ERR_ARG;
+  if (id >= 31 && id <= 35 && g_strip_form == 2) id += 20;
   switch (id) {
     case 1: return launch_cfg<128, 128, 2, 2, CONV, true>(st, p);
     case 2: return launch_cfg<256, 64, 4, 1, CONV, true>(st, p);
@@ -1075,9 +1605,15 @@ int launch_by_id(int id, hipStream_t st, GemmParams& p) {
     case 45: return k64 ? launch_pipe<256, 64, 8, 1, 3, CONV, 64>(st, p) : DM4D_ERR_ARG;   // 120 KB
     // 320-wide tile (see id 35), K-slab 64, 2 stages = 144 KB; per-wave tile 64 x 160 = 5 column blocks: no GEGLU pairing
     case 46: return (k64 && !geglu) ? launch_pipe<256, 320, 4, 2, 2, CONV, 64>(st, p) : DM4D_ERR_ARG;
-    case 31: case 32: case 33: case 34: case 35:
+    case 31: case 32: case 33: case 34: case 35: case 51: case 52: case 53: case 54: case 55:
       if constexpr (CONV) {
         if (!(k64 && p.stride == 1 && p.pad == 1 && !p.upsample && p.Ho == p.H && p.Wo == p.W)) return DM4D_ERR_ARG;
+        // 51-55: the VALU-free main loop (conv_strip2_kernel) on the tiles of 31-35; bit-identical results
+        if (id == 51) return launch_strip2<128, 128, 2, 2>(st, p);
+        if (id == 52) return launch_strip2<256, 128, 4, 2>(st, p);
+        if (id == 53) return launch_strip2<128, 64, 4, 1>(st, p);
+        if (id == 54) return launch_strip2<256, 256, 2, 4>(st, p);
+        if (id == 55) return launch_strip2<256, 320, 4, 2>(st, p);
         if (id == 31) return launch_strip<128, 128, 2, 2>(st, p);
         if (id == 32) return launch_strip<256, 128, 4, 2>(st, p);
         if (id == 33) return launch_strip<128, 64, 4, 1>(st, p);
@@ -1085,6 +1621,18 @@ int launch_by_id(int id, hipStream_t st, GemmParams& p) {
         // kernel row for N = 320 (level 0) and feeds 40 MFMAs per wave between two barriers
         if (id == 35) return launch_strip<256, 320, 4, 2>(st, p);
         return launch_strip<256, 256, 2, 4>(st, p);
+      } else {
+        return DM4D_ERR_ARG;
+      }
+    // Linear layers, second form (gemm_lin2_kernel): 61 = the tile of 14 / 41 (256x128, 8 waves, 3 stages), 62 = the tile
+    // of 46 (256x320, 2 stages, no GEGLU), 63 = 128x128 with 4 waves (2 workgroups per CU), 64 = 128x128 with 8 waves
+    case 61: case 62: case 63: case 64:
+      if constexpr (!CONV) {
+        if (!lin2_ok(p)) return DM4D_ERR_ARG;
+        if (id == 61) return launch_lin2<256, 128, 4, 2, 3>(st, p);
+        if (id == 62) return geglu ? DM4D_ERR_ARG : launch_lin2<256, 320, 4, 2, 2>(st, p);
+        if (id == 63) return launch_lin2<128, 128, 2, 2, 2>(st, p);
+        return launch_lin2<128, 128, 4, 2, 3>(st, p);
       } else {
         return DM4D_ERR_ARG;
       }
@@ -1172,6 +1720,12 @@ int launch(hipStream_t st, GemmParams& p) {
 
 extern "C" int dm4d_tune_set_gemm_config(int id) {
   g_tune_cfg = id;
+  return DM4D_OK;
+}
+
+extern "C" int dm4d_tune_set_strip_form(int form) {
+  if (form != 1 && form != 2) return dm4d_set_error(DM4D_ERR_ARG, "strip form must be 1 or 2");
+  g_strip_form = form;
   return DM4D_OK;
 }
 

@@ -178,6 +178,9 @@ int dm4d_postprocess_images_bf16(void* stream, const void* X, void* Y, int B, in
 /* Tuning hook (not part of the operator surface): force one GEMM/conv kernel configuration id for all
  * subsequent launches of this process; 0 restores the built-in heuristic.  Used by tools/gemm_tune.py. */
 int dm4d_tune_set_gemm_config(int id);
+/* Tuning hook: which of the two bit-identical forms of the stride-1 strip convolution runs (2, the default: main loop
+ * without vector-ALU address arithmetic; 1: the round-1 kernel).  Used by tools/dev/strip_ab.py.                      */
+int dm4d_tune_set_strip_form(int form);
 /* Tuning hook: 0 forces the two-launch GroupNorm (statistics, apply) for every shape; 1 (default) lets maps that fit
  * in registers take the single-launch kernel.  Used by tests/opcheck.py and tests/opbench.py for the A/B.            */
 int dm4d_tune_set_groupnorm_resident(int on);
