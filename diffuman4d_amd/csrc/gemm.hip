@@ -48,6 +48,12 @@
 #ifndef STRIP2_SCHED
 #define STRIP2_SCHED 1
 #endif
+// GEGLU gate activation: 1 = gelu_erf_f (the reference's function to 1.5e-7), 0 = gelu_fit_f (2.6e-5 from it, half the
+// instructions).  Measured in one call (profiles/r02_geglu_gelu_ab.log): the fit takes 1.2 % off the Linear family and
+// 0.35 % off a bench step -- not worth a second definition of GELU, so the erf form stays.
+#ifndef GEGLU_ERF
+#define GEGLU_ERF 1
+#endif
 #ifndef STRIP2_NOWAIT
 #define STRIP2_NOWAIT 0
 #endif
@@ -161,7 +167,11 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t
         float v = acc[i][J0 + j][r] + bias_h[j];
         if constexpr (geglu) {
           const float g = acc[i][J0 + j + NI / 2][r] + bias_g[j];
+#if GEGLU_ERF
           v = v * gelu_erf_f(g);
+#else
+          v = v * gelu_fit_f(g);
+#endif
         }
         if constexpr (MODE == 1) v = silu_f(v);
         srow[row * SLD + j * 32] = v;
@@ -1661,6 +1671,19 @@ int choose_cfg(const GemmParams& p) {
     // N = 320 with a deep K (the level-0 feed-forward output projection): one 320-wide tile reads A once instead of three
     // times (profiles/r02_gemm_tune_wide.log: 130 vs 146 us at CFG batch 32, 190 vs 207 at 48)
     if (!geglu && p.N == 320 && p.K >= 1024 && tm256 >= 256) return 46;
+    // deep-K layers (K >= 640: levels 1-3): the second form (gemm_lin2_kernel), bit-identical, -4..-17 % per launch
+    // (profiles/r02_lin2_ab.log): 128x128 tiles with two workgroups per CU wherever they fill the chip, the 8-wave
+    // 3-stage 128x128 tile for the few-row, very deep output projections of the deepest level, and the 256x128 tile
+    // for that level's GEGLU projection.  K = 320 (level 0) stays with the 2-workgroup K-slab-32 pipeline: there a tile is
+    // mostly prologue and epilogue, which only a second resident workgroup overlaps.
+    if (lin2_ok(p)) {
+      if (geglu) {
+        if (tm256 <= 12 && p.K >= 1280) return 61;
+      } else if (p.K >= 640 && p.N >= 640) {
+        if (tm128 * ((p.N + 127) / 128) >= 256) return 63;
+        if (p.K >= 2560) return 64;
+      }
+    }
     // Linear layers stream A once with little reuse (K = C or 4C): they are bound by L2->LDS bytes and DMA latency,
     // so the 8-wave 256x128 tile with 2 slabs of DMA in flight wins whenever it still fills the chip (1.2-1.35x)
     const long t = tm256 * tn;  // one 8-wave workgroup per CU => 256 slots per round; avoid a mostly empty last round
