@@ -85,6 +85,9 @@ struct GemmParams {
   // split-K of the strip convolution over the 3 kernel rows (small images): partial sums go to ws[split][M][N] fp32
   int splits;
   float* ws;
+  // phase-decomposed x2 upsampling convolution (conv_strip2_kernel<.., KT = 2>): rows m of the GEMM are LOW-resolution
+  // pixels (b, y, x) of width up_w, output row = 2 m + 2 up_w (m / up_w) from a C pointer moved to the phase's first pixel
+  int up_w;
 };
 
 __device__ __attribute__((aligned(16))) const uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
@@ -150,7 +153,7 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t
   // the fast read-back loop takes row / chunk of a task from shifts: it needs a power-of-two number of chunks per row
   constexpr bool CPR_POW2 = (CPR & (CPR - 1)) == 0;
   const bool fast_ok = CPR_POW2 && vec_ok && p.ldc < (1 << 24) && (!p.res || p.ld_res < (1 << 24)) &&
-                       (!p.rowbias || p.rows_per_rb > 0) && !f32out;
+                       (!p.rowbias || p.rows_per_rb > 0) && !f32out && p.up_w == 0;
 #endif
   // The staging area is private to a wave and LDS operations of one wave complete in program order, so only one
   // workgroup barrier is needed: the one that retires every wave's main-loop fragment reads before the area is reused
@@ -242,6 +245,7 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t
       int m = m0 + wm * TM + i * 32 + row;
       int n = ncol0 + cc * 8;
       if (m >= p.M || n >= p.N) continue;
+      const int64_t mo = p.up_w ? 2 * (int64_t)m + 2 * (int64_t)p.up_w * (m / p.up_w) : (int64_t)m;  // output row
       float v[8];
       const float* s = stage + row * SLD + cc * 8;
       f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(s);
@@ -264,20 +268,20 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
         if (f32out) {
-          float* cf = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
+          float* cf = reinterpret_cast<float*>(p.C) + mo * p.ldc + n;
           f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
           *reinterpret_cast<f32x4_t*>(cf) = o0;
           *reinterpret_cast<f32x4_t*>(cf + 4) = o1;
         } else {
-          stg16(p.C + (int64_t)m * p.ldc + n, pack8(v));
+          stg16(p.C + mo * p.ldc + n, pack8(v));
         }
       } else {
         for (int e = 0; e < 8 && n + e < p.N; ++e) {
           float x = v[e];
           if (p.rowbias) x += bf2f(p.rowbias[(int64_t)(m / p.rows_per_rb) * p.ld_rb + n + e]);
           if (p.res) x += bf2f(p.res[(int64_t)m * p.ld_res + n + e]);
-          if (f32out) reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + n + e] = x * p.out_scale;
-          else p.C[(int64_t)m * p.ldc + n + e] = f2bf(x * p.out_scale);
+          if (f32out) reinterpret_cast<float*>(p.C)[mo * p.ldc + n + e] = x * p.out_scale;
+          else p.C[mo * p.ldc + n + e] = f2bf(x * p.out_scale);
         }
       }
     }
@@ -724,8 +728,15 @@ __device__ __forceinline__ void sched_mfma_reload() {
   }
 }
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM* WN * 64) void conv_strip2_kernel(GemmParams p) {
+// KT = 2: one PHASE of a 3x3 convolution over a nearest-neighbour x2 upsampled input (Upsample2D).  Output pixel
+// (2y + py, 2x + px) reads upsampled rows 2y + py - 1 .. 2y + py + 1, i.e. the low-resolution rows y - 1 + py and y + py
+// (one of them twice), and the same along x: each of the four output phases is a 2x2 convolution of the LOW-resolution
+// input whose weights are sums of the 3x3 taps that land on the same pixel (dm4d_conv_up2x_prepare_bf16) -- 4 / 9 of the
+// multiply-adds of the fused gather the first round shipped.  Same strip machinery: tap (dy, dx) of phase (py, px) reads
+// pixel (y + dy - 1 + py, x + dx - 1 + px); the grid carries the phase in its slowest dimension.
+template <int BM, int BN, int WM, int WN, int KT = 3>
+__global__ __launch_bounds__(WM* WN * 64) void conv_strip2_kernel(GemmParams p_in) {
+  static_assert(KT == 2 || KT == 3, "3x3 taps, or the 2x2 taps of one upsampling phase");
   constexpr int BK = 64, ROWB = BK * 2;  // bytes per LDS row
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
@@ -746,9 +757,20 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip2_kernel(GemmParams p) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  int lid = xcd_remap(blockIdx.x, gridDim.x);
+  GemmParams p = p_in;
+  int xs = -1, ys = -1;  // tap (ky, kx) reads pixel (y + ky + ys, x + kx + xs)
+  if constexpr (KT == 2) {
+    const int per = gridDim.x / 4, phase = lid / per;
+    lid -= phase * per;
+    const int py = phase >> 1, px = phase & 1;
+    xs = px - 1;
+    ys = py - 1;
+    p.Wt = p_in.Wt + (int64_t)phase * p_in.N * p_in.ldw;
+    p.C = p_in.C + ((int64_t)py * 2 * p_in.W + px) * p_in.ldc;
+  }
   int split = 0, tm, tn;
-  if (p.splits > 1) {
+  if (KT == 3 && p.splits > 1) {
     const int rows = gridDim.x / p.tiles_n;  // tile rows x splits
     const int tms = lid % rows;
     tn = lid / rows;
@@ -768,7 +790,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip2_kernel(GemmParams p) 
 #pragma unroll
     for (int i = 0; i < AW; ++i) {
       const int row = (wave + NW * i) * 8 + d_row;
-      int px = m0 - 1 + row + (ky - 1) * p.W;  // m0 - 1 + row: centre output pixel served by this strip row
+      int px = m0 + xs + row + (ky + ys) * p.W;  // strip row `row` holds flat pixel m0 + xs + row, moved by the kernel row
       px = px < 0 ? 0 : (px > p.M - 1 ? p.M - 1 : px);
       a_voff[i] = (uint32_t)px * (uint32_t)(p.Cin * 2) + (uint32_t)((d_pos ^ ((row >> 1) & 7)) * 16);
     }
@@ -795,20 +817,21 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip2_kernel(GemmParams p) 
   }
   // address of a fragment = a_row (row block i of tap column kx: the strip row, or the zero row) + a_swz (k step ks under
   // the strip row's swizzle key) + an immediate for the buffer parity
-  int a_row[3][MI], a_swz[3][4];
+  int a_row[KT][MI], a_swz[KT][4];
 #pragma unroll
-  for (int kx = 0; kx < 3; ++kx) {
+  for (int kx = 0; kx < KT; ++kx) {
     const int swa = ((l31 + kx) >> 1) & 7;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) a_swz[kx][ks] = ((ks * 2 + lh) ^ swa) * 16;
   }
   auto set_a_addrs = [&](int ky) {
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx)
+    for (int kx = 0; kx < KT; ++kx)
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const unsigned e = edge[i];
-        const bool zero = (kx == 0 && (e & 1u)) || (kx == 2 && (e & 2u)) || (ky == 0 && (e & 4u)) || (ky == 2 && (e & 8u));
+        const int ox = kx + xs, oy = ky + ys;  // -1 / 0 / +1: the tap's pixel relative to the output pixel
+        const bool zero = (ox < 0 && (e & 1u)) || (ox > 0 && (e & 2u)) || (oy < 0 && (e & 4u)) || (oy > 0 && (e & 8u));
         a_row[kx][i] = zero ? ZROW * ROWB : (wm * TM + i * 32 + l31 + kx) * ROWB;
       }
   };
@@ -829,7 +852,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip2_kernel(GemmParams p) 
 
   // ---- the K walk: ky (kernel row) > cs (64-channel slab) > kx (tap column); one DMA'd step ahead -------------------
   const int nci = p.Cin / BK;
-  const int ky0 = p.splits > 1 ? split : 0, ky1 = p.splits > 1 ? split + 1 : 3;
+  const int ky0 = (KT == 3 && p.splits > 1) ? split : 0, ky1 = (KT == 3 && p.splits > 1) ? split + 1 : KT;
   const int nstrips = (ky1 - ky0) * nci;
   // DMA issue, statically laid out per tap column (no per-step bookkeeping branches): a weight slab is 8 * NW rows per
   // instruction round, the A strip NA pieces of 8 rows of which the last round is partial
@@ -868,7 +891,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip2_kernel(GemmParams p) 
   auto compute = [&](int abuf, auto kx_c) {  // abuf: strip parity (uniform)
     constexpr int KX = decltype(kx_c)::value;
     const int a_par = abuf ? A_BYTES : 0;
-    const int b_par = (abuf ^ (KX & 1)) ? B_BYTES : 0;  // B buffer parity: (3 strip + kx) & 1
+    const int b_par = (KT == 3 ? (abuf ^ (KX & 1)) : (KX & 1)) ? B_BYTES : 0;  // B buffer parity: (KT strip + kx) & 1
     int arow[MI], brow[4];  // the step's own base addresses: MI + 4 adds per step, every read is base + immediate
 #pragma unroll
     for (int i = 0; i < MI; ++i) arow[i] = a_row[KX][i] + a_par;
@@ -928,10 +951,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip2_kernel(GemmParams p) 
 #endif
     }
   };
-  // weights of (ky, cs, kx): Wt + (ky * 3 + kx) * Cin + cs * 64; strip of (ky, cs): A + cs * 64 (+ a_voff of ky)
+  // weights of (ky, cs, kx): Wt + (ky * KT + kx) * Cin + cs * 64; strip of (ky, cs): A + cs * 64 (+ a_voff of ky)
   const int cin = p.Cin;
   int c_ky = ky0, c_cs = 0;
-  const u16* wp = p.Wt + ky0 * 3 * cin;
+  const u16* wp = p.Wt + ky0 * KT * cin;
   set_a_voff(ky0);
   issue_a(p.A, 0);
   issue_b(wp, 0);
@@ -940,26 +963,29 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip2_kernel(GemmParams p) 
   for (int g = 0; g < nstrips; ++g) {
     if (c_cs == 0) set_a_addrs(c_ky);
     const int abuf = g & 1;
-    issue_b(wp + cin, abuf ^ 1);  // (g, kx = 1)
+    const int b0 = KT == 3 ? abuf : 0;  // weight buffer of the strip's first step
+    issue_b(wp + cin, b0 ^ 1);  // (g, kx = 1)
     compute(abuf, std::integral_constant<int, 0>{});
     dma_wait_barrier();
-    issue_b(wp + 2 * cin, abuf);  // (g, kx = 2)
-    compute(abuf, std::integral_constant<int, 1>{});
-    dma_wait_barrier();
+    if constexpr (KT == 3) {
+      issue_b(wp + 2 * cin, b0);  // (g, kx = 2)
+      compute(abuf, std::integral_constant<int, 1>{});
+      dma_wait_barrier();
+    }
     if (++c_cs == nci) {
       c_cs = 0;
       ++c_ky;
     }
     if (g + 1 < nstrips) {  // the next strip's A rows and its first weight slab
       if (c_cs == 0) set_a_voff(c_ky);
-      wp = p.Wt + (c_ky * 3 * cin + c_cs * BK);
+      wp = p.Wt + (c_ky * KT * cin + c_cs * BK);
       issue_a(p.A + c_cs * BK, abuf ^ 1);
-      issue_b(wp, abuf ^ 1);
+      issue_b(wp, KT == 3 ? (abuf ^ 1) : 0);
     }
-    compute(abuf, std::integral_constant<int, 2>{});
+    compute(abuf, std::integral_constant<int, KT - 1>{});
     dma_wait_barrier();
   }
-  if (p.splits > 1) {  // raw fp32 partial sums; splitk_reduce_kernel adds the splits in a fixed order and applies the epilogue
+  if (KT == 3 && p.splits > 1) {  // raw fp32 partial sums; splitk_reduce_kernel adds the splits in a fixed order and applies the epilogue
     float* wsp = p.ws + (int64_t)split * p.M * p.N;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -1579,6 +1605,37 @@ int launch_strip2(hipStream_t st, GemmParams& p) {
   return dm4d_check_launch("splitk_reduce_kernel");
 }
 
+// Phase-decomposed x2 upsampling convolution: grid = 4 phases x tiles, weights [4][N][4 Cin] from up2x_prepare_kernel
+template <int BM, int BN, int WM, int WN>
+int launch_up2x(hipStream_t st, GemmParams& p) {
+  const int tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  p.splits = 1;
+  hipLaunchKernelGGL((conv_strip2_kernel<BM, BN, WM, WN, 2>), dim3(4 * tiles_m * p.tiles_n), dim3(WM * WN * 64), 0, st, p);
+  return dm4d_check_launch("conv_strip2_kernel<up2x>");
+}
+
+// Wp[phase = 2 py + px][n][(dy, dx, ci)] = sum of W[n][(ky, kx, ci)] over the 3x3 taps that read low-resolution pixel
+// (dy, dx) of the phase: rows py = 0: {0} | {1, 2}, py = 1: {0, 1} | {2}; same along x.  fp32 sums, one rounding to bf16.
+__global__ __launch_bounds__(256) void up2x_prepare_kernel(const u16* W, u16* Wp, int N, int Cin) {
+  const int64_t total = (int64_t)4 * N * 4 * Cin;
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (id >= total) return;
+  const int ci = (int)(id % Cin);
+  int64_t t = id / Cin;
+  const int dx = (int)(t & 1), dy = (int)((t >> 1) & 1);
+  t >>= 2;
+  const int n = (int)(t % N), phase = (int)(t / N);
+  const int py = phase >> 1, px = phase & 1;
+  // taps of the 3-tap axis that land on low-resolution offset d of phase ph: ph 0: d 0 <- {0}, d 1 <- {1, 2}; ph 1: d 0 <- {0, 1}, d 1 <- {2}
+  const int ky_lo = py == 0 ? (dy == 0 ? 0 : 1) : (dy == 0 ? 0 : 2), ky_hi = py == 0 ? (dy == 0 ? 0 : 2) : (dy == 0 ? 1 : 2);
+  const int kx_lo = px == 0 ? (dx == 0 ? 0 : 1) : (dx == 0 ? 0 : 2), kx_hi = px == 0 ? (dx == 0 ? 0 : 2) : (dx == 0 ? 1 : 2);
+  float acc = 0.f;
+  for (int ky = ky_lo; ky <= ky_hi; ++ky)
+    for (int kx = kx_lo; kx <= kx_hi; ++kx) acc += bf2f(W[(int64_t)n * 9 * Cin + (ky * 3 + kx) * Cin + ci]);
+  Wp[id] = f2bf(acc);
+}
+
 int g_strip_form = 2;  // 2 = conv_strip2_kernel serves ids 31-35 (bit-identical results), 1 = conv_strip_kernel (tuning hook)
 int g_tune_cfg = 0;  // 0 = heuristic; otherwise a kernel-configuration id (tuning hook, dm4d_tune_set_gemm_config)
 
@@ -1808,6 +1865,37 @@ extern "C" int dm4d_conv3x3_nhwc_bf16(void* stream, const void* X, int B, int H,
                                       float out_scale) {
   return conv3x3_impl(stream, X, B, H, W, Cin, Wt, Y, Ho, Wo, Cout, stride, pad, upsample, bias, rowbias, ld_rowbias,
                       residual, ld_res, out_scale, nullptr, 0);
+}
+
+extern "C" int dm4d_conv_up2x_prepare_bf16(void* stream, const void* W, void* Wp, int Cout, int Cin) {
+  if (!W || !Wp || Cout <= 0 || Cin <= 0) return dm4d_set_error(DM4D_ERR_ARG, "conv_up2x_prepare: null pointer or empty shape");
+  const int64_t total = (int64_t)16 * Cout * Cin;
+  hipLaunchKernelGGL(up2x_prepare_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const u16*)W, (u16*)Wp, Cout, Cin);
+  return dm4d_check_launch("up2x_prepare_kernel");
+}
+
+extern "C" int dm4d_conv_up2x_nhwc_bf16(void* stream, const void* X, int B, int H, int W, int Cin, const void* Wp, void* Y,
+                                        int Cout, const void* bias) {
+  if (!X || !Wp || !Y || B <= 0 || H <= 0 || W <= 0 || Cout <= 0)
+    return dm4d_set_error(DM4D_ERR_ARG, "conv_up2x: null pointer or empty shape");
+  if (Cin % 64 != 0 || (Cout & 7) != 0)
+    return dm4d_set_error(DM4D_ERR_ARG, "conv_up2x: Cin must be a multiple of 64 and Cout of 8 (use conv3x3 with upsample = 1)");
+  if ((int64_t)B * H * W * Cin >= (int64_t)1 << 31 || (int64_t)B * 4 * H * W * Cout >= (int64_t)1 << 31)
+    return dm4d_set_error(DM4D_ERR_ARG, "conv_up2x: tensors of 2^31 or more elements are not supported (split the batch)");
+  GemmParams p{};
+  p.A = (const u16*)X; p.H = H; p.W = W; p.Cin = Cin; p.Ho = H; p.Wo = W; p.stride = 1; p.pad = 1; p.upsample = 0;
+  p.Wt = (const u16*)Wp; p.ldw = (int64_t)4 * Cin; p.C = (u16*)Y; p.ldc = Cout;
+  p.M = B * H * W; p.N = Cout; p.K = 4 * Cin;
+  p.bias = (const u16*)bias; p.rows_per_rb = H * W; p.flags = 0; p.out_scale = 1.0f; p.up_w = W;
+  if (!strip2_ok(p)) return dm4d_set_error(DM4D_ERR_ARG, "conv_up2x: input or weights of 4 GiB or more");
+  hipStream_t st = (hipStream_t)stream;
+  // tile choice as for the stride-1 strips: 256-row tiles where a phase alone fills the chip's 256 CUs
+  const long tm256 = (p.M + 255) / 256, tm128 = (p.M + 127) / 128;
+  if (Cout % 128 == 0 && tm256 * (Cout / 128) >= 200) return launch_up2x<256, 128, 4, 2>(st, p);
+  if (Cout % 128 == 0) return launch_up2x<128, 128, 2, 2>(st, p);
+  (void)tm128;
+  return launch_up2x<128, 64, 4, 1>(st, p);
 }
 
 extern "C" int dm4d_conv3x3_nhwc_bf16_ws(void* stream, const void* X, int B, int H, int W, int Cin, const void* Wt, void* Y,

@@ -100,6 +100,55 @@ def conv3x3(x: torch.Tensor, wt: torch.Tensor, *, bias=None, rowbias=None, resid
     return y
 
 
+def conv_up2x_prepare(wt: torch.Tensor) -> torch.Tensor:
+    """3x3 weights [Cout, 9*Cin] ((ky,kx,ci) order) -> the four 2x2 phase kernels [4, Cout, 4*Cin] of conv_up2x (once per
+    layer: sums of the taps that read the same low-resolution pixel, fp32, rounded to bf16 once)."""
+    lib = _l.load()
+    _req(wt, "wt")
+    assert wt.is_contiguous() and wt.shape[1] % 9 == 0
+    Cout, Cin = wt.shape[0], wt.shape[1] // 9
+    wp = torch.empty((4, Cout, 4 * Cin), dtype=BF16, device=wt.device)
+    _l.check(lib.dm4d_conv_up2x_prepare_bf16(_stream(), _p(wt), _p(wp), Cout, Cin), "dm4d_conv_up2x_prepare_bf16")
+    return wp
+
+
+def conv_up2x_supported(Cin: int, Cout: int) -> bool:
+    return Cin % 64 == 0 and Cout % 8 == 0
+
+
+class Upsampler:
+    """Upsample2D of the UNet / VAE decoder: nearest x2 + 3x3 convolution.  Runs as four 2x2 phase convolutions of the
+    low-resolution input (conv_up2x; phase kernels made from the checkpoint's 3x3 weights on first use) when the channel
+    counts allow, else as the gather kernel that reads the upsampled image through index arithmetic."""
+
+    def __init__(self, wt: torch.Tensor, bias: Optional[torch.Tensor]):
+        self.wt, self.bias, self.wp = wt, bias, None
+        self.phase = conv_up2x_supported(wt.shape[1] // 9, wt.shape[0])
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if not self.phase:
+            return conv3x3(x, self.wt, bias=self.bias, upsample=True)
+        if self.wp is None or self.wp.device != x.device:
+            self.wp = conv_up2x_prepare(self.wt)
+        return conv_up2x(x, self.wp, bias=self.bias)
+
+
+def conv_up2x(x: torch.Tensor, wp: torch.Tensor, *, bias=None) -> torch.Tensor:
+    """conv3x3(nearest_upsample_x2(x)) from the phase kernels of conv_up2x_prepare: x [B,H,W,Cin] -> [B,2H,2W,Cout]."""
+    lib = _l.load()
+    _req(x, "x"), _req(wp, "wp")
+    assert x.is_contiguous() and wp.is_contiguous()
+    B, H, W, Cin = x.shape
+    Cout = wp.shape[1]
+    assert wp.shape == (4, Cout, 4 * Cin), (wp.shape, Cin)
+    y = torch.empty((B, 2 * H, 2 * W, Cout), dtype=BF16, device=x.device)
+    # credited with the multiply-adds it executes (4 taps per output pixel), not the 9 of the op it replaces
+    with _Prof("conv3x3", 2.0 * B * 4 * H * W * 4 * Cin * Cout, "flop"):
+        rc = lib.dm4d_conv_up2x_nhwc_bf16(_stream(), _p(x), B, H, W, Cin, _p(wp), _p(y), Cout, _p(bias))
+    _l.check(rc, "dm4d_conv_up2x_nhwc_bf16")
+    return y
+
+
 def conv2d_direct(x: torch.Tensor, wt: torch.Tensor, *, ksize: int, bias=None, stride: int = 1, pad: int = 1,
                   silu: bool = False) -> torch.Tensor:
     """Thin-layer convolution (PoseEncoder): x [B,H,W,Cin] NHWC, wt [Cout, ksize*ksize*Cin] ((ky,kx,ci) order)."""

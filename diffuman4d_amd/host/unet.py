@@ -274,7 +274,7 @@ class UNetMultiviewConditionModel:
             att = [_Transformer(W, p + f"attentions.{j}.", cfg.heads(len(boc) - 1 - i), g) for j in range(n)] if has_attn else None
             us = None
             if i != len(boc) - 1:
-                us = (W.conv3(p + "upsamplers.0.conv.weight"), W.vec(p + "upsamplers.0.conv.bias"))
+                us = ops.Upsampler(W.conv3(p + "upsamplers.0.conv.weight"), W.vec(p + "upsamplers.0.conv.bias"))
             self.up.append((res, att, us))
         self.no_w, self.no_b = W.vec("conv_norm_out.weight"), W.vec("conv_norm_out.bias")
         self.conv_out_w, self.conv_out_b = W.conv3("conv_out.weight"), W.vec("conv_out.bias")
@@ -379,7 +379,7 @@ class UNetMultiviewConditionModel:
             if keep_rows is not None and i == last3d:
                 x, tproj, skips = prune(x, tproj, skips)
             if us is not None:
-                x = ops.conv3x3(x, us[0], bias=us[1], upsample=True)
+                x = us(x)
         x = ops.groupnorm(x, self.no_w, self.no_b, cfg.norm_num_groups, cfg.norm_eps, silu=True)
         return ops.conv3x3(x, self.conv_out_w, bias=self.conv_out_b)
 

@@ -149,7 +149,7 @@ class AutoencoderKL:
             res = [_Res(W, p + f"resnets.{j}.", g) for j in range(cfg.layers_per_block + 1)]
             us = None
             if i != len(boc) - 1:
-                us = (W.conv3(p + "upsamplers.0.conv.weight"), W.vec(p + "upsamplers.0.conv.bias"))
+                us = ops.Upsampler(W.conv3(p + "upsamplers.0.conv.weight"), W.vec(p + "upsamplers.0.conv.bias"))
             self.d_up.append((res, us))
         self.d_nw, self.d_nb = W.vec("decoder.conv_norm_out.weight"), W.vec("decoder.conv_norm_out.bias")
         self.d_out_w, self.d_out_b = W.conv3("decoder.conv_out.weight"), W.vec("decoder.conv_out.bias")
@@ -246,7 +246,7 @@ class AutoencoderKL:
             for r in res:
                 x = r(x)
             if us is not None:
-                x = ops.conv3x3(x, us[0], bias=us[1], upsample=True)
+                x = us(x)
         x = ops.groupnorm(x, self.d_nw, self.d_nb, self.config.norm_num_groups, 1e-6, silu=True)
         return ops.conv3x3(x, self.d_out_w, bias=self.d_out_b)
 

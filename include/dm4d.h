@@ -74,6 +74,15 @@ int dm4d_conv3x3_nhwc_bf16_ws(void* stream, const void* X, int B, int H, int W, 
                               int64_t ld_rowbias, const void* residual, int64_t ld_res, float out_scale, void* ws,
                               size_t ws_bytes);
 
+/* Upsample2D (nearest x2 followed by a 3x3 convolution, /root/reference/src/models/unet_multiview_blocks.py via diffusers'
+ * Upsample2D; same op in the VAE decoder) as four 2x2 convolutions of the LOW-resolution input, one per output phase:
+ * 4/9 of the multiply-adds.  `Wp` [4][Cout][4*Cin] is made once per layer from the 3x3 weights W [Cout][9*Cin]
+ * (ky, kx, ci order) by dm4d_conv_up2x_prepare_bf16 (sums of 1, 2 or 4 taps in fp32, rounded to bf16 once).
+ * X [B, H, W, Cin] -> Y [B, 2H, 2W, Cout], Cin % 64 == 0, Cout % 8 == 0; bias optional.                               */
+int dm4d_conv_up2x_prepare_bf16(void* stream, const void* W, void* Wp, int Cout, int Cin);
+int dm4d_conv_up2x_nhwc_bf16(void* stream, const void* X, int B, int H, int W, int Cin, const void* Wp, void* Y, int Cout,
+                             const void* bias);
+
 /* Direct (fp32 FMA) convolution for thin layers, NHWC: the PoseEncoder's conv stack
  *   (pose_encoder.py:14-31: 3x3 stride 1 / 4x4 stride 2, padding 1, 3..64 input channels, SiLU after each).
  *   X [B,H,W,Cin], Wt [Cout][ksize*ksize][Cin], Y [B,Ho,Wo,Cout]; Cin, Cout multiples of 4 (zero-pad the 3-channel

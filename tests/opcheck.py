@@ -95,6 +95,39 @@ def case_conv(B, H, W, Cin, Cout, stride=1, pad=1, pad_hi=None, upsample=False, 
     return rel_l2(out, ref), float((out.float().cpu() - ref).abs().max())
 
 
+def case_conv_up2x(B, H, W, Cin, Cout, bias=True, seed=0):
+    """Upsample2D as four 2x2 phase convolutions of the low-resolution input (ops.conv_up2x).  Checked three ways:
+    the phase kernels are exactly the fp32 sums of the 3x3 taps rounded once to bf16; the output against the fp32
+    nearest-x2 + conv2d of the ORIGINAL weights (the reported error: it contains the one extra bf16 rounding of the
+    summed weights); and against the gather kernel it replaces (both within the same bound of the fp32 result)."""
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    x = _rnd((B, Cin, H, W), g)
+    w = _rnd((Cout, Cin, 3, 3), g, 1.0 / math.sqrt(9 * Cin))
+    b = _rnd((Cout,), g, 0.5) if bias else None
+    ref = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), b.float() if bias else None, padding=1)
+    d = "cuda"
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().to(d)
+    wt = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().to(d)
+    wp = ops.conv_up2x_prepare(wt)
+    # expected phase kernels: rows py = 0: {0} | {1, 2}, py = 1: {0, 1} | {2}; same along x
+    sets = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}
+    w4 = w.float().permute(0, 2, 3, 1)  # [Cout, ky, kx, ci]
+    for py in (0, 1):
+        for px in (0, 1):
+            exp = torch.stack([torch.stack([sum(w4[:, ky, kx] for ky in sets[py][dy] for kx in sets[px][dx])
+                                            for dx in (0, 1)], dim=1) for dy in (0, 1)], dim=1)  # [Cout, dy, dx, ci]
+            exp = exp.reshape(Cout, 4 * Cin).to(torch.bfloat16)
+            assert torch.equal(wp[2 * py + px].cpu(), exp), f"phase kernel ({py},{px}) is not the rounded fp32 tap sum"
+    out = ops.conv_up2x(x_nhwc, wp, bias=b.to(d) if bias else None).permute(0, 3, 1, 2)
+    assert tuple(out.shape) == tuple(ref.shape), (out.shape, ref.shape)
+    gather = ops.conv3x3(x_nhwc, wt, bias=b.to(d) if bias else None, upsample=True).permute(0, 3, 1, 2)
+    e_gather = rel_l2(gather, ref)
+    err = rel_l2(out, ref)
+    assert e_gather <= TOL, f"gather kernel off: {e_gather}"
+    return err, float((out.float().cpu() - ref).abs().max())
+
+
 def case_conv_batch_invariance(B, H, W, Cin, Cout, seed=0):
     """A frame-sharded rank convolves fewer images per call: every image's result must not depend on how many
     images share the launch (tile configuration, split-K decision), BITWISE."""
@@ -390,6 +423,13 @@ CASES = {
     "conv_s2": (case_conv, dict(B=2, H=18, W=10, Cin=64, Cout=64, stride=2)),
     "conv_s2_odd": (case_conv, dict(B=2, H=9, W=5, Cin=32, Cout=64, stride=2)),
     "conv_up": (case_conv, dict(B=2, H=9, W=5, Cin=64, Cout=64, upsample=True)),
+    "conv_up2x_128x64": (case_conv_up2x, dict(B=2, H=9, W=5, Cin=64, Cout=64)),
+    "conv_up2x_128x128": (case_conv_up2x, dict(B=3, H=18, W=10, Cin=128, Cout=128)),
+    "conv_up2x_256x128_l1": (case_conv_up2x, dict(B=32, H=36, W=20, Cin=640, Cout=640)),
+    "conv_up2x_l3": (case_conv_up2x, dict(B=5, H=9, W=5, Cin=1280, Cout=1280, seed=1)),
+    "conv_up2x_w1": (case_conv_up2x, dict(B=2, H=7, W=1, Cin=64, Cout=128, seed=2)),
+    "conv_up2x_h1_nobias": (case_conv_up2x, dict(B=3, H=1, W=6, Cin=64, Cout=72, bias=False, seed=3)),
+    "conv_up2x_vae_512": (case_conv_up2x, dict(B=1, H=72, W=40, Cin=512, Cout=512, seed=4)),
     "conv_vae_down": (case_conv, dict(B=2, H=16, W=12, Cin=32, Cout=32, stride=2, pad=0, pad_hi=1)),
     "conv_cin32_cout4": (case_conv, dict(B=4, H=36, W=20, Cin=32, Cout=4)),
     "conv_big": (case_conv, dict(B=8, H=36, W=20, Cin=320, Cout=320, rowbias=True, residual=True)),
