@@ -72,6 +72,12 @@ def parse():
                     help="independent tasks in flight per GPU, each on its own HIP stream and worker thread (the runner's "
                          "gpu_streams). 1 = one task at a time")
     ap.add_argument("--grid-frames", type=int, default=N_FRAMES, help="grid mode: frames of the (48 camera x T frame) grid")
+    ap.add_argument("--config5", action="store_true",
+                    help="BASELINE.json configs[4]: 48 x 225 grid, sliding_default (window 12, stride 1, 3 rounds = 36 steps per "
+                         "latent) with the opt-in fp8 (e4m3) attention kernel; task mode, 1 GPU.  An EXTENSION line: fp8 "
+                         "attention has no reference parity target and its own tolerance (tests/opcheck.py attn_fp8_*)")
+    ap.add_argument("--attention", choices=["bf16", "fp8"], default=None,
+                    help="attention kernel (default bf16; --config5 defaults to fp8)")
     ap.add_argument("--prune-cond-rows", action="store_true",
                     help="opt-in extension, NOT the judged configuration: skip the per-frame tail of the UNet (after the last "
                          "3-D attention) for conditioning frames, whose noise prediction the reference discards")
@@ -316,8 +322,16 @@ def vae_secondary(dev):
 
 
 def main():
-    global LAT_H, LAT_W
+    global LAT_H, LAT_W, N_FRAMES, STRIDE, STEPS_PER_LATENT, LATENTS_PER_UNIT
     args = parse()
+    if args.config5:
+        if args.gpus != 1 or args.mode not in ("auto", "task"):
+            raise SystemExit("--config5 is a 1-GPU task-mode line")
+        N_FRAMES, STRIDE = 225, 1
+        STEPS_PER_LATENT = WINDOW // STRIDE * ROUNDS  # 36
+        LATENTS_PER_UNIT = 3 * WINDOW / STEPS_PER_LATENT  # 1.0
+        args.no_cpu_baseline = True  # the CPU sample and the parity object belong to the judged (bf16) line
+    fp8 = (args.attention or ("fp8" if args.config5 else "bf16")) == "fp8"
     LAT_H, LAT_W = (int(v) for v in args.latent.lower().split("x"))
     if LAT_H % 8 or LAT_W % 8:
         raise SystemExit("--latent: both sides must be multiples of 8 (three UNet down-samplings)")
@@ -364,6 +378,7 @@ def main():
     from diffuman4d_amd.host.unet import UNetConfig, UNetMultiviewConditionModel
     from diffuman4d_amd.host.weights import random_state_dict, unet_param_shapes
 
+    ops.ATTENTION_FP8 = fp8
     cfg = UNetConfig()
     state_dict = random_state_dict(unet_param_shapes(cfg), 0, dev)
     unet = UNetMultiviewConditionModel(cfg, state_dict, dev)
@@ -516,20 +531,25 @@ def main():
                        f"RCCL cell exchange at the 2 round boundaries)"}[mode]
         workload = ("demo_4d 44cam x 150fr, sliding_fast (window 12, stride 2, 3 rounds, 18 steps/latent), "
                     f"CFG 2.0, {LAT_H}x{LAT_W}x4 latents; ")
+        if args.config5:
+            workload = ("EXTENSION (BASELINE.json configs[4]): 44cam x 225fr, sliding_default (window 12, stride 1, 3 rounds, 36 "
+                        f"steps/latent), fp8 e4m3 attention, CFG 2.0, {LAT_H}x{LAT_W}x4 latents; ")
         if mode == "grid":
             workload += (f"ONE pass over the 48 x {args.grid_frames} grid job: {2 * args.grid_frames} spatial + 44 temporal tasks, "
                          f"first {grid_info['depth']['spatial']} / {grid_info['depth']['temporal']} window calls of every task's 22 / 75; "
                          f"value = executed latent-steps / 18 / time; VAE excluded")
         else:
-            workload += "step = 2 spatial (F=16) + 1 temporal (F=24) window calls = 2 denoised latents; VAE excluded"
+            workload += (f"step = 2 spatial (F=16) + 1 temporal (F=24) window calls = {LATENTS_PER_UNIT:g} denoised "
+                         f"latent{'s' if LATENTS_PER_UNIT != 1 else ''}; VAE excluded")
         out = {
-            "metric": "denoised view-frame latents/sec (44cam x 150fr grid)",
+            "metric": ("denoised view-frame latents/sec (44cam x 225fr grid, sliding_default, fp8 attention)" if args.config5
+                       else "denoised view-frame latents/sec (44cam x 150fr grid)"),
             "value": round(value, 4),
             "unit": "latents/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak" if mode == "task" else "strong", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "bf16 (attention operands fp8 e4m3)" if fp8 else "bf16", "data": "synthetic",
             "config": {
                 "workload": workload,
                 "mode": mode,
@@ -537,12 +557,13 @@ def main():
                 "parallelism": par,
                 "task_streams": S,
                 "finite_outputs": finite,
-                "extensions": ["prune_cond_rows"] if args.prune_cond_rows else [],
+                "extensions": (["prune_cond_rows"] if args.prune_cond_rows else []) + (["fp8_attention"] if fp8 else []),
             },
             "roofline": {
-                "kernel": "attn_kernel (2-D + 3-D view/time attention, all 48 launches of a step)",
-                "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "kernel": ("attn_fp8_kernel + its pack kernels" if fp8 else "attn_kernel") +
+                          " (2-D + 3-D view/time attention, all 48 launches of a step)",
+                "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS * (2 if fp8 else 1), "unit": "TFLOP/s",
+                "frac": round(achieved / (MFMA_PEAK_TFLOPS * (2 if fp8 else 1)), 4), "traffic": None if fp8 else traffic,
                 "traffic_note": f"avg HBM bytes per attn launch, PMC (2*FETCH_SIZE+WRITE_SIZE), profiles/{traffic_file}; "
                                 "algorithmic Q+K+V+O bytes average 152e6 per launch",
                 "avg_launch_ms": round(attn_ms / max(1, len(timer)), 4), "launches": len(timer),

@@ -11,7 +11,7 @@ ROOT = Path(__file__).resolve().parent
 CSRC = ROOT / "csrc"
 INCLUDE = ROOT.parent / "include"
 LIB = ROOT / "libdm4d.so"
-SOURCES = ["api.hip", "gemm.hip", "conv_direct.hip", "attention.hip", "norm.hip", "elementwise.hip"]
+SOURCES = ["api.hip", "gemm.hip", "conv_direct.hip", "attention.hip", "attention_fp8.hip", "norm.hip", "elementwise.hip"]
 
 
 def _hipcc() -> str:

@@ -42,6 +42,9 @@ SIGNATURES = {
     "dm4d_resize_nchw_f32_to_nhwc_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
     "dm4d_plucker_latent_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "dm4d_postprocess_images_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),
+    "dm4d_attention_fp8_ws_bytes": (C.c_size_t, [_i, _i, _i, _i]),
+    "dm4d_attention_fp8_kv_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _f, _i, _vp,
+                                        C.c_size_t, _vp]),
     "dm4d_conv_up2x_prepare_bf16": (_i, [_vp, _vp, _vp, _i, _i]),
     "dm4d_conv_up2x_nhwc_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "dm4d_tune_set_gemm_config": (_i, [_i]),

@@ -210,6 +210,16 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, hea
     """q/k/v: [batch*seq, >=heads*64] row-strided views (e.g. column slices of the fused QKV output).
     kv_seq: keys per batch when K/V hold more tokens than Q (frame-sharded 3-D attention); default = seq.
     q_scaled: q already carries scale * LOG2E (folded into the to_q weights, unet._TransformerBlock)."""
+    if ATTENTION_FP8:
+        prof = KERNEL_TIMER
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        out = attention_fp8(q, k, v, batch, heads, seq, scale, out, kv_seq, q_scaled)
+        if prof is not None:
+            e1.record()
+            prof.append(("attn_fp8_kernel", 4.0 * batch * heads * seq * (seq if kv_seq is None else kv_seq) * 64, e0, e1))
+        return out
     lib = _l.load()
     _req(q, "q"), _req(k, "k"), _req(v, "v")
     assert q.shape[0] == batch * seq and q.shape[1] == heads * 64, (q.shape, batch, seq, heads)
@@ -234,6 +244,37 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, hea
         e1.record()
         prof.append(("attn_kernel", 4.0 * batch * heads * seq * kv_seq * 64, e0, e1))
     _l.check(rc, "dm4d_attention_kv_bf16")
+    return out
+
+
+# Opt-in extension: route ops.attention through the fp8 (e4m3) kernel.  Nothing sets this by default; bench.py
+# --attention fp8 and the attn_fp8_* parity cases do.  FP8_SATURATED[device index] counts the Q / K / V elements the
+# pack kernels had to clamp to +-448 since it was created (a device int32, read it with .item()).
+ATTENTION_FP8 = False
+FP8_SATURATED: dict = {}
+
+
+def attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, heads: int, seq: int,
+                  scale: Optional[float] = None, out: Optional[torch.Tensor] = None, kv_seq: Optional[int] = None,
+                  q_scaled: bool = False) -> torch.Tensor:
+    """ops.attention with fp8 e4m3 operands on the MX-scaled MFMA (include/dm4d.h: dm4d_attention_fp8_kv_bf16)."""
+    lib = _l.load()
+    _req(q, "q"), _req(k, "k"), _req(v, "v")
+    assert q.shape[0] == batch * seq and q.shape[1] == heads * 64, (q.shape, batch, seq, heads)
+    kv_seq = seq if kv_seq is None else kv_seq
+    assert k.shape[0] == batch * kv_seq and v.shape[0] == batch * kv_seq, (k.shape, batch, kv_seq)
+    if out is None:
+        out = torch.empty((batch * seq, heads * 64), dtype=BF16, device=q.device)
+    ws_bytes = lib.dm4d_attention_fp8_ws_bytes(batch, heads, seq, kv_seq)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
+    sat = FP8_SATURATED.get(q.device.index)
+    if sat is None:
+        sat = FP8_SATURATED[q.device.index] = torch.zeros(1, dtype=torch.int32, device=q.device)
+    with _Prof("attention", 4.0 * batch * heads * seq * kv_seq * 64, "flop"):
+        rc = lib.dm4d_attention_fp8_kv_bf16(_stream(), _p(q), _p(k), _p(v), _p(out), q.stride(0), k.stride(0), v.stride(0),
+                                            out.stride(0), batch, heads, seq, kv_seq, 0.125 if scale is None else scale,
+                                            1 if q_scaled else 0, _p(ws), ws_bytes, _p(sat))
+    _l.check(rc, "dm4d_attention_fp8_kv_bf16")
     return out
 
 

@@ -127,6 +127,17 @@ int dm4d_attention_kv_bf16(void* stream, const void* Q, const void* K, const voi
 int dm4d_attention_qscaled_kv_bf16(void* stream, const void* Q, const void* K, const void* V, void* O, int64_t ldq,
                                    int64_t ldk, int64_t ldv, int64_t ldo, int batch, int heads, int Lq, int Lk);
 
+/* OPT-IN extension (BASELINE.json configs[4], "fp8 MFMA attention"; the reference has no fp8 path): the same
+ * attention with Q, K, V and the probabilities in OCP fp8 e4m3 on v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulation and
+ * softmax statistics, bf16 output.  Q, K, V are bf16 (same arguments as dm4d_attention_kv_bf16; q_scaled != 0: Q already
+ * carries scale * log2(e)); they are converted into `ws` (dm4d_attention_fp8_ws_bytes) by two pack kernels which clamp
+ * to +-448 and add the number of clamped elements to *saturated (device int, may be NULL) -- the probabilities cannot
+ * saturate by construction (lazy rescaling keeps them <= 2^8).  Tolerance: its own, see tests/opcheck.py attn_fp8_*.    */
+size_t dm4d_attention_fp8_ws_bytes(int batch, int heads, int Lq, int Lk);
+int dm4d_attention_fp8_kv_bf16(void* stream, const void* Q, const void* K, const void* V, void* O, int64_t ldq, int64_t ldk,
+                               int64_t ldv, int64_t ldo, int batch, int heads, int Lq, int Lk, float scale, int q_scaled,
+                               void* ws, size_t ws_bytes, int* saturated);
+
 /* Generic-head-dim attention pieces for the VAE mid block (AutoencoderKL mid_block.attentions.0: single head, d = 512,
  *   reached from pipeline_diffuman4d.py:52,65): P = softmax(S * scale) per row, P in bf16.  The f32in form takes the
  *   logits as dm4d_gemm_bf16(..., DM4D_EPI_F32OUT) leaves them (SDPA keeps its logits in fp32);
