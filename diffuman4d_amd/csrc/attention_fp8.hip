@@ -20,6 +20,7 @@
 #include "common.h"
 #include "dm4d.h"
 #include "errors.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -119,9 +120,10 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16_u(float lo, float hi) {
   return *reinterpret_cast<uint32_t*>(&b);
 }
 
-// 8 waves x 32 query rows per workgroup; per 64-key tile: K8 (64 x 64 B) and Vt8 (64 x 64 B) through a 2-stage LDS ring
-__global__ __launch_bounds__(512, 2) void attn_fp8_kernel(Fp8Params p) {
-  constexpr int NW = 8, LDS_LDO = 72;
+// NW waves x 32 query rows per workgroup; per 64-key tile: K8 (64 x 64 B) and Vt8 (64 x 64 B) through a 2-stage LDS ring
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fp8_kernel(Fp8Params p) {
+  constexpr int LDS_LDO = 72;
   constexpr int RING_BYTES = 2 * 2 * 4096;          // [stage][K | V][4096]
   constexpr int OUT_BYTES = NW * 32 * LDS_LDO * 2;  // O staging (after the loop)
   __shared__ __attribute__((aligned(16))) char smem[RING_BYTES > OUT_BYTES ? RING_BYTES : OUT_BYTES];
@@ -152,13 +154,13 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(Fp8Params p) {
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
   const int d_row = (wave & 3) * 16 + (lane >> 2), d_pos = lane & 3, d_chunk = d_pos ^ ((d_row >> 2) & 3);
   auto issue = [&](int t, int stage) {
-    if (wave < 4) {
+    if (NW == 4 || wave < 4) {
       int key = t * 64 + d_row;
       key = key > p.Lk - 1 ? p.Lk - 1 : key;  // rows past the end: any valid row (their scores are masked)
       dma16_fp8(Kb + (int64_t)key * C + d_chunk * 16, lds0 + stage * 8192 + (wave & 3) * 1024);
-    } else {
-      dma16_fp8(Vb + (int64_t)t * 4096 + d_row * 64 + d_chunk * 16, lds0 + stage * 8192 + 4096 + (wave & 3) * 1024);
     }
+    if (NW == 4 || wave >= 4)
+      dma16_fp8(Vb + (int64_t)t * 4096 + d_row * 64 + d_chunk * 16, lds0 + stage * 8192 + 4096 + (wave & 3) * 1024);
   };
   // fragment reads: row l31 (+ 32 per block), chunks 2 lh and 2 lh + 1 under the row's key
   const int fkey = (l31 >> 2) & 3;
@@ -318,9 +320,13 @@ extern "C" int dm4d_attention_fp8_kv_bf16(void* stream, const void* Q, const voi
     if (rc) return rc;
   }
   Fp8Params p{Q8, K8, Vt8, (u16*)O, ldo, Lq, Lk, heads, 0, ntiles};
-  p.nqt = (Lq + 255) / 256;
+  // 4 waves (128 query rows) per workgroup: several small workgroups per CU drift out of phase and cover each other's
+  // softmax with MFMAs (+4..+10 % over 8 waves on the long sequences, profiles/r02_attn_fp8.log); DM4D_FP8_NW=8 selects 8
+  static const int nw = [] { const char* e = getenv("DM4D_FP8_NW"); return (e && atoi(e) == 8) ? 8 : 4; }();
+  p.nqt = (Lq + nw * 32 - 1) / (nw * 32);
   const long nwg = (long)p.nqt * heads * batch;
   if (nwg > 0x7fffffffL) return dm4d_set_error(DM4D_ERR_ARG, "attention_fp8: grid too large");
-  hipLaunchKernelGGL(attn_fp8_kernel, dim3((unsigned)nwg), dim3(512), 0, st, p);
+  if (nw == 4) hipLaunchKernelGGL(attn_fp8_kernel<4>, dim3((unsigned)nwg), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(attn_fp8_kernel<8>, dim3((unsigned)nwg), dim3(512), 0, st, p);
   return dm4d_check_launch("attn_fp8_kernel");
 }

@@ -74,8 +74,10 @@ int dm4d_conv3x3_nhwc_bf16_ws(void* stream, const void* X, int B, int H, int W, 
                               int64_t ld_rowbias, const void* residual, int64_t ld_res, float out_scale, void* ws,
                               size_t ws_bytes);
 
-/* Upsample2D (nearest x2 followed by a 3x3 convolution, /root/reference/src/models/unet_multiview_blocks.py via diffusers'
- * Upsample2D; same op in the VAE decoder) as four 2x2 convolutions of the LOW-resolution input, one per output phase:
+/* Upsample2D -- third-party: diffusers==0.33.1 (requirements.txt:5), instantiated by the reference at
+ * src/diffusers/models/unets/unet_multiview_blocks.py:620 and by the VAE decoder; its published forward is
+ * F.interpolate(x, scale_factor=2.0, mode="nearest") then conv3x3(padding=1) -- as four 2x2 convolutions of the
+ * LOW-resolution input, one per output phase (restated and checked against that form in oracle/up2x.py):
  * 4/9 of the multiply-adds.  `Wp` [4][Cout][4*Cin] is made once per layer from the 3x3 weights W [Cout][9*Cin]
  * (ky, kx, ci order) by dm4d_conv_up2x_prepare_bf16 (sums of 1, 2 or 4 taps in fp32, rounded to bf16 once).
  * X [B, H, W, Cin] -> Y [B, 2H, 2W, Cout], Cin % 64 == 0, Cout % 8 == 0; bias optional.                               */
