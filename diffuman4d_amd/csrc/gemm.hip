@@ -226,8 +226,10 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += t[e];
         }
+        if (p.out_scale != 1.0f) {  // wave-uniform; x * 1.0f is exact, so skipping it changes nothing
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+          for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+        }
 #if GEMM_ABLATE == 1
         {
           U4 pk = pack8(v);

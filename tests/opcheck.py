@@ -566,6 +566,9 @@ CASES = {
     "gn_320_two_launch": (case_groupnorm, dict(B=4, HW=720, C1=320, C2=0, groups=32, silu=True, two_launch=True)),
     "gn_concat_1920_two_launch": (case_groupnorm, dict(B=3, HW=180, C1=1280, C2=640, groups=32, silu=True, two_launch=True)),
     "gn_l0_2880": (case_groupnorm, dict(B=2, HW=2880, C1=320, C2=0, groups=32, silu=True)),  # too big for registers
+    "gn_l0_concat_640_b8": (case_groupnorm, dict(B=8, HW=2880, C1=320, C2=320, groups=32, silu=True)),
+    "gn_l0_concat_960": (case_groupnorm, dict(B=2, HW=2880, C1=640, C2=320, groups=32, silu=True)),
+    "gn_batch_invariant_l0": (case_groupnorm_batch_invariant, dict(B=8, HW=2880, C1=320, C2=0, groups=32)),
     "gn_l1_640_b16": (case_groupnorm, dict(B=16, HW=720, C1=640, C2=0, groups=32, silu=True)),  # XCD-grouped grid
     "gn_l1_concat_1280_b8": (case_groupnorm, dict(B=8, HW=720, C1=640, C2=640, groups=32, silu=False)),
     "gn_l1_concat_960": (case_groupnorm, dict(B=2, HW=720, C1=640, C2=320, groups=32, silu=True)),  # 60-B groups: two-launch
