@@ -126,7 +126,8 @@ class Upsampler:
         self.phase = conv_up2x_supported(wt.shape[1] // 9, wt.shape[0])
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
-        if not self.phase:
+        # the phase kernel addresses its input with 32-bit byte offsets: inputs of 4 GiB or more take the gather kernel
+        if not self.phase or x.numel() * 2 >= (1 << 32):
             return conv3x3(x, self.wt, bias=self.bias, upsample=True)
         if self.wp is None or self.wp.device != x.device:
             self.wp = conv_up2x_prepare(self.wt)
