@@ -321,9 +321,10 @@ def vae_secondary(dev):
     return out
 
 
-def main():
-    global LAT_H, LAT_W, N_FRAMES, STRIDE, STEPS_PER_LATENT, LATENTS_PER_UNIT
-    args = parse()
+def apply_workload_flags(args) -> bool:
+    """--config5 / --attention: switch the module's workload constants to BASELINE.json configs[4] (48 x 225, sliding_default)
+    and return whether the fp8 attention extension is on.  The default line is untouched."""
+    global N_FRAMES, STRIDE, STEPS_PER_LATENT, LATENTS_PER_UNIT
     if args.config5:
         if args.gpus != 1 or args.mode not in ("auto", "task"):
             raise SystemExit("--config5 is a 1-GPU task-mode line")
@@ -331,7 +332,13 @@ def main():
         STEPS_PER_LATENT = WINDOW // STRIDE * ROUNDS  # 36
         LATENTS_PER_UNIT = 3 * WINDOW / STEPS_PER_LATENT  # 1.0
         args.no_cpu_baseline = True  # the CPU sample and the parity object belong to the judged (bf16) line
-    fp8 = (args.attention or ("fp8" if args.config5 else "bf16")) == "fp8"
+    return (args.attention or ("fp8" if args.config5 else "bf16")) == "fp8"
+
+
+def main():
+    global LAT_H, LAT_W
+    args = parse()
+    fp8 = apply_workload_flags(args)
     LAT_H, LAT_W = (int(v) for v in args.latent.lower().split("x"))
     if LAT_H % 8 or LAT_W % 8:
         raise SystemExit("--latent: both sides must be multiples of 8 (three UNet down-samplings)")

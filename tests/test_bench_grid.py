@@ -82,3 +82,23 @@ def test_self_launch_command(monkeypatch):
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_config5_switches_the_workload_and_nothing_else(monkeypatch):
+    """--config5 = BASELINE.json configs[4]: 225 frames, stride 1 (36 steps per latent, one latent per 3-call unit), fp8
+    attention on, CPU baseline off; the default line keeps sliding_fast and bf16."""
+    for name in ("N_FRAMES", "STRIDE", "STEPS_PER_LATENT", "LATENTS_PER_UNIT"):
+        monkeypatch.setattr(bench, name, getattr(bench, name))  # restored after the test
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    assert bench.apply_workload_flags(a) is False
+    assert (bench.N_FRAMES, bench.STRIDE, bench.STEPS_PER_LATENT, bench.LATENTS_PER_UNIT) == (150, 2, 18, 2.0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--attention", "fp8"])
+    assert bench.apply_workload_flags(bench.parse()) is True and bench.STRIDE == 2
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--config5"])
+    a = bench.parse()
+    assert bench.apply_workload_flags(a) is True and a.no_cpu_baseline
+    assert (bench.N_FRAMES, bench.STRIDE, bench.STEPS_PER_LATENT, bench.LATENTS_PER_UNIT) == (225, 1, 36, 1.0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--config5", "--gpus", "2"])
+    with pytest.raises(SystemExit):
+        bench.apply_workload_flags(bench.parse())
