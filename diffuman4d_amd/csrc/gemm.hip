@@ -1189,12 +1189,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_pipe(GemmParams p) {
 // the MFMAs of step s by scheduling directives.  Same K order as every other kernel of this file (ascending 16-wide k
 // steps into each accumulator), so results are bit-identical to gemm_kernel_pipe / gemm_kernel_glds.
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int NST>
+template <int BM, int BN, int WM, int WN, int NST, int BK = 64>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_lin2_kernel(GemmParams p) {
-  constexpr int BK = 64, ROWB = BK * 2;
+  static_assert(BK == 32 || BK == 64, "K-slab of 32 (64-byte rows, 16 per DMA instruction) or 64 (128-byte rows, 8 per instruction)");
+  constexpr int ROWB = BK * 2, RPI = 1024 / ROWB, CPR = BK / 8, KS = BK / 16;  // row bytes, rows per DMA instruction, chunks per row, k steps
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
-  constexpr int AW = BM / 8 / NW, BW = BN / 8 / NW;  // 1-KiB DMA instructions (8 rows of 128 B) per wave per slab
+  constexpr int AW = BM / RPI / NW, BW = BN / RPI / NW;  // 1-KiB DMA instructions per wave per slab
   static_assert(AW >= 1 && BW >= 1 && NST >= 2 && NST <= 3, "tile/wave/stage combination");
   constexpr int LD = AW + BW;
   constexpr int STAGE_BYTES = (BM + BN) * ROWB;
@@ -1213,13 +1214,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_lin2_kernel(GemmParams p) {
   const int m0 = tm * BM;
   const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
   const int n0 = tn * (geglu ? BN / 2 : BN);
-  const int d_row = lane >> 3, d_pos = lane & 7;
+  const int d_row = lane / CPR, d_pos = lane % CPR;
+  // LDS position (row, pos) holds chunk pos ^ key(row): key = (row >> 1) & 7 over 8 chunks, (row >> 2) & 3 over 4
+  auto key = [](int row) { return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
 
   uint32_t a_voff[AW], a2_voff[AW], w_voff[BW];
 #pragma unroll
   for (int i = 0; i < AW; ++i) {
-    const int row = (wave + NW * i) * 8 + d_row;
-    const uint32_t chunk = (uint32_t)(d_pos ^ ((row >> 1) & 7)) * 16u;
+    const int row = (wave + NW * i) * RPI + d_row;
+    const uint32_t chunk = (uint32_t)(d_pos ^ key(row)) * 16u;
     int m = m0 + row;
     if (m > p.M - 1) m = p.M - 1;
     a_voff[i] = (uint32_t)m * (uint32_t)(p.lda * 2) + chunk;
@@ -1227,8 +1230,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_lin2_kernel(GemmParams p) {
   }
 #pragma unroll
   for (int i = 0; i < BW; ++i) {
-    const int row = (wave + NW * i) * 8 + d_row;
-    w_voff[i] = (uint32_t)weight_row<TN>(p, n0, row, geglu) * (uint32_t)(p.ldw * 2) + (uint32_t)(d_pos ^ ((row >> 1) & 7)) * 16u;
+    const int row = (wave + NW * i) * RPI + d_row;
+    w_voff[i] = (uint32_t)weight_row<TN>(p, n0, row, geglu) * (uint32_t)(p.ldw * 2) + (uint32_t)(d_pos ^ key(row)) * 16u;
   }
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
   const uint32_t a_dst0 = lds0 + wave * 1024, b_dst0 = lds0 + BM * ROWB + wave * 1024;
@@ -1251,11 +1254,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_lin2_kernel(GemmParams p) {
   };
 
   // fragment read addresses: row base + k-step swizzle (A and B rows share the key: both are l31 + a multiple of 32)
-  int a_rd[4], b_rd[4];
+  int a_rd[KS], b_rd[KS];
   {
-    const int sw = (l31 >> 1) & 7;
+    const int sw = key(l31);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       const int z = ((ks * 2 + lh) ^ sw) * 16;
       a_rd[ks] = (wm * TM + l31) * ROWB + z;
       b_rd[ks] = BM * ROWB + (wn * TN + l31) * ROWB + z;
@@ -1273,9 +1276,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_lin2_kernel(GemmParams p) {
   constexpr bool TWO_SETS = MI * NI <= 8;
   auto compute = [&](int st) {
     const int so = st * STAGE_BYTES;
-    int ar[4], br[4];
+    int ar[KS], br[KS];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       ar[ks] = a_rd[ks] + so;
       br[ks] = b_rd[ks] + so;
     }
@@ -1291,8 +1294,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_lin2_kernel(GemmParams p) {
       };
       read_frags(0, 0);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if (ks + 1 < 4) read_frags(ks + 1, (ks + 1) & 1);
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) read_frags(ks + 1, (ks + 1) & 1);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -1302,8 +1305,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_lin2_kernel(GemmParams p) {
 #if STRIP2_SCHED
       __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
       sched_mfma_with_reads<MI * NI, MI + NI>();
-      sched_mfma_with_reads<MI * NI, MI + NI>();
-      sched_mfma_with_reads<MI * NI, MI + NI>();
+      if constexpr (KS == 4) {
+        sched_mfma_with_reads<MI * NI, MI + NI>();
+        sched_mfma_with_reads<MI * NI, MI + NI>();
+      }
       sched_mfma_with_reads<MI * NI, 0>();
 #endif
     } else {
@@ -1313,13 +1318,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_lin2_kernel(GemmParams p) {
 #pragma unroll
       for (int j = 0; j < NI; ++j) bfr[j] = read_b(0, j);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NI; ++j) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-            if (ks + 1 < 4) {
+            if (ks + 1 < KS) {
               if (j == NI - 1) af[i] = read_a(ks + 1, i);
               if (i == MI - 1) bfr[j] = read_b(ks + 1, j);
             }
@@ -1327,8 +1332,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_lin2_kernel(GemmParams p) {
 #if STRIP2_SCHED
       __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
       sched_mfma_reload<MI, NI, true>();
-      sched_mfma_reload<MI, NI, true>();
-      sched_mfma_reload<MI, NI, true>();
+      if constexpr (KS == 4) {
+        sched_mfma_reload<MI, NI, true>();
+        sched_mfma_reload<MI, NI, true>();
+      }
       sched_mfma_reload<MI, NI, false>();
 #endif
     }
@@ -1517,13 +1524,13 @@ __host__ inline bool lin2_ok(const GemmParams& p) {
          (uint64_t)(2 * (uint64_t)p.N) * (uint64_t)p.ldw * 2u < (1ull << 32);
 }
 
-template <int BM, int BN, int WM, int WN, int NST>
+template <int BM, int BN, int WM, int WN, int NST, int BK = 64>
 int launch_lin2(hipStream_t st, GemmParams& p) {
   const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
   const int bn_out = geglu ? BN / 2 : BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + bn_out - 1) / bn_out;
-  hipLaunchKernelGGL((gemm_lin2_kernel<BM, BN, WM, WN, NST>), dim3(tiles_m * p.tiles_n), dim3(WM * WN * 64), 0, st, p);
+  hipLaunchKernelGGL((gemm_lin2_kernel<BM, BN, WM, WN, NST, BK>), dim3(tiles_m * p.tiles_n), dim3(WM * WN * 64), 0, st, p);
   return dm4d_check_launch("gemm_lin2_kernel");
 }
 
@@ -1695,9 +1702,11 @@ int launch_by_id(int id, hipStream_t st, GemmParams& p) {
       }
     // Linear layers, second form (gemm_lin2_kernel): 61 = the tile of 14 / 41 (256x128, 8 waves, 3 stages), 62 = the tile
     // of 46 (256x320, 2 stages, no GEGLU), 63 = 128x128 with 4 waves (2 workgroups per CU), 64 = 128x128 with 8 waves
-    case 61: case 62: case 63: case 64:
+    case 61: case 62: case 63: case 64: case 65:
       if constexpr (!CONV) {
         if (!lin2_ok(p)) return DM4D_ERR_ARG;
+        // 65 = the geometry of 14 (256x128, 8 waves, K-slab 32, 3 stages = 74 KB: two workgroups per CU) in the second form
+        if (id == 65) return launch_lin2<256, 128, 4, 2, 3, 32>(st, p);
         if (id == 61) return launch_lin2<256, 128, 4, 2, 3>(st, p);
         if (id == 62) return geglu ? DM4D_ERR_ARG : launch_lin2<256, 320, 4, 2, 2>(st, p);
         if (id == 63) return launch_lin2<128, 128, 2, 2, 2>(st, p);
@@ -1730,15 +1739,15 @@ int choose_cfg(const GemmParams& p) {
     // N = 320 with a deep K (the level-0 feed-forward output projection): one 320-wide tile reads A once instead of three
     // times (profiles/r02_gemm_tune_wide.log: 130 vs 146 us at CFG batch 32, 190 vs 207 at 48)
     if (!geglu && p.N == 320 && p.K >= 1024 && tm256 >= 256) return 46;
-    // deep-K layers (K >= 640: levels 1-3): the second form (gemm_lin2_kernel), bit-identical, -4..-17 % per launch
+    // deep-K layers (K >= 1280): the second form (gemm_lin2_kernel), bit-identical, -4..-17 % per launch
     // (profiles/r02_lin2_ab.log): 128x128 tiles with two workgroups per CU wherever they fill the chip, the 8-wave
-    // 3-stage 128x128 tile for the few-row, very deep output projections of the deepest level, and the 256x128 tile
-    // for that level's GEGLU projection.  K = 320 (level 0) stays with the 2-workgroup K-slab-32 pipeline: there a tile is
-    // mostly prologue and epilogue, which only a second resident workgroup overlaps.
+    // 3-stage 128x128 tile for the few-row, very deep output projections of the deepest level, and the 256x128 K-slab-64
+    // tile for that level's GEGLU projection.  Shorter K needs two resident workgroups (a tile is mostly prologue and
+    // epilogue): see id 65 below.
     if (lin2_ok(p)) {
       if (geglu) {
         if (tm256 <= 12 && p.K >= 1280) return 61;
-      } else if (p.K >= 640 && p.N >= 640) {
+      } else if (p.K >= 1280 && p.N >= 640) {
         if (tm128 * ((p.N + 127) / 128) >= 256) return 63;
         if (p.K >= 2560) return 64;
       }
@@ -1746,7 +1755,13 @@ int choose_cfg(const GemmParams& p) {
     // Linear layers stream A once with little reuse (K = C or 4C): they are bound by L2->LDS bytes and DMA latency,
     // so the 8-wave 256x128 tile with 2 slabs of DMA in flight wins whenever it still fills the chip (1.2-1.35x)
     const long t = tm256 * tn;  // one 8-wave workgroup per CU => 256 slots per round; avoid a mostly empty last round
-    if (t >= 256 && 5 * t >= 4 * ((t + 255) / 256) * 256) return 14;
+    if (t >= 256 && 5 * t >= 4 * ((t + 255) / 256) * 256) {
+      // the same 74 KB geometry (two workgroups per CU) in the second form: -2..-9 % on the GEGLU projections of levels 0-2,
+      // -9..-16 % on the K = 640 layers of level 1, +-1 % on the narrow K = 320 layers; the wide K = 320 QKV projection
+      // (N = 960) is the one shape where it is not ahead at both batch sizes (profiles/r02_lin2_ab.log, id 65 vs auto)
+      if (lin2_ok(p) && (geglu || p.K >= 640 || p.N <= 640)) return 65;
+      return 14;
+    }
   } else {
     // stride-1 convs: the strip kernels stage A once per kernel row (profiles/r01_conv_strip.log)
     if (p.stride == 1 && p.pad == 1 && !p.upsample && p.Ho == p.H && p.Wo == p.W) {
