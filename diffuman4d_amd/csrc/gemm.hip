@@ -44,6 +44,11 @@
 #ifndef GEMM_ABLATE
 #define GEMM_ABLATE 0
 #endif
+// Read-back of residual / row-bias layers: 1 = blocks entirely inside the matrix take a branch-free path that issues the
+// global loads of two tasks together (same arithmetic, same order)
+#ifndef GEMM_EPI_STRAIGHT
+#define GEMM_EPI_STRAIGHT 1
+#endif
 // conv_strip2_kernel: 1 = sched_group_barrier directives put the fragment reads of k step s+1 behind the MFMAs of step s
 #ifndef STRIP2_SCHED
 #define STRIP2_SCHED 1
@@ -109,17 +114,99 @@ __device__ __forceinline__ int weight_row(const GemmParams& p, int n0, int r, bo
   return n;
 }
 
-// D fragment layout (32x32): lane holds column (lane & 31), rows (r&3) + 8*(r>>2) + 4*(lane>>5).
-//
+// Every kernel of this file multiplies with the operands SWAPPED: the weight fragment goes in as the MFMA's A operand and
+// the activation fragment as its B operand (both fragment formats are "lane & 31 = row / column, lane >> 5 = k half", so the
+// same registers serve either role).  The unit then delivers the TRANSPOSED 32x32 block: lane holds output ROW m = lane & 31
+// and the 16 COLUMNS n = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), i.e. four runs of four consecutive columns.  Every output
+// element is the same sum of the same products in the same order as with the operands the other way round (bit-identical
+// results), but the epilogue can now stage four columns per LDS instruction (ds_write_b128 of fp32, or ds_write_b64 of four
+// packed bf16) instead of one element per ds_write_b32 -- a quarter of the LDS store instructions -- and layers without a
+// residual / row bias round to bf16 BEFORE staging (same rounding point: nothing else is applied to them afterwards), which
+// halves the staged bytes and leaves a read-back loop of LDS reads and global stores only.
+__device__ __forceinline__ f32x16_t mfma_t(const bf16x8_t& a_rows, const bf16x8_t& w_rows, const f32x16_t& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_rows, a_rows, c, 0, 0, 0);
+}
+
+// Stage one 32-row block of a wave (JN 32-column blocks of the transposed accumulators `a`, first one J0; the bias is
+// already in them, see gemm_epilogue_impl): GEGLU / SiLU applied, four columns per LDS store -- PLAIN: rounded to bf16 and
+// packed (srow = this lane's halfword row + 4 lh), otherwise fp32 (srow = this lane's float row + 4 lh).
+template <int NI, int MODE, int J0, int JN, bool PLAIN>
+__device__ __forceinline__ void stage_block(const f32x16_t (&a)[NI], void* srow) {
+  constexpr bool geglu = MODE == 2;
+#pragma unroll
+  for (int j = 0; j < JN; ++j) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * q + e;
+        v[e] = a[J0 + j][r];
+        if constexpr (geglu) {
+#if GEGLU_ERF
+          v[e] = v[e] * gelu_erf_f(a[J0 + j + NI / 2][r]);
+#else
+          v[e] = v[e] * gelu_fit_f(a[J0 + j + NI / 2][r]);
+#endif
+        }
+        if constexpr (MODE == 1) v[e] = silu_f(v[e]);
+      }
+      if constexpr (PLAIN) {
+        uint2 pk;
+        pk.x = pack_bf2(v[0], v[1]);
+        pk.y = pack_bf2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(srow) + j * 32 + 8 * q) = pk;
+      } else {
+        const f32x4_t v4 = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(srow) + j * 32 + 8 * q) = v4;
+      }
+    }
+  }
+}
+
+// The bias as one more k step of the product -- the FIRST one: the accumulators do not start from zero but from an MFMA
+// whose activation fragment is e_0 (1.0 in k slot 0 of every row) and whose weight fragment holds the bias in k slot 0 of its
+// column's row: fifteen exact zeros and one exact product.  Each lane needs the bias of ONE column per 32-column block
+// (lane & 31, the row of the weight tile it would read), whatever the accumulator layout; the 16 v_mov per block of a zero
+// initialisation and the 16 v_add_f32 per block of a register-side bias add (VALU time is not hidden behind other waves'
+// MFMAs on this chip) become one MFMA.  Without a bias (and for split-K partial sums, whose bias the
+// reduce kernel adds) the fragment is zero and the accumulators start at +0.
+__device__ __forceinline__ bf16x8_t k0_fragment(u16 bits, int lh) {
+  union {
+    uint32_t u[4];
+    bf16x8_t v;
+  } f;
+  f.u[0] = lh ? 0u : (uint32_t)bits;
+  f.u[1] = f.u[2] = f.u[3] = 0u;
+  return f.v;
+}
+
+template <int MI, int NI, int TN>
+__device__ __forceinline__ void acc_init(const GemmParams& p, f32x16_t (&acc)[MI][NI], int n0, int wn, int lane, bool geglu) {
+  const int l31 = lane & 31, lh = lane >> 5;
+  const bf16x8_t one0 = k0_fragment(0x3f80, lh);
+  f32x16_t zero;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+  const bool use = p.bias != nullptr && p.splits <= 1;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    u16 bits = 0;
+    if (use) bits = p.bias[weight_row<TN>(p, n0, wn * TN + j * 32 + l31, geglu)];  // clamped columns are never stored
+    const bf16x8_t bf = k0_fragment(bits, lh);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) acc[i][j] = mfma_t(one0, bf, zero);
+  }
+}
+
 // The epilogue is specialised at compile time on what it has to apply (MODE: 0 = bias only, 1 = + SiLU, 2 = GEGLU): the
 // flags are wave-uniform, but with a runtime `if (do_silu)` inside the 16-element loops hipcc if-converts the branch --
 // every output element of every Linear layer and convolution then pays v_exp + v_rcp + a select for a SiLU only the
 // two time-embedding GEMMs use, plus one scalar branch per element for GEGLU and per-element staging address arithmetic
 // (runtime row stride).  Ablation (profiles/r02_gemm_ablation.log): the epilogue was 39 % of the K = 320 Linear layers'
 // time, the stores only 8 %.  With MODE a template parameter the staging stride, the chunk geometry and the trip counts
-// are constants: the staging stores take immediate offsets and the read-back loop unrolls.  Same floating-point
-// operations in the same order as before: results are bit-identical.
-template <int MI, int NI, int TM, int TN, int MODE, int EPW, int J0, int JN, bool SYNC>
+// are constants: the staging stores take immediate offsets and the read-back loop unrolls.
+template <int MI, int NI, int TM, int TN, int MODE, int EPW, int J0, int JN, bool SYNC, bool STRAIGHT>
 __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t (&acc)[MI][NI], float* smem_f, int m0, int n0,
                                                    int wm, int wn, int wave, int lane) {
   // This instance handles output blocks [J0, J0 + JN) of the wave's NJ 32-column blocks (a "column group"): wide per-wave
@@ -129,31 +216,27 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t
   constexpr int NJ = geglu ? NI / 2 : NI;
   static_assert(J0 + JN <= NJ && JN * 32 <= EPW, "column group outside the wave's tile or wider than its staging area");
   constexpr int TNO = JN * 32;   // output columns of this group
-  constexpr int SLD = TNO + 4;   // fp32 staging row stride
+  constexpr int SLD = TNO + 4;   // fp32 staging row stride (floats): rows stay 16-byte aligned, b128 stores of 16 lanes tile the banks
+  constexpr int SBH = TNO + 4;   // bf16 staging row stride (halfwords) = TNO / 2 + 2 dwords: b64 stores of 32 lanes tile the banks
   constexpr int CPR = TNO / 8;   // 8-column chunks per row
   constexpr int TASKS = 32 * CPR;
   float* stage = smem_f + wave * 32 * (EPW + 4);
   const int ncol0 = n0 + wn * (NJ * 32) + J0 * 32;
 
-  float bias_h[JN], bias_g[JN];
-#pragma unroll
-  for (int j = 0; j < JN; ++j) {
-    bias_h[j] = 0.f;
-    bias_g[j] = 0.f;
-    const int n = ncol0 + j * 32 + l31;
-    if (p.bias && n < p.N) {
-      bias_h[j] = bf2f(p.bias[n]);
-      if (geglu) bias_g[j] = bf2f(p.bias[p.N + n]);
-    }
-  }
   const bool vec_ok = ((p.ldc & 7) == 0) && ((p.N & 7) == 0) && (!p.res || (p.ld_res & 7) == 0) &&
                       (!p.rowbias || (p.ld_rb & 7) == 0);
   const bool f32out = (p.flags & DM4D_EPI_F32OUT) != 0;  // C is float* (fp32 logits of the VAE mid-block attention)
-#if GEMM_FAST_EPI
-  // the fast read-back loop takes row / chunk of a task from shifts: it needs a power-of-two number of chunks per row
+  // the fast read-back loops take row / chunk of a task from shifts: they need a power-of-two number of chunks per row
   constexpr bool CPR_POW2 = (CPR & (CPR - 1)) == 0;
+  constexpr int cshift = CPR >= 16 ? 4 : (CPR >= 8 ? 3 : (CPR >= 4 ? 2 : (CPR >= 2 ? 1 : 0)));
+  constexpr int cmask = CPR - 1;
+#if GEMM_FAST_EPI
   const bool fast_ok = CPR_POW2 && vec_ok && p.ldc < (1 << 24) && (!p.res || p.ld_res < (1 << 24)) &&
                        (!p.rowbias || p.rows_per_rb > 0) && !f32out && p.up_w == 0;
+  // nothing is applied after the staging: round to bf16 first, stage packed halfwords, copy rows out
+  const bool plain = fast_ok && !p.res && !p.rowbias && p.out_scale == 1.0f && GEMM_ABLATE == 0;
+#else
+  const bool fast_ok = false, plain = false;
 #endif
   // The staging area is private to a wave and LDS operations of one wave complete in program order, so only one
   // workgroup barrier is needed: the one that retires every wave's main-loop fragment reads before the area is reused
@@ -161,40 +244,124 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t
   if constexpr (SYNC) __syncthreads();
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    float* srow = stage + (4 * lh) * SLD + l31;  // this lane's first staging row; the other 15 are compile-time offsets away
+    const int m_base = m0 + wm * TM + i * 32;
+    if (plain) {
+      u16* sb = reinterpret_cast<u16*>(stage);
+      u16* srow = sb + l31 * SBH + 4 * lh;  // this lane's staging row; column runs are compile-time offsets away
+      stage_block<NI, MODE, J0, JN, true>(acc[i], srow);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // compiler: keep the staging stores ahead of the row reads
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      u16* c_base = p.C + (int64_t)m_base * p.ldc + ncol0;
+      if (TASKS % 64 == 0 && m_base + 32 <= p.M && ncol0 + TNO <= p.N) {
+        // block entirely inside the matrix (wave-uniform): straight-line code, every LDS read issued before the first store
+        U4 o[TASKS / 64 > 0 ? TASKS / 64 : 1];
 #pragma unroll
-    for (int j = 0; j < JN; ++j) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2);  // + 4 * lh, folded into srow
-        float v = acc[i][J0 + j][r] + bias_h[j];
-        if constexpr (geglu) {
-          const float g = acc[i][J0 + j + NI / 2][r] + bias_g[j];
-#if GEGLU_ERF
-          v = v * gelu_erf_f(g);
-#else
-          v = v * gelu_fit_f(g);
-#endif
+        for (int it = 0; it < TASKS / 64; ++it) {
+          const int id = lane + it * 64;
+          const int row = id >> cshift, cc = id & cmask;
+          const uint2* s = reinterpret_cast<const uint2*>(sb + row * SBH + cc * 8);  // rows are 8-byte aligned
+          const uint2 lo = s[0], hi = s[1];
+          o[it].x = lo.x; o[it].y = lo.y; o[it].z = hi.x; o[it].w = hi.y;
         }
-        if constexpr (MODE == 1) v = silu_f(v);
-        srow[row * SLD + j * 32] = v;
+#pragma unroll
+        for (int it = 0; it < TASKS / 64; ++it) {
+          const int id = lane + it * 64;
+          const int row = id >> cshift, cc = id & cmask;
+          stg16(c_base + (uint32_t)(row * (int)p.ldc + cc * 8), o[it]);
+        }
+      } else {
+#pragma unroll
+        for (int it = 0; it < (TASKS + 63) / 64; ++it) {
+          const int id = lane + it * 64;
+          if (TASKS % 64 != 0 && id >= TASKS) continue;
+          const int row = id >> cshift, cc = id & cmask;
+          if (m_base + row >= p.M || ncol0 + cc * 8 >= p.N) continue;
+          const uint2* s = reinterpret_cast<const uint2*>(sb + row * SBH + cc * 8);  // rows are 8-byte aligned
+          const uint2 lo = s[0], hi = s[1];
+          U4 o;
+          o.x = lo.x; o.y = lo.y; o.z = hi.x; o.w = hi.y;
+          stg16(c_base + (uint32_t)(row * (int)p.ldc + cc * 8), o);
+        }
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // ... and the row reads ahead of the next block's stores
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      continue;  // next 32-row block of this wave
     }
+    float* srow = stage + l31 * SLD + 4 * lh;  // this lane's staging row; column runs are compile-time offsets away
+    stage_block<NI, MODE, J0, JN, false>(acc[i], srow);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // compiler: keep the staging stores ahead of the row reads
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #if GEMM_FAST_EPI
     if (fast_ok) {
       // 32-bit offsets from wave-uniform row-block bases, and the rowbias row (m / rows_per_rb) from one division per
       // 32-row block: rows of a block are consecutive, so row r lies in image q0 + (r0 + r >= rows_per_rb).
-      const int m_base = m0 + wm * TM + i * 32;
-      constexpr int cshift = CPR >= 16 ? 4 : (CPR >= 8 ? 3 : (CPR >= 4 ? 2 : (CPR >= 2 ? 1 : 0)));
-      constexpr int cmask = CPR - 1;
       const u16* res_base = p.res ? p.res + (int64_t)m_base * p.ld_res + ncol0 : nullptr;
       u16* c_base = p.C + (int64_t)m_base * p.ldc + ncol0;
       int q0 = 0, r0 = 0;
       if (p.rowbias) {
         q0 = m_base / p.rows_per_rb;
         r0 = m_base - q0 * p.rows_per_rb;
+      }
+      if (STRAIGHT && GEMM_ABLATE == 0 && TASKS % 64 == 0 && m_base + 32 <= p.M && ncol0 + TNO <= p.N &&
+          (!p.rowbias || p.rows_per_rb >= 32)) {
+        // block entirely inside the matrix (wave-uniform): straight-line code -- the residual / row-bias loads of all of a
+        // lane's tasks are issued together and ahead of the staging read-back instead of one load-wait-store chain per task
+        auto run = [&](auto has_rb, auto has_res) {
+          constexpr bool RB = decltype(has_rb)::value, RS = decltype(has_res)::value;
+          constexpr int T = TASKS / 64;      // tasks per lane
+          constexpr int CH = T >= 2 ? 2 : 1;  // issued together (more would cost the 74 KB geometries their 128-register budget)
+#pragma unroll
+          for (int c0 = 0; c0 < T; c0 += CH) {
+            U4 trb[RB ? CH : 1], trs[RS ? CH : 1];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+              const int id = lane + (c0 + u) * 64;
+              const int row = id >> cshift, cc = id & cmask;
+              if constexpr (RB) {
+                const int q = q0 + ((r0 + row >= p.rows_per_rb) ? 1 : 0);
+                trb[u] = ldg16(p.rowbias + (int64_t)q * p.ld_rb + ncol0 + cc * 8);
+              }
+              if constexpr (RS) trs[u] = ldg16(res_base + (uint32_t)(row * (int)p.ld_res + cc * 8));
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+              const int id = lane + (c0 + u) * 64;
+              const int row = id >> cshift, cc = id & cmask;
+              float v[8];
+              const float* s = stage + row * SLD + cc * 8;
+              f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(s);
+              f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(s + 4);
+              v[0] = s0[0]; v[1] = s0[1]; v[2] = s0[2]; v[3] = s0[3];
+              v[4] = s1[0]; v[5] = s1[1]; v[6] = s1[2]; v[7] = s1[3];
+              if constexpr (RB) {
+                float t[8];
+                unpack8(trb[u], t);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += t[e];
+              }
+              if constexpr (RS) {
+                float t[8];
+                unpack8(trs[u], t);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += t[e];
+              }
+              if (p.out_scale != 1.0f) {  // wave-uniform; x * 1.0f is exact, so skipping it changes nothing
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+              }
+              stg16(c_base + (uint32_t)(row * (int)p.ldc + cc * 8), pack8(v));
+            }
+          }
+        };
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        if (p.rowbias && p.res) run(T_{}, T_{});
+        else if (p.rowbias) run(T_{}, F_{});
+        else if (p.res) run(F_{}, T_{});
+        else run(F_{}, F_{});
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // ... and the row reads ahead of the next block's stores
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        continue;  // next 32-row block of this wave
       }
 #pragma unroll
       for (int it = 0; it < (TASKS + 63) / 64; ++it) {
@@ -239,12 +406,14 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t
         stg16(c_base + (uint32_t)(row * (int)p.ldc + cc * 8), pack8(v));
 #endif
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // ... and the row reads ahead of the next block's stores
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       continue;  // next 32-row block of this wave
     }
 #endif
     for (int id = lane; id < TASKS; id += 64) {
       int row = id / CPR, cc = id % CPR;
-      int m = m0 + wm * TM + i * 32 + row;
+      int m = m_base + row;
       int n = ncol0 + cc * 8;
       if (m >= p.M || n >= p.N) continue;
       const int64_t mo = p.up_w ? 2 * (int64_t)m + 2 * (int64_t)p.up_w * (m / p.up_w) : (int64_t)m;  // output row
@@ -287,6 +456,8 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t
         }
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // ... and the row reads ahead of the next block's stores
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 
@@ -296,22 +467,30 @@ struct EpiGeom {
   static constexpr int EPW = TN <= 128 ? TN : 128;
 };
 
-template <int MI, int NI, int TM, int TN, int MODE>
+template <int MI, int NI, int TM, int TN, int MODE, bool STRAIGHT>
 __device__ __forceinline__ void gemm_epilogue_mode(const GemmParams& p, f32x16_t (&acc)[MI][NI], float* smem_f, int m0, int n0,
                                                    int wm, int wn, int wave, int lane) {
   constexpr int NJ = MODE == 2 ? NI / 2 : NI;
   constexpr int EPW = EpiGeom<TN>::EPW;
   constexpr int G = EPW / 32;  // blocks per full column group
   if constexpr (NJ <= G) {
-    gemm_epilogue_impl<MI, NI, TM, TN, MODE, EPW, 0, NJ, true>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
+    gemm_epilogue_impl<MI, NI, TM, TN, MODE, EPW, 0, NJ, true, STRAIGHT>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
   } else {
     static_assert(NJ <= 2 * G, "at most two column groups");
-    gemm_epilogue_impl<MI, NI, TM, TN, MODE, EPW, 0, G, true>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
-    gemm_epilogue_impl<MI, NI, TM, TN, MODE, EPW, G, NJ - G, false>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
+    gemm_epilogue_impl<MI, NI, TM, TN, MODE, EPW, 0, G, true, STRAIGHT>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
+    gemm_epilogue_impl<MI, NI, TM, TN, MODE, EPW, G, NJ - G, false, STRAIGHT>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
   }
 }
 
-template <int MI, int NI, int TM, int TN>
+// STRAIGHT (EpiBudget): whether the kernel can afford the ~20 extra VGPRs of the branch-free residual read-back
+template <int NW, int MI, int NI, int SMEM>
+struct EpiBudget {
+  // not for 16-wave workgroups (128 registers per lane), for the wide 64x160 wave tiles (their 160 accumulators fill the
+  // register file), or for the 8-wave tiles of <= 80 KB that rely on a second resident workgroup (128 registers again)
+  static constexpr bool STRAIGHT = GEMM_EPI_STRAIGHT && NW <= 8 && MI * NI <= 8 && !(NW == 8 && SMEM <= 80 * 1024);
+};
+
+template <int MI, int NI, int TM, int TN, bool STRAIGHT = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[MI][NI], float* smem_f, int m0, int n0,
                                               int wm, int wn, int wave, int lane) {
 #if GEMM_ABLATE == 2
@@ -327,12 +506,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
   // wave-uniform dispatch; GEGLU pairs hidden block j with gate block j + NI/2 inside the wave, so it needs an even NI
   if constexpr (NI >= 2 && NI % 2 == 0) {
     if (p.flags & DM4D_EPI_GEGLU) {
-      gemm_epilogue_mode<MI, NI, TM, TN, 2>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
+      gemm_epilogue_mode<MI, NI, TM, TN, 2, STRAIGHT>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
       return;
     }
   }
-  if (p.flags & DM4D_EPI_SILU) gemm_epilogue_mode<MI, NI, TM, TN, 1>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
-  else gemm_epilogue_mode<MI, NI, TM, TN, 0>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
+  if (p.flags & DM4D_EPI_SILU) gemm_epilogue_mode<MI, NI, TM, TN, 1, STRAIGHT>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
+  else gemm_epilogue_mode<MI, NI, TM, TN, 0, STRAIGHT>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
 #endif
 }
 
@@ -399,12 +578,7 @@ __global__ __launch_bounds__(256) void gemm_kernel_glds(GemmParams p) {
   }
 
   f32x16_t acc[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  acc_init<MI, NI, TN>(p, acc, n0, wn, lane, geglu);
 
   const int nk = p.K / BK;
   const int Hin = p.upsample ? 2 * p.H : p.H, Win = p.upsample ? 2 * p.W : p.W;
@@ -479,11 +653,11 @@ __global__ __launch_bounds__(256) void gemm_kernel_glds(GemmParams p) {
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_t(af[ks & 1][i], bfr[ks & 1][j], acc[i][j]);
     }
     __syncthreads();  // all waves done with `buf`; the DMA into buf^1 has landed (vmcnt(0) before the barrier)
   }
-  gemm_epilogue<MI, NI, TM, TN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
+  gemm_epilogue<MI, NI, TM, TN, EpiBudget<WM * WN, MI, NI, SMEM_BYTES>::STRAIGHT>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -568,12 +742,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip_kernel(GemmParams p) {
   }
 
   f32x16_t acc[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  acc_init<MI, NI, TN>(p, acc, n0, wn, lane, false);
 
   const int nci = p.Cin / BK;
   const int nstrips = (p.splits > 1 ? 1 : 3) * nci, nsteps = 3 * nstrips;
@@ -653,28 +822,22 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip_kernel(GemmParams p) {
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NI; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma_t(af[ks & 1][i], bfr[ks & 1][j], acc[i][j]);
 #endif
       }
       __syncthreads();
     }
   }
-  if (p.splits > 1) {  // raw fp32 partial sums; splitk_reduce_kernel adds the splits in a fixed order and applies the epilogue
-    float* wsp = p.ws + (int64_t)split * p.M * p.N;
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int n = n0 + wn * TN + j * 32 + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (m < p.M && n < p.N) wsp[(int64_t)m * p.N + n] = acc[i][j][r];
-        }
-      }
-    return;
+  if (p.splits > 1) {
+    // raw fp32 partial sums (splitk_reduce_kernel adds the splits in a fixed order and applies the real epilogue): the
+    // same staged, row-coalesced write-out with the workspace slice as an fp32 output matrix and nothing else applied
+    p.C = reinterpret_cast<u16*>(p.ws + (int64_t)split * p.M * p.N);
+    p.ldc = p.N;
+    p.flags = DM4D_EPI_F32OUT;
+    p.bias = p.rowbias = p.res = nullptr;
+    p.out_scale = 1.0f;
   }
-  gemm_epilogue<MI, NI, TM, TN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
+  gemm_epilogue<MI, NI, TM, TN, EpiBudget<WM * WN, MI, NI, SMEM_BYTES>::STRAIGHT>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -845,12 +1008,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip2_kernel(GemmParams p_i
   }
 
   f32x16_t acc[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  acc_init<MI, NI, TN>(p, acc, n0, wn, lane, false);
 
   // ---- the K walk: ky (kernel row) > cs (64-channel slab) > kx (tap column); one DMA'd step ahead -------------------
   const int nci = p.Cin / BK;
@@ -917,7 +1075,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip2_kernel(GemmParams p_i
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NI; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma_t(af[ks & 1][i], bfr[ks & 1][j], acc[i][j]);
       }
 #if STRIP2_SCHED
       __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);  // fragments of k step 0
@@ -938,7 +1096,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip2_kernel(GemmParams p_i
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NI; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma_t(af[i], bfr[j], acc[i][j]);
             if (ks + 1 < 4) {
               if (j == NI - 1) af[i] = read_a(ks + 1, i);
               if (i == MI - 1) bfr[j] = read_b(ks + 1, j);
@@ -987,22 +1145,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip2_kernel(GemmParams p_i
     compute(abuf, std::integral_constant<int, KT - 1>{});
     dma_wait_barrier();
   }
-  if (KT == 3 && p.splits > 1) {  // raw fp32 partial sums; splitk_reduce_kernel adds the splits in a fixed order and applies the epilogue
-    float* wsp = p.ws + (int64_t)split * p.M * p.N;
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int n = n0 + wn * TN + j * 32 + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (m < p.M && n < p.N) wsp[(int64_t)m * p.N + n] = acc[i][j][r];
-        }
-      }
-    return;
+  if (KT == 3 && p.splits > 1) {
+    // raw fp32 partial sums (splitk_reduce_kernel adds the splits in a fixed order and applies the real epilogue): the
+    // same staged, row-coalesced write-out with the workspace slice as an fp32 output matrix and nothing else applied
+    p.C = reinterpret_cast<u16*>(p.ws + (int64_t)split * p.M * p.N);
+    p.ldc = p.N;
+    p.flags = DM4D_EPI_F32OUT;
+    p.bias = p.rowbias = p.res = nullptr;
+    p.out_scale = 1.0f;
   }
-  gemm_epilogue<MI, NI, TM, TN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
+  gemm_epilogue<MI, NI, TM, TN, EpiBudget<WM * WN, MI, NI, SMEM_BYTES>::STRAIGHT>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1077,12 +1229,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_pipe(GemmParams p) {
                src_chunk((wave + NW * i) * RPI + d_row) * 8;
 
   f32x16_t acc[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  acc_init<MI, NI, TN>(p, acc, n0, wn, lane, geglu);
 
   const int nk = p.K / BK;
   const int Hin = p.upsample ? 2 * p.H : p.H, Win = p.upsample ? 2 * p.W : p.W;
@@ -1173,13 +1320,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_pipe(GemmParams p) {
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NI; ++j) acc[i][j] = mfma_t(af[i], bfr[j], acc[i][j]);
 #endif
     }
     st = (st + 1 == NST) ? 0 : st + 1;
     st_issue = (st_issue + 1 == NST) ? 0 : st_issue + 1;
   }
-  gemm_epilogue<MI, NI, TM, TN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
+  gemm_epilogue<MI, NI, TM, TN, EpiBudget<WM * WN, MI, NI, SMEM_BYTES>::STRAIGHT>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1266,12 +1413,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_lin2_kernel(GemmParams p) {
   }
 
   f32x16_t acc[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  acc_init<MI, NI, TN>(p, acc, n0, wn, lane, geglu);
 
   constexpr bool TWO_SETS = MI * NI <= 8;
   auto compute = [&](int st) {
@@ -1300,7 +1442,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_lin2_kernel(GemmParams p) {
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NI; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma_t(af[ks & 1][i], bfr[ks & 1][j], acc[i][j]);
       }
 #if STRIP2_SCHED
       __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
@@ -1323,7 +1465,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_lin2_kernel(GemmParams p) {
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NI; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma_t(af[i], bfr[j], acc[i][j]);
             if (ks + 1 < KS) {
               if (j == NI - 1) af[i] = read_a(ks + 1, i);
               if (i == MI - 1) bfr[j] = read_b(ks + 1, j);
@@ -1364,7 +1506,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_lin2_kernel(GemmParams p) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // all fragment reads done: the epilogue stages through the same LDS
   asm volatile("" ::: "memory");
-  gemm_epilogue<MI, NI, TM, TN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
+  gemm_epilogue<MI, NI, TM, TN, EpiBudget<WM * WN, MI, NI, SMEM_BYTES>::STRAIGHT>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1420,12 +1562,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   for (int i = 0; i < BI; ++i) w_base[i] = p.Wt + (int64_t)weight_row<TN>(p, n0, a_r + 64 * i, geglu) * p.ldw;
 
   f32x16_t acc[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  acc_init<MI, NI, TN>(p, acc, n0, wn, lane, geglu);
 
   const int nk = p.K / 32;
   const int Hin = p.upsample ? 2 * p.H : p.H, Win = p.upsample ? 2 * p.W : p.W;
@@ -1485,12 +1622,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NI; ++j) acc[i][j] = mfma_t(af[i], bfr[j], acc[i][j]);
     }
     if (kt + 1 < nk) store_slab(buf ^ 1);
     __syncthreads();
   }
-  gemm_epilogue<MI, NI, TM, TN>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
+  gemm_epilogue<MI, NI, TM, TN, EpiBudget<WM * WN, MI, NI, SMEM_BYTES>::STRAIGHT>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
 }
 
 template <int BM, int BN, int WM, int WN, bool CONV, bool GLDS>
@@ -1702,9 +1839,14 @@ int launch_by_id(int id, hipStream_t st, GemmParams& p) {
       }
     // Linear layers, second form (gemm_lin2_kernel): 61 = the tile of 14 / 41 (256x128, 8 waves, 3 stages), 62 = the tile
     // of 46 (256x320, 2 stages, no GEGLU), 63 = 128x128 with 4 waves (2 workgroups per CU), 64 = 128x128 with 8 waves
-    case 61: case 62: case 63: case 64: case 65:
+    case 61: case 62: case 63: case 64: case 65: case 66: case 67:
       if constexpr (!CONV) {
         if (!lin2_ok(p)) return DM4D_ERR_ARG;
+        // 67 = 256x256 tile on eight waves (128x64 per wave), K-slab 64, 2 stages = 128 KB.  (66 was the same tile on FOUR waves,
+        // one per SIMD with 128x128 = 256 accumulator registers each: 1.3-2x slower than 67 on every shape under the compiler's
+        // schedule -- profiles/r02_lin_tiles_256.log -- and removed.)
+        if (id == 66) return DM4D_ERR_ARG;
+        if (id == 67) return launch_lin2<256, 256, 2, 4, 2>(st, p);
         // 65 = the geometry of 14 (256x128, 8 waves, K-slab 32, 3 stages = 74 KB: two workgroups per CU) in the second form
         if (id == 65) return launch_lin2<256, 128, 4, 2, 3, 32>(st, p);
         if (id == 61) return launch_lin2<256, 128, 4, 2, 3>(st, p);
@@ -1745,6 +1887,15 @@ int choose_cfg(const GemmParams& p) {
     // tile for that level's GEGLU projection.  Shorter K needs two resident workgroups (a tile is mostly prologue and
     // epilogue): see id 65 below.
     if (lin2_ok(p)) {
+      // 256x256 tiles on 8 waves (128x64 per wave: 6 fragment reads feed 8 MFMAs instead of 4 feeding 4) for the wide layers
+      // -- the GEGLU projections and the N >= 1280 projections with K >= 640 -- whenever whole rounds of 256 tiles use at
+      // least 85 % of their slots and columns: -5..-16 % per launch (profiles/r02_lin_tiles_256.log: ff1 level 2 182 -> 156 us,
+      // level-1 QKV 70.6 -> 64.8, level-2 QKV at CFG batch 48 95.4 -> 80.3); bit-identical to every other id
+      if (geglu || (p.K >= 640 && p.N >= 1280)) {
+        const long nw = geglu ? 2L * p.N : p.N, tn256 = (nw + 255) / 256, t = tm256 * tn256;
+        const double fill = (double)t / (double)(((t + 255) / 256) * 256) * (double)nw / (double)(tn256 * 256);
+        if (fill >= 0.85) return 67;
+      }
       if (geglu) {
         if (tm256 <= 12 && p.K >= 1280) return 61;
       } else if (p.K >= 1280 && p.N >= 640) {

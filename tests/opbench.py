@@ -87,8 +87,54 @@ def bench_ln(M, C, tag=""):
     print(f"ln  {tag:10s} M={M:6d} C={C:5d}  {t*1e6:9.1f} us  {by/t/1e9:7.1f} GB/s(alg)", flush=True)
 
 
+def vendor_yardstick():
+    """The vendor libraries on the same shapes, as a yardstick only (nothing in the product calls them): hipBLASLt / rocBLAS
+    through torch.nn.functional.linear (bias epilogue, no GEGLU / residual fusion) and the flash attention torch ships
+    (scaled_dot_product_attention restricted to its fused backends)."""
+    import torch.nn.functional as F
+    print("vendor yardstick: torch", torch.__version__, flush=True)
+    B = 32
+    for lvl, (hw, c) in enumerate([(2880, 320), (720, 640), (180, 1280), (45, 1280)]):
+        M = B * hw
+        for tag, N, K in ((f"qkv L{lvl}", 3 * c, c), (f"out L{lvl}", c, c), (f"ff1 L{lvl} (2N, no GEGLU)", 8 * c, c),
+                          (f"ff2 L{lvl}", c, 4 * c)):
+            a, w, b = rnd(M, K), rnd(N, K, scale=1 / math.sqrt(K)), rnd(N)
+            t = timeit(lambda: F.linear(a, w, b))
+            print(f"F.linear {tag:26s} M={M:6d} N={N:5d} K={K:5d}  {t*1e6:9.1f} us  {2.0*M*N*K/t/1e12:7.1f} TF/s", flush=True)
+    try:
+        from torch.nn.attention import SDPBackend, sdpa_kernel
+        for tag, batch, heads, L in (("2D L0", 32, 5, 2880), ("3D L1 F16", 2, 10, 11520), ("3D L1 F24", 2, 10, 17280),
+                                     ("3D L2 F16", 2, 20, 2880), ("3D L1 128", 2, 10, 65536)):
+            q, k, v = (rnd(batch, heads, L, 64) for _ in range(3))
+            with sdpa_kernel([SDPBackend.FLASH_ATTENTION, SDPBackend.EFFICIENT_ATTENTION]):
+                t = timeit(lambda: F.scaled_dot_product_attention(q, k, v), iters=5, warmup=2)
+            print(f"SDPA     {tag:26s} b={batch:3d} h={heads:3d} L={L:6d}  {t*1e6:9.1f} us  {4.0*batch*heads*L*L*64/t/1e12:7.1f} TF/s",
+                  flush=True)
+    except Exception as e:  # a yardstick, not a dependency
+        print("SDPA yardstick unavailable:", type(e).__name__, str(e)[:200], flush=True)
+
+
 def main():
     only = sys.argv[1] if len(sys.argv) > 1 else None
+    if only == "vendor":
+        vendor_yardstick()
+        return
+    if only == "gemm":
+        B = 32
+        for lvl, (hw, c) in enumerate([(2880, 320), (720, 640), (180, 1280), (45, 1280)]):
+            M = B * hw
+            bench_gemm(M, 3 * c, c, residual=False, tag=f" qkv L{lvl}")
+            bench_gemm(M, c, c, tag=f" out L{lvl}")
+            bench_gemm(M, c, c, residual=False, tag=f" pin L{lvl}")
+            bench_gemm(M, 4 * c, c, geglu=True, residual=False, tag=f" ff1 L{lvl}")
+            bench_gemm(M, c, 4 * c, tag=f" ff2 L{lvl}")
+        bench_conv(B, 72, 40, 320, 320, tag=" L0")
+        bench_conv(B, 72, 40, 960, 320, tag=" L0 up")
+        bench_conv(B, 36, 20, 640, 640, tag=" L1")
+        bench_conv(B, 36, 20, 1920, 640, tag=" L1 up")
+        bench_conv(B, 18, 10, 1280, 1280, tag=" L2")
+        bench_conv(B, 9, 5, 1280, 1280, tag=" L3")
+        return
     if only == "attn":
         print("attn q_scaled:", QS, flush=True)
         bench_attn(32, 5, 2880, " 2D L0")
