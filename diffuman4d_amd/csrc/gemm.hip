@@ -1880,21 +1880,28 @@ int choose_cfg(const GemmParams& p) {
   if (!CONV) {
     // N = 320 with a deep K (the level-0 feed-forward output projection): one 320-wide tile reads A once instead of three
     // times (profiles/r02_gemm_tune_wide.log: 130 vs 146 us at CFG batch 32, 190 vs 207 at 48)
-    if (!geglu && p.N == 320 && p.K >= 1024 && tm256 >= 256) return 46;
+    // (the second form of that tile, id 62, is another 3-5 % ahead: 123.0 vs 128.9 us / 182.1 vs 187.1, r02_lin_tiles_256.log)
+    if (!geglu && p.N == 320 && p.K >= 1024 && tm256 >= 256) return lin2_ok(p) ? 62 : 46;
     // deep-K layers (K >= 1280): the second form (gemm_lin2_kernel), bit-identical, -4..-17 % per launch
     // (profiles/r02_lin2_ab.log): 128x128 tiles with two workgroups per CU wherever they fill the chip, the 8-wave
     // 3-stage 128x128 tile for the few-row, very deep output projections of the deepest level, and the 256x128 K-slab-64
     // tile for that level's GEGLU projection.  Shorter K needs two resident workgroups (a tile is mostly prologue and
     // epilogue): see id 65 below.
     if (lin2_ok(p)) {
-      // 256x256 tiles on 8 waves (128x64 per wave: 6 fragment reads feed 8 MFMAs instead of 4 feeding 4) for the wide layers
-      // -- the GEGLU projections and the N >= 1280 projections with K >= 640 -- whenever whole rounds of 256 tiles use at
-      // least 85 % of their slots and columns: -5..-16 % per launch (profiles/r02_lin_tiles_256.log: ff1 level 2 182 -> 156 us,
-      // level-1 QKV 70.6 -> 64.8, level-2 QKV at CFG batch 48 95.4 -> 80.3); bit-identical to every other id
-      if (geglu || (p.K >= 640 && p.N >= 1280)) {
+      // 256x256 tiles on 8 waves (128x64 per wave: 6 fragment reads feed 8 MFMAs instead of 4 feeding 4), one workgroup per
+      // CU.  Chosen from TWO sweeps of every id (all bit-identical): the usual timing loop (profiles/r02_lin_tiles_256.log) and
+      // single launches after a cache flush with only the activations re-touched (profiles/r02_lin_cold.log) -- the state a
+      // layer meets inside a UNet pass, where this tile's exposed prologue costs more.  It wins both ways on the deep-K wide
+      // layers (K >= 1280: GEGLU projection of level 2 182 -> 156 us hot, 176 -> 156 cold; QKV of level 2 at CFG batch 48
+      // 95 -> 80 / 98 -> 82) and on the K = 640 ones only when the rounds of 256 tiles are nearly full; at K = 320 the
+      // two-workgroup 74 KB tile (id 65) is 8 % ahead cold and stays.
+      {
         const long nw = geglu ? 2L * p.N : p.N, tn256 = (nw + 255) / 256, t = tm256 * tn256;
         const double fill = (double)t / (double)(((t + 255) / 256) * 256) * (double)nw / (double)(tn256 * 256);
-        if (fill >= 0.85) return 67;
+        if (geglu && ((p.K >= 1280 && fill >= 0.85) || (p.K >= 640 && fill >= 0.95))) return 67;
+        if (!geglu && p.K >= 640 && p.N >= 1280 && fill >= 0.85) return 67;
+        // one partial round (160-256 tiles) of the N = 1280 projections of level 2 at CFG batch 48: 42 vs 45 us, 122 vs 135 us
+        if (!geglu && p.K >= 1280 && p.N == 1280 && t >= 160 && t <= 256) return 67;
       }
       if (geglu) {
         if (tm256 <= 12 && p.K >= 1280) return 61;

@@ -250,19 +250,30 @@ __global__ __launch_bounds__(GN_THREADS) void gn_resident_kernel(GNParams p, int
       sm2[(part * SC + c) * 2 + 1] = q;
     }
     __syncthreads();
-    if (tid < gps) {
+    // one WAVE per group: the PARTS x gs partials of a group are summed 64 at a time and folded with a butterfly.  (This
+    // was one THREAD per group walking up to 6 x 80 LDS entries serially -- ~10 us of latency in a kernel that moves a few
+    // KB at the 18x10 and 9x5 levels.)  The order depends on (HW, C, groups) only, never on the batch.
+    const int wv = tid >> 6, ln = tid & 63;
+    for (int g = wv; g < gps; g += GN_THREADS / 64) {
       float s = 0.f, q = 0.f;
-      for (int pt = 0; pt < PARTS; ++pt)
-        for (int cc = tid * gs; cc < (tid + 1) * gs; ++cc) {
-          s += sm2[(pt * SC + cc) * 2 + 0];
-          q += sm2[(pt * SC + cc) * 2 + 1];
-        }
-      const float n = (float)gs * (float)p.HW;
-      const float mu = s / n;
-      float var = q / n - mu * mu;
-      var = var < 0.f ? 0.f : var;
-      stat[tid * 2 + 0] = mu;
-      stat[tid * 2 + 1] = rsqrtf(var + p.eps);
+      for (int e = ln; e < PARTS * gs; e += 64) {
+        const int pt = e / gs, cc = g * gs + (e - pt * gs);
+        s += sm2[(pt * SC + cc) * 2 + 0];
+        q += sm2[(pt * SC + cc) * 2 + 1];
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_xor(s, off);
+        q += __shfl_xor(q, off);
+      }
+      if (ln == 0) {
+        const float n = (float)gs * (float)p.HW;
+        const float mu = s / n;
+        float var = q / n - mu * mu;
+        var = var < 0.f ? 0.f : var;
+        stat[g * 2 + 0] = mu;
+        stat[g * 2 + 1] = rsqrtf(var + p.eps);
+      }
     }
   }
   __syncthreads();
