@@ -12,6 +12,10 @@ CSRC = ROOT / "csrc"
 INCLUDE = ROOT.parent / "include"
 LIB = ROOT / "libdm4d.so"
 SOURCES = ["api.hip", "gemm.hip", "conv_direct.hip", "attention.hip", "attention_fp8.hip", "norm.hip", "elementwise.hip"]
+# attention.hip: the 4-wave x 64-row kernel form needs more than 256 registers per lane; without this flag hipcc puts every MFMA
+# result of such a kernel into AGPRs and copies the score accumulators to VGPRs and back on every step (0.67x, measured);
+# kernels that fit in 256 registers are unaffected
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc() -> str:
@@ -51,7 +55,7 @@ def build(force: bool = False, verbose: bool = True, defines=()) -> Path:
     for s in SOURCES:
         src, obj = CSRC / s, objdir / (Path(s).stem + ".o")
         if force or defines or _stale(obj, src, headers):
-            jobs.append([hipcc, *flags, "-c", str(src), "-o", str(obj)])
+            jobs.append([hipcc, *flags, *EXTRA_FLAGS.get(s, []), "-c", str(src), "-o", str(obj)])
 
     def run(cmd):
         if verbose:
