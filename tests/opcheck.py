@@ -298,13 +298,13 @@ def case_attention_kv_split(batch, heads, L, parts, seed=0, q_scaled=False):
     return worst, worst
 
 
-def case_groupnorm(B, HW, C1, C2, groups, silu, eps=1e-5, seed=0, two_launch=False):
+def case_groupnorm(B, HW, C1, C2, groups, silu, eps=1e-5, seed=0, two_launch=False, offset=0.5):
     """two_launch=True forces the statistics + apply kernel pair for a shape the single-launch kernel would take."""
     from diffuman4d_amd.host import lib, ops
     if two_launch:
         lib.load().dm4d_tune_set_groupnorm_resident(0)
     try:
-        return _groupnorm(ops, B, HW, C1, C2, groups, silu, eps, seed)
+        return _groupnorm(ops, B, HW, C1, C2, groups, silu, eps, seed, offset)
     finally:
         lib.load().dm4d_tune_set_groupnorm_resident(1)
 
@@ -332,14 +332,14 @@ def case_groupnorm_batch_invariant(B, HW, C1, C2, groups, seed=0):
     return rel_l2(outs[0], outs[1].cpu()), float((outs[0] - outs[1]).abs().max())
 
 
-def _groupnorm(ops, B, HW, C1, C2, groups, silu, eps, seed):
+def _groupnorm(ops, B, HW, C1, C2, groups, silu, eps, seed, offset=0.5):
     g = torch.Generator().manual_seed(seed)
-    x1 = _rnd((B, HW, C1), g) + 0.5
+    x1 = _rnd((B, HW, C1), g) + offset  # offset = the groups' mean in units of their standard deviation
     x2 = (_rnd((B, HW, C2), g) * 2.0 - 0.25) if C2 else None
     C = C1 + C2
     gamma, beta = _rnd((C,), g) + 1.0, _rnd((C,), g, 0.3)
     x = torch.cat([x1, x2], dim=-1) if C2 else x1
-    ref = F.group_norm(x.float().permute(0, 2, 1), groups, gamma.float(), beta.float(), eps).permute(0, 2, 1)
+    ref = F.group_norm(x.double().permute(0, 2, 1), groups, gamma.double(), beta.double(), eps).permute(0, 2, 1).float()
     if silu:
         ref = F.silu(ref)
     d = "cuda"
@@ -606,6 +606,11 @@ CASES = {
     "gn_l3_1280_b32": (case_groupnorm, dict(B=32, HW=45, C1=1280, C2=0, groups=32, silu=True)),
     "gn_batch_invariant_l1": (case_groupnorm_batch_invariant, dict(B=9, HW=720, C1=640, C2=0, groups=32)),
     "gn_batch_invariant_l2_concat": (case_groupnorm_batch_invariant, dict(B=16, HW=180, C1=1280, C2=640, groups=32)),
+    # |mean| >> std: the statistics are taken of (x - shift), see norm.hip; raw fp32 sums lose 11 / 15 bits at 50 / 200 sigma
+    "gn_mean_50sigma": (case_groupnorm, dict(B=2, HW=720, C1=640, C2=0, groups=32, silu=False, offset=50.0)),
+    "gn_mean_50sigma_l0": (case_groupnorm, dict(B=2, HW=2880, C1=320, C2=0, groups=32, silu=False, offset=50.0)),
+    "gn_mean_200sigma": (case_groupnorm, dict(B=2, HW=720, C1=640, C2=0, groups=32, silu=False, offset=-200.0)),
+    "gn_mean_200sigma_l0_concat": (case_groupnorm, dict(B=2, HW=2880, C1=320, C2=320, groups=32, silu=True, offset=200.0)),
     "gn_tiny64": (case_groupnorm, dict(B=5, HW=100, C1=64, C2=0, groups=32, silu=True)),
     "gn_tiny_concat": (case_groupnorm, dict(B=2, HW=50, C1=128, C2=64, groups=32, silu=True)),
     "ln_320": (case_layernorm, dict(M=1000, C=320)),
