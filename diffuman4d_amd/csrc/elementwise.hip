@@ -114,6 +114,34 @@ __global__ void cfg_ddim_kernel(u16* latents, const u16* np, int64_t ldn, const 
   }
 }
 
+// Linear multistep update (DPM-Solver++ and every other solver whose update is linear in the sample, the model output and one
+// stored prediction): x' = a x + b m + c p,  p' = d x + e m with per-frame rows (a, b, c, d, e, -, -, -) planned on the host
+// (host/scheduler.py); m = the guided model output, p = x0_prev (the latent's previous x0 prediction, updated in place).
+__global__ void cfg_linear_step_kernel(u16* latents, u16* x0_prev, const u16* np, int64_t ldn, const float* coef,
+                                       const int32_t* is_cond, const int32_t* frame_idx, int F, int HW, int use_cfg, float gs) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // window-local (frame, pixel)
+  if (o >= (int64_t)F * HW) return;
+  const int f = (int)(o / HW);
+  if (is_cond[f] != 0) return;  // "only denoise target latents" (pipeline_diffuman4d.py:418-420)
+  const int64_t i = frame_idx ? (int64_t)frame_idx[f] * HW + (o - (int64_t)f * HW) : o;
+  const float a = coef[f * 8 + 0], b = coef[f * 8 + 1], c = coef[f * 8 + 2], d = coef[f * 8 + 3], e = coef[f * 8 + 4];
+#pragma unroll
+  for (int ch = 0; ch < 4; ++ch) {
+    float m;
+    if (use_cfg) {
+      const float u = bf2f(np[o * ldn + ch]);
+      const float cc = bf2f(np[((int64_t)F * HW + o) * ldn + ch]);
+      m = u + gs * (cc - u);
+    } else {
+      m = bf2f(np[o * ldn + ch]);
+    }
+    const float x = bf2f(latents[i * 4 + ch]);
+    const float p = c != 0.f ? bf2f(x0_prev[i * 4 + ch]) : 0.f;  // first step of a latent in a call: the slot holds nothing yet
+    latents[i * 4 + ch] = f2bf(a * x + b * m + c * p);
+    x0_prev[i * 4 + ch] = f2bf(d * x + e * m);
+  }
+}
+
 __global__ void nchw_to_nhwc_kernel(const u16* X, u16* Y, int B, int C, int HW, int cpad) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over B*HW*cpad
   if (i >= (int64_t)B * HW * cpad) return;
@@ -298,6 +326,16 @@ extern "C" int dm4d_cfg_ddim_step_bf16(void* stream, void* latents, const void* 
   hipLaunchKernelGGL(cfg_ddim_kernel, grid1d((int64_t)F * HW, 256), dim3(256), 0, (hipStream_t)stream, (u16*)latents,
                      (const u16*)noise_pred, ldn, coef, is_cond, frame_idx, F, HW, use_cfg, guidance_scale, v_prediction);
   return dm4d_check_launch("cfg_ddim_kernel");
+}
+
+extern "C" int dm4d_cfg_linear_step_bf16(void* stream, void* latents, void* x0_prev, const void* noise_pred, int64_t ldn,
+                                         const float* coef, const int32_t* is_cond, const int32_t* frame_idx, int F, int HW,
+                                         int use_cfg, float guidance_scale) {
+  if (!latents || !x0_prev || !noise_pred || !coef || !is_cond || F <= 0 || HW <= 0 || ldn < 4)
+    return dm4d_set_error(DM4D_ERR_ARG, "cfg_linear_step: bad arguments");
+  hipLaunchKernelGGL(cfg_linear_step_kernel, grid1d((int64_t)F * HW, 256), dim3(256), 0, (hipStream_t)stream, (u16*)latents,
+                     (u16*)x0_prev, (const u16*)noise_pred, ldn, coef, is_cond, frame_idx, F, HW, use_cfg, guidance_scale);
+  return dm4d_check_launch("cfg_linear_step_kernel");
 }
 
 extern "C" int dm4d_nchw_to_nhwc_bf16(void* stream, const void* X, void* Y, int B, int C, int HW, int cpad) {

@@ -378,6 +378,23 @@ def cfg_ddim_step(latents, noise_pred, coef, is_cond, use_cfg: bool, guidance_sc
     return latents
 
 
+def cfg_linear_step(latents, x0_prev, noise_pred, coef, is_cond, use_cfg: bool, guidance_scale: float,
+                    frame_idx: Optional[torch.Tensor] = None):
+    """In-place linear multistep update (x' = a x + b m + c p; p' = d x + e m) of rows frame_idx of `latents` and `x0_prev`
+    [N,HW,4] from noise_pred [cfg*F, HW, ldn]; coef [F,8] fp32 rows from scheduler.step_rows."""
+    lib = _l.load()
+    _req(latents, "latents"), _req(x0_prev, "x0_prev"), _req(noise_pred, "noise_pred"), _req(coef, "coef", torch.float32)
+    _req(is_cond, "is_cond", torch.int32)
+    assert x0_prev.shape == latents.shape and coef.shape[-1] == 8 and coef.is_contiguous()
+    F, HW = is_cond.shape[0], latents.shape[1]
+    if frame_idx is not None:
+        _req(frame_idx, "frame_idx", torch.int32)
+    rc = lib.dm4d_cfg_linear_step_bf16(_stream(), _p(latents), _p(x0_prev), _p(noise_pred), noise_pred.stride(-2), _p(coef),
+                                       _p(is_cond), _p(frame_idx), F, HW, 1 if use_cfg else 0, guidance_scale)
+    _l.check(rc, "dm4d_cfg_linear_step_bf16")
+    return latents
+
+
 def nchw_to_nhwc(x: torch.Tensor, cpad: Optional[int] = None) -> torch.Tensor:
     lib = _l.load()
     _req(x, "x")

@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .schedule import SweepPlan, plan_sweep
+from .schedule import SweepPlan, history_flags, plan_sweep
 from .scheduler import DDIMScheduler
 from .unet import UNetMultiviewConditionModel
 
@@ -160,7 +160,15 @@ class Diffuman4DPipeline:
         cond = np.stack(plan.is_cond)                              # [calls, F] bool
         t = ts[np.stack(plan.timestep_index)].astype(np.int64)     # [calls, F]
         t[cond] = 0                                                # get_timestep :277
-        coef = self.scheduler.step_coefficients(t)                 # [calls, F, 4]
+        if getattr(self.scheduler, "is_multistep", False):
+            # stateful scheduler (one deep copy per latent in the reference, made afresh for this call: :265-271, :500-501): which
+            # update a latent gets depends on its step index and on whether it has been stepped before IN THIS CALL -- both known
+            # from the plan -- so the objects collapse to one coefficient row per (call, frame)
+            tix = np.stack(plan.timestep_index)
+            has_prev = np.stack(history_flags(plan.windows, plan.is_cond))
+            coef = self.scheduler.step_rows(np.where(cond, 0, tix), has_prev)   # [calls, F, 8]
+        else:
+            coef = self.scheduler.step_coefficients(t)             # [calls, F, 4]
         win_full = win
         if shard is not None:
             sl = shard.local_frames(win.shape[1])
@@ -195,12 +203,16 @@ class Diffuman4DPipeline:
         vpred = self.scheduler.config.prediction_type == "v_prediction"
         F = tb["win"].shape[1]  # frames of a window handled by THIS rank
         domains = [domain] * tb["cfg"]
+        # multistep schedulers: the latents' previous x0 predictions, the only state the reference's per-latent scheduler copies carry
+        x0_prev = torch.zeros_like(lat3) if getattr(self.scheduler, "is_multistep", False) else None
         for i in tqdm(range(tb["calls"]), total=tb["calls"]):
-            self.window_call(lat3, pv3, pl3, sk3, cm3, tb, i, h, w, domains, guidance_scale, use_cfg, vpred, shard)
+            self.window_call(lat3, pv3, pl3, sk3, cm3, tb, i, h, w, domains, guidance_scale, use_cfg, vpred, shard, x0_prev)
         return lat
 
-    def window_call(self, lat3, pv3, pl3, sk3, cm3, tb, i, h, w, domains, guidance_scale, use_cfg, vpred, shard=None):
-        """One window: pack -> UNet -> CFG + DDIM (pipeline_diffuman4d.py:369-423), all on device, no host sync."""
+    def window_call(self, lat3, pv3, pl3, sk3, cm3, tb, i, h, w, domains, guidance_scale, use_cfg, vpred, shard=None,
+                    x0_prev=None):
+        """One window: pack -> UNet -> CFG + scheduler step (pipeline_diffuman4d.py:369-423), all on device, no host sync.
+        x0_prev: [N, HW, 4] state of a multistep scheduler (None for DDIM)."""
         widx, cond = tb["win"][i], tb["cond"][i]
         F, HW = widx.shape[0], h * w
         pose = None
@@ -216,11 +228,18 @@ class Diffuman4DPipeline:
         if keep is not None:  # back to one row per CFG-batch entry; the rows left at zero are never read by the step kernel
             full = torch.zeros((tb["cfg"] * F,) + tuple(eps.shape[1:]), dtype=eps.dtype, device=eps.device)
             eps = full.index_copy_(0, keep, eps)
-        ops.cfg_ddim_step(lat3, eps.view(tb["cfg"] * F, HW, -1), tb["coef"][i], cond, use_cfg, float(guidance_scale), vpred,
-                          frame_idx=widx)
-        if shard is not None:  # F/P updated rows per rank -> every rank's copy of the task latents
+        if x0_prev is not None:
+            ops.cfg_linear_step(lat3, x0_prev, eps.view(tb["cfg"] * F, HW, -1), tb["coef"][i], cond, use_cfg,
+                                float(guidance_scale), frame_idx=widx)
+        else:
+            ops.cfg_ddim_step(lat3, eps.view(tb["cfg"] * F, HW, -1), tb["coef"][i], cond, use_cfg, float(guidance_scale), vpred,
+                              frame_idx=widx)
+        if shard is not None:  # F/P updated rows per rank -> every rank's copy of the task latents (and of the scheduler state)
             rows = shard.gather_rows(lat3.index_select(0, widx.long()))
             lat3.index_copy_(0, tb["win_full"][i], rows)
+            if x0_prev is not None:
+                rows = shard.gather_rows(x0_prev.index_select(0, widx.long()))
+                x0_prev.index_copy_(0, tb["win_full"][i], rows)
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -92,3 +92,15 @@ def plan_sweep(cond_flags: Sequence[bool], timestep_indices: Sequence[int], doma
     if (idx[input_indices] != 0).any():
         raise ValueError(f"Timesteps of input samples have changed, timestep_indices = {idx}")
     return SweepPlan(num_inference_steps, windows, conds, tidx, idx, target_indices, input_indices)
+
+
+def history_flags(windows: Sequence[np.ndarray], is_cond: Sequence[np.ndarray]) -> List[np.ndarray]:
+    """Per call: which frames of the window have been stepped EARLIER IN THIS PLAN.  The reference makes one fresh scheduler
+    object per latent for every sliding_iterative_denoise call (pipeline_diffuman4d.py:500-501), so a multistep scheduler has
+    a previous prediction for a latent exactly from that latent's second step of the call on."""
+    stepped = set()
+    out = []
+    for w, c in zip(windows, is_cond):
+        out.append(np.array([(not ic) and int(i) in stepped for i, ic in zip(w, c)], dtype=bool))
+        stepped.update(int(i) for i, ic in zip(w, c) if not ic)
+    return out

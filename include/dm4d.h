@@ -173,6 +173,15 @@ int dm4d_cfg_ddim_step_bf16(void* stream, void* latents, const void* noise_pred,
                             const int32_t* is_cond, const int32_t* frame_idx, int F, int HW, int use_cfg,
                             float guidance_scale, int v_prediction);
 
+/* CFG combine + per-latent LINEAR MULTISTEP step: the update of any scheduler whose step is linear in the sample, the model
+ * output and one stored prediction -- DPM-Solver++ of order 1 / 2, where the reference keeps one stateful scheduler object per
+ * latent (pipeline_diffuman4d.py:265-271, 420, 500-501):   m = u + s (c - u);  x <- a x + b m + c p;  p <- d x + e m
+ * for non-cond rows.  coef [F,8] fp32 = {a, b, c, d, e, -, -, -} per frame (host/scheduler.py::step_rows); x0_prev = the task's
+ * stored x0 predictions, same shape and indexing as latents (rows whose c is 0 are not read).                                */
+int dm4d_cfg_linear_step_bf16(void* stream, void* latents, void* x0_prev, const void* noise_pred, int64_t ldn,
+                              const float* coef, const int32_t* is_cond, const int32_t* frame_idx, int F, int HW, int use_cfg,
+                              float guidance_scale);
+
 /* VAE posterior sample, DiagonalGaussianDistribution.sample() * scaling_factor
  *   (pipeline_diffuman4d.py:52,55): out[m,c] = (mean + exp(0.5*clamp(logvar,-30,20)) * noise[m,c]) * scale
  *   moments rows hold [mean(C) | logvar(C) | ...] with row stride ldm; noise/out are [M, C].          */

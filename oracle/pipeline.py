@@ -7,6 +7,8 @@ Follows ``/root/reference/src/diffusers/pipelines/diffuman4d/pipeline_diffuman4d
 """
 from __future__ import annotations
 
+import copy
+
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -89,9 +91,11 @@ class OraclePipeline:
     # -- pipeline_diffuman4d.py:289-437 ------------------------------------------------
     def denoise_window(self, pv_lat, pl_lat, sk_lat, cm_lat, latents, domains: List[str], num_inference_steps: int,
                        timesteps: torch.Tensor, timestep_indices: torch.Tensor, guidance_scale: float,
-                       trace: Optional[list] = None):
+                       trace: Optional[list] = None, schedulers: Optional[list] = None):
         dt = self.dtype
         num_frames = pv_lat.shape[0]
+        if schedulers is None:  # :361-363 -- one scheduler object per latent (stateful schedulers keep their history there)
+            schedulers = [copy.deepcopy(self.scheduler) for _ in range(num_frames)]
         latents = latents * self.scheduler.init_noise_sigma  # :190 (second pass through prepare_latents)
         is_cond = cm_lat[:, 0, 0, 0] == 0  # :345
         do_cfg = guidance_scale > 1
@@ -130,7 +134,7 @@ class OraclePipeline:
             for j in range(num_frames):  # :413-422
                 lat = latents[j : j + 1]
                 if not is_cond[j]:
-                    lat = self.scheduler.step(noise_pred[j : j + 1], int(timestep[j]), lat)
+                    lat = schedulers[j].step(noise_pred[j : j + 1], int(timestep[j]), lat)
                 new.append(lat.to(dt))
             latents = torch.cat(new)
             timestep_indices[~is_cond] += 1
@@ -156,13 +160,15 @@ class OraclePipeline:
         pv_lat, pl_lat, sk_lat, cm_lat, latents = self.prepare_all_latents(
             pixel_values, plucker_embeds, skeletons, cond_masks, latents, noise)
         timesteps = self.scheduler.set_timesteps(num_inference_steps)
+        schedulers = [copy.deepcopy(self.scheduler) for _ in range(len(latents))]  # :265-271, :500-501 ("a scheduler for each latent")
         tws, iws = build_windows(target_indices, input_indices, domain, window_size, sliding_stride, sliding_shift,
                                  bidirectional)
         for tw, iw in zip(tws, iws):
             window = torch.cat([iw, tw])
             out = self.denoise_window(pv_lat[window], pl_lat[window], sk_lat[window] if sk_lat is not None else None,
                                       cm_lat[window], latents[window], [domain], num_denoising_steps, timesteps,
-                                      timestep_indices[window], guidance_scale, trace)
+                                      timestep_indices[window], guidance_scale, trace,
+                                      schedulers=[schedulers[int(k)] for k in window])  # :535
             timestep_indices[tw] += num_denoising_steps  # :542
             latents[window] = out  # :543
         if (timestep_indices[target_indices] != id_end).any():

@@ -317,12 +317,26 @@ def synthetic_task(n, H, W, input_rows, seed=7):
 
 
 def case_pipeline(domain="spatial", n_cams=8, T=4, window=4, stride=2, rounds=1, steps=1, bidir=False, gs=2.0,
-                  pred="epsilon", seed=11, pose=False):
-    """One full task through sliding_iterative_denoise (VAE encode -> window sweep -> VAE decode)."""
+                  pred="epsilon", seed=11, pose=False, sched="ddim", sched_kw=None):
+    """One full task through sliding_iterative_denoise (VAE encode -> window sweep -> VAE decode).
+    sched="dpm": DPM-Solver++ multistep -- the oracle keeps one stateful scheduler object per latent as the reference does
+    (pipeline_diffuman4d.py:265-271, 420), the HIP path runs its planned coefficient rows (host/scheduler.py)."""
     from diffuman4d_amd.host.pipeline import Diffuman4DPipeline
-    from diffuman4d_amd.host.scheduler import DDIMConfig as HC, DDIMScheduler as HS
-    from oracle.ddim import DDIMConfig, DDIMScheduler
     from oracle.pipeline import OraclePipeline
+    if sched == "dpm":
+        from diffuman4d_amd.host.scheduler import DPMSolverConfig as HC, DPMSolverMultistepScheduler as HS
+        from oracle.dpmsolver import DPMSolverConfig as _OC, DPMSolverMultistepScheduler as _OS
+
+        def HC_(**kw):
+            return HC(**{**(sched_kw or {}), **kw})
+
+        def DDIMConfig(**kw):
+            return _OC(**{**(sched_kw or {}), **kw})
+        DDIMScheduler, HCf = _OS, HC_
+    else:
+        from diffuman4d_amd.host.scheduler import DDIMConfig as HC, DDIMScheduler as HS
+        from oracle.ddim import DDIMConfig, DDIMScheduler
+        HCf = HC
     cfg_u, ou = make_unet(seed, **(dict(enable_pose_encoder=True, in_channels=11) if pose else {}))
     cfg_v, ov = make_vae(seed + 1)
     H, W = 64, 64
@@ -339,7 +353,7 @@ def case_pipeline(domain="spatial", n_cams=8, T=4, window=4, stride=2, rounds=1,
     op = OraclePipeline(ov, ou, DDIMScheduler(DDIMConfig(prediction_type=pred)), torch.float32)
     noise_f = {k: v.float() for k, v in noise.items()}
     ref = op.sliding_iterative_denoise(pv, pl, sk, cm, None, domain, tidx, noise_f, **kw)
-    hp = Diffuman4DPipeline(hip_vae(cfg_v, ov), hip_unet(cfg_u, ou), HS(HC(prediction_type=pred)), "cuda")
+    hp = Diffuman4DPipeline(hip_vae(cfg_v, ov), hip_unet(cfg_u, ou), HS(HCf(prediction_type=pred)), "cuda")
     out = hp.sliding_iterative_denoise(pixel_values=pv, plucker_embeds=pl, skeletons=sk, cond_masks=cm, latents=None,
                                        domain=domain, timestep_indices=tidx, noise=noise, **kw)
     exact = bool((out["timestep_indices"].cpu() == ref["timestep_indices"]).all()) and \
@@ -496,6 +510,12 @@ CASES = {
     "pipeline_plucker_on_device": (case_pipeline_plucker_on_device, dict()),
     "vae": (case_vae, dict()),
     "resize": (case_resize, dict()),
+    # stateful scheduler: DPM-Solver++ 2M (first-order first / final steps, second order in between), two denoising steps per
+    # window so that latents carry history inside a window and across windows
+    "pipeline_dpm_spatial": (case_pipeline, dict(domain="spatial", sched="dpm", steps=2, window=4, stride=2, bidir=True)),
+    "pipeline_dpm_temporal_v_heun": (case_pipeline, dict(domain="temporal", T=4, window=4, stride=1, pred="v_prediction", sched="dpm",
+                                                         sched_kw=dict(solver_type="heun", final_sigmas_type="sigma_min",
+                                                                       timestep_spacing="leading", steps_offset=1))),
     "pipeline_spatial": (case_pipeline, dict(domain="spatial")),
     "pipeline_temporal_v": (case_pipeline, dict(domain="temporal", T=4, window=4, stride=1, pred="v_prediction")),
     "pipeline_bidir_nocfg": (case_pipeline, dict(domain="spatial", window=3, stride=3, bidir=True, gs=1.0, steps=2)),

@@ -483,6 +483,37 @@ def case_pack_ddim(F_, HW, use_cfg, vpred, skel=True, seed=0):
     return (e_step if ok else 1.0), max(e_pack, e_alias)
 
 
+def case_linear_step(F_, HW, use_cfg, seed=0):
+    """dm4d_cfg_linear_step_bf16 vs its definition in fp32: m = u + s (c - u); x' = a x + b m + c p; p' = d x + e m on the
+    target rows (scattered through frame_idx), conditioning rows and rows outside the window untouched."""
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    N, gs = F_ + 3, 2.5
+    lat, prev = _rnd((N, HW, 4), g), _rnd((N, HW, 4), g)
+    cfg = 2 if use_cfg else 1
+    npred = _rnd((cfg * F_, HW, 8), g)  # ldn = 8: only the first four channels are read
+    coef = torch.randn((F_, 8), generator=g)
+    coef[0, 2] = 0.0  # a first step: the stored prediction is not read
+    is_cond = torch.zeros(F_, dtype=torch.int32)
+    is_cond[1] = 1
+    fidx = torch.randperm(N, generator=g)[:F_].to(torch.int32)
+    m = npred[..., :4].float()
+    m = m[:F_] + gs * (m[F_:] - m[:F_]) if use_cfg else m
+    x, p = lat.float()[fidx.long()], prev.float()[fidx.long()]
+    a, b, c, d, e = (coef[:, k].view(F_, 1, 1) for k in range(5))
+    ref_lat, ref_prev = lat.float().clone(), prev.float().clone()
+    tgt = (is_cond == 0)
+    ref_lat[fidx.long()[tgt]] = (a * x + b * m + c * p)[tgt]
+    ref_prev[fidx.long()[tgt]] = (d * x + e * m)[tgt]
+    dl, dp = lat.cuda(), prev.cuda()
+    ops.cfg_linear_step(dl, dp, npred.cuda(), coef.cuda(), is_cond.cuda(), use_cfg, gs, frame_idx=fidx.cuda())
+    untouched = torch.ones(N, dtype=torch.bool)
+    untouched[fidx.long()[tgt]] = False
+    assert torch.equal(dl.cpu()[untouched], lat[untouched]) and torch.equal(dp.cpu()[untouched], prev[untouched]), "rows outside the targets changed"
+    err = max(rel_l2(dl, ref_lat), rel_l2(dp, ref_prev))
+    return err, float((dl.float().cpu() - ref_lat).abs().max())
+
+
 CASES = {
     # --- GEMM: every tile config, tails, epilogues -------------------------------------------
     "gemm_256x128_plain": (case_gemm, dict(M=1024, N=256, K=320)),
@@ -576,6 +607,8 @@ CASES = {
     "attn_qs_128sq_L65536": (case_attention, dict(batch=1, heads=1, L=65536, q_scaled=True, threads=32)),
     "attn_128sq_L65536": (case_attention, dict(batch=1, heads=1, L=65536, threads=32)),
     # --- fp8 (e4m3) attention: opt-in extension with its own tolerance (TOL_FP8) --------------------------------------
+    "linear_step_cfg": (case_linear_step, dict(F_=6, HW=45, use_cfg=True)),
+    "linear_step_nocfg": (case_linear_step, dict(F_=5, HW=2880, use_cfg=False, seed=1)),
     "attn_forms_tail": (case_attention_forms, dict(batch=3, heads=1, L=45)),
     "attn_forms_L129": (case_attention_forms, dict(batch=2, heads=2, L=129, q_scaled=False)),
     "attn_forms_L257": (case_attention_forms, dict(batch=1, heads=2, L=257)),
