@@ -228,12 +228,15 @@ def run_grid_pass(pipe, depth, frames, world, rank, gpu_streams):
                                       input_spa_labels=INPUT_CAMS)
     sampler.result_writer = None
     if world > 1:
-        DistributedSamplingRunner(sampler, prefetch_depth=2, writers=1, gpu_streams=gpu_streams).inference()
+        runner = DistributedSamplingRunner(sampler, prefetch_depth=2, writers=1, gpu_streams=gpu_streams)
+        runner.inference()
+        last_tasks = runner.tasks_of(ROUNDS - 1, rank)  # the deal of the last round (rate-weighted when the ranks' speeds differ)
     else:
         for tasks in sampler.all_tasks:
             run_round_pipelined(sampler, tasks, 0, 2, 1, gpu_streams)
+        last_tasks = sampler.all_tasks[ROUNDS - 1]
     done = all(sampler.timestep_indices[c][f] == STEPS_PER_LATENT
-               for t in sampler.partition(ROUNDS - 1, rank, world) for c in sampler.target_spa_labels for f in [t["domain_label"]])
+               for t in last_tasks for c in sampler.target_spa_labels for f in [t["domain_label"]])
     if not done:
         raise RuntimeError("grid pass: a target cell of this rank's last-round tasks did not reach the final timestep index")
     return adapter.calls_run

@@ -184,10 +184,17 @@ class DistributedSamplingRunner:
     each rank holds (``_holds``) and which rank wrote a cell last (``_written``).  That state is a pure function of the
     task lists, so the ranks agree on every transfer without negotiating, and a rank that ran no task in a round (more
     GPUs than frames or target cameras) still takes part in the exchange: it is sent every cell its next tasks read,
-    whoever holds them."""
+    whoever holds them.
+
+    Load balance.  The reference's pipelines drain ONE queue (sampling_runner.py:27-33), so a slower GPU simply takes fewer
+    tasks.  Across processes the tasks of a round have to be known before the round (the exchange ships each rank the cells
+    its next tasks read), so the balance is applied between rounds instead of inside them: every rank measures its task rate,
+    the rates are all-gathered at the round boundary and `balance=True` deals the next round's tasks in proportion to them
+    (`weighted_deal`: a pure function of the gathered numbers, so the replicated bookkeeping stays in agreement).  Rates within
+    10 % of each other are treated as equal, which reproduces the round-robin deal exactly."""
 
     def __init__(self, sampler: SlidingIterativeSampler, group=None, prefetch_depth: int = 2, writers: int = 2,
-                 gpu_streams: int = 2):
+                 gpu_streams: int = 2, balance: bool = True):
         import torch.distributed as dist
         self.dist = dist
         self.sampler = sampler
@@ -198,6 +205,40 @@ class DistributedSamplingRunner:
         self._written: Dict[Tuple[str, str], Tuple[int, int]] = {}  # cell -> (round of the last write, sending rank)
         self._holds: List[Dict[Tuple[str, str], int]] = [dict() for _ in range(self.world)]  # rank -> {cell: round held}
         self._proto = None  # (shape, dtype) of a grid cell, agreed once
+        self.balance = balance
+        self._assign: Dict[int, List[List[dict]]] = {}  # round -> tasks per rank (absent: the sampler's round-robin deal)
+        self.rates: List[float] = [1.0] * self.world     # relative task rates measured in the last round that ran tasks
+
+    @staticmethod
+    def weighted_deal(n_tasks: int, rates: List[float]) -> List[List[int]]:
+        """Task indices per rank: task k goes to the rank that would finish it first, (assigned + 1) / rate minimal, ties to
+        the lowest rank.  Equal rates give the round-robin deal [r::world]."""
+        world = len(rates)
+        out: List[List[int]] = [[] for _ in range(world)]
+        for k in range(n_tasks):
+            r = min(range(world), key=lambda q: ((len(out[q]) + 1) / rates[q], q))
+            out[r].append(k)
+        return out
+
+    def tasks_of(self, round_index: int, rank: int) -> List[dict]:
+        a = self._assign.get(round_index)
+        return a[rank] if a is not None else self.sampler.partition(round_index, rank, self.world)
+
+    def _plan_next_round(self, round_index: int, seconds: float, n_done: int) -> None:
+        """Gather (seconds, tasks) of the round that just ran and deal round_index + 1 accordingly."""
+        nxt = round_index + 1
+        if not self.balance or self.world == 1 or nxt >= len(self.sampler.all_tasks):
+            return
+        stats = [None] * self.world
+        self.dist.all_gather_object(stats, (float(seconds), int(n_done)), group=self.group)
+        measured = [n / t for t, n in stats if n > 0 and t > 0]
+        if measured:
+            mean = sum(measured) / len(measured)
+            # ranks without a task in this round keep their last rate; 10 % steps: noise does not reshuffle the deal
+            self.rates = [max(0.1, round((n / t) / mean, 1)) if n > 0 and t > 0 else self.rates[q]
+                          for q, (t, n) in enumerate(stats)]
+        tasks = self.sampler.all_tasks[nxt]
+        self._assign[nxt] = [[tasks[k] for k in idx] for idx in self.weighted_deal(len(tasks), self.rates)]
 
     def _input_camera_of(self, target_label: str) -> str:
         ds = self.sampler.dataset
@@ -220,7 +261,7 @@ class DistributedSamplingRunner:
         as data -- any rank's copy will do.)"""
         s = self.sampler
         cells = []
-        for t in s.partition(round_index, rank, self.world):
+        for t in self.tasks_of(round_index, rank):
             if t["domain"] == "spatial":
                 cells += [(c, t["domain_label"]) for c in s.target_spa_labels]
             else:
@@ -230,7 +271,7 @@ class DistributedSamplingRunner:
     def _record_round(self, round_index: int) -> None:
         """Replay what every rank wrote in `round_index` into the replicated bookkeeping (lowest writer rank sends)."""
         for r in range(self.world):
-            for t in self.sampler.partition(round_index, r, self.world):
+            for t in self.tasks_of(round_index, r):
                 for cell in self._task_cells(t):
                     w = self._written.get(cell)
                     if w is None or w[0] < round_index:
@@ -267,7 +308,7 @@ class DistributedSamplingRunner:
         recv_cells: Dict[int, list] = {q: [] for q in range(self.world)}
         for q in range(self.world):
             need = set()
-            for t in s.partition(round_index + 1, q, self.world):
+            for t in self.tasks_of(round_index + 1, q):
                 need.update(self._task_cells(t))
             for cell in sorted(need):  # deterministic cell order on both sides of every pair
                 w = self._written.get(cell)
@@ -305,9 +346,13 @@ class DistributedSamplingRunner:
 
     def inference(self):
         s = self.sampler
+        import time
         for ri in range(len(s.all_tasks)):
-            run_round_pipelined(s, s.partition(ri, self.rank, self.world), 0, self.prefetch_depth, self.writers,
-                                self.gpu_streams)
+            mine = self.tasks_of(ri, self.rank)
+            t0 = time.perf_counter()
+            run_round_pipelined(s, mine, 0, self.prefetch_depth, self.writers, self.gpu_streams)
+            dt = time.perf_counter() - t0
+            self._plan_next_round(ri, dt, len(mine))  # before the exchange: it ships what the NEXT deal reads
             self.dist.barrier(self.group)
             self.exchange(ri)
         if s.result_writer is not None and self.rank == 0:

@@ -39,16 +39,27 @@ def grid_state(s, cells=None):
     return out
 
 
-def _worker(rank, world, port, outdir, kw=None):
+def _worker(rank, world, port, outdir, kw=None, slow_rank=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         s = make_sampler(kw)
-        runner = DistributedSamplingRunner(s)
+        if slow_rank is not None:  # one GPU three times slower than the others
+            import time
+            pipe, delay = s.pipelines[0], (0.09 if rank == slow_rank else 0.03)
+            inner = pipe.sliding_iterative_denoise
+
+            def slowed(**kwargs):
+                time.sleep(delay)
+                return inner(**kwargs)
+            pipe.sliding_iterative_denoise = slowed
+        runner = DistributedSamplingRunner(s, gpu_streams=1, prefetch_depth=1)
         runner.inference()
         last = len(s.all_tasks) - 1
         owned = set(runner._owned_after(last, rank))
-        torch.save({"state": grid_state(s, owned), "n_calls": len(s.pipelines[0].calls)}, f"{outdir}/rank{rank}.pt")
+        torch.save({"state": grid_state(s, owned), "n_calls": len(s.pipelines[0].calls),
+                    "deal": [[len(runner.tasks_of(ri, q)) for q in range(world)] for ri in range(len(s.all_tasks))]},
+                   f"{outdir}/rank{rank}.pt")
     finally:
         dist.destroy_process_group()
 
@@ -80,6 +91,40 @@ def test_ranks_match_single_process(world, kw, steps):
         ridx, rlat = ref_state[cell]
         assert idx == ridx == steps
         assert torch.equal(lat, rlat)
+
+
+@pytest.mark.timeout(300)
+def test_slow_rank_gets_fewer_tasks_and_the_grid_is_unchanged():
+    """The reference's pipelines drain one queue, so a slow GPU takes fewer tasks (sampling_runner.py:27-33); here the rates
+    measured in a round re-deal the next one.  Same grid as the single-process run, cell for cell."""
+    ref = make_sampler(KW)
+    for tasks in ref.all_tasks:
+        for t in tasks:
+            ref.execute_one_task(t)
+    ref_state = grid_state(ref)
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        port = 29500 + (os.getpid() % 2000) + 7
+        mp.spawn(_worker, args=(world, port, d, KW, 1), nprocs=world, join=True)
+        blobs = [torch.load(f"{d}/rank{r}.pt") for r in range(world)]
+    assert blobs[0]["deal"] == blobs[1]["deal"]  # replicated bookkeeping: both ranks computed the same deals
+    deal = blobs[0]["deal"]
+    assert deal[0][0] == deal[0][1]            # first round: nothing measured yet, round-robin
+    assert deal[1][0] > deal[1][1] and deal[2][0] > deal[2][1], deal  # the slow rank 1 gets fewer tasks afterwards
+    assert sum(b["n_calls"] for b in blobs) == sum(len(t) for t in ref.all_tasks)
+    merged = {}
+    for b in blobs:
+        merged.update(b["state"])
+    for cell in {(c, f) for c in ref.target_spa_labels for f in ref.tem_labels}:
+        assert merged[cell][0] == ref_state[cell][0] and torch.equal(merged[cell][1], ref_state[cell][1])
+
+
+def test_weighted_deal():
+    deal = DistributedSamplingRunner.weighted_deal
+    assert deal(7, [1.0, 1.0, 1.0]) == [[0, 3, 6], [1, 4], [2, 5]]  # equal rates: the round-robin deal [r::world]
+    d = deal(12, [1.0, 0.5])
+    assert sorted(d[0] + d[1]) == list(range(12)) and len(d[0]) == 8 and len(d[1]) == 4
+    assert deal(0, [1.0, 2.0]) == [[], []]
 
 
 def test_partition_is_a_disjoint_cover():
