@@ -209,6 +209,8 @@ class DistributedSamplingRunner:
         self._assign: Dict[int, List[List[dict]]] = {}  # round -> tasks per rank (absent: the sampler's round-robin deal)
         self.rates: List[float] = [1.0] * self.world     # relative task rates measured in the last round that ran tasks
 
+    MIN_ROUND_SECONDS = 0.25  # rounds shorter than this do not update a rank's rate
+
     @staticmethod
     def weighted_deal(n_tasks: int, rates: List[float]) -> List[List[int]]:
         """Task indices per rank: task k goes to the rank that would finish it first, (assigned + 1) / rate minimal, ties to
@@ -231,12 +233,13 @@ class DistributedSamplingRunner:
             return
         stats = [None] * self.world
         self.dist.all_gather_object(stats, (float(seconds), int(n_done)), group=self.group)
-        measured = [n / t for t, n in stats if n > 0 and t > 0]
+        ok = [n > 0 and t >= self.MIN_ROUND_SECONDS for t, n in stats]  # a round of milliseconds measures the scheduler, not the GPU
+        measured = [n / t for (t, n), good in zip(stats, ok) if good]
         if measured:
             mean = sum(measured) / len(measured)
-            # ranks without a task in this round keep their last rate; 10 % steps: noise does not reshuffle the deal
-            self.rates = [max(0.1, round((n / t) / mean, 1)) if n > 0 and t > 0 else self.rates[q]
-                          for q, (t, n) in enumerate(stats)]
+            # ranks without a (long enough) round keep their last rate; 10 % steps: noise does not reshuffle the deal
+            self.rates = [max(0.1, round((n / t) / mean, 1)) if good else self.rates[q]
+                          for q, ((t, n), good) in enumerate(zip(stats, ok))]
         tasks = self.sampler.all_tasks[nxt]
         self._assign[nxt] = [[tasks[k] for k in idx] for idx in self.weighted_deal(len(tasks), self.rates)]
 

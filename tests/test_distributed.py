@@ -46,7 +46,7 @@ def _worker(rank, world, port, outdir, kw=None, slow_rank=None):
         s = make_sampler(kw)
         if slow_rank is not None:  # one GPU three times slower than the others
             import time
-            pipe, delay = s.pipelines[0], (0.09 if rank == slow_rank else 0.03)
+            pipe, delay = s.pipelines[0], (0.18 if rank == slow_rank else 0.06)
             inner = pipe.sliding_iterative_denoise
 
             def slowed(**kwargs):
