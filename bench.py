@@ -506,10 +506,14 @@ def main():
             f["launches"] += 1
             f["ms"] += e0.elapsed_time(e1)
             f["work"] += work
-        breakdown = {k: {"launches": v["launches"], "ms": round(v["ms"], 2),
-                         ("tflops" if v["unit"] == "flop" else "gb_per_s"):
-                             round(v["work"] / (v["ms"] * 1e-3) / (1e12 if v["unit"] == "flop" else 1e9), 1)}
-                     for k, v in fam.items()}
+        # per family: achieved rate on algorithmic work and its fraction of the roofline that bounds it (dense bf16 MFMA peak
+        # 2500 TFLOP/s, HBM 8000 GB/s: MI355X_MICROARCH.md) -- `roofline` above is the largest single kernel, this is everything
+        breakdown = {}
+        for k, v in fam.items():
+            rate = v["work"] / (v["ms"] * 1e-3) / (1e12 if v["unit"] == "flop" else 1e9)
+            breakdown[k] = {"launches": v["launches"], "ms": round(v["ms"], 2),
+                            ("tflops" if v["unit"] == "flop" else "gb_per_s"): round(rate, 1),
+                            "roofline_frac": round(rate / (2500.0 if v["unit"] == "flop" else 8000.0), 3)}
     if world > 1:
         dist.barrier()
     finite = bool(torch.isfinite(tasks["spatial"]["lat"].float()).all() and torch.isfinite(tasks["temporal"]["lat"].float()).all())
