@@ -477,6 +477,23 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # Extension figure, reported beside `value` and never as it: the same units with `prune_cond_rows` (the UNet's per-frame
+    # tail after the last 3-D attention runs only for the frames whose noise prediction the scheduler step consumes; the
+    # reference computes it for the conditioning frames too and drops it; latents bitwise equal, modelcheck
+    # pipeline_prune_cond_rows*).
+    prune_info = None
+    if mode == "task" and world == 1 and not args.prune_cond_rows and not args.no_vae:
+        k_pr = max(2, min(args.steps, 8))
+        pipe.prune_cond_rows = True
+        run_units(args.warmup + args.steps, 2)
+        barrier()
+        tp = time.perf_counter()
+        run_units(args.warmup + args.steps + 2, k_pr)
+        barrier()
+        tp = time.perf_counter() - tp
+        pipe.prune_cond_rows = False
+        prune_info = {"ms_per_step": round(tp / k_pr * 1e3, 3), "latents_per_s": round(LATENTS_PER_UNIT * k_pr / tp, 4), "steps": k_pr,
+                      "note": "extension, not the judged value: noise predictions of conditioning frames are not computed (bitwise-equal latents)"}
     # roofline pass: K units, one task at a time, an event pair around every attention launch on the launch
     # stream.  With several task streams the launches of different tasks overlap on the device, so per-launch intervals
     # taken inside the timed region above would measure the mix, not the kernel.
@@ -597,6 +614,8 @@ def main():
             "unet_calls_per_s": round(units_total * 3 / dt, 3),
             "unet_tflops_sustained": round(units_total * (2 * ut[0] + ut[1]) / dt, 1) if ut else None,
         }
+        if prune_info is not None:
+            out["secondary"]["prune_cond_rows"] = prune_info
         if world == 1 and not args.no_vae and LAT_H * LAT_W <= 128 * 128:
             out["secondary"]["vae"] = vae_secondary(dev)
         if want_cpu:  # rank 0 at N = 1 only (the CPU sample would skew multi-rank timing)
