@@ -64,7 +64,9 @@ def test_grid_pass_two_ranks_gloo():
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(2, 29400 + os.getpid() % 500, d), nprocs=2, join=True)
         per_rank = [torch.load(f"{d}/r{r}.pt") for r in range(2)]
-    assert per_rank == [6 + 22 * 3 + 6, 6 + 22 * 3 + 6]
+    # every window call of the job ran exactly once; an even split unless the runner measured different task rates on a
+    # loaded test machine and re-dealt a round (DistributedSamplingRunner.balance)
+    assert sum(per_rank) == 2 * (6 + 22 * 3 + 6) and min(per_rank) >= 6 + 6
 
 
 def test_self_launch_command(monkeypatch):
