@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--latent", default="72x40",
                     help="latent grid HxW: 72x40 = BASELINE.json's synthetic grid (default, the judged line); 128x128 = the "
                          "1024^2 images the reference's demo configs run (SURVEY.md 8d asks for both)")
+    ap.add_argument("--task-batch", type=int, default=1,
+                    help="tasks of a round stacked into ONE window call (host/pipeline.py upload_plan copies; the runner's "
+                         "task_batch): K steps are then K / task-batch stacked units")
     ap.add_argument("--task-streams", type=int, default=2,
                     help="independent tasks in flight per GPU, each on its own HIP stream and worker thread (the runner's "
                          "gpu_streams). 1 = one task at a time")
@@ -104,8 +107,12 @@ def self_launch(args) -> None:
 # ---------------------------------------------------------------------------------------------------------------------
 # task mode: resident synthetic tasks, units of 2 spatial + 1 temporal window calls
 # ---------------------------------------------------------------------------------------------------------------------
+TASK_BATCH = 1  # tasks of a round stacked into one window call (--task-batch)
+
+
 def build_tasks(pipe, dev, shard=None):
-    """Device-resident synthetic task tensors + window plans for one spatial and one temporal task."""
+    """Device-resident synthetic task tensors + window plans for one spatial and one temporal task (TASK_BATCH of each,
+    stacked along the frame axis, when task batching is on)."""
     from diffuman4d_amd.host.schedule import plan_sweep
     g = torch.Generator(device=dev).manual_seed(1234)
 
@@ -116,13 +123,14 @@ def build_tasks(pipe, dev, shard=None):
     for domain, n, cond in (("spatial", N_CAMS, [i in INPUT_CAMS for i in range(N_CAMS)]),
                             ("temporal", 2 * N_FRAMES, [i < N_FRAMES for i in range(2 * N_FRAMES)])):
         plan = plan_sweep(cond, [0] * n, domain, WINDOW, STRIDE, 0, False, 1, ROUNDS)
-        mask = torch.tensor([0.0 if c else 1.0 for c in cond], device=dev).to(torch.bfloat16)
+        kb = TASK_BATCH
+        mask = torch.tensor([0.0 if c else 1.0 for c in cond] * kb, device=dev).to(torch.bfloat16)
         hw = LAT_H * LAT_W
         tasks[domain] = dict(
-            pv=rnd(n, hw, 4, scale=0.18215 * 4), pl=rnd(n, hw, 6, scale=0.5).clamp(-1, 1),
-            sk=rnd(n, hw, 4, scale=0.18215 * 4), lat=rnd(n, hw, 4),
-            cm=mask[:, None, None].expand(n, hw, 1).contiguous(), plan=plan,
-            tables=pipe.upload_plan(plan, GUIDANCE, shard), domain=domain)
+            pv=rnd(kb * n, hw, 4, scale=0.18215 * 4), pl=rnd(kb * n, hw, 6, scale=0.5).clamp(-1, 1),
+            sk=rnd(kb * n, hw, 4, scale=0.18215 * 4), lat=rnd(kb * n, hw, 4),
+            cm=mask[:, None, None].expand(kb * n, hw, 1).contiguous(), plan=plan,
+            tables=pipe.upload_plan(plan, GUIDANCE, shard, copies=kb, rows_per_task=n), domain=domain)
     return tasks
 
 
@@ -406,7 +414,11 @@ def main():
     # Tasks of a round are independent, so the runner keeps `gpu_streams` of them in flight per GPU (host/runner.py);
     # here: S task states, S worker threads, one HIP stream each, one set of weights.  Collectives of the frame-shard
     # mode must be issued in one order on every rank, so that mode runs one task at a time.
-    S = 1 if shard is not None else max(1, min(args.task_streams, max(1, args.steps)))
+    global TASK_BATCH
+    TASK_BATCH = kb = max(1, args.task_batch) if (shard is None and mode == "task") else 1
+    if kb > 1 and (args.steps % kb or args.warmup % kb):
+        raise SystemExit(f"--steps and --warmup must be multiples of --task-batch ({kb})")
+    S = 1 if shard is not None else max(1, min(args.task_streams, max(1, args.steps // kb)))
     task_sets = [build_tasks(pipe, dev, shard) for _ in range(S if mode != "grid" else 1)]
     tasks = task_sets[0]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [None]
@@ -417,7 +429,10 @@ def main():
         torch.cuda.synchronize()
 
     def run_units(first, count):
-        """`count` units starting at per-task unit index `first`, dealt round-robin to the S task streams."""
+        """`count` units starting at per-task unit index `first`, dealt round-robin to the S task streams (with task batching a
+        stacked unit carries TASK_BATCH of them)."""
+        first, count = first // kb, count // kb
+
         def work(si):
             torch.cuda.set_device(dev)
             with torch.no_grad(), torch.cuda.stream(streams[si]):
@@ -586,7 +601,7 @@ def main():
                 "mode": mode,
                 "unet": "SD-2.1 geometry (320,640,1280,1280), 815.6M params, random init seed 0",
                 "parallelism": par,
-                "task_streams": S,
+                "task_streams": S, "task_batch": kb,
                 "finite_outputs": finite,
                 "extensions": (["prune_cond_rows"] if args.prune_cond_rows else []) + (["fp8_attention"] if fp8 else []),
             },

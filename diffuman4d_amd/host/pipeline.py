@@ -150,10 +150,16 @@ class Diffuman4DPipeline:
         return pv_lat, pl_lat, sk_lat, cm_lat, lat
 
     # ------------------------------------------------------------------------------------------
-    def upload_plan(self, plan: SweepPlan, guidance_scale: float, shard=None):
+    def upload_plan(self, plan: SweepPlan, guidance_scale: float, shard=None, copies: int = 1, rows_per_task: int = 0):
         """Host plan -> device index / timestep / coefficient tables (one H2D each, no syncs later).
         With `shard` (parallel.FrameShard) the per-call rows are cut down to this rank's frames of every window;
-        `win_full` keeps the whole window for the latent all-gather."""
+        `win_full` keeps the whole window for the latent all-gather.
+        copies > 1 (task batching): the tables of `copies` tasks with THIS plan whose tensors are stacked along the frame axis
+        (task k occupies rows k * rows_per_task ...): every window call then carries copies x F frames, the 3-D attention still
+        folds F frames per group (`frames_per_group`), and each task's arithmetic is what it is alone (per-row GEMMs, per-sample
+        GroupNorm, per-(batch, head) attention; every tile choice is bit-identical)."""
+        if copies > 1 and (shard is not None or rows_per_task <= 0):
+            raise ValueError("task batching needs rows_per_task and is not combined with frame sharding")
         ts = self.scheduler.set_timesteps(plan.num_inference_steps)
         cfg = 2 if guidance_scale > 1 else 1
         win = np.stack(plan.windows).astype(np.int32)              # [calls, F]
@@ -169,10 +175,15 @@ class Diffuman4DPipeline:
             coef = self.scheduler.step_rows(np.where(cond, 0, tix), has_prev)   # [calls, F, 8]
         else:
             coef = self.scheduler.step_coefficients(t)             # [calls, F, 4]
+        group = win.shape[1]  # frames folded into one 3-D attention sequence
+        if copies > 1:
+            win = np.concatenate([win + k * rows_per_task for k in range(copies)], axis=1).astype(np.int32)
+            cond, t, coef = (np.concatenate([a] * copies, axis=1) for a in (cond, t, coef))
         win_full = win
         if shard is not None:
             sl = shard.local_frames(win.shape[1])
             win, cond, t, coef = win[:, sl], cond[:, sl], t[:, sl], coef[:, sl]
+            group = win.shape[1]
         t_in = np.concatenate([t] * cfg, axis=1).astype(np.float32)
         dev = self._device
 
@@ -183,7 +194,7 @@ class Diffuman4DPipeline:
         F = win.shape[1]
         keep = [up(np.concatenate([np.nonzero(~c)[0] + h * F for h in range(cfg)]).astype(np.int64)) for c in cond]
         return dict(win=up(win), cond=up(cond.astype(np.int32)), t=up(t_in), coef=up(coef), calls=win.shape[0], cfg=cfg,
-                    win_full=up(win_full.astype(np.int64)), keep=keep)
+                    win_full=up(win_full.astype(np.int64)), keep=keep, frames_per_group=group, copies=copies)
 
     def denoise_latents(self, pv_lat, pl_lat, sk_lat, cm_lat, lat, plan: SweepPlan, domain: str, guidance_scale: float,
                         tqdm: Callable = _identity_tqdm, tables=None, shard=None):
@@ -223,7 +234,10 @@ class Diffuman4DPipeline:
             sk3 = None
         x = ops.pack_model_input(lat3, pv3, pl3, sk3, cm3, cond, self.unet.IN_PAD, use_cfg, frame_idx=widx)
         keep = tb["keep"][i] if self.prune_cond_rows else None
-        eps = self.unet(x.view(tb["cfg"] * F, h, w, self.unet.IN_PAD), tb["t"][i], domains=domains, num_frames=F, shard=shard,
+        fpg = tb.get("frames_per_group", F)  # < F when several tasks share the call (upload_plan copies)
+        if len(domains) * fpg != tb["cfg"] * F:
+            domains = list(domains[:1]) * (tb["cfg"] * F // fpg)
+        eps = self.unet(x.view(tb["cfg"] * F, h, w, self.unet.IN_PAD), tb["t"][i], domains=domains, num_frames=fpg, shard=shard,
                         pose_features=pose, keep_rows=keep)
         if keep is not None:  # back to one row per CFG-batch entry; the rows left at zero are never read by the step kernel
             full = torch.zeros((tb["cfg"] * F,) + tuple(eps.shape[1:]), dtype=eps.dtype, device=eps.device)

@@ -208,6 +208,37 @@ def case_pipeline_shard_world1(seed=21):
             dist.destroy_process_group()
 
 
+def case_task_batching(domain="spatial", copies=2, sched="ddim", seed=23):
+    """Tasks of a round stacked into one window call (upload_plan copies): every task's latents equal, bit for bit, what the
+    task gives alone -- GEMMs and convolutions are per row, GroupNorm per sample, attention per (batch, head), and every
+    tile choice the larger batch may trigger is bit-identical."""
+    from diffuman4d_amd.host.pipeline import Diffuman4DPipeline
+    from diffuman4d_amd.host.schedule import plan_sweep
+    if sched == "dpm":
+        from diffuman4d_amd.host.scheduler import DPMSolverMultistepScheduler as S_
+    else:
+        from diffuman4d_amd.host.scheduler import DDIMScheduler as S_
+    cfg, om = make_unet(seed)
+    pipe = Diffuman4DPipeline(None, hip_unet(cfg, om), S_(), "cuda")
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    h, w = 16, 8
+    if domain == "spatial":
+        n, cond = 8, [i in (1, 5) for i in range(8)]
+    else:
+        n, cond = 8, [i < 4 for i in range(8)]
+    rnd = lambda c, s=1.0: (torch.randn(copies * n, h, w, c, generator=g, device="cuda") * s).to(BF)  # noqa: E731
+    mask = torch.tensor([0.0 if c else 1.0 for c in cond] * copies, device="cuda").to(BF)[:, None, None, None].expand(copies * n, h, w, 1).contiguous()
+    pv, pl, sk, lat0 = rnd(4), rnd(6, 0.5), rnd(4), rnd(4)
+    plan = plan_sweep(cond, [0] * n, domain, 4, 2 if domain == "spatial" else 1, 0, True, 2, 1)
+    alone = [pipe.denoise_latents(pv[k * n:(k + 1) * n], pl[k * n:(k + 1) * n], sk[k * n:(k + 1) * n], mask[k * n:(k + 1) * n],
+                                  lat0[k * n:(k + 1) * n].clone(), plan, domain, 2.0) for k in range(copies)]
+    tables = pipe.upload_plan(plan, 2.0, copies=copies, rows_per_task=n)
+    stacked = pipe.denoise_latents(pv, pl, sk, mask, lat0.clone(), plan, domain, 2.0, tables=tables)
+    ref = torch.cat(alone)
+    assert bool(torch.isfinite(stacked.float()).all()) and not torch.equal(stacked, lat0)
+    return float((stacked.float() - ref.float()).abs().max()), 0.0
+
+
 def case_vae(h=64, w=64, seed=1):
     from diffuman4d_amd.host import ops
     cfg, ov = make_vae(seed)
@@ -502,6 +533,9 @@ CASES = {
     "unet_frame_shard_p4": (case_unet_frame_shard, dict(P=4, num_frames=8)),
     "unet_frame_shard_p8": (case_unet_frame_shard, dict(P=8, num_frames=8, tem=False)),
     "pipeline_shard_rccl_world1": (case_pipeline_shard_world1, dict()),
+    "task_batching_spatial": (case_task_batching, dict(domain="spatial")),
+    "task_batching_temporal_x3": (case_task_batching, dict(domain="temporal", copies=3)),
+    "task_batching_dpm": (case_task_batching, dict(domain="spatial", sched="dpm")),
     "unet_pose_encoder": (case_unet, dict(num_frames=4, cfg_batch=2, pose=True)),
     "pipeline_pose_encoder": (case_pipeline, dict(domain="spatial", pose=True)),
     "pipeline_cache_lazy_decode": (case_pipeline_cache_lazy, dict()),
@@ -531,7 +565,7 @@ CASES = {
 }
 # Cases with a fixed bound of their own: bitwise equalities (0.0), extension-vs-strict comparisons, exact resampling.
 # Every other case is judged against its bf16-oracle yardstick (YARD_FACTOR, see the module docstring).
-TOL = {"pipeline_shard_rccl_world1": 0.0, "unet_frame_shard_p4": 0.0, "unet_frame_shard_p8": 0.0,
+TOL = {"task_batching_spatial": 0.0, "task_batching_temporal_x3": 0.0, "task_batching_dpm": 0.0, "pipeline_shard_rccl_world1": 0.0, "unet_frame_shard_p4": 0.0, "unet_frame_shard_p8": 0.0,
        "pipeline_cache_lazy_decode": 0.0, "pipeline_prune_cond_rows": 5e-3, "pipeline_prune_cond_rows_temporal": 5e-3,
        "pipeline_plucker_on_device": 5e-3, "resize": 4e-3}
 
