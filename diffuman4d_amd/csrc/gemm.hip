@@ -24,8 +24,14 @@
 //  * gemm_kernel (fallback, K-slab 32, register staged, padded LDS rows): shapes whose K (or conv
 //    Cin) is a multiple of 32 but not of 64.
 //
-// The epilogue goes back through LDS in fp32 so that bias / GEGLU / SiLU / rowbias (time-embedding
-// add) / residual / scale are fused and every global store is a coalesced 16-byte row write.
+//  * gemm_lin2_kernel (Linear layers, second form: uniform-base DMA, scheduled fragment reads; 256x128 on the 74 KB
+//    geometry for short K, 256x256 / 128x128 / 256x320 tiles for the wide, deep and N = 320 layers) and
+//    conv_strip2_kernel (the strip convolution in the same form; KT = 2 = one phase of the x2-upsampling convolution).
+//
+// Every MFMA takes its operands swapped (weights as A, activations as B), so a lane holds one output ROW and runs of four
+// consecutive columns (mfma_t below).  The bias enters as the first k step of the product (acc_init); GEGLU / SiLU are
+// applied in registers; the tile then goes through the LDS -- packed bf16 when nothing else is applied, fp32 when the row
+// bias (time-embedding add), residual or scale follow -- so that every global store is a coalesced 16-byte row write.
 #include "common.h"
 #include "dm4d.h"
 #include "errors.h"
