@@ -33,6 +33,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import ddim as _ddim
+from . import dpmsolver as _dpm
 from . import unet as _ou
 from . import vae as _ov
 
@@ -361,6 +362,25 @@ class DDIMSchedulerAdapter:
 
     def __init__(self, cfg: _ddim.DDIMConfig = _ddim.DDIMConfig()):
         self._s = _ddim.DDIMScheduler(cfg)
+        self.init_noise_sigma = 1.0
+        self.timesteps = None
+
+    def set_timesteps(self, n, device=None):
+        self.timesteps = self._s.set_timesteps(n)
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def step(self, model_output, timestep, sample, return_dict=True, **kw):
+        return (self._s.step(model_output, int(timestep), sample),)
+
+
+class DPMSolverSchedulerAdapter:
+    """diffusers-API adapter over the oracle DPM-Solver++ scheduler.  STATEFUL (history of x0 predictions, step index) and
+    deep-copyable: exactly what the reference's "a scheduler for each latent" copies (pipeline_diffuman4d.py:265-271)."""
+
+    def __init__(self, cfg: "_dpm.DPMSolverConfig" = None):
+        self._s = _dpm.DPMSolverMultistepScheduler(cfg or _dpm.DPMSolverConfig())
         self.init_noise_sigma = 1.0
         self.timesteps = None
 

@@ -118,6 +118,52 @@ def golden_pipeline():
     torch.save(out, OUT / "pipeline_sliding.pt")
 
 
+def golden_pipeline_dpm():
+    """The reference's own pipeline with a STATEFUL scheduler (oracle/dpmsolver.py behind the diffusers API): pins what the
+    product's planned coefficient rows assume about the reference's control flow -- one deep copy per latent made afresh in
+    every sliding_iterative_denoise call (pipeline_diffuman4d.py:265-271, 500-501), indexed by window (:535), stepped only for
+    target rows (:418-420)."""
+    from oracle.dpmsolver import DPMSolverConfig
+    out = {}
+    cases = {
+        "dpm_spatial_bidir": dict(domain="spatial", n=8, inputs=[1, 5], sched=dict(prediction_type="epsilon"),
+                                  kw=dict(window_size=4, sliding_stride=2, sliding_shift=0, bidirectional=True,
+                                          num_denoising_steps=2, alternation_rounds=1, guidance_scale=2.0)),
+        "dpm_temporal_v_heun_round2": dict(domain="temporal", n=8, inputs=[0, 1, 2, 3], start_idx=4,
+                                           sched=dict(prediction_type="v_prediction", solver_type="heun", final_sigmas_type="sigma_min",
+                                                      timestep_spacing="leading", steps_offset=1),
+                                           kw=dict(window_size=4, sliding_stride=1, sliding_shift=0, bidirectional=False,
+                                                   num_denoising_steps=1, alternation_rounds=3, guidance_scale=2.0)),
+    }
+    for name, c in cases.items():
+        cfg_u, ou = mc.make_unet(11)
+        cfg_v, ov = mc.make_vae(12)
+        pipe = RefPipeline(vae=refshim.AutoencoderKL(ov), unet=ref_unet_from(cfg_u, ou),
+                           scheduler=refshim.DPMSolverSchedulerAdapter(DPMSolverConfig(**c["sched"])))
+        n = c["n"]
+        pv, pl, sk, cm = mc.synthetic_task(n, 64, 64, c["inputs"], 11)
+        g = torch.Generator().manual_seed(13)
+        noise = {k: torch.randn(n, 4, 8, 8, generator=g) for k in ("pixel", "skeleton", "latents")}
+        tidx = torch.zeros(n, dtype=torch.int64)
+        latents_in = None
+        refshim.NOISE_QUEUE.clear()
+        refshim.NOISE_QUEUE.extend([noise["pixel"], noise["skeleton"]])
+        if c.get("start_idx"):
+            tidx[[i for i in range(n) if i not in c["inputs"]]] = c["start_idx"]
+            latents_in = torch.randn(n, 4, 8, 8, generator=g)
+        else:
+            refshim.NOISE_QUEUE.append(noise["latents"])
+        res = pipe.sliding_iterative_denoise(pixel_values=pv, plucker_embeds=pl, skeletons=sk, cond_masks=cm,
+                                             latents=latents_in, domain=c["domain"], timestep_indices=tidx.clone(),
+                                             tqdm=lambda it, total=None: it, **c["kw"])
+        assert not refshim.NOISE_QUEUE
+        out[name] = dict(case=c, seeds=dict(unet=11, vae=12, task=11, noise=13), noise=noise, latents_in=latents_in,
+                         timestep_indices_in=tidx, latents=res["latents"], images=res["images"].half(),
+                         timestep_indices=res["timestep_indices"], fully_denoised=res["fully_denoised"])
+        print(f"pipeline_dpm[{name}]: idx {res['timestep_indices'].tolist()} denoised {int(res['fully_denoised'].sum())}")
+    torch.save(out, OUT / "pipeline_dpm.pt")
+
+
 def golden_pose():
     """enable_pose_encoder checkpoints (pose_encoder.py; unet_multiview_condition.py:551-552;
     pipeline_diffuman4d.py:229-231,352-353,389-395): the reference UNet and pipeline with raw skeleton images."""
@@ -195,7 +241,7 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     only = sys.argv[1:]  # e.g. `make_golden.py pose` regenerates one fixture file
     for name, fn in (("unet", golden_unet), ("pipeline", golden_pipeline), ("sampler", golden_sampler),
-                     ("pose", golden_pose)):
+                     ("pose", golden_pose), ("dpm", golden_pipeline_dpm)):
         if not only or name in only:
             fn()
     print("golden fixtures written to", OUT)

@@ -496,14 +496,24 @@ def case_golden_pipeline(name):
     """HIP sliding_iterative_denoise vs the output of the REFERENCE's own pipeline code (committed
     fixture tests/golden/pipeline_sliding.pt, fp32): same seeded weights, task tensors and noise."""
     from diffuman4d_amd.host.pipeline import Diffuman4DPipeline
-    from diffuman4d_amd.host.scheduler import DDIMConfig as HC, DDIMScheduler as HS
     gdir = Path(__file__).resolve().parent / "golden"
-    g = torch.load(gdir / "pose_encoder.pt")["pipeline"] if name == "pose_encoder" else torch.load(gdir / "pipeline_sliding.pt")[name]
+    dpm = name.startswith("dpm_")  # fixture of the reference pipeline run with one stateful DPM-Solver++ object per latent
+    if dpm:
+        from diffuman4d_amd.host.scheduler import DPMSolverConfig as HC, DPMSolverMultistepScheduler as HS
+        from oracle.dpmsolver import DPMSolverConfig as OC_, DPMSolverMultistepScheduler as OS_
+        g = torch.load(gdir / "pipeline_dpm.pt")[name]
+        host_sched, oracle_sched = HS(HC(**g["case"]["sched"])), (lambda: OS_(OC_(**g["case"]["sched"])))
+    else:
+        from diffuman4d_amd.host.scheduler import DDIMConfig as HC, DDIMScheduler as HS
+        from oracle.ddim import DDIMConfig, DDIMScheduler
+        g = torch.load(gdir / "pose_encoder.pt")["pipeline"] if name == "pose_encoder" else torch.load(gdir / "pipeline_sliding.pt")[name]
+        host_sched = HS(HC(prediction_type=g["case"]["pred"]))
+        oracle_sched = lambda: DDIMScheduler(DDIMConfig(prediction_type=g["case"]["pred"]))  # noqa: E731
     c, seeds = g["case"], g["seeds"]
     cfg_u, ou = make_unet(seeds["unet"], **g.get("cfg_kw", {}))
     cfg_v, ov = make_vae(seeds["vae"])
     pv, pl, sk, cm = synthetic_task(c["n"], 64, 64, c["inputs"], seeds["task"])
-    hp = Diffuman4DPipeline(hip_vae(cfg_v, ov), hip_unet(cfg_u, ou), HS(HC(prediction_type=c["pred"])), "cuda")
+    hp = Diffuman4DPipeline(hip_vae(cfg_v, ov), hip_unet(cfg_u, ou), host_sched, "cuda")
     lat_in = g["latents_in"].to(BF) if g["latents_in"] is not None else None
     out = hp.sliding_iterative_denoise(pixel_values=pv, plucker_embeds=pl, skeletons=sk, cond_masks=cm, latents=lat_in,
                                        domain=c["domain"], timestep_indices=g["timestep_indices_in"],
@@ -512,10 +522,9 @@ def case_golden_pipeline(name):
         torch.equal(out["fully_denoised"].cpu(), g["fully_denoised"])
     e_lat, e_img = rel_l2(out["latents"], g["latents"]), rel_l2(out["images"], g["images"])
     # yardstick: the oracle run in bf16 on the same task, measured against the same fixture (= the reference's fp32 output)
-    from oracle.ddim import DDIMConfig, DDIMScheduler
     from oracle.pipeline import OraclePipeline
     ov.to(BF), ou.to(BF)
-    opb = OraclePipeline(ov, ou, DDIMScheduler(DDIMConfig(prediction_type=c["pred"])), BF)
+    opb = OraclePipeline(ov, ou, oracle_sched(), BF)
     refb = opb.sliding_iterative_denoise(pv, pl, sk, cm, lat_in, c["domain"], g["timestep_indices_in"],
                                          {k: v.to(BF) for k, v in g["noise"].items()}, **c["kw"])
     y_lat, y_img = rel_l2(refb["latents"], g["latents"]), rel_l2(refb["images"], g["images"])
@@ -558,6 +567,8 @@ CASES = {
     "golden_bidir_nocfg": (case_golden_pipeline, dict(name="bidir_nocfg")),
     "golden_round2_shift": (case_golden_pipeline, dict(name="round2_shift")),
     "golden_pose_encoder": (case_golden_pipeline, dict(name="pose_encoder")),
+    "golden_dpm_spatial_bidir": (case_golden_pipeline, dict(name="dpm_spatial_bidir")),
+    "golden_dpm_temporal_v_heun_round2": (case_golden_pipeline, dict(name="dpm_temporal_v_heun_round2")),
     # the judged configuration (BASELINE.json configs[1..2]): SD-2.1 geometry at 72x40, vs tests/golden/sd21_72x40.pt
     "unet_sd21_72x40_f16": (case_unet_sd21, dict(name="unet_f16_spatial")),
     "unet_sd21_72x40_f24": (case_unet_sd21, dict(name="unet_f24_temporal")),

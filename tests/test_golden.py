@@ -113,3 +113,78 @@ def test_sampler_grid_bookkeeping_matches_reference_sampler():
     assert pipe.calls == g["calls"]  # same task order, same cond rows, same latents-None decisions
     assert {c: dict(v) for c, v in s.timestep_indices.items()} == g["final_idx"]
     assert {c: {f: float(l.flatten()[0]) for f, l in v.items()} for c, v in s.latents.items()} == g["final_lat0"]
+
+
+# ---- stateful scheduler (DPM-Solver++): fixture = the REFERENCE's pipeline run with one deep copy of the scheduler per latent ----
+DPM_CASES = ["dpm_spatial_bidir", "dpm_temporal_v_heun_round2"]
+
+
+def _dpm_task(name):
+    g = torch.load(G / "pipeline_dpm.pt")[name]
+    c, seeds = g["case"], g["seeds"]
+    _, ou = mc.make_unet(seeds["unet"])
+    _, ov = mc.make_vae(seeds["vae"])
+    pv, pl, sk, cm = mc.synthetic_task(c["n"], 64, 64, c["inputs"], seeds["task"])
+    return g, c, ou, ov, (pv, pl, sk, cm)
+
+
+@pytest.mark.parametrize("name", DPM_CASES)
+def test_oracle_pipeline_with_stateful_scheduler_matches_reference_pipeline(name):
+    from oracle.dpmsolver import DPMSolverConfig, DPMSolverMultistepScheduler
+    g, c, ou, ov, (pv, pl, sk, cm) = _dpm_task(name)
+    op = OraclePipeline(ov, ou, DPMSolverMultistepScheduler(DPMSolverConfig(**c["sched"])), torch.float32)
+    res = op.sliding_iterative_denoise(pv, pl, sk, cm, g["latents_in"], c["domain"], g["timestep_indices_in"], g["noise"], **c["kw"])
+    assert torch.equal(res["timestep_indices"], g["timestep_indices"])
+    assert rel(res["latents"], g["latents"]) <= 1e-5
+    assert rel(res["images"], g["images"]) <= 1e-3
+
+
+class _PlannedRows:
+    """What the PRODUCT does with a multistep scheduler, on the CPU: no scheduler object per latent, only the host's coefficient
+    rows (host/scheduler.py::step_rows) and one stored x0 prediction per latent.  Deep-copied per latent by the oracle pipeline
+    exactly like a real scheduler; records whether each step had a previous prediction."""
+    init_noise_sigma = 1.0
+
+    def __init__(self, host_sched, log):
+        self.h, self.log, self.p, self.timesteps = host_sched, log, None, None
+
+    def __deepcopy__(self, memo):
+        c = _PlannedRows(self.h, self.log)  # the row tables and the log are shared, the state is per latent
+        c.timesteps = self.timesteps
+        return c
+
+    def set_timesteps(self, n):
+        self.timesteps = torch.from_numpy(self.h.set_timesteps(n))
+        return self.timesteps
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def step(self, model_output, t, sample):
+        i = int((self.timesteps == int(t)).nonzero()[0])
+        has_prev = self.p is not None
+        self.log.append(has_prev)
+        a, b, cc, d, e = (float(v) for v in self.h.step_rows([i], [has_prev])[0, :5])
+        p = self.p if has_prev else torch.zeros_like(sample)
+        self.p = d * sample + e * model_output
+        return a * sample + b * model_output + cc * p
+
+
+@pytest.mark.parametrize("name", DPM_CASES)
+def test_planned_rows_reproduce_the_reference_pipeline_with_a_stateful_scheduler(name):
+    """The reference pipeline's output with one stateful scheduler object per latent == a pipeline that only has the product's
+    planned rows + one stored prediction per latent; and the plan's history flags are the ones observed."""
+    from diffuman4d_amd.host.schedule import history_flags
+    from diffuman4d_amd.host.scheduler import DPMSolverConfig as HC, DPMSolverMultistepScheduler as HS
+    g, c, ou, ov, (pv, pl, sk, cm) = _dpm_task(name)
+    log = []
+    op = OraclePipeline(ov, ou, _PlannedRows(HS(HC(**c["sched"])), log), torch.float32)
+    res = op.sliding_iterative_denoise(pv, pl, sk, cm, g["latents_in"], c["domain"], g["timestep_indices_in"], g["noise"], **c["kw"])
+    assert rel(res["latents"], g["latents"]) <= 2e-5
+    k = c["kw"]
+    cond = [i in c["inputs"] for i in range(c["n"])]
+    plan = plan_sweep(cond, g["timestep_indices_in"].tolist(), c["domain"], k["window_size"], k["sliding_stride"],
+                      k["sliding_shift"], k["bidirectional"], k["num_denoising_steps"], k["alternation_rounds"])
+    flags = history_flags(plan.windows, plan.is_cond)
+    planned = [bool(f) for fl, ic in zip(flags, plan.is_cond) for f, is_c in zip(fl, ic) if not is_c]
+    assert planned == log and any(log) and not all(log)
