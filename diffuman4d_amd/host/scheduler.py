@@ -38,6 +38,8 @@ class DDIMConfig:
     prediction_type: str = "epsilon"
     timestep_spacing: str = "leading"
     clip_sample: bool = False
+    rescale_betas_zero_snr: bool = False
+    thresholding: bool = False
 
     @classmethod
     def from_dict(cls, d: Dict) -> "DDIMConfig":
@@ -45,13 +47,25 @@ class DDIMConfig:
         return cls(**{k: v for k, v in d.items() if k in names})
 
 
+def rescale_zero_terminal_snr(betas):
+    """Betas with zero terminal SNR (Lin et al. 2023, Algorithm 1; diffusers' `rescale_betas_zero_snr`): checkpoints fine-tuned
+    that way (v-prediction, trailing spacing) reach alpha_cumprod = 0 at the last training step."""
+    import torch
+    alphas_bar_sqrt = torch.cumprod(1.0 - betas, dim=0).sqrt()
+    a0, aT = alphas_bar_sqrt[0].clone(), alphas_bar_sqrt[-1].clone()
+    alphas_bar_sqrt = (alphas_bar_sqrt - aT) * (a0 / (a0 - aT))
+    alphas_bar = alphas_bar_sqrt**2
+    alphas = torch.cat([alphas_bar[0:1], alphas_bar[1:] / alphas_bar[:-1]])
+    return 1 - alphas
+
+
 class DDIMScheduler:
     init_noise_sigma = 1.0
 
     def __init__(self, config: DDIMConfig = DDIMConfig()):
         self.config = c = config
-        if c.clip_sample:
-            raise NotImplementedError("clip_sample=True is not supported")
+        if c.clip_sample or c.thresholding:
+            raise NotImplementedError("DDIMScheduler: clip_sample / thresholding are not supported (the step kernel does not clamp x0)")
         n = c.num_train_timesteps
         # built with the same torch fp32 ops as diffusers' DDIMScheduler so the table is bit-identical
         import torch
@@ -61,6 +75,8 @@ class DDIMScheduler:
             betas = torch.linspace(c.beta_start, c.beta_end, n, dtype=torch.float32)
         else:
             raise NotImplementedError(f"beta_schedule {c.beta_schedule}")
+        if c.rescale_betas_zero_snr:
+            betas = rescale_zero_terminal_snr(betas)
         self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0).numpy()
         self.final_alpha_cumprod = np.float32(1.0) if c.set_alpha_to_one else self.alphas_cumprod[0]
         self.num_inference_steps = None
@@ -84,6 +100,8 @@ class DDIMScheduler:
         elif c.timestep_spacing == "trailing":
             ratio = c.num_train_timesteps / num_inference_steps
             ts = np.round(np.arange(c.num_train_timesteps, 0, -ratio)).astype(np.int64) - 1
+        elif c.timestep_spacing == "linspace":
+            ts = np.linspace(0, c.num_train_timesteps - 1, num_inference_steps).round()[::-1].copy().astype(np.int64)
         else:
             raise NotImplementedError(f"timestep_spacing {c.timestep_spacing}")
         self.timesteps = ts

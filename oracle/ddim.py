@@ -24,6 +24,7 @@ class DDIMConfig:
     set_alpha_to_one: bool = False
     prediction_type: str = "epsilon"  # or "v_prediction"
     timestep_spacing: str = "leading"
+    rescale_betas_zero_snr: bool = False
 
 
 class DDIMScheduler:
@@ -38,6 +39,12 @@ class DDIMScheduler:
             betas = torch.linspace(cfg.beta_start, cfg.beta_end, n, dtype=torch.float32)
         else:
             raise NotImplementedError(cfg.beta_schedule)
+        if cfg.rescale_betas_zero_snr:  # diffusers rescale_zero_terminal_snr
+            abs_ = torch.cumprod(1.0 - betas, dim=0).sqrt()
+            a0, aT = abs_[0].clone(), abs_[-1].clone()
+            abs_ = (abs_ - aT) * (a0 / (a0 - aT))
+            ab = abs_**2
+            betas = 1 - torch.cat([ab[0:1], ab[1:] / ab[:-1]])
         self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
         self.final_alpha_cumprod = torch.tensor(1.0) if cfg.set_alpha_to_one else self.alphas_cumprod[0]
         self.num_inference_steps = None
@@ -55,6 +62,8 @@ class DDIMScheduler:
         elif cfg.timestep_spacing == "trailing":
             ratio = cfg.num_train_timesteps / num_inference_steps
             ts = np.round(np.arange(cfg.num_train_timesteps, 0, -ratio)).astype(np.int64) - 1
+        elif cfg.timestep_spacing == "linspace":
+            ts = np.linspace(0, cfg.num_train_timesteps - 1, num_inference_steps).round()[::-1].copy().astype(np.int64)
         else:
             raise NotImplementedError(cfg.timestep_spacing)
         self.timesteps = torch.from_numpy(ts)

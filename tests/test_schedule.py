@@ -80,6 +80,29 @@ def test_ddim_tables_match_oracle_bitwise():
     assert h.step_coefficients(np.array([1]))[0][2] == np.sqrt(h.alphas_cumprod[0])
 
 
+def test_ddim_linspace_and_zero_terminal_snr_match_oracle():
+    """The other DDIM configurations a checkpoint may name: "linspace" spacing and zero-terminal-SNR betas (v-prediction
+    fine-tunes), host tables against the oracle's; the last training step then has alpha_cumprod = 0 exactly."""
+    from oracle.ddim import DDIMConfig as OC
+    kw = dict(timestep_spacing="linspace", rescale_betas_zero_snr=True, prediction_type="v_prediction")
+    h, o = DDIMScheduler(DDIMConfig(**kw)), OracleDDIM(OC(**kw))
+    assert np.array_equal(h.alphas_cumprod, o.alphas_cumprod.numpy()) and h.alphas_cumprod[-1] == 0.0
+    ts = h.set_timesteps(12)
+    assert list(map(int, ts)) == list(map(int, o.set_timesteps(12))) and int(ts[0]) == 999 and int(ts[-1]) == 0
+    c = h.step_coefficients(np.array([999]))[0]
+    assert c[0] == 0.0 and c[1] == 1.0  # pure noise at the first step: x0 = -v (v-prediction), no division by sqrt(alpha)
+    x, v = torch.randn(3, 4), torch.randn(3, 4)
+    sa, sb, sap, sbp = (float(k) for k in c)
+    mine = sap * (sa * x - sb * v) + sbp * (sa * v + sb * x)
+    assert torch.allclose(mine, o.step(v, 999, x), atol=1e-6)
+    import json, tempfile, pathlib
+    from diffuman4d_amd.host.scheduler import load_scheduler
+    with tempfile.TemporaryDirectory() as d:
+        (pathlib.Path(d) / "scheduler_config.json").write_text(json.dumps({"_class_name": "DDIMScheduler", "clip_sample": True}))
+        with pytest.raises(NotImplementedError, match="clip_sample"):
+            load_scheduler(d)
+
+
 @pytest.mark.parametrize("domain,n_t,n_i", [("spatial", 44, 4), ("temporal", 16, 16), ("temporal", 150, 150)])
 @pytest.mark.parametrize("window,stride,shift,bidir,steps", [(12, 1, 0, False, 1), (12, 2, 0, False, 1), (4, 1, 0, False, 1),
                                                              (12, 2, 0, True, 1), (12, 3, 1, False, 2), (8, 4, 2, True, 2)])
