@@ -91,3 +91,22 @@ def test_last_error_is_thread_local(lib):
     t.join()
     assert "silu" in seen[0]
     assert last(lib) == mine  # the other thread's failure did not overwrite this thread's message
+
+
+def test_scheduler_steps_reject_bad_arguments(lib):
+    lin = lib.dm4d_cfg_linear_step_bf16
+    # latents, x0_prev, noise_pred, ldn, coef, is_cond, frame_idx, F, HW, use_cfg, guidance_scale
+    assert lin(None, P, None, P, 4, P, P, None, 4, 45, 1, 2.0) == ERR_ARG  # a multistep scheduler has state: x0_prev is required
+    assert "cfg_linear_step" in last(lib)
+    assert lin(None, P, P, P, 3, P, P, None, 4, 45, 1, 2.0) == ERR_ARG     # fewer than four prediction channels per row
+    assert lin(None, P, P, P, 4, P, P, None, 0, 45, 1, 2.0) == ERR_ARG
+    ddim = lib.dm4d_cfg_ddim_step_bf16
+    assert ddim(None, P, P, 4, None, P, None, 4, 45, 1, 2.0, 0) == ERR_ARG
+    assert "cfg_ddim_step" in last(lib)
+
+
+def test_tuning_hooks_reject_unknown_forms(lib):
+    assert lib.dm4d_tune_set_attention_form(0) == ERR_ARG and "attention form" in last(lib)
+    assert lib.dm4d_tune_set_attention_form(6) == ERR_ARG
+    for form in (2, 3, 4, 5, 1):  # selecting a form launches nothing
+        assert lib.dm4d_tune_set_attention_form(form) == 0
