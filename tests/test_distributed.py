@@ -39,14 +39,14 @@ def grid_state(s, cells=None):
     return out
 
 
-def _worker(rank, world, port, outdir, kw=None, slow_rank=None):
+def _worker(rank, world, port, outdir, kw=None, slow_rank=None, slow_delay=0.18):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         s = make_sampler(kw)
         if slow_rank is not None:  # one GPU three times slower than the others
             import time
-            pipe, delay = s.pipelines[0], (0.18 if rank == slow_rank else 0.06)
+            pipe, delay = s.pipelines[0], (slow_delay if rank == slow_rank else 0.06)
             inner = pipe.sliding_iterative_denoise
 
             def slowed(**kwargs):
@@ -111,6 +111,31 @@ def test_slow_rank_gets_fewer_tasks_and_the_grid_is_unchanged():
     deal = blobs[0]["deal"]
     assert deal[0][0] == deal[0][1]            # first round: nothing measured yet, round-robin
     assert deal[1][0] > deal[1][1] and deal[2][0] > deal[2][1], deal  # the slow rank 1 gets fewer tasks afterwards
+    assert sum(b["n_calls"] for b in blobs) == sum(len(t) for t in ref.all_tasks)
+    merged = {}
+    for b in blobs:
+        merged.update(b["state"])
+    for cell in {(c, f) for c in ref.target_spa_labels for f in ref.tem_labels}:
+        assert merged[cell][0] == ref_state[cell][0] and torch.equal(merged[cell][1], ref_state[cell][1])
+
+
+@pytest.mark.timeout(300)
+def test_very_slow_rank_may_get_no_task_and_still_exchanges():
+    """World 3, one rank an order of magnitude slower: its share of the later rounds shrinks to (almost) nothing; ranks without
+    a task still take part in the exchanges and the grid equals the single-process run."""
+    ref = make_sampler(KW)
+    for tasks in ref.all_tasks:
+        for t in tasks:
+            ref.execute_one_task(t)
+    ref_state = grid_state(ref)
+    world = 3
+    with tempfile.TemporaryDirectory() as d:
+        port = 29500 + (os.getpid() % 2000) + 11
+        mp.spawn(_worker, args=(world, port, d, KW, 2, 0.6), nprocs=world, join=True)
+        blobs = [torch.load(f"{d}/rank{r}.pt") for r in range(world)]
+    deal = blobs[0]["deal"]
+    assert all(b["deal"] == deal for b in blobs)
+    assert deal[1][2] < deal[1][0] and deal[2][2] < deal[2][0] and deal[2][2] <= 2, deal
     assert sum(b["n_calls"] for b in blobs) == sum(len(t) for t in ref.all_tasks)
     merged = {}
     for b in blobs:
