@@ -1923,6 +1923,8 @@ int choose_cfg(const GemmParams& p) {
       // the same 74 KB geometry (two workgroups per CU) in the second form: -2..-9 % on the GEGLU projections of levels 0-2,
       // -9..-16 % on the K = 640 layers of level 1, +-1 % on the narrow K = 320 layers; the wide K = 320 QKV projection
       // (N = 960) is the one shape where it is not ahead at both batch sizes (profiles/r02_lin2_ab.log, id 65 vs auto)
+      // (id 61, the 147 KB three-stage tile, for the residual layers with K <= 640 -- ahead in the cold sweep, behind in the timing
+      // loop -- measured in a bench step: Linear family 27.6 -> 27.8 ms, profiles/r02_lin_heuristic_cold_ab.log; not taken)
       if (lin2_ok(p) && (geglu || p.K >= 640 || p.N <= 640)) return 65;
       return 14;
     }
