@@ -49,7 +49,7 @@ def test_sampler_samples_pass_the_reference_checks():
     s = SlidingIterativeSampler(ds, [StubPipeline()], "/tmp/unused", spa_label_range=[0, 20, 1], tem_label_range=[0, 6, 1],
                                 input_spa_labels=[1, 9], window_size=6, sliding_stride=2, alternation_rounds=2, bidirectional=False)
     for tasks in s.all_tasks[:2]:
-        sample = s.load_sample(tasks[0])
+        sample = s.load_sample(**tasks[0])
         check_output(sample, tasks[0]["domain"])
         masks = sample["cond_masks"][:, 0, 0, 0]
         assert set(masks.tolist()) <= {0.0, 1.0} and 0 < int((masks == 0).sum()) < len(masks)  # inputs 0, targets 1 (:134-139)
