@@ -45,32 +45,11 @@ constexpr int LDS_LD = 72;   // exact loop, K rows: 64 + 8 pad bf16 = 144 B  (co
 constexpr int LDS_LDV = 96;  // exact loop, V rows: 64 + 32 pad bf16 = 192 B (4 consecutive rows tile the 64 banks)
 constexpr int LDS_LDO = 72;  // O staging rows: 64 + 8 pad bf16 = 144 B
 constexpr int TILE = KV * 64;  // elements of one un-padded [64 keys][64 d] stage of the pipelined loop
-// Stages per operand ring of the pipelined loop.  2 (shipped): one DMA round and one barrier per tile.  4 (experimental,
-// NOT yet run on a GPU -- build with -DATTN_RING=4 and run `python tests/opcheck.py attn`): the main loop handles tiles
-// in pairs, one DMA round (2 K + 2 V tiles) and one barrier per pair; DMA runs two tiles ahead instead of one.
-#ifndef ATTN_RING
-#define ATTN_RING 2
-#endif
-#ifndef ATTN_PRIO_YOUNG
-#define ATTN_PRIO_YOUNG 0  // experimental: see attn_kernel
-#endif
-// Software-pipelined softmax (see compute_swp): the exponentials of a tile are spread over the MFMA shadows of TWO steps so
-// that every one of a step's 16 MFMAs has two v_exp behind it; 0 = the straight-line body (compute), which is what ships:
-// measured on MI355X the regular schedule is SLOWER than the compiler's own irregular one (-6 % with the
-// sched_group_barrier slots, -2.5 % without them, -4..-10 % with other fragment-read leads; 38/38 parity cases pass either
-// way; profiles/r02_attn_swp_ab.log) -- the same sign as round 1's attempts at steering this loop.
-#ifndef ATTN_SWP
-#define ATTN_SWP 0
-#endif
-// sched_group_barrier pattern for compute_swp: 0 = leave the order to the compiler
-#ifndef ATTN_SWP_SGB
-#define ATTN_SWP_SGB 1
-#endif
-#ifndef ATTN_SWP_LEAD
-#define ATTN_SWP_LEAD 4  // fragment reads issued ahead of the first MFMA of a step
-#endif
-constexpr int RING = ATTN_RING, AHEAD = RING / 2;
-static_assert(RING == 2 || RING == 4, "ATTN_RING must be 2 or 4");
+// Two stages per operand ring: one DMA round and one barrier per tile, DMA one tile ahead.  (A four-stage ring with one
+// barrier per two tiles, a software-pipelined softmax with sched_group_barrier slots, static priority for the younger half of
+// the workgroup and a one-wave-per-SIMD form with 64 query rows per wave were all built and measured in rounds 1-2 at
+// 0.88-1.01x of this loop -- DESIGN.md section 4 -- and removed.)
+constexpr int RING = 2, AHEAD = 1;
 // waves per workgroup (template parameter NW): 8 = 256 query rows per workgroup, one workgroup per CU; 4 = 128 rows, two
 // independent workgroups per CU, so that a wave waiting at its workgroup's barrier shares its SIMD with a wave that is not
 constexpr float RESCALE_THR = 8.0f;  // in log2 units
@@ -351,16 +330,9 @@ __device__ __forceinline__ void kv_loop_pipelined(const AttnParams& p, const u16
 
   // prologue: K(0) .. K(AHEAD), V(0) .. V(AHEAD-1) -> LDS (clamped past the end of the sequence); tile i lives in
   // stage i % RING of its ring
-  if (RING == 2) {
-    issue_k(0, 0, true);
-    issue_v(0, 0, true);
-    issue_k(1, 1, true);
-  } else {
-#pragma unroll
-    for (int i = 0; i <= AHEAD; ++i) issue_k(i, i % RING, true);
-#pragma unroll
-    for (int i = 0; i < AHEAD; ++i) issue_v(i, i % RING, true);
-  }
+  issue_k(0, 0, true);
+  issue_v(0, 0, true);
+  issue_k(1, 1, true);
   dma_wait_barrier();
   f32x16_t s_cur[2], s_nxt[2];
   qk_block(0, 0, s_cur[0]);  // negm is still zero here
@@ -403,122 +375,12 @@ __device__ __forceinline__ void kv_loop_pipelined(const AttnParams& p, const u16
     compute(t, sa, sb);
     dma_wait_barrier();
   };
-#if ATTN_SWP
-  // The same step with the softmax spread over the MFMA shadows.  On this chip a wave's VALU work hides only behind its
-  // OWN MFMAs, about two v_exp (or four plain VALU) per 32-cycle MFMA (tools/probes/issue_probe.hip: 1 MFMA + 2 v_exp = 39
-  // cycles, + 4 = 48, + 8 = 78), and `compute` gives the scheduler 7 exponentials per gap in places and none in others.
-  // A step has 16 MFMAs and 32 exponentials, but their deadlines do not line up inside one step: P of key block 0 must
-  // be complete before PV0 and P of block 1 before PV1, which leaves nothing for PV1's four shadows.  So the first half of
-  // block 0's exponentials is taken one step early, in the PV1 shadows of the PREVIOUS step (S(t+1) block 0 is ready by
-  // then: its QK^T MFMAs open this step), and carried in `pc`:
-  //   QK0 x4 | exp S(t).0[8..16]    QK1 x4 | exp S(t).1[0..8]    PV0 x4 | exp S(t).1[8..16]    PV1 x4 | exp S(t+1).0[0..8] -> pc
-  // Row sums go as two 8-term trees per block next to the exponentials they consume.  PV MFMAs run (d0,k0) (d1,k0) (d0,k1)
-  // (d1,k1) so that the second k-slot half of P is needed two MFMAs later; each accumulator still sees its k-slots in
-  // the same order as in `compute`.
-  auto exp8 = [&](const f32x16_t& sv, int r0, float (&pv)[8]) {
-#pragma unroll
-    for (int r = 0; r < 8; ++r) pv[r] = FOLD ? __builtin_amdgcn_exp2f(sv[r0 + r]) : __builtin_amdgcn_exp2f(sv[r0 + r] * cs - mc);
-  };
-  auto sum8 = [&](const float (&pv)[8]) { return ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7])); };
-  auto pack8p = [&](const float (&pv)[8]) {
-    U4 w;
-    w.x = cvt_pk_bf16(pv[0], pv[1]);
-    w.y = cvt_pk_bf16(pv[2], pv[3]);
-    w.z = cvt_pk_bf16(pv[4], pv[5]);
-    w.w = cvt_pk_bf16(pv[6], pv[7]);
-    return *reinterpret_cast<bf16x8_t*>(&w);
-  };
-  auto v_frag = [&](int stage, int kb, int db, int jj) {
-    const u16* vp = Vs + stage * TILE + (kb * 32 + jj * 16) * 64 + v_lane[db];
-    s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)vp);
-    s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vp + 8 * 64));
-    s16x8_t v01 = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-    return *reinterpret_cast<bf16x8_t*>(&v01);
-  };
-  auto compute_swp = [&](int t, f32x16_t (&sa)[2], f32x16_t (&sb)[2], float (&pc)[8]) {
-    const int kst = (t + 1) % RING, vst = t % RING;
-    float pa[8], pb[8], pn[8];
-    bf16x8_t f0lo = pack8p(pc), f0hi, f1lo, f1hi;
-    // QK0 (S(t+1) block 0)  ||  second half of block 0's exponentials
-    qk_block(kst, 0, sb[0]);
-    exp8(sa[0], 8, pa);
-    l_run += sum8(pc) + sum8(pa);
-    f0hi = pack8p(pa);
-    // QK1  ||  first half of block 1
-    qk_block(kst, 1, sb[1]);
-    exp8(sa[1], 0, pb);
-    f1lo = pack8p(pb);
-    // PV0  ||  second half of block 1
-    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_frag(vst, 0, 0, 0), f0lo, o[0], 0, 0, 0);
-    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_frag(vst, 0, 1, 0), f0lo, o[1], 0, 0, 0);
-    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_frag(vst, 0, 0, 1), f0hi, o[0], 0, 0, 0);
-    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_frag(vst, 0, 1, 1), f0hi, o[1], 0, 0, 0);
-    exp8(sa[1], 8, pa);
-    l_run += sum8(pb) + sum8(pa);
-    f1hi = pack8p(pa);
-    // PV1  ||  first half of the NEXT tile's block 0 (carried)
-    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_frag(vst, 1, 0, 0), f1lo, o[0], 0, 0, 0);
-    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_frag(vst, 1, 1, 0), f1lo, o[1], 0, 0, 0);
-    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_frag(vst, 1, 0, 1), f1hi, o[0], 0, 0, 0);
-    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_frag(vst, 1, 1, 1), f1hi, o[1], 0, 0, 0);
-    exp8(sb[0], 0, pn);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) pc[r] = pn[r];
-#if ATTN_SWP_SGB
-    // 16 x { 1 MFMA, 2 transcendentals, up to 3 other VALU (adds, packs), LDS reads }.  Fragment reads lead their MFMA by
-    // about three slots: four K fragments up front, then one read per QK^T slot and two per PV slot (a PV fragment is two
-    // transposing reads).
-    __builtin_amdgcn_sched_group_barrier(0x100, ATTN_SWP_LEAD, 0);
-#define DM4D_SGB_SLOT(NDS)                                                                                  \
-  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   /* MFMA */                                           \
-  __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);   /* TRANS */                                          \
-  __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   /* VALU */                                           \
-  __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0); /* DS read */
-    DM4D_SGB_SLOT(1) DM4D_SGB_SLOT(1) DM4D_SGB_SLOT(1) DM4D_SGB_SLOT(1) DM4D_SGB_SLOT(1) DM4D_SGB_SLOT(1) DM4D_SGB_SLOT(1) DM4D_SGB_SLOT(1)
-    DM4D_SGB_SLOT(2) DM4D_SGB_SLOT(2) DM4D_SGB_SLOT(2) DM4D_SGB_SLOT(2) DM4D_SGB_SLOT(2) DM4D_SGB_SLOT(2) DM4D_SGB_SLOT(2) DM4D_SGB_SLOT(2)
-#undef DM4D_SGB_SLOT
-#endif
-    asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(sb[0]), "v"(sb[1]));  // every MFMA of the step is issued before what follows
-  };
-  auto step_swp = [&](int t, f32x16_t (&sa)[2], f32x16_t (&sb)[2], float (&pc)[8]) {
-    issue_k(t + AHEAD + 1, (t + AHEAD + 1) % RING, false);
-    issue_v(t + AHEAD, (t + AHEAD) % RING, false);
-    compute_swp(t, sa, sb, pc);
-    dma_wait_barrier();
-  };
-#endif
   int t = 0;
   const int n_full = Lk / KV;
-  if (RING == 2) {
-    // main loop: every tile it loads (up to t + 3) is a full tile, so the uniform-base addressing applies
-#if ATTN_SWP
-    if (t + 3 < n_full) {
-      float pc[8];  // exponentials of S(t) block 0, first half: produced one step ahead (see compute_swp)
-      exp8(s_cur[0], 0, pc);
-      for (; t + 3 < n_full; t += 2) {
-        step_swp(t, s_cur, s_nxt, pc);
-        step_swp(t + 1, s_nxt, s_cur, pc);
-      }
-      // the carry of the first tile of the tail is dropped: the tail recomputes those eight exponentials
-    }
-#else
-    for (; t + 3 < n_full; t += 2) {  // two steps per trip: the S register sets swap roles instead of being copied
-      step(t, s_cur, s_nxt, false);
-      step(t + 1, s_nxt, s_cur, false);
-    }
-#endif
-  } else {
-    // tiles in pairs: the DMA of both steps (K(t+3), K(t+4), V(t+2), V(t+3)) goes out at the top, one barrier at the end;
-    // the four tiles land in the four stages that do not hold K(t+1), K(t+2) / V(t), V(t+1)
-    for (; t + 4 < n_full; t += 2) {
-      issue_k(t + 3, (t + 3) % RING, false);
-      issue_k(t + 4, (t + 4) % RING, false);
-      issue_v(t + 2, (t + 2) % RING, false);
-      issue_v(t + 3, (t + 3) % RING, false);
-      compute(t, s_cur, s_nxt);
-      compute(t + 1, s_nxt, s_cur);
-      dma_wait_barrier();
-    }
+  // main loop: every tile it loads (up to t + 3) is a full tile, so the uniform-base addressing applies
+  for (; t + 3 < n_full; t += 2) {  // two steps per trip: the S register sets swap roles instead of being copied
+    step(t, s_cur, s_nxt, false);
+    step(t + 1, s_nxt, s_cur, false);
   }
   for (; t < nt; ++t) {  // last tiles: clamped source rows, tail mask, no look-ahead on the final one
     if (t + 1 < nt) {
@@ -573,11 +435,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnParams p) {  // tw
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
   float l_tot = -1.f;
-#if ATTN_PRIO_YOUNG
-  // static priority for the second-dispatched half of the workgroup (the VALU-arbitration loser on every segment when two
-  // waves share a SIMD: MI355X_MICROARCH "two waves per SIMD", item 4); `wave` is an SGPR, so this is one scalar branch
-  if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
-#endif
   if (!p.exact_only) {
     kv_loop_pipelined<FOLD, NW>(p, Kb, Vb, smem, smem + RING * TILE, qf, o, m_run, l_run, lane, wave, l31, lh);
     l_tot = l_run + __shfl_xor(l_run, 32);
@@ -621,392 +478,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnParams p) {  // tw
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// Second form: QB = 2 query blocks (64 rows) per wave on FOUR waves per workgroup (256 rows, as before).  Every K and V
-// fragment read from the LDS feeds two MFMAs instead of one (half the LDS reads, DMA issues and barriers per MFMA), and
-// with more than 256 registers per lane a CU holds one workgroup = ONE wave per SIMD: on this chip a wave's VALU work hides
-// only in the shadow of its OWN MFMAs (tools/probes/issue_probe.hip), and two waves sharing a SIMD starve each other's
-// VALU issue.  Same arithmetic per query row as attn_kernel (same tile order, same k-slot order into every accumulator):
-// results are bit-identical.  Selected by dm4d_tune_set_attention_form(2).
-// ------------------------------------------------------------------------------------------------
-template <bool FOLD, int NW, int QB, int MODE>
-__device__ __forceinline__ void kv_loop_pipelined_qb(const AttnParams& p, const u16* Kb, const u16* Vb, u16* Ks, u16* Vs,
-                                                     const bf16x8_t (&qf)[QB][4], f32x16_t (&o)[QB][2], float (&m_run)[QB],
-                                                     float (&l_run)[QB], int lane, int wave, int l31, int lh) {
-  const int Lk = p.Lk;
-  const int nt = (Lk + KV - 1) / KV;
-  const float cs = FOLD ? 1.0f : p.c;
-  constexpr int PPW = 8 / NW;
-  const int d_row = wave * 8 + (lane >> 3), d_slot = lane & 7;
-  const int k_chunk = d_slot ^ ((d_row >> 1) & 7), v_chunk = d_slot ^ (((d_row >> 1) & 1) << 2);
-  const uint32_t koff = (uint32_t)d_row * (uint32_t)p.ldk + (uint32_t)k_chunk * 8u;
-  const uint32_t voff = (uint32_t)d_row * (uint32_t)p.ldv + (uint32_t)v_chunk * 8u;
-  const uint32_t k_dst = lds_addr(Ks) + wave * 1024, v_dst = lds_addr(Vs) + wave * 1024;
-  auto issue_k = [&](int t, int stage, bool clamp) {
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const int r0 = i * NW * 8;
-      if (clamp) {
-        int key = t * KV + d_row + r0;
-        key = key > Lk - 1 ? Lk - 1 : key;
-        dma16(Kb + (int64_t)key * p.ldk + k_chunk * 8, k_dst + stage * (TILE * 2) + r0 * 128);
-      } else {
-        dma16(Kb + ((int64_t)t * KV + r0) * p.ldk, koff * 2u, k_dst + stage * (TILE * 2) + r0 * 128);
-      }
-    }
-  };
-  auto issue_v = [&](int t, int stage, bool clamp) {
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const int r0 = i * NW * 8;
-      if (clamp) {
-        int key = t * KV + d_row + r0;
-        key = key > Lk - 1 ? Lk - 1 : key;
-        dma16(Vb + (int64_t)key * p.ldv + v_chunk * 8, v_dst + stage * (TILE * 2) + r0 * 128);
-      } else {
-        dma16(Vb + ((int64_t)t * KV + r0) * p.ldv, voff * 2u, v_dst + stage * (TILE * 2) + r0 * 128);
-      }
-    }
-  };
-  auto dma_wait_barrier = [&]() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  };
-  int k_lane[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) k_lane[j] = l31 * 64 + (((2 * j + lh) ^ ((l31 >> 1) & 7)) * 8);
-  int v_lane[2];
-#pragma unroll
-  for (int db = 0; db < 2; ++db)
-    v_lane[db] = (4 * lh + ((lane & 15) >> 2)) * 64 + ((4 * (db ^ ((lane >> 3) & 1)) + 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1)) * 8) +
-                 4 * (lane & 1);
-
-  f32x16_t negm[QB];
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) negm[qb][r] = 0.f;
-  // one 32-key block of S^T for every query block: each K fragment is read once and multiplied QB times
-  auto qk_block = [&](int stage, int kb, f32x16_t (&s)[QB][2]) {
-    if (!FOLD) {
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[qb][kb][r] = 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + stage * TILE + kb * 32 * 64 + k_lane[j]);
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb)
-        s[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][j], (FOLD && j == 0) ? negm[qb] : s[qb][kb], 0, 0, 0);
-    }
-  };
-  auto mask_tail = [&](int t, f32x16_t (&s)[QB][2]) {
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const int key0 = t * KV + kb * 32 + 4 * lh;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (key0 + (r & 3) + 8 * (r >> 2) >= Lk) s[qb][kb][r] = -1e30f;
-      }
-  };
-  float mc[QB];
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) mc[qb] = 0.f;
-  auto softmax_block = [&](const f32x16_t& s, bf16x8_t (&pf)[2], int qb) {
-    float pv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) pv[r] = FOLD ? __builtin_amdgcn_exp2f(s[r]) : __builtin_amdgcn_exp2f(s[r] * cs - mc[qb]);
-    float sum = pv[0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) sum += pv[r];
-    l_run[qb] += sum;
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-      U4 w;
-      w.x = cvt_pk_bf16(pv[jj * 8 + 0], pv[jj * 8 + 1]);
-      w.y = cvt_pk_bf16(pv[jj * 8 + 2], pv[jj * 8 + 3]);
-      w.z = cvt_pk_bf16(pv[jj * 8 + 4], pv[jj * 8 + 5]);
-      w.w = cvt_pk_bf16(pv[jj * 8 + 6], pv[jj * 8 + 7]);
-      pf[jj] = *reinterpret_cast<bf16x8_t*>(&w);
-    }
-  };
-  // O^T += V^T P^T for one 32-key block: each V fragment (two transposing reads) is read once and multiplied QB times
-  auto pv_block = [&](int stage, int kb, const bf16x8_t (&pf)[QB][2]) {
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const u16* vp = Vs + stage * TILE + (kb * 32 + jj * 16) * 64 + v_lane[db];
-        s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)vp);
-        s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vp + 8 * 64));
-        s16x8_t v01 = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-        bf16x8_t vf = *reinterpret_cast<bf16x8_t*>(&v01);
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][jj], o[qb][db], 0, 0, 0);
-      }
-  };
-
-  static_assert(RING == 2, "the second form is written for the two-stage rings");
-  issue_k(0, 0, true);
-  issue_v(0, 0, true);
-  issue_k(1, 1, true);
-  dma_wait_barrier();
-  // ONE set of score registers, used in place: block kb of S(t+1) is written into the registers block kb of S(t) was just
-  // read from (64 registers instead of the 128 of two sets; with 64 query rows per wave two sets do not fit beside O and Q
-  // in 256 VGPRs, and what overflows into AGPRs comes back as v_accvgpr moves -- VALU work -- on every step).
-  f32x16_t sc[QB][2];
-  qk_block(0, 0, sc);  // negm is still zero here
-  qk_block(0, 1, sc);
-  if (nt == 1 && (Lk % KV) != 0) mask_tail(0, sc);
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    float mx = fmaxf(sc[qb][0][0], sc[qb][1][0]);
-#pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sc[qb][0][r], sc[qb][1][r]));
-    m_run[qb] = fmaxf(mx, __shfl_xor(mx, 32));
-    mc[qb] = m_run[qb] * cs;
-    if (FOLD) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        negm[qb][r] = -m_run[qb];
-        sc[qb][0][r] -= m_run[qb];
-        sc[qb][1][r] -= m_run[qb];
-      }
-    }
-  }
-  __syncthreads();  // every wave has read K(0): step 0 overwrites its stage
-
-  // Software pipeline at block granularity.  Entering step t: pf0 = P(t) block 0 (packed), sc[.][1] = S(t) block 1,
-  // sc[.][0] free.  Each half of the step is 16 MFMAs (QK^T of S(t+1) into the freed registers, then PV of the block whose P
-  // is ready) followed in program order by the softmax of the OTHER block, which depends on none of them: 80 VALU
-  // instructions in the shadow of the wave's own 16 MFMAs.
-  //   QK(t+1).0  PV(t).0  || softmax S(t).1 -> pf1      QK(t+1).1  PV(t).1  || softmax S(t+1).0 -> pf0
-  bf16x8_t pf0[QB][2], pf1[QB][2];
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) softmax_block(sc[qb][0], pf0[qb], qb);
-  auto step = [&](int t, int kst, int vst, bool clamp, bool mask_next) {
-    issue_k(t + 2, kst ^ 1, clamp);  // K(t+2) over K(t), V(t+1) over V(t-1): both last read before the previous barrier
-    issue_v(t + 1, vst ^ 1, clamp);
-    qk_block(kst, 0, sc);
-    pv_block(vst, 0, pf0);
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) softmax_block(sc[qb][1], pf1[qb], qb);
-    qk_block(kst, 1, sc);
-    pv_block(vst, 1, pf1);
-    if (mask_next) mask_tail(t + 1, sc);
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) softmax_block(sc[qb][0], pf0[qb], qb);
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb)
-      asm volatile("" ::"v"(o[qb][0]), "v"(o[qb][1]), "v"(sc[qb][0]), "v"(sc[qb][1]));  // every MFMA of the step is issued before what follows
-    dma_wait_barrier();
-  };
-  // MODE >= 1: the same step with every fragment read written out ahead of its use -- the K / V fragments of block 0 at the
-  // top of the step, those of block 1 behind the MFMAs of block 0 -- in registers of their own (64 more; QB = 1 only).  Left to
-  // itself hipcc reads every fragment into ONE register quad right in front of its MFMA and waits for it (ds_read,
-  // s_waitcnt lgkmcnt(0), v_mfma, sixteen times per step).  MODE 2 adds scheduling directives: 12 reads up front, then
-  // sixteen slots of {1 MFMA, 2 transcendentals, 3 other VALU, reads of the next block}.
-  auto read_k = [&](int stage, int kb, bf16x8_t (&kf)[4]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) kf[j] = *reinterpret_cast<const bf16x8_t*>(Ks + stage * TILE + kb * 32 * 64 + k_lane[j]);
-  };
-  auto read_v = [&](int stage, int kb, bf16x8_t (&vf)[2][2]) {
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const u16* vp = Vs + stage * TILE + (kb * 32 + jj * 16) * 64 + v_lane[db];
-        s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)vp);
-        s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vp + 8 * 64));
-        s16x8_t v01 = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-        vf[db][jj] = *reinterpret_cast<bf16x8_t*>(&v01);
-      }
-  };
-  auto qk_mma = [&](int kb, const bf16x8_t (&kf)[4]) {
-    if (!FOLD) {
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sc[qb][kb][r] = 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb)
-        sc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[j], qf[qb][j], (FOLD && j == 0) ? negm[qb] : sc[qb][kb], 0, 0, 0);
-  };
-  auto pv_mma = [&](const bf16x8_t (&vf)[2][2], const bf16x8_t (&pf)[QB][2]) {
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][jj], pf[qb][jj], o[qb][db], 0, 0, 0);
-  };
-  auto step_pf = [&](int t, int kst, int vst, bool clamp, bool mask_next) {
-    issue_k(t + 2, kst ^ 1, clamp);
-    issue_v(t + 1, vst ^ 1, clamp);
-    bf16x8_t kfa[4], kfb[4], vfa[2][2], vfb[2][2];
-    read_k(kst, 0, kfa);
-    read_v(vst, 0, vfa);
-    qk_mma(0, kfa);
-    read_k(kst, 1, kfb);
-    pv_mma(vfa, pf0);
-    read_v(vst, 1, vfb);
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) softmax_block(sc[qb][1], pf1[qb], qb);
-    qk_mma(1, kfb);
-    pv_mma(vfb, pf1);
-    if (mask_next) mask_tail(t + 1, sc);
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) softmax_block(sc[qb][0], pf0[qb], qb);
-    if constexpr (MODE == 2) {
-      if (!mask_next) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
-#define DM4D_QB_SLOT(NDS)                                                   \
-  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   /* MFMA */           \
-  __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);   /* TRANS */          \
-  __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   /* VALU */           \
-  __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0); /* DS read */
-        DM4D_QB_SLOT(2) DM4D_QB_SLOT(2) DM4D_QB_SLOT(2) DM4D_QB_SLOT(2) DM4D_QB_SLOT(2) DM4D_QB_SLOT(2) DM4D_QB_SLOT(0) DM4D_QB_SLOT(0)
-        DM4D_QB_SLOT(0) DM4D_QB_SLOT(0) DM4D_QB_SLOT(0) DM4D_QB_SLOT(0) DM4D_QB_SLOT(0) DM4D_QB_SLOT(0) DM4D_QB_SLOT(0) DM4D_QB_SLOT(0)
-#undef DM4D_QB_SLOT
-      }
-    }
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb)
-      asm volatile("" ::"v"(o[qb][0]), "v"(o[qb][1]), "v"(sc[qb][0]), "v"(sc[qb][1]));
-    dma_wait_barrier();
-  };
-  int t = 0;
-  const int n_full = Lk / KV;
-  for (; t + 3 < n_full; t += 2) {  // t even: stage numbers are literals; every tile loaded here (up to t + 3) is full
-    if constexpr (MODE >= 1) {
-      step_pf(t, 1, 0, false, false);
-      step_pf(t + 1, 0, 1, false, false);
-    } else {
-      step(t, 1, 0, false, false);
-      step(t + 1, 0, 1, false, false);
-    }
-  }
-  for (; t + 1 < nt; ++t)  // last tiles: clamped source rows, tail mask on the final one
-    step(t, (t + 1) & 1, t & 1, true, (t + 2 == nt) && (Lk % KV) != 0);
-  // final tile: its block-0 P is in pf0, its block-1 scores in sc[.][1]
-  pv_block(t & 1, 0, pf0);
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) softmax_block(sc[qb][1], pf1[qb], qb);
-  pv_block(t & 1, 1, pf1);
-  __syncthreads();
-}
-
-template <bool FOLD, int NW, int QB, int MODE>
-__global__ __launch_bounds__(NW * 64, NW * QB == 8 && QB > 1 ? 1 : 2) void attn_qb_kernel(AttnParams p) {
-  static_assert(MODE == 0 || QB == 1, "fragment prefetch registers exist for one query block per wave only");
-  constexpr int SMEM_EXACT = 2 * KV * LDS_LD + 2 * KV * LDS_LDV, SMEM_RINGS = 2 * RING * TILE;  // u16 elements
-  __shared__ __attribute__((aligned(16))) u16 smem[SMEM_EXACT > SMEM_RINGS ? SMEM_EXACT : SMEM_RINGS];  // >= NW * 32 * LDS_LDO
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, lh = lane >> 5;
-  const int L = p.L, Lk = p.Lk;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int qt = lid % p.nqt, bh = lid / p.nqt;
-  const int head = bh % p.heads, batch = bh / p.heads;
-  const int q_tile0 = qt * (NW * QB * 32) + wave * (QB * 32);
-  const u16* Qb = p.Q + (int64_t)batch * L * p.ldq + head * 64;
-  const u16* Kb = p.K + (int64_t)batch * Lk * p.ldk + head * 64;
-  const u16* Vb = p.V + (int64_t)batch * Lk * p.ldv + head * 64;
-  u16* Ob = p.O + (int64_t)batch * L * p.ldo + head * 64;
-
-  bf16x8_t qf[QB][4];
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    int q = q_tile0 + qb * 32 + l31;
-    if (q > L - 1) q = L - 1;
-    const u16* qp = Qb + (int64_t)q * p.ldq + lh * 8;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      U4 v = ldg16(qp + j * 16);
-      qf[qb][j] = *reinterpret_cast<bf16x8_t*>(&v);
-    }
-  }
-  f32x16_t o[QB][2];
-  float m_run[QB], l_run[QB], l_tot[QB];
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    m_run[qb] = -1e30f;
-    l_run[qb] = 0.f;
-    l_tot[qb] = -1.f;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[qb][db][r] = 0.f;
-  }
-  if (!p.exact_only) {
-    kv_loop_pipelined_qb<FOLD, NW, QB, MODE>(p, Kb, Vb, smem, smem + RING * TILE, qf, o, m_run, l_run, lane, wave, l31, lh);
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) l_tot[qb] = l_run[qb] + __shfl_xor(l_run[qb], 32);
-  }
-  bool bad = false;
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) bad = bad || !(l_tot[qb] < 0x1p60f) || !(l_tot[qb] > 0x1p-100f);
-  // out of range or NaN: redo with the exact loop, one query block at a time (same per-row arithmetic as attn_kernel)
-  if (__syncthreads_or(bad)) {
-    u16* Ks = smem;
-    u16* Vs = smem + 2 * KV * LDS_LD;
-    const u16* v_lane = Vs + (4 * (lane >> 5) + ((lane & 15) >> 2)) * LDS_LDV + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-      m_run[qb] = -1e30f;
-      l_run[qb] = 0.f;
-#pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[qb][db][r] = 0.f;
-      kv_loop<true, FOLD, NW>(p, Kb, Vb, Ks, Vs, v_lane, qf[qb], o[qb], m_run[qb], l_run[qb], tid, l31, lh);
-      l_tot[qb] = l_run[qb] + __shfl_xor(l_run[qb], 32);
-    }
-  }
-  u16* Os = smem + wave * (32 * LDS_LDO);
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    const float inv = 1.0f / l_tot[qb];
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        uint2 w;
-        w.x = cvt_pk_bf16(o[qb][db][4 * g + 0] * inv, o[qb][db][4 * g + 1] * inv);
-        w.y = cvt_pk_bf16(o[qb][db][4 * g + 2] * inv, o[qb][db][4 * g + 3] * inv);
-        *reinterpret_cast<uint2*>(Os + l31 * LDS_LDO + db * 32 + 8 * g + 4 * lh) = w;
-      }
-    // the same wave reads back what it wrote (the LDS executes a wave's accesses in order): no barrier
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int row = 8 * k + (lane >> 3), ch = lane & 7;
-      const u32x4_t v = *reinterpret_cast<const u32x4_t*>(Os + row * LDS_LDO + ch * 8);
-      const int q = q_tile0 + qb * 32 + row;
-      if (q < L) *reinterpret_cast<u32x4_t*>(Ob + (int64_t)q * p.ldo + ch * 8) = v;
-    }
-  }
-}
-
-// Which kernel form runs (dm4d_tune_set_attention_form); all five produce the same bits.  1 (default) = attn_kernel (8 waves x 32
-// rows, two score register sets); 2 = attn_qb_kernel<4 waves, 2 query blocks> (one wave per SIMD); 3 / 4 / 5 =
-// attn_qb_kernel<8 waves, 1 block> as written / with the fragment reads written out ahead of their use / plus scheduling
-// directives (its step is exactly 12 reads, then 16 x {1 MFMA, 2 v_exp, 3 VALU, reads of the next block} with counted lgkmcnt).
-// Measured (profiles/r02_attn_forms.log): form 2 0.88-0.94x of form 1 (256 VGPRs + 41 AGPRs: no registers left to prefetch
-// fragments, every read is waited for in front of its MFMA); forms 3 and 5 0.98-1.01x from L = 2880 (20 heads) to L = 65536 and
-// +3..6 % on the per-frame attention of level 0 (L = 2880, 160 (batch, head) pairs) when the forms are timed in alternation
-// (+11..15 % when form 1 is simply timed first: the first configuration of a timing loop runs on a colder, slower-clocked chip);
-// inside a bench step the attention family takes 22.79 ms with form 1 and 22.79 ms with form 5 below 8192 keys.  So the
-// hand-shaped issue order reaches what hipcc's own interleave of form 1 reaches: the tile costs its MFMA cycles PLUS its VALU
-// cycles either way, and form 1 stays the default.
-int g_attn_form = 1;
 
 }  // namespace
 
@@ -1032,34 +503,9 @@ static int attention_launch(void* stream, const void* Q, const void* K, const vo
   if (nwg > 0x7fffffffL) return dm4d_set_error(DM4D_ERR_ARG, "attention: grid too large");
   const dim3 grid((unsigned)nwg), block(nw * 64);
   hipStream_t st = (hipStream_t)stream;
-  const int form = g_attn_form;
-  if (form == 2) {  // 4 waves x 64 rows: same 256-row tiles, same grid
-    if (q_scaled) hipLaunchKernelGGL((attn_qb_kernel<true, 4, 2, 0>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((attn_qb_kernel<false, 4, 2, 0>), grid, dim3(256), 0, st, p);
-    return dm4d_check_launch("attn_qb_kernel<4, 2>");
-  }
-  if (form >= 3) {  // 8 waves x 32 rows with the in-place score registers and the block-level pipeline of the second form
-    // 3: as written; 4: fragment reads written out ahead of their use; 5: 4 + scheduling directives
-#define DM4D_QB_LAUNCH(MODE)                                                                                     \
-  do {                                                                                                           \
-    if (q_scaled) hipLaunchKernelGGL((attn_qb_kernel<true, 8, 1, MODE>), grid, block, 0, st, p);                 \
-    else hipLaunchKernelGGL((attn_qb_kernel<false, 8, 1, MODE>), grid, block, 0, st, p);                         \
-  } while (0)
-    if (form == 3) DM4D_QB_LAUNCH(0);
-    else if (form == 4) DM4D_QB_LAUNCH(1);
-    else DM4D_QB_LAUNCH(2);
-#undef DM4D_QB_LAUNCH
-    return dm4d_check_launch("attn_qb_kernel<8, 1>");
-  }
   if (q_scaled) hipLaunchKernelGGL((attn_kernel<true, nw>), grid, block, 0, st, p);
   else hipLaunchKernelGGL((attn_kernel<false, nw>), grid, block, 0, st, p);
   return dm4d_check_launch("attn_kernel");
-}
-
-extern "C" int dm4d_tune_set_attention_form(int form) {
-  if (form < 1 || form > 5) return dm4d_set_error(DM4D_ERR_ARG, "attention form must be 1 .. 5");
-  g_attn_form = form;
-  return DM4D_OK;
 }
 
 extern "C" int dm4d_attention_kv_bf16(void* stream, const void* Q, const void* K, const void* V, void* O, int64_t ldq,

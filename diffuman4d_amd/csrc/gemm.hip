@@ -17,16 +17,16 @@
 //    chunk pos ^ ((row >> 1) & 7) of that row, and fragment reads apply the same XOR -- conflict-free
 //    ds_read_b128 for every 16-lane group.  Convolution padding / stride / upsample only change the
 //    per-lane source address (out-of-image taps read a 16-byte zero page).
-//  * conv_strip_kernel (stride-1 convs): same staging, but the A operand is loaded once per kernel row
-//    and read at three row offsets for kx = 0,1,2 (see the comment at the kernel).
+//  * conv_strip2_kernel (stride-1 convs): same staging, but the A operand is loaded once per kernel row
+//    and read at three row offsets for kx = 0,1,2 (see the comment at the kernel); KT = 2 = one phase of the
+//    x2-upsampling convolution.
 //  * gemm_kernel_pipe (K-slab 32, 3-4 LDS stages, counted vmcnt + raw s_barrier, 4 or 8 waves): the
 //    Linear layers, whose short K leaves the two-stage loop latency-bound.
 //  * gemm_kernel (fallback, K-slab 32, register staged, padded LDS rows): shapes whose K (or conv
 //    Cin) is a multiple of 32 but not of 64.
 //
-//  * gemm_lin2_kernel (Linear layers, second form: uniform-base DMA, scheduled fragment reads; 256x128 on the 74 KB
-//    geometry for short K, 256x256 / 128x128 / 256x320 tiles for the wide, deep and N = 320 layers) and
-//    conv_strip2_kernel (the strip convolution in the same form; KT = 2 = one phase of the x2-upsampling convolution).
+//  * gemm_lin2_kernel (Linear layers: uniform-base DMA, scheduled fragment reads; 256x128 on the 74 KB geometry for
+//    short K, 256x256 / 128x128 / 256x320 tiles for the wide, deep and N = 320 layers).
 //
 // Every MFMA takes its operands swapped (weights as A, activations as B), so a lane holds one output ROW and runs of four
 // consecutive columns (mfma_t below).  The bias enters as the first k step of the product (acc_init); GEGLU / SiLU are
@@ -38,36 +38,10 @@
 #include <stdlib.h>
 #include <type_traits>
 
-// Epilogue read-back loop with shift / 32-bit-offset index arithmetic (see gemm_epilogue); 0 = the generic loop only.
-// Same floating-point operations in the same order, so results are bit-identical either way (tools/dev/fe_check.py).
-// (The compile-time staging stride that used to be GEMM_FAST_EPI=2 is now part of the MODE-specialised epilogue.)
-#ifndef GEMM_FAST_EPI
-#define GEMM_FAST_EPI 1
-#endif
-// Ablation builds for profiling only (tools/dev/build_variant.sh ... -DGEMM_ABLATE=n; results are WRONG by construction):
-// 1 = no global stores in the epilogue, 2 = no epilogue at all, 3 = gemm_kernel_pipe without its in-loop DMA (MFMA + LDS
-// reads + barriers only), 4 = gemm_kernel_pipe without its MFMAs (DMA + LDS reads + barriers only).
-#ifndef GEMM_ABLATE
-#define GEMM_ABLATE 0
-#endif
-// Read-back of residual / row-bias layers: 1 = blocks entirely inside the matrix take a branch-free path that issues the
-// global loads of two tasks together (same arithmetic, same order)
-#ifndef GEMM_EPI_STRAIGHT
-#define GEMM_EPI_STRAIGHT 1
-#endif
-// conv_strip2_kernel: 1 = sched_group_barrier directives put the fragment reads of k step s+1 behind the MFMAs of step s
-#ifndef STRIP2_SCHED
-#define STRIP2_SCHED 1
-#endif
-// GEGLU gate activation: 1 = gelu_erf_f (the reference's function to 1.5e-7), 0 = gelu_fit_f (2.6e-5 from it, half the
-// instructions).  Measured in one call (profiles/r02_geglu_gelu_ab.log): the fit takes 1.2 % off the Linear family and
-// 0.35 % off a bench step -- not worth a second definition of GELU, so the erf form stays.
-#ifndef GEGLU_ERF
-#define GEGLU_ERF 1
-#endif
-#ifndef STRIP2_NOWAIT
-#define STRIP2_NOWAIT 0
-#endif
+// Build switches that rounds 1-2 used for A/B and ablation runs (GEMM_FAST_EPI, GEMM_EPI_STRAIGHT, STRIP2_SCHED, GEGLU_ERF, GEMM_ABLATE,
+// STRIP2_NOWAIT) are resolved to the shipped values: shift / 32-bit-offset index arithmetic in the epilogue read-back loop, the
+// branch-free read-back of residual / row-bias blocks, sched_group_barrier placement of the fragment reads in the strip and
+// second-form loops, the erf form of GELU in the GEGLU epilogue (DESIGN.md section 4 has the measurements).
 
 namespace {
 
@@ -149,11 +123,7 @@ __device__ __forceinline__ void stage_block(const f32x16_t (&a)[NI], void* srow)
         const int r = 4 * q + e;
         v[e] = a[J0 + j][r];
         if constexpr (geglu) {
-#if GEGLU_ERF
           v[e] = v[e] * gelu_erf_f(a[J0 + j + NI / 2][r]);
-#else
-          v[e] = v[e] * gelu_fit_f(a[J0 + j + NI / 2][r]);
-#endif
         }
         if constexpr (MODE == 1) v[e] = silu_f(v[e]);
       }
@@ -236,14 +206,10 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t
   constexpr bool CPR_POW2 = (CPR & (CPR - 1)) == 0;
   constexpr int cshift = CPR >= 16 ? 4 : (CPR >= 8 ? 3 : (CPR >= 4 ? 2 : (CPR >= 2 ? 1 : 0)));
   constexpr int cmask = CPR - 1;
-#if GEMM_FAST_EPI
   const bool fast_ok = CPR_POW2 && vec_ok && p.ldc < (1 << 24) && (!p.res || p.ld_res < (1 << 24)) &&
                        (!p.rowbias || p.rows_per_rb > 0) && !f32out && p.up_w == 0;
   // nothing is applied after the staging: round to bf16 first, stage packed halfwords, copy rows out
-  const bool plain = fast_ok && !p.res && !p.rowbias && p.out_scale == 1.0f && GEMM_ABLATE == 0;
-#else
-  const bool fast_ok = false, plain = false;
-#endif
+  const bool plain = fast_ok && !p.res && !p.rowbias && p.out_scale == 1.0f;
   // The staging area is private to a wave and LDS operations of one wave complete in program order, so only one
   // workgroup barrier is needed: the one that retires every wave's main-loop fragment reads before the area is reused
   // (SYNC: the first column group of the tile issues it).
@@ -297,7 +263,6 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t
     stage_block<NI, MODE, J0, JN, false>(acc[i], srow);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // compiler: keep the staging stores ahead of the row reads
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#if GEMM_FAST_EPI
     if (fast_ok) {
       // 32-bit offsets from wave-uniform row-block bases, and the rowbias row (m / rows_per_rb) from one division per
       // 32-row block: rows of a block are consecutive, so row r lies in image q0 + (r0 + r >= rows_per_rb).
@@ -308,7 +273,7 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t
         q0 = m_base / p.rows_per_rb;
         r0 = m_base - q0 * p.rows_per_rb;
       }
-      if (STRAIGHT && GEMM_ABLATE == 0 && TASKS % 64 == 0 && m_base + 32 <= p.M && ncol0 + TNO <= p.N &&
+      if (STRAIGHT && TASKS % 64 == 0 && m_base + 32 <= p.M && ncol0 + TNO <= p.N &&
           (!p.rowbias || p.rows_per_rb >= 32)) {
         // block entirely inside the matrix (wave-uniform): straight-line code -- the residual / row-bias loads of all of a
         // lane's tasks are issued together and ahead of the staging read-back instead of one load-wait-store chain per task
@@ -403,20 +368,12 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
         }
-#if GEMM_ABLATE == 1
-        {
-          U4 pk = pack8(v);
-          if (pk.x == 0x12345678u && pk.y == 0x9abcdef0u && pk.z == pk.w) c_base[0] = 0;
-        }
-#else
         stg16(c_base + (uint32_t)(row * (int)p.ldc + cc * 8), pack8(v));
-#endif
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // ... and the row reads ahead of the next block's stores
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       continue;  // next 32-row block of this wave
     }
-#endif
     for (int id = lane; id < TASKS; id += 64) {
       int row = id / CPR, cc = id % CPR;
       int m = m_base + row;
@@ -493,22 +450,12 @@ template <int NW, int MI, int NI, int SMEM>
 struct EpiBudget {
   // not for 16-wave workgroups (128 registers per lane), for the wide 64x160 wave tiles (their 160 accumulators fill the
   // register file), or for the 8-wave tiles of <= 80 KB that rely on a second resident workgroup (128 registers again)
-  static constexpr bool STRAIGHT = GEMM_EPI_STRAIGHT && NW <= 8 && MI * NI <= 8 && !(NW == 8 && SMEM <= 80 * 1024);
+  static constexpr bool STRAIGHT = NW <= 8 && MI * NI <= 8 && !(NW == 8 && SMEM <= 80 * 1024);
 };
 
 template <int MI, int NI, int TM, int TN, bool STRAIGHT = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[MI][NI], float* smem_f, int m0, int n0,
                                               int wm, int wn, int wave, int lane) {
-#if GEMM_ABLATE == 2
-  float keep = 0.f;  // keep the accumulators (and with them the main loop) alive without an epilogue
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) keep += acc[i][j][r];
-  if (p.out_scale == 12345.678f) p.C[lane] = f2bf(keep);
-#else
   // wave-uniform dispatch; GEGLU pairs hidden block j with gate block j + NI/2 inside the wave, so it needs an even NI
   if constexpr (NI >= 2 && NI % 2 == 0) {
     if (p.flags & DM4D_EPI_GEGLU) {
@@ -518,7 +465,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
   }
   if (p.flags & DM4D_EPI_SILU) gemm_epilogue_mode<MI, NI, TM, TN, 1, STRAIGHT>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
   else gemm_epilogue_mode<MI, NI, TM, TN, 0, STRAIGHT>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -667,7 +613,7 @@ __global__ __launch_bounds__(256) void gemm_kernel_glds(GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// stride-1 3x3 convolution with horizontal tap reuse ("strip" kernel)
+// stride-1 3x3 convolution with horizontal tap reuse ("strip" tiling; the kernel is conv_strip2_kernel below)
 //
 // The M tile is BM consecutive output pixels of the flattened (b, y, x) index.  For one kernel row ky the three
 // taps kx = 0,1,2 read the SAME input pixels shifted by one flat position, so the A operand is staged once per
@@ -679,176 +625,10 @@ __global__ __launch_bounds__(256) void gemm_kernel_glds(GemmParams p) {
 // select per fragment row and tap; masking the fragment registers instead costs 32 VALU instructions per 16 MFMAs,
 // and VALU work is not hidden behind other waves' MFMAs on this chip).  K order is (ky, ci-slab, kx).
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM* WN * 64) void conv_strip_kernel(GemmParams p) {
-  constexpr int BK = 64;
-  constexpr int NW = WM * WN;
-  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
-  constexpr int SR = BM + 8;  // strip rows held in LDS (BM + 2 needed, DMA granularity is 8 rows)
-  constexpr int NA = SR / 8;  // 1-KiB DMA instructions per strip
-  constexpr int AW = (NA + NW - 1) / NW, BW = BN / (8 * NW);
-  constexpr int SMEM_MAIN = 2 * (SR + BN) * BK * 2 + BK * 2;  // + one zero row
-  constexpr int SMEM_EPI = NW * 32 * (EpiGeom<TN>::EPW + 4) * 4;
-  constexpr int SMEM_BYTES = SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI;
-  __shared__ __attribute__((aligned(16))) u16 smem[SMEM_BYTES / 2];
-  u16* As = smem;                       // [2][SR][64]
-  u16* Bs = smem + 2 * SR * BK;         // [2][BN][64]
-  u16* Zs = smem + 2 * (SR + BN) * BK;  // [64] zeros: the A "row" of taps that fall off the left / right image edge
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const int l31 = lane & 31, lh = lane >> 5;
-  // split s of 3 handles kernel row ky = s only.  Column-major tile order for split launches: they exist for
-  // weight-dominated shapes (B*45 output rows against 30-60 MB of weights), where an XCD should see few weight columns.
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  int split = 0, tm, tn;
-  if (p.splits > 1) {
-    const int rows = gridDim.x / p.tiles_n;  // tile rows x splits
-    const int tms = lid % rows;
-    tn = lid / rows;
-    split = tms / (rows / p.splits);
-    tm = tms % (rows / p.splits);
-  } else {
-    tn = lid % p.tiles_n;
-    tm = lid / p.tiles_n;
-  }
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int d_row = lane >> 3, d_pos = lane & 7;
-  if (tid < 8) *reinterpret_cast<U4*>(Zs + tid * 8) = U4{0u, 0u, 0u, 0u};  // visible after the first barrier
-
-  int a_off[AW];
-  unsigned a_ok[AW];  // bit ky: the strip row is inside the image for kernel row ky
-#pragma unroll
-  for (int i = 0; i < AW; ++i) {
-    const int row = (wave + NW * i) * 8 + d_row;
-    const int chunk = d_pos ^ ((row >> 1) & 7);
-    const int mc = m0 - 1 + row;  // centre output pixel served by this strip row
-    const bool inr = mc >= 0 && mc < p.M;
-    const int mcl = mc < 0 ? 0 : (mc > p.M - 1 ? p.M - 1 : mc);
-    const int y = (mcl / p.W) % p.H;
-    a_off[i] = mcl * p.Cin + chunk * 8;
-    a_ok[i] = inr ? ((y >= 1 ? 1u : 0u) | 2u | (y <= p.H - 2 ? 4u : 0u)) : 0u;
-  }
-  const u16* w_src[BW];
-#pragma unroll
-  for (int i = 0; i < BW; ++i) {
-    const int row = (wave + NW * i) * 8 + d_row;
-    const int chunk = d_pos ^ ((row >> 1) & 7);
-    int n = n0 + row;
-    if (n > p.N - 1) n = p.N - 1;
-    w_src[i] = p.Wt + (int64_t)n * p.ldw + chunk * 8;
-  }
-  bool x_first[MI], x_last[MI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int x = (m0 + wm * TM + i * 32 + l31) % p.W;
-    x_first[i] = x == 0;
-    x_last[i] = x == p.W - 1;
-  }
-
-  f32x16_t acc[MI][NI];
-  acc_init<MI, NI, TN>(p, acc, n0, wn, lane, false);
-
-  const int nci = p.Cin / BK;
-  const int nstrips = (p.splits > 1 ? 1 : 3) * nci, nsteps = 3 * nstrips;
-  int i_ky = p.splits > 1 ? split : 0, i_cs = 0, i_kx = 0, i_step = 0, i_strip = 0;  // next step to be issued
-
-  typedef const __attribute__((address_space(1))) void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  auto issue_step = [&]() {
-    if (i_kx == 0) {
-      const int abuf = i_strip & 1;
-      const int dky = (i_ky - 1) * p.W * p.Cin + i_cs * BK;
-#pragma unroll
-      for (int i = 0; i < AW; ++i) {
-        const int ia = wave + NW * i;
-        if (ia < NA) {
-          const u16* src = ((a_ok[i] >> i_ky) & 1u) ? p.A + (a_off[i] + dky) : reinterpret_cast<const u16*>(g_zero16);
-          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (abuf * SR + ia * 8) * BK), 16, 0, 0);
-        }
-      }
-    }
-    const int bbuf = i_step & 1;
-    const int koff = (i_ky * 3 + i_kx) * p.Cin + i_cs * BK;
-#pragma unroll
-    for (int i = 0; i < BW; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + koff), (lptr_t)(Bs + (bbuf * BN + (wave + NW * i) * 8) * BK), 16, 0, 0);
-    ++i_step;
-    if (++i_kx == 3) {
-      i_kx = 0;
-      ++i_strip;
-      if (++i_cs == nci) {
-        i_cs = 0;
-        ++i_ky;
-      }
-    }
-  };
-
-  const int swb = (l31 >> 1) & 7;
-  issue_step();
-  __syncthreads();
-  for (int g = 0; g < nstrips; ++g) {
-    const int abuf = g & 1;
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const int bbuf = (g + kx) & 1;  // == (3 g + kx) & 1
-#if GEMM_ABLATE != 3
-      if (g * 3 + kx + 1 < nsteps) issue_step();
-#endif
-      const int swa = ((l31 + kx) >> 1) & 7;
-      bf16x8_t af[2][MI], bfr[2][NI];
-      const u16* arow[MI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        arow[i] = As + (abuf * SR + wm * TM + i * 32 + l31 + kx) * BK;
-        if (kx == 0 && x_first[i]) arow[i] = Zs;
-        if (kx == 2 && x_last[i]) arow[i] = Zs;
-      }
-      auto read_frags = [&](int ks, int slot) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-          af[slot][i] = *reinterpret_cast<const bf16x8_t*>(arow[i] + ((ks * 2 + lh) ^ swa) * 8);
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-          bfr[slot][j] =
-              *reinterpret_cast<const bf16x8_t*>(Bs + (bbuf * BN + wn * TN + j * 32 + l31) * BK + ((ks * 2 + lh) ^ swb) * 8);
-      };
-      read_frags(0, 0);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if (ks + 1 < 4) read_frags(ks + 1, (ks + 1) & 1);
-#if GEMM_ABLATE == 4
-#pragma unroll
-        for (int i = 0; i < MI; ++i) acc[i][0][0] += (float)af[ks & 1][i][0];
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[0][j][1] += (float)bfr[ks & 1][j][0];
-#else
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NI; ++j)
-            acc[i][j] = mfma_t(af[ks & 1][i], bfr[ks & 1][j], acc[i][j]);
-#endif
-      }
-      __syncthreads();
-    }
-  }
-  if (p.splits > 1) {
-    // raw fp32 partial sums (splitk_reduce_kernel adds the splits in a fixed order and applies the real epilogue): the
-    // same staged, row-coalesced write-out with the workspace slice as an fp32 output matrix and nothing else applied
-    p.C = reinterpret_cast<u16*>(p.ws + (int64_t)split * p.M * p.N);
-    p.ldc = p.N;
-    p.flags = DM4D_EPI_F32OUT;
-    p.bias = p.rowbias = p.res = nullptr;
-    p.out_scale = 1.0f;
-  }
-  gemm_epilogue<MI, NI, TM, TN, EpiBudget<WM * WN, MI, NI, SMEM_BYTES>::STRAIGHT>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
-}
-
 // ------------------------------------------------------------------------------------------------
-// Strip convolution, second form: the SAME tiling, LDS layout, K order and MFMA accumulation order as conv_strip_kernel
-// (results are bit-identical), with a main loop that issues nothing but MFMAs, LDS reads, DMA instructions and scalar
+// Strip convolution kernel.  (Round 1 shipped this tiling as conv_strip_kernel; this form keeps its LDS layout, K order and MFMA
+// accumulation order -- results were bit-identical over every shape, tools/dev/strip_ab.py in the round-2 tree -- and replaced it.)
+// A main loop that issues nothing but MFMAs, LDS reads, DMA instructions and scalar
 // bookkeeping.  The ISA of conv_strip_kernel<256,128,4,2> spends about six VALU instructions per MFMA in its loop:
 // 64-bit source pointers rebuilt per DMA instruction (plus a select against a zero page for rows outside the image and a
 // PC-relative address of that page), fragment addresses rebuilt per read (swizzle XOR, buffer parity, edge selects); and
@@ -1042,11 +822,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip2_kernel(GemmParams p_i
   auto dma_wait_barrier = [&]() {
     // lgkmcnt: the fragment reads of this step must have executed before any wave's next DMA (or the epilogue's staging
     // stores) may overwrite the buffers they read
-#if !STRIP2_NOWAIT  // profiling only: without the wait results are WRONG; bounds what hiding the DMA latency could buy
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#else
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
@@ -1083,13 +859,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip2_kernel(GemmParams p_i
           for (int j = 0; j < NI; ++j)
             acc[i][j] = mfma_t(af[ks & 1][i], bfr[ks & 1][j], acc[i][j]);
       }
-#if STRIP2_SCHED
       __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);  // fragments of k step 0
       sched_mfma_with_reads<MI * NI, MI + NI>();
       sched_mfma_with_reads<MI * NI, MI + NI>();
       sched_mfma_with_reads<MI * NI, MI + NI>();
       sched_mfma_with_reads<MI * NI, 0>();
-#endif
     } else {
       bf16x8_t af[MI], bfr[NI];
 #pragma unroll
@@ -1108,13 +882,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip2_kernel(GemmParams p_i
               if (i == MI - 1) bfr[j] = read_b(ks + 1, j);
             }
           }
-#if STRIP2_SCHED
       __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
       sched_mfma_reload<MI, NI, true>();
       sched_mfma_reload<MI, NI, true>();
       sched_mfma_reload<MI, NI, true>();
       sched_mfma_reload<MI, NI, false>();
-#endif
     }
   };
   // weights of (ky, cs, kx): Wt + (ky * KT + kx) * Cin + cs * 64; strip of (ky, cs): A + cs * 64 (+ a_voff of ky)
@@ -1304,9 +1076,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_pipe(GemmParams p) {
     }
     __builtin_amdgcn_s_barrier();  // every wave's part of slab kt is in LDS; everyone is done reading slab kt-1
     asm volatile("" ::: "memory");
-#if GEMM_ABLATE != 3
     if (kt + NST - 1 < nk) issue_slab(kt + NST - 1, st_issue);  // overwrites the stage slab kt-1 lived in
-#endif
     const u16* As = smem + st * STAGE;
     const u16* Bs = As + BM * BK;
 #pragma unroll
@@ -1317,17 +1087,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_pipe(GemmParams p) {
       for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(As + (wm * TM + i * 32 + l31) * BK + pos);
 #pragma unroll
       for (int j = 0; j < NI; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(Bs + (wn * TN + j * 32 + l31) * BK + pos);
-#if GEMM_ABLATE == 4
-#pragma unroll
-      for (int i = 0; i < MI; ++i) acc[i][0][0] += (float)af[i][0];
-#pragma unroll
-      for (int j = 0; j < NI; ++j) acc[0][j][1] += (float)bfr[j][0];
-#else
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = mfma_t(af[i], bfr[j], acc[i][j]);
-#endif
     }
     st = (st + 1 == NST) ? 0 : st + 1;
     st_issue = (st_issue + 1 == NST) ? 0 : st_issue + 1;
@@ -1450,7 +1213,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_lin2_kernel(GemmParams p) {
           for (int j = 0; j < NI; ++j)
             acc[i][j] = mfma_t(af[ks & 1][i], bfr[ks & 1][j], acc[i][j]);
       }
-#if STRIP2_SCHED
       __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
       sched_mfma_with_reads<MI * NI, MI + NI>();
       if constexpr (KS == 4) {
@@ -1458,7 +1220,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_lin2_kernel(GemmParams p) {
         sched_mfma_with_reads<MI * NI, MI + NI>();
       }
       sched_mfma_with_reads<MI * NI, 0>();
-#endif
     } else {
       bf16x8_t af[MI], bfr[NI];
 #pragma unroll
@@ -1477,7 +1238,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_lin2_kernel(GemmParams p) {
               if (i == MI - 1) bfr[j] = read_b(ks + 1, j);
             }
           }
-#if STRIP2_SCHED
       __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
       sched_mfma_reload<MI, NI, true>();
       if constexpr (KS == 4) {
@@ -1485,7 +1245,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_lin2_kernel(GemmParams p) {
         sched_mfma_reload<MI, NI, true>();
       }
       sched_mfma_reload<MI, NI, false>();
-#endif
     }
   };
 
@@ -1725,27 +1484,14 @@ __host__ inline bool strip_split_ok(const GemmParams& p) {
          (!p.rowbias || (p.ld_rb & 7) == 0) && p.flags == 0;
 }
 
-template <int BM, int BN, int WM, int WN>
-int launch_strip(hipStream_t st, GemmParams& p) {
-  const int tiles_m = (p.M + BM - 1) / BM;
-  p.tiles_n = (p.N + BN - 1) / BN;
-  if (p.splits < 1) p.splits = 1;
-  hipLaunchKernelGGL((conv_strip_kernel<BM, BN, WM, WN>), dim3(tiles_m * p.tiles_n * p.splits), dim3(WM * WN * 64), 0, st, p);
-  int rc = dm4d_check_launch("conv_strip_kernel");
-  if (rc || p.splits == 1) return rc;
-  const int64_t nthreads = (int64_t)p.M * (p.N / 8);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, p);
-  return dm4d_check_launch("splitk_reduce_kernel");
-}
-
-// the second form addresses A and W with 32-bit byte offsets from a uniform base
+// the strip kernel addresses A and W with 32-bit byte offsets from a uniform base
 __host__ inline bool strip2_ok(const GemmParams& p) {
   return (uint64_t)p.M * (uint64_t)p.Cin * 2u < (1ull << 32) && (uint64_t)p.N * (uint64_t)p.ldw * 2u < (1ull << 32);
 }
 
 template <int BM, int BN, int WM, int WN>
 int launch_strip2(hipStream_t st, GemmParams& p) {
-  if (!strip2_ok(p)) return launch_strip<BM, BN, WM, WN>(st, p);
+  if (!strip2_ok(p)) return DM4D_ERR_ARG;  // 4 GiB or more of input or weights: the gather kernels take such a launch
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   if (p.splits < 1) p.splits = 1;
@@ -1788,7 +1534,6 @@ __global__ __launch_bounds__(256) void up2x_prepare_kernel(const u16* W, u16* Wp
   Wp[id] = f2bf(acc);
 }
 
-int g_strip_form = 2;  // 2 = conv_strip2_kernel serves ids 31-35 (bit-identical results), 1 = conv_strip_kernel (tuning hook)
 int g_tune_cfg = 0;  // 0 = heuristic; otherwise a kernel-configuration id (tuning hook, dm4d_tune_set_gemm_config)
 
 // Kernel configurations.  glds: K-slab 64, 2 LDS stages, 4 waves.  pipe: K-slab 32, 3-4 stages, 4 or 8 waves.
@@ -1796,64 +1541,40 @@ template <bool CONV>
 int launch_by_id(int id, hipStream_t st, GemmParams& p) {
   const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
   const bool k64 = CONV ? (p.Cin % 64 == 0) : (p.K % 64 == 0 && (!p.A2 || p.K1 % 64 == 0));
-  if (id >= 1 && id <= 5 && !k64) return DM4D_ERR_ARG;
-  if (id >= 31 && id <= 35 && g_strip_form == 2) id += 20;
+  if (id >= 1 && id <= 4 && !k64) return DM4D_ERR_ARG;
   switch (id) {
     case 1: return launch_cfg<128, 128, 2, 2, CONV, true>(st, p);
     case 2: return launch_cfg<256, 64, 4, 1, CONV, true>(st, p);
     case 3: return launch_cfg<128, 64, 4, 1, CONV, true>(st, p);
     case 4: return geglu ? DM4D_ERR_ARG : launch_cfg<64, 64, 2, 2, CONV, true>(st, p);
-    case 5: return launch_cfg<256, 128, 2, 2, CONV, true>(st, p);
-    case 11: return launch_pipe<128, 128, 2, 2, 4, CONV>(st, p);
-    case 12: return launch_pipe<256, 128, 4, 2, 4, CONV>(st, p);
     case 13: return launch_pipe<256, 256, 2, 4, 4, CONV>(st, p);
     case 14: return launch_pipe<256, 128, 4, 2, 3, CONV>(st, p);
-    case 15: return launch_pipe<128, 128, 2, 2, 3, CONV>(st, p);
-    case 16: return launch_pipe<256, 256, 2, 4, 3, CONV>(st, p);
-    case 17: return launch_pipe<256, 64, 4, 1, 4, CONV>(st, p);
-    case 18: return launch_pipe<128, 64, 4, 1, 4, CONV>(st, p);
     // 16 waves (one 1024-thread workgroup per CU, four waves per SIMD like two 8-wave workgroups) on a 256x256 tile: the
-    // per-wave work of id 14 (64x64) with 2/3 of its L2->LDS bytes per flop -- these kernels run at the CU's fill rate
-    case 19: return launch_pipe<256, 256, 4, 4, 3, CONV>(st, p);
+    // per-wave work of id 14 (64x64) with 2/3 of its L2->LDS bytes per flop
     case 20: return launch_pipe<256, 256, 4, 4, 4, CONV>(st, p);
-    // K-slab 64 (whole 128-byte lines per DMA row) on the counted-vmcnt pipeline; need K (conv: Cin) % 64 == 0
-    case 41: return k64 ? launch_pipe<256, 128, 4, 2, 2, CONV, 64>(st, p) : DM4D_ERR_ARG;  // 98 KB, 1 workgroup / CU
-    case 42: return k64 ? launch_pipe<128, 128, 4, 2, 2, CONV, 64>(st, p) : DM4D_ERR_ARG;  // 64 KB, 2 workgroups / CU
-    case 43: return k64 ? launch_pipe<128, 128, 4, 2, 3, CONV, 64>(st, p) : DM4D_ERR_ARG;  // 96 KB, 1 workgroup / CU
-    case 44: return k64 ? launch_pipe<256, 128, 4, 2, 3, CONV, 64>(st, p) : DM4D_ERR_ARG;  // 144 KB, 1 workgroup / CU
-    case 45: return k64 ? launch_pipe<256, 64, 8, 1, 3, CONV, 64>(st, p) : DM4D_ERR_ARG;   // 120 KB
     // 320-wide tile (see id 35), K-slab 64, 2 stages = 144 KB; per-wave tile 64 x 160 = 5 column blocks: no GEGLU pairing
     case 46: return (k64 && !geglu) ? launch_pipe<256, 320, 4, 2, 2, CONV, 64>(st, p) : DM4D_ERR_ARG;
-    case 31: case 32: case 33: case 34: case 35: case 51: case 52: case 53: case 54: case 55:
+    // stride-1 3x3 convolutions on the strip kernel (same K order on every tile, so the choice never changes a result)
+    case 31: case 32: case 33: case 34: case 35:
       if constexpr (CONV) {
         if (!(k64 && p.stride == 1 && p.pad == 1 && !p.upsample && p.Ho == p.H && p.Wo == p.W)) return DM4D_ERR_ARG;
-        // 51-55: the VALU-free main loop (conv_strip2_kernel) on the tiles of 31-35; bit-identical results
-        if (id == 51) return launch_strip2<128, 128, 2, 2>(st, p);
-        if (id == 52) return launch_strip2<256, 128, 4, 2>(st, p);
-        if (id == 53) return launch_strip2<128, 64, 4, 1>(st, p);
-        if (id == 54) return launch_strip2<256, 256, 2, 4>(st, p);
-        if (id == 55) return launch_strip2<256, 320, 4, 2>(st, p);
-        if (id == 31) return launch_strip<128, 128, 2, 2>(st, p);
-        if (id == 32) return launch_strip<256, 128, 4, 2>(st, p);
-        if (id == 33) return launch_strip<128, 64, 4, 1>(st, p);
+        if (id == 31) return launch_strip2<128, 128, 2, 2>(st, p);
+        if (id == 32) return launch_strip2<256, 128, 4, 2>(st, p);
+        if (id == 33) return launch_strip2<128, 64, 4, 1>(st, p);
         // every channel count of an SD-class UNet is a multiple of 320: a 320-wide tile reads the A strip once per
         // kernel row for N = 320 (level 0) and feeds 40 MFMAs per wave between two barriers
-        if (id == 35) return launch_strip<256, 320, 4, 2>(st, p);
-        return launch_strip<256, 256, 2, 4>(st, p);
+        if (id == 35) return launch_strip2<256, 320, 4, 2>(st, p);
+        return launch_strip2<256, 256, 2, 4>(st, p);
       } else {
         return DM4D_ERR_ARG;
       }
-    // Linear layers, second form (gemm_lin2_kernel): 61 = the tile of 14 / 41 (256x128, 8 waves, 3 stages), 62 = the tile
-    // of 46 (256x320, 2 stages, no GEGLU), 63 = 128x128 with 4 waves (2 workgroups per CU), 64 = 128x128 with 8 waves
-    case 61: case 62: case 63: case 64: case 65: case 66: case 67:
+    // Linear layers on gemm_lin2_kernel: 61 = 256x128, 8 waves, K-slab 64, 3 stages; 62 = 256x320, 2 stages, no GEGLU; 63 = 128x128
+    // with 4 waves (2 workgroups per CU); 64 = 128x128 with 8 waves; 65 = 256x128, 8 waves, K-slab 32, 3 stages = 74 KB (two
+    // workgroups per CU); 67 = 256x256 on eight waves (128x64 per wave), K-slab 64, 2 stages = 128 KB
+    case 61: case 62: case 63: case 64: case 65: case 67:
       if constexpr (!CONV) {
         if (!lin2_ok(p)) return DM4D_ERR_ARG;
-        // 67 = 256x256 tile on eight waves (128x64 per wave), K-slab 64, 2 stages = 128 KB.  (66 was the same tile on FOUR waves,
-        // one per SIMD with 128x128 = 256 accumulator registers each: 1.3-2x slower than 67 on every shape under the compiler's
-        // schedule -- profiles/r02_lin_tiles_256.log -- and removed.)
-        if (id == 66) return DM4D_ERR_ARG;
         if (id == 67) return launch_lin2<256, 256, 2, 4, 2>(st, p);
-        // 65 = the geometry of 14 (256x128, 8 waves, K-slab 32, 3 stages = 74 KB: two workgroups per CU) in the second form
         if (id == 65) return launch_lin2<256, 128, 4, 2, 3, 32>(st, p);
         if (id == 61) return launch_lin2<256, 128, 4, 2, 3>(st, p);
         if (id == 62) return geglu ? DM4D_ERR_ARG : launch_lin2<256, 320, 4, 2, 2>(st, p);
@@ -1930,7 +1651,7 @@ int choose_cfg(const GemmParams& p) {
     }
   } else {
     // stride-1 convs: the strip kernels stage A once per kernel row (profiles/r01_conv_strip.log)
-    if (p.stride == 1 && p.pad == 1 && !p.upsample && p.Ho == p.H && p.Wo == p.W) {
+    if (p.stride == 1 && p.pad == 1 && !p.upsample && p.Ho == p.H && p.Wo == p.W && strip2_ok(p)) {
       if (!n128) {
         // N = 320 (level 0) with Cin >= 640 (the up path's concatenated inputs): the 320-wide strip tile (-5..-6 % at CFG
         // batch 32, even at 48); same K order as every strip kernel, so the choice never changes a result
@@ -1971,7 +1692,7 @@ int launch(hipStream_t st, GemmParams& p) {
   }
   if constexpr (CONV) {
     if (p.ws && p.stride == 1 && p.pad == 1 && !p.upsample && p.Ho == p.H && p.Wo == p.W && p.Cin % 64 == 0 &&
-        strip_split_ok(p)) {
+        strip_split_ok(p) && strip2_ok(p)) {
       p.splits = 3;
       return launch_by_id<CONV>(31, st, p);  // 128x128 strip tiles x 3 kernel rows
     }
@@ -1983,12 +1704,6 @@ int launch(hipStream_t st, GemmParams& p) {
 
 extern "C" int dm4d_tune_set_gemm_config(int id) {
   g_tune_cfg = id;
-  return DM4D_OK;
-}
-
-extern "C" int dm4d_tune_set_strip_form(int form) {
-  if (form != 1 && form != 2) return dm4d_set_error(DM4D_ERR_ARG, "strip form must be 1 or 2");
-  g_strip_form = form;
   return DM4D_OK;
 }
 

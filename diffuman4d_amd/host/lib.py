@@ -49,9 +49,7 @@ SIGNATURES = {
     "dm4d_conv_up2x_prepare_bf16": (_i, [_vp, _vp, _vp, _i, _i]),
     "dm4d_conv_up2x_nhwc_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "dm4d_tune_set_gemm_config": (_i, [_i]),
-    "dm4d_tune_set_strip_form": (_i, [_i]),
     "dm4d_tune_set_groupnorm_resident": (_i, [_i]),
-    "dm4d_tune_set_attention_form": (_i, [_i]),
     "dm4d_nchw_to_nhwc_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),
     "dm4d_nhwc_to_nchw_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),
 }

@@ -209,17 +209,9 @@ int dm4d_postprocess_images_bf16(void* stream, const void* X, void* Y, int B, in
 /* Tuning hook (not part of the operator surface): force one GEMM/conv kernel configuration id for all
  * subsequent launches of this process; 0 restores the built-in heuristic.  Used by tools/gemm_tune.py. */
 int dm4d_tune_set_gemm_config(int id);
-/* Tuning hook: which of the two bit-identical forms of the stride-1 strip convolution runs (2, the default: main loop
- * without vector-ALU address arithmetic; 1: the round-1 kernel).  Used by tools/dev/strip_ab.py.                      */
-int dm4d_tune_set_strip_form(int form);
 /* Tuning hook: 0 forces the two-launch GroupNorm (statistics, apply) for every shape; 1 (default) lets maps that fit
  * in registers take the single-launch kernel.  Used by tests/opcheck.py and tests/opbench.py for the A/B.            */
 int dm4d_tune_set_groupnorm_resident(int on);
-/* Tuning hook: which of the bit-identical forms of the attention kernel runs.  1 (default) = 8 waves x 32 query rows with two
- * score register sets; 2 = 4 waves x 64 query rows (every K / V fragment feeds two MFMAs, one wave per SIMD); 3 / 4 / 5 =
- * 8 waves x 32 rows with in-place score registers and a block-level software pipeline: as written / with prefetched fragment
- * reads / plus scheduling directives.  Used by tests/opcheck.py (bitwise equality of the forms) and tools/dev/attn_form_ab.py. */
-int dm4d_tune_set_attention_form(int form);
 
 /* layout converters at the pipeline boundary (NCHW <-> NHWC, any C) */
 int dm4d_nchw_to_nhwc_bf16(void* stream, const void* X, void* Y, int B, int C, int HW, int cpad);

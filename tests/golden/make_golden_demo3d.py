@@ -1,0 +1,156 @@
+#!/usr/bin/env python
+"""Golden vectors for ONE FULL TASK on the judged geometry: BASELINE.json configs[0] (`demo_3d`) end to end.
+
+Reference configuration restated (read-only source: /root/reference):
+  * configs/exp/demo_3d.yaml:3-10       48 cameras x 1 frame, input cameras [1, 13, 25, 37], sampler `sliding_3d`
+  * configs/sampler/sliding_3d.yaml     alternation_rounds 1 on top of sliding_default: window 12, stride 1, shift 0,
+                                        not bidirectional, 1 denoising step per window, guidance 2.0
+  * pipeline_diffuman4d.py:439-559      => 12 inference steps per latent, 44 windows = 44 UNet calls of F = 4 + 12 = 16 frames
+                                        (CFG batch 32), 2 x 48 VAE encodes, 48 VAE decodes
+
+Geometry: SD-2.1 UNet (320, 640, 1280, 1280), SD VAE (128, 256, 512, 512), 576 x 320 images = 72 x 40 latents.
+
+    python tests/golden/make_golden_demo3d.py fp32      # ~55 min on 8 cores: fp32 oracle latents + decoded RGB
+    python tests/golden/make_golden_demo3d.py bf16      # ~85 min: the oracle in bf16 = the reference's own arithmetic -> yardsticks
+    python tests/golden/make_golden_demo3d.py budget    # optional, per-call error budget (see tools/error_budget.py)
+
+writes tests/golden/demo3d_sd21_72x40.pt:
+  latents            fp32 oracle result, all 48 rows [48, 4, 72, 40] (fp32)
+  images_u16         decoded RGB of the rows IMAGE_ROWS, 16-bit fixed point of [0, 1] (abs. error 7.6e-6)
+  image_rows         which rows those are (5 targets spread over the ring + 1 conditioning row)
+  timestep_indices, fully_denoised      bit-exact bookkeeping
+  yard_latents, yard_images             rel-L2 of the bf16 oracle against the fp32 oracle (images: same rows)
+  checksums of weights / inputs / noise (the GPU test rebuilds them from the seeds and verifies first)
+
+Weights are NOT stored: both sides rebuild them with ``random_state_dict(shapes, seed, device="cpu")``.
+The GPU test (tests/modelcheck.py::case_demo3d_sd21) never runs the oracle at this size on the GPU box.
+"""
+from __future__ import annotations
+
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+OUT = Path(__file__).resolve().parent / "demo3d_sd21_72x40.pt"
+
+BF = torch.bfloat16
+LAT_H, LAT_W = 72, 40
+N_CAMS = 48
+INPUT_CAMS = [1, 13, 25, 37]            # configs/exp/demo_3d.yaml:10
+IMAGE_ROWS = [0, 9, 13, 22, 31, 44]     # decoded rows kept in the fixture (row 13 is a conditioning camera)
+UNET_SEED, VAE_SEED, TASK_SEED, NOISE_SEED = 0, 1, 1234, 4321   # SURVEY 8d seeds
+KW = dict(window_size=12, sliding_stride=1, sliding_shift=0, bidirectional=False, num_denoising_steps=1,
+          alternation_rounds=1, guidance_scale=2.0)
+
+
+def rel_l2(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def task_inputs():
+    """48 views of one frame with the value ranges of spatem_dataset.py:191-228: smooth images, white outside an
+    ellipse (:166); skeleton maps = -1 background + coloured segments (:215-218); Pluecker maps in [-1, 1] (smooth,
+    per-camera); cond mask 0 on the input cameras (sliding_iterative_sampler.py:134-139)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(TASK_SEED)
+    n, H, W = N_CAMS, LAT_H * 8, LAT_W * 8
+    base = F.interpolate(torch.randn(n, 3, H // 16, W // 16, generator=g), size=(H, W), mode="bilinear")
+    pv = (0.6 * base + 0.15 * torch.randn(n, 3, H, W, generator=g)).clamp(-1, 1)
+    ys, xs = torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, W), indexing="ij")
+    inside = ((xs / 0.7) ** 2 + (ys / 0.9) ** 2) < 1.0
+    pv = torch.where(inside, pv, torch.ones_like(pv))
+    sk = -torch.ones(n, 3, H, W)
+    for i in range(n):  # a few thick coloured segments per view
+        for _ in range(6):
+            y0, x0 = int(torch.randint(40, H - 120, (1,), generator=g)), int(torch.randint(20, W - 60, (1,), generator=g))
+            hh, ww = int(torch.randint(8, 100, (1,), generator=g)), int(torch.randint(4, 40, (1,), generator=g))
+            sk[i, :, y0:y0 + hh, x0:x0 + ww] = (torch.rand(3, 1, 1, generator=g) * 2 - 1)
+    pl = F.interpolate(torch.randn(n, 6, H // 32, W // 32, generator=g) * 0.6, size=(H, W), mode="bilinear").clamp(-1, 1)
+    cm = torch.ones(n, 1, H, W)
+    cm[INPUT_CAMS] = 0.0
+    return pv, pl, sk, cm
+
+
+def task_noise():
+    g = torch.Generator().manual_seed(NOISE_SEED)
+    return {k: torch.randn(N_CAMS, 4, LAT_H, LAT_W, generator=g).to(BF) for k in ("pixel", "skeleton", "latents")}
+
+
+def checksums(pv, pl, sk, cm, noise, usd, vsd):
+    f = lambda t: float(t.float().abs().sum())  # noqa: E731
+    return dict(pixel_values=f(pv), plucker=f(pl), skeletons=f(sk), cond_masks=f(cm),
+                noise={k: f(v) for k, v in noise.items()},
+                unet_weights=float(sum(f(v) for v in usd.values())), vae_weights=float(sum(f(v) for v in vsd.values())))
+
+
+def state_dicts():
+    from diffuman4d_amd.host.unet import UNetConfig as HU
+    from diffuman4d_amd.host.vae import VAEConfig as HV
+    from diffuman4d_amd.host.weights import random_state_dict, unet_param_shapes, vae_param_shapes
+    return (random_state_dict(unet_param_shapes(HU()), UNET_SEED, "cpu"),
+            random_state_dict(vae_param_shapes(HV()), VAE_SEED, "cpu"))
+
+
+def build_oracle(dtype):
+    from oracle.ddim import DDIMConfig, DDIMScheduler
+    from oracle.pipeline import OraclePipeline
+    from oracle.unet import UNetConfig, UNetMultiviewConditionModel
+    from oracle.vae import AutoencoderKL, VAEConfig
+    usd, vsd = state_dicts()
+    u = UNetMultiviewConditionModel(UNetConfig()).eval()
+    assert not any(u.load_state_dict({k: v.float() for k, v in usd.items()}, strict=True))
+    v = AutoencoderKL(VAEConfig()).eval()
+    assert not any(v.load_state_dict({k: t.float() for k, t in vsd.items()}, strict=True))
+    return OraclePipeline(v, u, DDIMScheduler(DDIMConfig()), dtype), usd, vsd
+
+
+def run(dtype):
+    op, usd, vsd = build_oracle(dtype)
+    pv, pl, sk, cm = task_inputs()
+    noise = task_noise()
+    nz = noise if dtype == BF else {k: v.float() for k, v in noise.items()}
+    t0 = time.time()
+    trace = []
+    out = op.sliding_iterative_denoise(pv, pl, sk, cm, None, "spatial", torch.zeros(N_CAMS, dtype=torch.int64), nz,
+                                       decode=False, trace=None, **KW)
+    t_den = time.time() - t0
+    lat = out["latents"]
+    images = op.post_process(lat[IMAGE_ROWS])
+    print(f"[{dtype}] denoise {t_den:.0f}s, decode of {len(IMAGE_ROWS)} rows {time.time() - t0 - t_den:.0f}s", flush=True)
+    del trace
+    return out, images, checksums(pv, pl, sk, cm, noise, usd, vsd), t_den
+
+
+def main():
+    which = set(sys.argv[1:]) or {"fp32", "bf16"}
+    blob = torch.load(OUT) if OUT.exists() else {}
+    if "fp32" in which:
+        out, images, chk, secs = run(torch.float32)
+        blob.update(latents=out["latents"].float(), images_u16=(images.float() * 65535.0).round().to(torch.int32).to(torch.uint16),
+                    image_rows=IMAGE_ROWS, timestep_indices=out["timestep_indices"], fully_denoised=out["fully_denoised"],
+                    checksums=chk, kw=KW, input_cams=INPUT_CAMS, oracle_seconds_fp32=secs, threads=torch.get_num_threads(),
+                    seeds=dict(unet=UNET_SEED, vae=VAE_SEED, task=TASK_SEED, noise=NOISE_SEED))
+        torch.save(blob, OUT)
+        print("fp32 pass stored", flush=True)
+    if "bf16" in which:
+        assert "latents" in blob, "run the fp32 pass first"
+        out, images, chk, secs = run(BF)
+        assert chk == blob["checksums"]
+        assert torch.equal(out["timestep_indices"], blob["timestep_indices"])
+        ref_img = blob["images_u16"].to(torch.int32).float() / 65535.0
+        blob.update(yard_latents=rel_l2(out["latents"], blob["latents"]), yard_images=rel_l2(images, ref_img),
+                    yard_latents_targets=rel_l2(out["latents"][blob["fully_denoised"]], blob["latents"][blob["fully_denoised"]]),
+                    oracle_seconds_bf16=secs)
+        torch.save(blob, OUT)
+        print(f"bf16 pass stored: yardsticks latents {blob['yard_latents']:.3e} images {blob['yard_images']:.3e}", flush=True)
+    print("wrote", OUT, {k: (tuple(v.shape) if torch.is_tensor(v) else v) for k, v in blob.items() if k != "checksums"})
+
+
+if __name__ == "__main__":
+    main()

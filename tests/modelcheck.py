@@ -313,6 +313,51 @@ def case_vae_sd(name="vae_576x320"):
             {"latents": g["yard_z"], "images": g["yard_images"]})
 
 
+def case_demo3d_sd21():
+    """BASELINE.json configs[0] END TO END on the judged geometry: `demo_3d` (configs/exp/demo_3d.yaml:3-10 + sampler/sliding_3d.yaml:
+    48 cameras x 1 frame, 4 input cameras, window 12, stride 1, one alternation round => 12 steps per latent, 44 UNet calls of F = 16
+    = CFG batch 32) through `sliding_iterative_denoise` (pipeline_diffuman4d.py:439-559) with the SD-2.1 UNet, the SD VAE and 576 x 320
+    images: 96 VAE encodes, 44 window calls, 48 decodes.  Compared with the fp32 CPU oracle's latents (all 48 rows), its decoded RGB (six
+    rows kept in the fixture as 16-bit fixed point) and -- bit for bit -- its timestep bookkeeping, all recorded in
+    tests/golden/demo3d_sd21_72x40.pt by tests/golden/make_golden_demo3d.py together with the bf16-oracle yardsticks."""
+    from diffuman4d_amd.host.pipeline import Diffuman4DPipeline
+    from diffuman4d_amd.host.scheduler import DDIMConfig as HC, DDIMScheduler as HS
+    from diffuman4d_amd.host.unet import UNetConfig, UNetMultiviewConditionModel
+    from diffuman4d_amd.host.vae import AutoencoderKL, VAEConfig
+    sys.path.insert(0, str(GOLDEN))
+    import make_golden_demo3d as mk
+    g = torch.load(GOLDEN / "demo3d_sd21_72x40.pt")
+    usd, vsd = mk.state_dicts()
+    pv, pl, sk, cm = mk.task_inputs()
+    noise = mk.task_noise()
+    got, want = mk.checksums(pv, pl, sk, cm, noise, usd, vsd), g["checksums"]
+    for k in ("pixel_values", "plucker", "skeletons", "cond_masks", "unet_weights", "vae_weights"):
+        _check_fixture_inputs("demo3d " + k, got[k], want[k])
+    for k in noise:
+        _check_fixture_inputs("demo3d noise " + k, got["noise"][k], want["noise"][k])
+    hp = Diffuman4DPipeline(AutoencoderKL(VAEConfig(), vsd, "cuda"), UNetMultiviewConditionModel(UNetConfig(), usd, "cuda"), HS(HC()), "cuda")
+    del usd, vsd
+    t0 = time.time()
+    out = hp.sliding_iterative_denoise(pixel_values=pv, plucker_embeds=pl, skeletons=sk, cond_masks=cm, latents=None, domain="spatial",
+                                       timestep_indices=torch.zeros(mk.N_CAMS, dtype=torch.int64), noise=noise, **g["kw"])
+    torch.cuda.synchronize()
+    secs = time.time() - t0
+    exact = torch.equal(out["timestep_indices"].cpu(), g["timestep_indices"]) and torch.equal(out["fully_denoised"].cpu(), g["fully_denoised"])
+    ref_img = g["images_u16"].to(torch.int32).float() / 65535.0
+    fd = g["fully_denoised"]
+    e = {"latents": rel_l2(out["latents"], g["latents"]), "images": rel_l2(out["images"][g["image_rows"]], ref_img)}
+    e_t = rel_l2(out["latents"].cpu()[fd], g["latents"][fd])
+    y = {"latents": g.get("yard_latents", float("nan")), "images": g.get("yard_images", float("nan"))}
+    print(f"    [demo_3d, SD-2.1 + SD VAE, 72x40, 44 calls, {secs:.1f}s] latents rel_l2={e['latents']:.3e} (targets only {e_t:.3e}; oracle-bf16 "
+          f"{y['latents']:.3e}) images rel_l2={e['images']:.3e} (oracle-bf16 {y['images']:.3e}; north_star {NORTH_STAR:.0e}: "
+          f"{'met' if e['images'] <= NORTH_STAR else 'NOT met'}) bookkeeping_exact={exact}", flush=True)
+    del hp
+    torch.cuda.empty_cache()
+    if not exact:
+        return {"bookkeeping": 1.0}, {"bookkeeping": 0.0}
+    return e, y
+
+
 def case_resize(seed=3):
     import torch.nn.functional as F
     from diffuman4d_amd.host import ops
@@ -573,6 +618,8 @@ CASES = {
     "unet_sd21_72x40_f16": (case_unet_sd21, dict(name="unet_f16_spatial")),
     "unet_sd21_72x40_f24": (case_unet_sd21, dict(name="unet_f24_temporal")),
     "vae_sd_576x320": (case_vae_sd, dict()),
+    # BASELINE.json configs[0] end to end at the judged geometry, vs tests/golden/demo3d_sd21_72x40.pt
+    "demo3d_sd21_72x40": (case_demo3d_sd21, dict()),
 }
 # Cases with a fixed bound of their own: bitwise equalities (0.0), extension-vs-strict comparisons, exact resampling.
 # Every other case is judged against its bf16-oracle yardstick (YARD_FACTOR, see the module docstring).

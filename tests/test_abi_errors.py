@@ -103,10 +103,3 @@ def test_scheduler_steps_reject_bad_arguments(lib):
     ddim = lib.dm4d_cfg_ddim_step_bf16
     assert ddim(None, P, P, 4, None, P, None, 4, 45, 1, 2.0, 0) == ERR_ARG
     assert "cfg_ddim_step" in last(lib)
-
-
-def test_tuning_hooks_reject_unknown_forms(lib):
-    assert lib.dm4d_tune_set_attention_form(0) == ERR_ARG and "attention form" in last(lib)
-    assert lib.dm4d_tune_set_attention_form(6) == ERR_ARG
-    for form in (2, 3, 4, 5, 1):  # selecting a form launches nothing
-        assert lib.dm4d_tune_set_attention_form(form) == 0
