@@ -21,6 +21,9 @@ Modes (--mode; default `auto` = `task` at --gpus 1, `grid` at --gpus N > 1):
          2 : 1 call mix), so wave quantisation (150 and 44 tasks over N GPUs), the exchange and host contention are
          in the number; --steps K sets that depth and `value` counts the latent-steps actually executed / 18.
   frame-shard  every window split over all ranks with RCCL K/V all-gathers (latency mode, BASELINE config 4).
+Scaling curves compare like with like: the --gpus 1 line (task mode, `value` = resident steady state) ALSO runs one grid pass and
+reports it as `secondary.grid` ({latents_per_s, calls, timed_seconds, window_calls_per_task}); --gpus N > 1 lines (grid mode)
+carry the same object, so 1 -> N is `secondary.grid.latents_per_s` over `secondary.grid.latents_per_s`.
 
 `python bench.py --gpus N` launches its own N ranks (torch.distributed.run on 127.0.0.1) when it is not already
 running under a launcher; rank 0 prints ONE JSON line: the contract fields, `roofline` (attention kernel: HIP-event
@@ -69,8 +72,9 @@ def parse():
                     help="latent grid HxW: 72x40 = BASELINE.json's synthetic grid (default, the judged line); 128x128 = the "
                          "1024^2 images the reference's demo configs run (SURVEY.md 8d asks for both)")
     ap.add_argument("--task-batch", type=int, default=1,
-                    help="tasks of a round stacked into ONE window call (host/pipeline.py upload_plan copies; the runner's "
-                         "task_batch): K steps are then K / task-batch stacked units")
+                    help="BENCH-ONLY EXPERIMENT (the runners have no task batching; the judged line uses 1): tasks of a round "
+                         "stacked into ONE window call through host/pipeline.py upload_plan(copies=); K steps are then "
+                         "K / task-batch stacked units")
     ap.add_argument("--task-streams", type=int, default=2,
                     help="independent tasks in flight per GPU, each on its own HIP stream and worker thread (the runner's "
                          "gpu_streams). 1 = one task at a time")
@@ -84,6 +88,11 @@ def parse():
     ap.add_argument("--prune-cond-rows", action="store_true",
                     help="opt-in extension, NOT the judged configuration: skip the per-frame tail of the UNet (after the last "
                          "3-D attention) for conditioning frames, whose noise prediction the reference discards")
+    ap.add_argument("--no-grid-secondary", action="store_true",
+                    help="task mode at --gpus 1: skip the extra (untimed-for-`value`) pass over the real 48 x 150 round structure "
+                         "that fills `secondary.grid` (the same-mode baseline of the N > 1 grid lines)")
+    ap.add_argument("--no-parity-bf16", action="store_true",
+                    help="skip the second CPU forward (the oracle in bf16 = the reference's own arithmetic) of the `parity` object")
     ap.add_argument("--cpu-frames", type=int, default=16,
                     help="frames of the CPU-baseline UNet call (16 = a full spatial window, about 20 s with 32 threads)")
     ap.add_argument("--cpu-threads", type=int, default=32,
@@ -253,7 +262,7 @@ def run_grid_pass(pipe, depth, frames, world, rank, gpu_streams):
 # ---------------------------------------------------------------------------------------------------------------------
 # CPU baseline + parity on the judged configuration
 # ---------------------------------------------------------------------------------------------------------------------
-def cpu_baseline_and_parity(pipe, state_dict, task, frames: int, threads: int):
+def cpu_baseline_and_parity(pipe, state_dict, task, frames: int, threads: int, bf16_oracle: bool = True):
     """The CPU oracle (oracle/: plain PyTorch restatement of the reference) on one spatial-window UNet call with the SAME
     weights and the SAME packed input as the HIP UNet: timed (cpu_baseline) and compared (parity)."""
     from diffuman4d_amd.host import ops
@@ -276,6 +285,15 @@ def cpu_baseline_and_parity(pipe, state_dict, task, frames: int, threads: int):
         ref = m(x_cpu, t_in.cpu().long(), domains=["spatial"] * 2, num_frames=frames)
         dt = time.time() - t0
     err = float((hip - ref).norm() / ref.norm())
+    err_vs_bf16 = yard_live = dt_bf = None
+    if bf16_oracle:  # the reference's own arithmetic (configs/model/diffuman4d.yaml: bf16): the same oracle, parameters and activations in bf16
+        with torch.no_grad():
+            m.to(torch.bfloat16)
+            t0 = time.time()
+            ref_bf = m(x_cpu.to(torch.bfloat16), t_in.cpu().long(), domains=["spatial"] * 2, num_frames=frames).float()
+            dt_bf = time.time() - t0
+        err_vs_bf16 = float((hip - ref_bf).norm() / ref_bf.norm())
+        yard_live = float((ref_bf - ref).norm() / ref.norm())
     # a unit = 2 F=16 calls + 1 F=24 call; the F=24 call is priced by its FLOP ratio to the measured F=16 call
     f16, f24 = UNIT_TFLOP.get((LAT_H, LAT_W), (1.0, 1.64))
     unit_s = dt * (2 + f24 / f16) if frames >= 16 else None
@@ -295,6 +313,11 @@ def cpu_baseline_and_parity(pipe, state_dict, task, frames: int, threads: int):
         "case": f"UNet forward, SD-2.1 geometry, F={frames} spatial window, CFG batch {B}, {LAT_H}x{LAT_W}: HIP (bf16) vs CPU oracle (fp32), "
                 "same weights and input",
         "rel_l2": round(err, 6), "north_star_tolerance": 1e-3, "meets_north_star": bool(err <= 1e-3),
+        # the three distances between {HIP, oracle fp32, oracle bf16} on THIS input and THESE weights
+        "hip_vs_oracle_fp32": round(err, 6),
+        "hip_vs_oracle_bf16": None if err_vs_bf16 is None else round(err_vs_bf16, 6),
+        "oracle_bf16_vs_oracle_fp32": None if yard_live is None else round(yard_live, 6),
+        "oracle_bf16_seconds": None if dt_bf is None else round(dt_bf, 1),
         "yardstick_oracle_bf16_vs_fp32": yard,
         "note": "bf16 activations end to end: the reference's own bf16 arithmetic (the oracle run in bf16) is as far from the fp32 "
                 "oracle as this path is; 1e-3 needs fp32 activations (DESIGN.md section 3)",
@@ -492,6 +515,21 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # Same-mode baseline for the N > 1 lines (which default to `grid`): ONE pass over the real 48 x 150 round structure on this
+    # GPU, same depth rule, same runner code path (loader pool, task streams, per-round barrier) -> secondary.grid.  Not `value`.
+    grid_secondary = None
+    if mode == "task" and world == 1 and not args.config5 and not args.no_grid_secondary and kb == 1:
+        gdepth = grid_depth(args.steps)
+        barrier()
+        tg = time.perf_counter()
+        gcalls = run_grid_pass(pipe, gdepth, args.grid_frames, 1, 0, S)
+        barrier()
+        tg = time.perf_counter() - tg
+        grid_secondary = {"latents_per_s": round(gcalls * WINDOW / STEPS_PER_LATENT / tg, 4), "calls": gcalls,
+                          "timed_seconds": round(tg, 3), "window_calls_per_task": gdepth, "n_gpus": 1,
+                          "tasks": f"{args.grid_frames} + 44 + {args.grid_frames} (3 alternation rounds of the 48 x {args.grid_frames} grid)",
+                          "note": "one pass over the real round structure through run_round_pipelined (what --gpus N > 1 --mode grid "
+                                  "times through DistributedSamplingRunner): executed latent-steps / 18 / time"}
     # Extension figure, reported beside `value` and never as it: the same units with `prune_cond_rows` (the UNet's per-frame
     # tail after the last 3-D attention runs only for the frames whose noise prediction the scheduler step consumes; the
     # reference computes it for the conditioning frames too and drops it; latents bitwise equal, modelcheck
@@ -629,13 +667,19 @@ def main():
             "unet_calls_per_s": round(units_total * 3 / dt, 3),
             "unet_tflops_sustained": round(units_total * (2 * ut[0] + ut[1]) / dt, 1) if ut else None,
         }
+        if grid_secondary is not None:
+            out["secondary"]["grid"] = grid_secondary
+        elif mode == "grid":  # the same field names as the N = 1 line's secondary.grid, so that a 1 -> N curve is grid / grid
+            out["secondary"]["grid"] = {"latents_per_s": round(value, 4), "calls": total_calls, "timed_seconds": round(dt, 3),
+                                        "window_calls_per_task": grid_info["depth"], "n_gpus": world,
+                                        "tasks": f"{args.grid_frames} + 44 + {args.grid_frames} (3 alternation rounds of the 48 x {args.grid_frames} grid)"}
         if prune_info is not None:
             out["secondary"]["prune_cond_rows"] = prune_info
         if world == 1 and not args.no_vae and LAT_H * LAT_W <= 128 * 128:
             out["secondary"]["vae"] = vae_secondary(dev)
         if want_cpu:  # rank 0 at N = 1 only (the CPU sample would skew multi-rank timing)
             out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(pipe, state_dict, tasks["spatial"], args.cpu_frames,
-                                                                         args.cpu_threads)
+                                                                         args.cpu_threads, not args.no_parity_bf16)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -118,19 +118,26 @@ def conv_up2x_supported(Cin: int, Cout: int) -> bool:
 
 class Upsampler:
     """Upsample2D of the UNet / VAE decoder: nearest x2 + 3x3 convolution.  Runs as four 2x2 phase convolutions of the
-    low-resolution input (conv_up2x; phase kernels made from the checkpoint's 3x3 weights on first use) when the channel
-    counts allow, else as the gather kernel that reads the upsampled image through index arithmetic."""
+    low-resolution input (conv_up2x) when the channel counts allow, else as the gather kernel that reads the upsampled
+    image through index arithmetic.  The phase kernels are made from the checkpoint's 3x3 weights HERE, at load time, and the
+    stream is drained before the object is handed out: the runner's task streams (one worker thread and HIP stream each,
+    sharing one pipeline) must never see a published `wp` whose prepare kernel is still queued on another stream."""
 
     def __init__(self, wt: torch.Tensor, bias: Optional[torch.Tensor]):
         self.wt, self.bias, self.wp = wt, bias, None
         self.phase = conv_up2x_supported(wt.shape[1] // 9, wt.shape[0])
+        if self.phase and wt.is_cuda:
+            with torch.cuda.device(wt.device):
+                self.wp = conv_up2x_prepare(wt)
+                torch.cuda.current_stream(wt.device).synchronize()
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         # the phase kernel addresses its input with 32-bit byte offsets: inputs of 4 GiB or more take the gather kernel
         if not self.phase or x.numel() * 2 >= (1 << 32):
             return conv3x3(x, self.wt, bias=self.bias, upsample=True)
         if self.wp is None or self.wp.device != x.device:
-            self.wp = conv_up2x_prepare(self.wt)
+            raise _l.Dm4dError(f"Upsampler: phase kernels live on {None if self.wp is None else self.wp.device}, input on {x.device} "
+                            "(reload the pipeline on the new device: host/loader.py does)")
         return conv_up2x(x, self.wp, bias=self.bias)
 
 

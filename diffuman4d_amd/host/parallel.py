@@ -34,9 +34,11 @@ class FrameShard:
     def gather_rows(self, x_local: torch.Tensor) -> torch.Tensor:
         """[n, ...] on every rank -> [world*n, ...] in rank order."""
         x_local = x_local.contiguous()
-        out = torch.empty((self.world,) + tuple(x_local.shape), dtype=x_local.dtype, device=x_local.device)
-        self.dist.all_gather(list(out.unbind(0)), x_local, group=self.group)
-        return out.view((self.world * x_local.shape[0],) + tuple(x_local.shape[1:]))
+        out = torch.empty((self.world * x_local.shape[0],) + tuple(x_local.shape[1:]), dtype=x_local.dtype, device=x_local.device)
+        # one contiguous output buffer: RCCL writes every rank's block in place (the list form of all_gather goes through a
+        # flatten + per-rank copy-out)
+        self.dist.all_gather_into_tensor(out, x_local, group=self.group)
+        return out
 
     def gather_kv_start(self, kv_local: torch.Tensor):
         """Start the all-gather of kv_local [cfg, Ls, 2C] (this rank's frames) and return a handle for gather_kv_finish.
@@ -46,8 +48,8 @@ class FrameShard:
         out = torch.empty((cfg, self.world, ls, c2), dtype=kv_local.dtype, device=kv_local.device)
         works = []
         for b in range(cfg):  # one collective per CFG half: each output block is contiguous and in frame order
-            works.append(self.dist.all_gather(list(out[b].unbind(0)), kv_local[b].contiguous(), group=self.group,
-                                              async_op=True))
+            works.append(self.dist.all_gather_into_tensor(out[b].view(self.world * ls, c2), kv_local[b].contiguous(),
+                                                          group=self.group, async_op=True))
         return out, works
 
     def gather_kv_finish(self, handle) -> torch.Tensor:

@@ -139,6 +139,10 @@ class DPMSolverConfig:
     use_lu_lambdas: bool = False
     use_flow_sigmas: bool = False
     variance_type: object = None
+    # keys that change the sigma table: carried so that a checkpoint which sets them fails loudly instead of getting wrong coefficients
+    rescale_betas_zero_snr: bool = False
+    trained_betas: object = None
+    lambda_min_clipped: float = -float("inf")
 
     @classmethod
     def from_dict(cls, d: Dict) -> "DPMSolverConfig":
@@ -157,7 +161,11 @@ class DPMSolverMultistepScheduler:
     def __init__(self, config: DPMSolverConfig = DPMSolverConfig()):
         self.config = c = config
         unsupported = [k for k in ("thresholding", "use_karras_sigmas", "use_exponential_sigmas", "use_beta_sigmas", "use_lu_lambdas",
-                                   "use_flow_sigmas") if getattr(c, k)]
+                                   "use_flow_sigmas", "rescale_betas_zero_snr") if getattr(c, k)]
+        if c.trained_betas is not None:
+            unsupported.append("trained_betas")
+        if c.lambda_min_clipped is not None and c.lambda_min_clipped > -1e30:
+            unsupported.append("lambda_min_clipped")
         if unsupported or c.algorithm_type != "dpmsolver++" or c.solver_order not in (1, 2) or \
                 c.solver_type not in ("midpoint", "heun") or c.variance_type not in (None, "fixed_small", "fixed_large") or \
                 c.prediction_type not in ("epsilon", "v_prediction"):

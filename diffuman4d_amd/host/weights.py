@@ -186,7 +186,10 @@ def load_component_state_dict(path, variant: str = None) -> Dict[str, torch.Tens
     of the reference downloaded into the same directory (sampling_utils.py:28-33 keeps both patterns in one folder).
     ``variant="fp16"``: ``diffusion_pytorch_model.fp16.safetensors``, falling back to the un-suffixed file (what
     ``from_pretrained(torch_dtype=float16)`` loads when no variant file exists).  A sharded checkpoint
-    (``<name>.safetensors.index.json`` with a ``weight_map``) is merged from all of its shards."""
+    (``<name>.safetensors.index.json`` with a ``weight_map``) is merged from all of its shards; a sharded VARIANT follows
+    diffusers' naming: index ``diffusion_pytorch_model.safetensors.index.fp16.json``, shards
+    ``diffusion_pytorch_model.fp16-0000x-of-0000y.safetensors`` (the ``<stem>.fp16.safetensors.index.json`` spelling is
+    accepted too)."""
     import json
     from pathlib import Path
 
@@ -199,6 +202,8 @@ def load_component_state_dict(path, variant: str = None) -> Dict[str, torch.Tens
         single, index = path / f"{stem}.safetensors", path / f"{stem}.safetensors.index.json"
         if single.is_file():
             return load_file(str(single))
+        if variant and stem.endswith(f".{variant}") and not index.is_file():
+            index = path / f"diffusion_pytorch_model.safetensors.index.{variant}.json"  # diffusers' own name for a sharded variant
         if index.is_file():
             shards = sorted(set(json.loads(index.read_text())["weight_map"].values()))
             sd: Dict[str, torch.Tensor] = {}

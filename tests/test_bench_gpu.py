@@ -14,7 +14,7 @@ REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 @pytest.mark.gpu
 def test_bench_prints_one_contract_line():
-    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "1", "--warmup", "1", "--cpu-frames", "2"],
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "1", "--warmup", "1", "--cpu-frames", "2", "--grid-frames", "12"],
                        cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -35,13 +35,19 @@ def test_bench_prints_one_contract_line():
     # the CPU-baseline forward doubles as a parity check on the SD-2.1 geometry (same weights, same input): bf16 noise floor
     pr = d["parity"]
     assert 0.0 < pr["rel_l2"] < 2.5e-2 and pr["north_star_tolerance"] == 1e-3 and pr["meets_north_star"] == (pr["rel_l2"] <= 1e-3)
+    # three distances: HIP vs oracle fp32, HIP vs oracle bf16 (the reference's arithmetic), oracle bf16 vs oracle fp32
+    assert pr["hip_vs_oracle_fp32"] == pr["rel_l2"] and 0.0 < pr["hip_vs_oracle_bf16"] < 3e-2 and 0.0 < pr["oracle_bf16_vs_oracle_fp32"] < 3e-2
+    # the same-mode baseline of the N > 1 (grid) lines: one pass over the real round structure on this GPU
+    g = d["secondary"]["grid"]
+    assert g["n_gpus"] == 1 and g["window_calls_per_task"] == {"spatial": 1, "temporal": 3} and g["calls"] == (12 + 12) * 1 + 44 * 3
+    assert abs(g["latents_per_s"] - g["calls"] * 12 / 18 / g["timed_seconds"]) < 1e-2 * g["latents_per_s"]
 
 
 @pytest.mark.gpu
 def test_bench_with_two_task_streams():
     """Default scheduling: the K steps are dealt to two tasks in flight (one HIP stream each); the roofline figures
     come from the one-task-at-a-time pass that follows the timed region."""
-    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-grid-secondary"],
                        cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -73,3 +79,5 @@ def test_bench_self_launches_grid_mode_for_two_ranks():
     assert g["window_calls_per_task"] == {"spatial": 1, "temporal": 3} and g["calls_per_rank"] == [6 + 66 + 6, 6 + 66 + 6]
     assert abs(d["value"] - sum(g["calls_per_rank"]) * 12 / 18 / g["timed_seconds"]) < 1e-2 * d["value"]
     assert d["config"]["finite_outputs"] is True
+    sg = d["secondary"]["grid"]  # same field names as the N = 1 line's secondary.grid: a 1 -> N curve is grid / grid
+    assert sg["n_gpus"] == 2 and sg["latents_per_s"] == d["value"] and sg["calls"] == sum(g["calls_per_rank"])

@@ -34,6 +34,19 @@ def test_sharded_checkpoint_is_merged(tmp_path):
     assert sorted(load_component_state_dict(tmp_path)) == ["a", "b"]
 
 
+def test_sharded_fp16_variant_uses_the_diffusers_index_name(tmp_path):
+    # diffusers names a sharded variant's index `<stem>.safetensors.index.fp16.json` and its shards `<stem>.fp16-0000x-of-0000y.safetensors`;
+    # an un-suffixed (bf16) checkpoint in the same folder must not be picked by an fp16 run
+    _write(tmp_path / "diffusion_pytorch_model.safetensors", 32)
+    s1, s2 = "diffusion_pytorch_model.fp16-00001-of-00002.safetensors", "diffusion_pytorch_model.fp16-00002-of-00002.safetensors"
+    save_file({"a": torch.full((1,), 16.0)}, str(tmp_path / s1))
+    save_file({"b": torch.full((1,), 16.0)}, str(tmp_path / s2))
+    (tmp_path / "diffusion_pytorch_model.safetensors.index.fp16.json").write_text(json.dumps({"weight_map": {"a": s1, "b": s2}}))
+    sd = load_component_state_dict(tmp_path, "fp16")
+    assert sorted(sd) == ["a", "b"] and float(sd["a"][0]) == 16.0
+    assert sorted(load_component_state_dict(tmp_path)) == ["w"]  # the bf16 run still reads the plain file
+
+
 def test_missing_checkpoint(tmp_path):
     with pytest.raises(FileNotFoundError):
         load_component_state_dict(tmp_path)

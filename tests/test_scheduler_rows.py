@@ -69,3 +69,13 @@ def test_history_flags_follow_the_plan():
             assert f[k] == ((not ic) and int(i) in seen)
         seen.update(int(i) for i, ic in zip(w, c) if not ic)
     assert flags[0].sum() == 0 and any(f.any() for f in flags)
+
+
+def test_dpm_config_keys_that_change_the_sigma_table_are_not_dropped():
+    """scheduler_config.json keys that alter the sigma table must raise, not be ignored (host/scheduler.py policy)."""
+    import pytest
+    from diffuman4d_amd.host.scheduler import DPMSolverConfig, DPMSolverMultistepScheduler
+    DPMSolverMultistepScheduler(DPMSolverConfig.from_dict({"rescale_betas_zero_snr": False, "trained_betas": None, "lambda_min_clipped": -float("inf")}))
+    for bad in ({"rescale_betas_zero_snr": True}, {"trained_betas": [0.1, 0.2]}, {"lambda_min_clipped": -5.1}):
+        with pytest.raises(NotImplementedError):
+            DPMSolverMultistepScheduler(DPMSolverConfig.from_dict(bad))
