@@ -10,6 +10,9 @@ Mirror of ``/root/reference/src/samplers/utils/sampling_utils.py:54-129``:
     tuples ``SpaTemDataset`` returns, spatem_dataset.py:58,157);
   * optional ``{output_dir}/crops/{cam}/{frame}.json`` (:112-113);
   * ``check_sampling_results`` counts the images (:117-129).
+``pack_results_on_device`` + ``imgwrite.write_package`` are the same contract split for the MI355X host pipeline:
+everything arithmetic (mosaic rows, |output - input|, the antialiased down-scale, the float -> uint8 conversions) runs on the
+device right after the decode, one small uint8 package per task crosses PCIe, and the file encoding runs in writer processes.
 ``write_nerfstudio_transforms`` is the camera-file half of scripts/nerfstudio/diffuman4d_to_nerfstudio.py:14-35 (the
 matting half of that script runs a third-party segmentation network and is out of scope).
 """
@@ -34,25 +37,7 @@ def _to_pil(img: torch.Tensor):
     return Image.fromarray(arr)
 
 
-def restore_cropped_image(image, crop_param: Optional[Sequence[int]], ori_size=None, background_color: str = "white"):
-    """Undo ``crop (ct, cl, ch, cw)`` + ``resize to (h, w)`` (image_utils.py:62-93): bicubic-resize the image back to
-    the crop's ``(ch, cw)`` and paste it at ``(cl, ct)`` of a ``(w, h)`` canvas; parts of the crop that lay outside the
-    original frame (negative ``ct`` / ``cl``, or a crop larger than the frame) are cut off, uncovered canvas is white."""
-    from PIL import Image
-    if crop_param is None:
-        return image
-    crop_param = tuple(int(v) for v in crop_param)
-    if len(crop_param) == 4:
-        ct, cl, ch, cw = crop_param
-        w, h = image.size
-    elif len(crop_param) == 6:
-        ct, cl, ch, cw, h, w = crop_param
-    else:
-        raise ValueError(f"Invalid crop_param: {crop_param}")
-    patch = image.resize((cw, ch), Image.BICUBIC)
-    canvas = Image.new(image.mode, (w, h), (255, 255, 255) if background_color == "white" else (0, 0, 0))
-    canvas.paste(patch, (cl, ct))  # PIL clips what falls outside the canvas
-    return canvas
+from .imgwrite import restore_cropped_image, write_package  # noqa: E402,F401  (PIL-only half, importable without torch)
 
 
 def _resize_smaller_edge(x: torch.Tensor, size: int) -> torch.Tensor:
@@ -78,6 +63,99 @@ def make_image_grid(images: torch.Tensor, nrow: int, padding: int = 2, pad_value
         grid[:, y * (h + padding) + padding: y * (h + padding) + padding + h,
              x * (w + padding) + padding: x * (w + padding) + padding + w] = images[k]
     return grid
+
+
+def make_image_grid_device(images: torch.Tensor, nrow: int, padding: int = 2) -> torch.Tensor:
+    """``make_image_grid`` for a full rectangle of equally sized images (len(images) a multiple of nrow), vectorised: pad every
+    image on its top / left, interleave, pad the mosaic on its bottom / right.  Same layout as torchvision's make_grid."""
+    n, c, h, w = images.shape
+    assert n % nrow == 0
+    rows = n // nrow
+    x = torch.nn.functional.pad(images, (padding, 0, padding, 0))
+    x = x.view(rows, nrow, c, h + padding, w + padding).permute(2, 0, 3, 1, 4).reshape(c, rows * (h + padding), nrow * (w + padding))
+    return torch.nn.functional.pad(x, (0, padding, 0, padding))
+
+
+@torch.no_grad()
+def pack_results_on_device(sample: Dict[str, Any], images: torch.Tensor, output_dir: str = "./results", save_image_grid: bool = True,
+                           save_output_image: bool = True, save_crop_param: bool = False, image_ext: str = ".jpg",
+                           image_quality: int = 90, max_image_size: int = 8192) -> Dict[str, Any]:
+    """``save_sampling_results`` up to (not including) the file encoding, evaluated on the device `images` lives on.
+
+    images: the pipeline's decoded output [N, 3, H, W] in [0, 1], still on the GPU.  ``sample`` as the sampler builds it
+    (``pixel_values`` / ``skeletons`` are the host tensors: they are uploaded once more in fp32, which is what the reference's
+    arithmetic reads).  Returns the package ``imgwrite.write_package`` consumes: uint8 HWC numpy arrays + paths + crop tuples."""
+    dev = images.device
+    out = images.float()
+    input_indices = sample["input_indices"].to(dev)
+    target_indices = set(int(i) for i in sample["target_indices"])
+    inp = sample["pixel_values"].to(dev, non_blocking=True).float() * 0.5 + 0.5  # denorm_vae_tensor
+    pkg: Dict[str, Any] = {"grid": None, "images": [], "crops": [], "quality": int(image_quality)}
+    staged = []  # (device uint8 tensor, consumer) pairs: one synchronisation for all D2H copies
+
+    if save_image_grid:
+        errors = (out - inp).abs().clamp(0, 1)
+        dimmed = out.clone()
+        dimmed[input_indices] *= 0.2
+        rows = [inp, dimmed, errors]
+        if sample.get("skeletons") is not None:
+            rows.insert(0, (sample["skeletons"].to(dev, non_blocking=True).float() * 0.5 + 0.5) * 0.8 + inp * 0.2)
+        mosaic = torch.cat(rows)
+        n = len(out)
+        max_size = min(max_image_size // n, max(mosaic.shape[-2:]))
+        mosaic = _resize_smaller_edge(mosaic, max(1, max_size))
+        axis = "spa" if sample["domain"] == "temporal" else "tem"
+        path = f'{output_dir}/grids/alt{sample["alt"]}_{axis}{sample["domain_label"]}.webp'
+        grid = make_image_grid_device(mosaic, nrow=n, padding=2)
+        staged.append(((grid * 255.0 + 0.5).clamp(0, 255).to(torch.uint8).permute(1, 2, 0).contiguous(), ("grid", path)))
+
+    crops = sample.get("crops")
+    if crops is None:
+        crops = [None] * len(out)
+    fully = sample["fully_denoised"]
+    rows_to_save, meta = [], []
+    for i, (crop, (_, spa_label, tem_label)) in enumerate(zip(crops, sample["labels"])):
+        if save_output_image:
+            path = f"{output_dir}/images/{spa_label}/{tem_label}{image_ext}"
+            if (not bool(fully[i]) and i in target_indices) or os.path.isfile(path):
+                continue  # still noisy, or written by an earlier task: the reference skips the row's crop file too
+            rows_to_save.append(i)
+            meta.append((path, crop))
+        if save_crop_param:
+            pkg["crops"].append((f"{output_dir}/crops/{spa_label}/{tem_label}.json", crop))
+    if rows_to_save:
+        idx = torch.tensor(rows_to_save, device=dev)
+        is_input = torch.zeros(len(out), dtype=torch.bool, device=dev)
+        is_input[input_indices] = True
+        sel = torch.where(is_input[idx][:, None, None, None], inp[idx], out[idx])  # input views are saved from the input images
+        u8 = (sel.clamp(0, 1) * 255.0).to(torch.uint8).permute(0, 2, 3, 1).contiguous()  # to_pil_image: mul(255).byte()
+        staged.append((u8, ("images", meta)))
+    host = []
+    for t, tag in staged:
+        if dev.type == "cuda":
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h.copy_(t, non_blocking=True)
+        else:  # CPU tensors (tests): nothing to stage
+            h = t
+        host.append((h, tag))
+    if dev.type == "cuda":
+        torch.cuda.current_stream(dev).synchronize()
+    for h, (kind, info) in host:
+        arr = h.numpy()
+        if kind == "grid":
+            pkg["grid"] = (info, arr)
+        else:
+            pkg["images"] = [(path, arr[k], crop) for k, (path, crop) in enumerate(info)]
+    return pkg
+
+
+def write_packed_results(sample: Dict[str, Any], output_dir: str = "./results", **_kw) -> None:
+    """``result_writer`` of a sampler built with ``device_results=True`` when no writer-process pool is in use: the package
+    ``denoise`` left in ``sample["_package"]`` is written on the calling thread."""
+    pkg = sample.get("_package")
+    if pkg is None:
+        raise ValueError("write_packed_results: the sample carries no '_package' (was it denoised with device_results on a HIP device?)")
+    write_package(pkg)
 
 
 def save_sampling_results(sample: Dict[str, Any], output_dir: str = "./results", save_image_grid: bool = True,

@@ -41,7 +41,7 @@ def _denoise_on_own_stream(sampler: SlidingIterativeSampler, sample: dict, pipe_
 
 
 def run_round_pipelined(sampler: SlidingIterativeSampler, tasks: List[dict], pipe_idx: int = 0, depth: int = 1,
-                        writers: int = 1, gpu_streams: int = 1) -> None:
+                        writers: int = 1, gpu_streams: int = 1, writer_pool=None) -> None:
     """Execute the tasks of ONE alternation round on one pipeline as a 3-stage software pipeline:
 
         loader pool: load_sample(task i+1 .. i+depth)  ||  denoise(task i) on the GPU  ||  writer pool: save(task < i)
@@ -60,7 +60,9 @@ def run_round_pipelined(sampler: SlidingIterativeSampler, tasks: List[dict], pip
     cells are conditioning rows whose grid value is never consumed), so loading task i+k before task i has
     written back is equivalent to the serial order; rounds are never overlapped.  Samples are denoised in task
     order whatever order the loads finish in.
-    ``depth`` = tasks loaded ahead, each on its own thread (host memory: one task's tensors each); 0 = serial."""
+    ``depth`` = tasks loaded ahead, each on its own thread (host memory: one task's tensors each); 0 = serial.
+    ``writer_pool`` (imgwrite.WriterPool): samples that carry a ``_package`` (sampler.device_results) are encoded by its writer
+    PROCESSES instead of the writer threads -- JPEG / WebP encoding off the interpreter lock the launch threads need."""
     if (depth <= 0 and gpu_streams <= 1) or len(tasks) <= 1:
         for t in tasks:
             sampler.execute_one_task(t, pipe_idx=pipe_idx)
@@ -110,9 +112,12 @@ def run_round_pipelined(sampler: SlidingIterativeSampler, tasks: List[dict], pip
                 for f in saves:
                     if f.done():
                         f.result()  # surface a writer error as soon as it is known
-                while len(saves) > depth + writers:  # bound the samples held for writing
+                while len(saves) > depth + max(writers, len(getattr(writer_pool, "_procs", ()))):  # bound what is held for writing
                     saves.pop(0).result()
-                saves.append(savers.submit(sampler.result_writer, sample, output_dir=sampler.output_dir))
+                if writer_pool is not None and sample.get("_package") is not None:
+                    saves.append(writer_pool.submit(sample.pop("_package")))
+                else:
+                    saves.append(savers.submit(sampler.result_writer, sample, output_dir=sampler.output_dir))
         for f in saves:
             f.result()
     finally:
@@ -125,10 +130,20 @@ def run_round_pipelined(sampler: SlidingIterativeSampler, tasks: List[dict], pip
             savers.shutdown(wait=True)
 
 
+def _make_writer_pool(sampler, writer_processes: int):
+    """Writer processes make sense only for packaged results (sampler.device_results on a HIP device)."""
+    if writer_processes <= 0 or sampler.result_writer is None or not getattr(sampler, "device_results", False):
+        return None
+    from .imgwrite import WriterPool
+    return WriterPool(writer_processes)
+
+
 class SamplingRunner:
-    def __init__(self, sampler: SlidingIterativeSampler, prefetch_depth: int = 2, writers: int = 2, gpu_streams: int = 2):
+    def __init__(self, sampler: SlidingIterativeSampler, prefetch_depth: int = 2, writers: int = 2, gpu_streams: int = 2,
+                 writer_processes: int = 0):
         self.sampler = sampler
         self.prefetch_depth, self.writers, self.gpu_streams = prefetch_depth, writers, gpu_streams
+        self.writer_processes = writer_processes
 
     def prepare_task_queues(self):
         self.task_queues = []
@@ -170,8 +185,13 @@ class SamplingRunner:
             if s.result_writer is not None and not check_sampling_results(s.spa_labels, s.tem_labels, s.output_dir):
                 raise ValueError("Sampling failed.")
         else:
-            for tasks in s.all_tasks:
-                run_round_pipelined(s, tasks, 0, self.prefetch_depth, self.writers, self.gpu_streams)
+            pool = _make_writer_pool(s, self.writer_processes)
+            try:
+                for tasks in s.all_tasks:
+                    run_round_pipelined(s, tasks, 0, self.prefetch_depth, self.writers, self.gpu_streams, pool)
+            finally:
+                if pool is not None:
+                    pool.shutdown()
             if s.result_writer is not None and not check_sampling_results(s.spa_labels, s.tem_labels, s.output_dir):
                 raise ValueError("Sampling failed.")
 
@@ -194,11 +214,12 @@ class DistributedSamplingRunner:
     10 % of each other are treated as equal, which reproduces the round-robin deal exactly."""
 
     def __init__(self, sampler: SlidingIterativeSampler, group=None, prefetch_depth: int = 2, writers: int = 2,
-                 gpu_streams: int = 2, balance: bool = True):
+                 gpu_streams: int = 2, balance: bool = True, writer_processes: int = 0):
         import torch.distributed as dist
         self.dist = dist
         self.sampler = sampler
         self.prefetch_depth, self.writers, self.gpu_streams = prefetch_depth, writers, gpu_streams
+        self.writer_processes = writer_processes
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
@@ -351,14 +372,19 @@ class DistributedSamplingRunner:
     def inference(self):
         s = self.sampler
         import time
-        for ri in range(len(s.all_tasks)):
-            mine = self.tasks_of(ri, self.rank)
-            t0 = time.perf_counter()
-            run_round_pipelined(s, mine, 0, self.prefetch_depth, self.writers, self.gpu_streams)
-            dt = time.perf_counter() - t0
-            self._plan_next_round(ri, dt, len(mine))  # before the exchange: it ships what the NEXT deal reads
-            self.dist.barrier(self.group)
-            self.exchange(ri)
+        pool = _make_writer_pool(s, self.writer_processes)
+        try:
+            for ri in range(len(s.all_tasks)):
+                mine = self.tasks_of(ri, self.rank)
+                t0 = time.perf_counter()
+                run_round_pipelined(s, mine, 0, self.prefetch_depth, self.writers, self.gpu_streams, pool)
+                dt = time.perf_counter() - t0
+                self._plan_next_round(ri, dt, len(mine))  # before the exchange: it ships what the NEXT deal reads
+                self.dist.barrier(self.group)
+                self.exchange(ri)
+        finally:
+            if pool is not None:
+                pool.shutdown()
         if s.result_writer is not None and self.rank == 0:
             if not check_sampling_results(s.spa_labels, s.tem_labels, s.output_dir):
                 raise ValueError("Sampling failed.")

@@ -11,8 +11,8 @@ What is organised differently here:
     a task's cells are two small methods under one lock;
   * ``result_writer`` is injectable (the reference hard-wires ``save_sampling_results``);
   * ``partition(round, rank, world)`` exposes the per-round task sharding used by the one-process-per-GPU runner;
-  * optional pipeline extensions (``vae_cache``, ``decode_policy``, ``prune_cond_rows``, ``plucker_on_device``), off by
-    default.
+  * optional pipeline extensions (``vae_cache``, ``decode_policy``, ``prune_cond_rows``, ``plucker_on_device``,
+    ``device_results``), off by default.
 """
 from __future__ import annotations
 
@@ -63,12 +63,19 @@ class SlidingIterativeSampler:
                  spa_labels: Optional[Sequence[int]] = None, tem_labels: Optional[Sequence[int]] = None,
                  input_spa_labels: Sequence[int] = (1, 13, 25, 37), result_writer: Optional[Callable] = None,
                  vae_cache: bool = False, decode_policy: str = "all", prune_cond_rows: bool = False,
-                 plucker_on_device: bool = False):
+                 plucker_on_device: bool = False, device_results: bool = False):
         self.dataset, self.pipelines, self.output_dir = dataset, pipelines, output_dir
         self.sweep = SweepConfig(window_size, sliding_stride, sliding_shift, bidirectional, num_denoising_steps,
                                  alternation_rounds, guidance_scale)
+        # device_results: the arithmetic of the result writer (mosaic, |output - input|, down-scale, uint8 conversion) runs on the GPU
+        # inside `denoise` and the task leaves it as a small uint8 package (results.pack_results_on_device); the writer then only
+        # encodes files (imgwrite.write_package: in the runner's writer processes, or on the calling thread)
+        self.device_results = bool(device_results)
         if result_writer is None:
-            from .results import save_sampling_results as result_writer
+            if self.device_results:
+                from .results import write_packed_results as result_writer
+            else:
+                from .results import save_sampling_results as result_writer
         self.result_writer = result_writer
         if decode_policy not in ("all", "denoised"):
             raise ValueError("decode_policy must be 'all' or 'denoised'")
@@ -193,9 +200,14 @@ class SlidingIterativeSampler:
             tensors["plucker_embeds"] = None
         result = pipe.sliding_iterative_denoise(domain=sample["domain"], tqdm=bar, **tensors, **asdict(self.sweep),
                                                 **self._pipeline_extensions(sample))
-        sample["images"] = result["images"].float().cpu()
         sample["timestep_indices"] = result["timestep_indices"].cpu()
         sample["fully_denoised"] = result["fully_denoised"].cpu()
+        if self.device_results and on_gpu and self.result_writer is not None:
+            from .results import pack_results_on_device
+            sample["_package"] = pack_results_on_device(sample, result["images"], output_dir=self.output_dir)
+            sample["images"] = None  # the float images never leave the device (the package holds what gets written)
+        else:
+            sample["images"] = result["images"].float().cpu()
         # hand the cells over only when they are complete: with several task streams per GPU (runner gpu_streams) another
         # task's thread, another stream or the round-boundary exchange may read the grid as soon as the cells are in it.
         # The copies above are not a reliable barrier (host-resident results do not synchronise), so drain explicitly.

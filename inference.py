@@ -39,7 +39,16 @@ def inference(cfg: dict):
     sampler = cfglib.instantiate(cfg["sampler"], dataset=dataset, pipelines=pipelines)
     # runner.gpu_streams=N (default 2): tasks of a round in flight per GPU, one HIP stream each; 1 = the reference's
     # one-task-at-a-time order
-    rk = {k: int(v) for k, v in (cfg.get("runner") or {}).items() if k in ("prefetch_depth", "writers", "gpu_streams")}
+    # runner.writer_processes=N (default 0): with sampler.device_results=true the JPEG / WebP encoding of every task's uint8
+    # package runs in N writer processes (host/imgwrite.py) instead of the writer threads
+    rk = {k: int(v) for k, v in (cfg.get("runner") or {}).items()
+          if k in ("prefetch_depth", "writers", "gpu_streams", "writer_processes")}
+    # runner.host_threads=N: torch's intra-op CPU threads for the host-side stages (loader, writer).  The 256-thread GPU hosts
+    # default to 128-256 threads per op, and several loader / writer threads each fanning small tensor ops out over all of
+    # them is what made the host stages the bottleneck (profiles/r02_e2e_demo.log)
+    ht = (cfg.get("runner") or {}).get("host_threads")
+    if ht:
+        torch.set_num_threads(max(1, int(ht)))
     runner = DistributedSamplingRunner(sampler, **rk) if distributed else SamplingRunner(sampler, **rk)
     if cfg.get("sampling", True):
         runner.inference()

@@ -28,13 +28,15 @@ def test_cli_path_on_synthetic_checkpoint(tmp_path, fast):
           "data.height=64", "data.width=64", "data.num_cameras=8", f"result_dir={tmp_path / 'results'}",
           "sampler.spa_label_range=[0,8,1]", "sampler.tem_label_range=[0,4,1]", "sampler.input_spa_labels=[1,5]",
           "sampler.window_size=4", "sampler.sliding_stride=2"]
-    if fast:  # every opt-in extension at once: VAE moment cache, decode-on-demand, Pluecker maps from the cameras on the device
-        ov += ["sampler.vae_cache=true", "sampler.decode_policy=denoised", "sampler.plucker_on_device=true", "data.plucker=cameras"]
+    if fast:  # every opt-in extension at once: VAE moment cache, decode-on-demand, Pluecker maps from the cameras on the device,
+        # result arithmetic on the device + file encoding in writer processes
+        ov += ["sampler.vae_cache=true", "sampler.decode_policy=denoised", "sampler.plucker_on_device=true", "data.plucker=cameras",
+               "sampler.device_results=true"]
     cfg = cfglib.compose(ov)
     pipelines = cfglib.instantiate(cfg["model"])
     assert len(pipelines) == 1 and pipelines[0].device.type == "cuda"
     sampler = cfglib.instantiate(cfg["sampler"], dataset=cfglib.instantiate(cfg["data"]), pipelines=pipelines)
-    SamplingRunner(sampler, prefetch_depth=2, writers=2).inference()
+    SamplingRunner(sampler, prefetch_depth=2, writers=2, writer_processes=2 if fast else 0).inference()
     steps = 4 // 2 * 3
     assert all(sampler.timestep_indices[c][f] == steps for c in sampler.target_spa_labels for f in sampler.tem_labels)
     assert check_sampling_results(sampler.spa_labels, sampler.tem_labels, sampler.output_dir)
@@ -42,6 +44,37 @@ def test_cli_path_on_synthetic_checkpoint(tmp_path, fast):
     assert bool(torch.isfinite(lat).all())
     if fast:
         assert len(pipelines[0]._vae_cache["pixel"]) == 8 * 4
+    import glob
+    assert len(glob.glob(f"{sampler.output_dir}/grids/*.webp")) == 4 + 6 + 4  # one snapshot mosaic per task
+
+
+@pytest.mark.parametrize("domain,n", [("spatial", 8), ("temporal", 12)])
+def test_device_results_match_the_host_writer(tmp_path, domain, n):
+    """results.pack_results_on_device on the GPU + imgwrite.write_package vs save_sampling_results on the host copy of the
+    same decoded images: identical file sets, byte-identical JPEGs (same uint8 pixels into the same encoder); the WebP
+    mosaics agree up to the device's antialiased down-scale (a few uint8 levels on isolated pixels)."""
+    import filecmp
+    import os
+    from glob import glob
+    import numpy as np
+    from PIL import Image
+    from diffuman4d_amd.host.results import pack_results_on_device, save_sampling_results, write_package
+    from test_results import _pack_sample
+    s = _pack_sample(n, 192, 96, domain)
+    img_dev = s["images"].to(torch.bfloat16).cuda()  # what the VAE decode returns
+    s["images"] = img_dev.float().cpu()              # what sampler.denoise hands the host writer
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    save_sampling_results(s, output_dir=a, save_crop_param=True)
+    write_package(pack_results_on_device(s, img_dev, output_dir=b, save_crop_param=True))
+    fa = sorted(os.path.relpath(f, a) for f in glob(a + "/**/*.*", recursive=True))
+    fb = sorted(os.path.relpath(f, b) for f in glob(b + "/**/*.*", recursive=True))
+    assert fa == fb
+    for f in fa:
+        if f.endswith(".webp"):
+            x, y = (np.asarray(Image.open(os.path.join(d, f)).convert("RGB"), dtype=np.int32) for d in (a, b))
+            assert x.shape == y.shape and float(np.abs(x - y).mean()) < 1.0
+        else:
+            assert filecmp.cmp(os.path.join(a, f), os.path.join(b, f), shallow=False), f
 
 
 def test_from_pretrained_equals_direct_construction(tmp_path):

@@ -113,3 +113,55 @@ def test_nerfstudio_transforms(tmp_path):
     full = json.load(open(dst / "transforms.json"))
     assert [f["file_path"] for f in full["frames"]] == [f"images_alpha/{c}/000000.png" for c in ("00", "01", "13")]
     assert [f["camera_label"] for f in json.load(open(dst / "transforms_input.json"))["frames"]] == ["01", "13"]
+
+
+def _pack_sample(n, H, W, domain):
+    g = torch.Generator().manual_seed(0)
+    if domain == "spatial":
+        inp = [1, 3]
+        tgt = [i for i in range(n) if i not in inp]
+        labels = [(i, "%02d" % i, "000007") for i in range(n)]
+    else:
+        T = n // 2
+        inp, tgt = list(range(T)), list(range(T, n))
+        labels = [(i, "01", "%06d" % i) for i in range(T)] + [(T + i, "05", "%06d" % i) for i in range(T)]
+    fd = torch.zeros(n, dtype=torch.bool)
+    fd[tgt[::2]] = True
+    return dict(images=torch.rand(n, 3, H, W, generator=g), pixel_values=torch.rand(n, 3, H, W, generator=g) * 2 - 1,
+                skeletons=torch.rand(n, 3, H, W, generator=g) * 2 - 1, input_indices=torch.tensor(inp), target_indices=torch.tensor(tgt),
+                domain=domain, alt=2, domain_label="000007" if domain == "spatial" else "05", labels=labels, fully_denoised=fd,
+                crops=[(3, 5, H - 10, W - 8, H + 6, W + 4)] * n)
+
+
+@pytest.mark.parametrize("domain,n", [("spatial", 8), ("temporal", 12)])
+def test_packed_writer_produces_the_same_files_as_the_reference_order(tmp_path, domain, n):
+    """pack_results_on_device (arithmetic, here on CPU tensors) + imgwrite.write_package (PIL only, runs in writer processes)
+    write byte-for-byte the files save_sampling_results writes: same mosaic, same JPEG inputs, same crop files, same skips."""
+    import filecmp
+    import sys
+    from glob import glob
+    from diffuman4d_amd.host.results import pack_results_on_device, save_sampling_results, write_package
+    s = _pack_sample(n, 64, 40, domain)
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    save_sampling_results(s, output_dir=a, save_crop_param=True)
+    pkg = pack_results_on_device(s, s["images"], output_dir=b, save_crop_param=True)
+    import pickle
+    pkg = pickle.loads(pickle.dumps(pkg))  # what crossing into a writer process does to it
+    write_package(pkg)
+    fa = sorted(os.path.relpath(f, a) for f in glob(a + "/**/*.*", recursive=True))
+    fb = sorted(os.path.relpath(f, b) for f in glob(b + "/**/*.*", recursive=True))
+    assert fa == fb and len(fa) > 4
+    assert [f for f in fa if not filecmp.cmp(os.path.join(a, f), os.path.join(b, f), shallow=False)] == []
+    # a second task that shares the input views: they exist already and are skipped (and never staged)
+    pkg2 = pack_results_on_device(s, s["images"], output_dir=b)
+    assert pkg2["images"] == []
+
+
+def test_imgwrite_imports_without_torch():
+    """The writer-process half must not import torch (a spawned writer pays the import and its threads)."""
+    import subprocess
+    import sys
+    code = "import sys; import diffuman4d_amd.host.imgwrite as m; assert 'torch' not in sys.modules, 'torch imported'; print('ok')"
+    from pathlib import Path
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(Path(__file__).resolve().parent.parent))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr

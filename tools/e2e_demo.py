@@ -41,6 +41,12 @@ def main():
                     help="sampler.vae_cache=true sampler.decode_policy=denoised (encoder moments cached per grid cell, "
                          "decode only the rows that are saved)")
     ap.add_argument("--prune", action="store_true", help="sampler.prune_cond_rows=true (UNet tail only for consumed rows)")
+    ap.add_argument("--device-results", action="store_true",
+                    help="sampler.device_results=true: the result writer's arithmetic (mosaic, |out - in|, down-scale, uint8) on the GPU, "
+                         "one uint8 package per task over PCIe")
+    ap.add_argument("--writer-processes", type=int, default=0, help="runner.writer_processes: encode the packages in N processes")
+    ap.add_argument("--host-threads", type=int, default=0, help="torch.set_num_threads for the host stages (0 = torch's default)")
+    ap.add_argument("--timeline", default=None, help="write per-task stage intervals (load / denoise / save: start, end, thread) as JSON")
     ap.add_argument("--workdir", default=None)
     ap.add_argument("overrides", nargs="*")
     a = ap.parse_args()
@@ -52,7 +58,10 @@ def main():
     cfg = cfglib.compose([f"exp={a.exp}", "model=diffuman4d_mi355x", "data=synthetic", f"model.model_dir={ckpt}",
                           "model.gpu_ids=[0]", f"data.height={H}", f"data.width={W}", f"result_dir={work / 'results'}"]
                          + (["sampler.vae_cache=true", "sampler.decode_policy=denoised"] if a.fast_vae else [])
-                         + (["sampler.prune_cond_rows=true"] if a.prune else []) + a.overrides)
+                         + (["sampler.prune_cond_rows=true"] if a.prune else [])
+                         + (["sampler.device_results=true"] if a.device_results else []) + a.overrides)
+    if a.host_threads > 0:
+        torch.set_num_threads(a.host_threads)
     t0 = time.perf_counter()
     dataset = cfglib.instantiate(cfg["data"])
     pipelines = cfglib.instantiate(cfg["model"])
@@ -61,6 +70,7 @@ def main():
     t_load = time.perf_counter() - t0
 
     acc, lock = {"load_sample": 0.0, "denoise": 0.0, "save": 0.0}, threading.Lock()
+    events = []  # (stage, start, end, thread name): the timeline of the run
 
     def timed(name, fn):
         def w(*args, **kw):
@@ -68,8 +78,10 @@ def main():
             try:
                 return fn(*args, **kw)
             finally:
+                t1 = time.perf_counter()
                 with lock:
-                    acc[name] += time.perf_counter() - t
+                    acc[name] += t1 - t
+                    events.append((name, t, t1, threading.current_thread().name))
         return w
 
     sampler.load_sample = timed("load_sample", sampler.load_sample)
@@ -79,9 +91,22 @@ def main():
 
     n_tasks = sum(len(t) for t in sampler.all_tasks)
     t0 = time.perf_counter()
-    SamplingRunner(sampler, prefetch_depth=a.depth, writers=a.writers, gpu_streams=a.gpu_streams).inference()
+    SamplingRunner(sampler, prefetch_depth=a.depth, writers=a.writers, gpu_streams=a.gpu_streams,
+                   writer_processes=a.writer_processes).inference()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    # GPU-stage occupancy: fraction of the wall time during which at least one / every denoise worker was inside `denoise`
+    den = sorted((s0 - t0, e0 - t0) for n_, s0, e0, _ in events if n_ == "denoise")
+    busy_any, cur_s, cur_e = 0.0, None, None
+    for s0, e0 in den:
+        if cur_e is None or s0 > cur_e:
+            busy_any += (cur_e - cur_s) if cur_e is not None else 0.0
+            cur_s, cur_e = s0, e0
+        else:
+            cur_e = max(cur_e, e0)
+    busy_any += (cur_e - cur_s) if cur_e is not None else 0.0
+    if a.timeline:
+        Path(a.timeline).write_text(json.dumps([(n_, round(s0 - t0, 4), round(e0 - t0, 4), th) for n_, s0, e0, th in events]))
     n_lat = len(sampler.target_spa_labels) * len(sampler.tem_labels)
     done = sum(sampler.timestep_indices[c][f] > 0 for c in sampler.target_spa_labels for f in sampler.tem_labels)
     n_img = len(list(Path(sampler.output_dir).rglob("*.jpg")))
@@ -90,6 +115,8 @@ def main():
         "target_latents": n_lat, "denoised": int(done), "images_written": n_img, "wall_s": round(wall, 3),
         "latents_per_s_end_to_end": round(n_lat / wall, 3),
         "stage_seconds": {k: round(v, 3) for k, v in acc.items()},
+        "denoise_stage_busy_fraction": round(busy_any / wall, 4),
+        "device_results": a.device_results, "writer_processes": a.writer_processes, "host_threads": torch.get_num_threads(),
         "checkpoint_write_s": round(t_ckpt, 2), "pipeline_load_s": round(t_load, 2),
     }), flush=True)
     if a.workdir is None:
