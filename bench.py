@@ -326,32 +326,42 @@ def cpu_baseline_and_parity(pipe, state_dict, task, frames: int, threads: int, b
 
 
 def vae_secondary(dev):
-    """SD-geometry AutoencoderKL on 8 images of the bench's pixel size: encode and decode time per image (outside the
-    timed region: SURVEY.md 8d reports the VAE separately).  FLOPs scale with the pixel count from SURVEY's per-image
-    figures at 576x320 (0.78 TF encode, 1.76 TF decode)."""
+    """SD-geometry AutoencoderKL: encode and decode time per image (outside the timed region: SURVEY.md 8d reports the VAE
+    separately) on 8 images of the bench's pixel size AND on 2 images of 1024 x 1024, the reference's native image size
+    (spatem_dataset.py:27-28; mid-block attention over 16 384 tokens).  FLOPs scale with the pixel count from SURVEY's
+    per-image figures at 576x320 (0.78 TF encode, 1.76 TF decode); the mid-block attention's quadratic part is not in them."""
     from diffuman4d_amd.host.vae import AutoencoderKL, VAEConfig
     from diffuman4d_amd.host.weights import random_state_dict, vae_param_shapes
     cfg = VAEConfig()
     vae = AutoencoderKL(cfg, random_state_dict(vae_param_shapes(cfg), 1, dev), dev)
-    H, W, n = 8 * LAT_H, 8 * LAT_W, 8
-    g = torch.Generator(device=dev).manual_seed(5)
-    img = (torch.rand(n, 3, H, W, generator=g, device=dev) * 2 - 1).to(torch.bfloat16)
-    noise = torch.randn(n, 4, LAT_H, LAT_W, generator=g, device=dev).to(torch.bfloat16)
-    out = {}
-    with torch.no_grad():
-        z = vae.encode_scaled(img, noise)
-        vae.decode_to_images(z)
-        for name, fn, tf in (("encode", lambda: vae.encode_scaled(img, noise), 0.78), ("decode", lambda: vae.decode_to_images(z), 1.76)):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(3):
-                fn()
-            e1.record()
+
+    def measure(H, W, n):
+        g = torch.Generator(device=dev).manual_seed(5)
+        img = (torch.rand(n, 3, H, W, generator=g, device=dev) * 2 - 1).to(torch.bfloat16)
+        noise = torch.randn(n, 4, H // 8, W // 8, generator=g, device=dev).to(torch.bfloat16)
+        res = {}
+        with torch.no_grad():
+            z = vae.encode_scaled(img, noise)
+            vae.decode_to_images(z)
             torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 3 / n
-            flops = tf * 1e12 * (H * W) / (576 * 320)
-            out[name] = {"ms_per_image": round(ms, 3), "tflops": round(flops / (ms * 1e-3) / 1e12, 1)}
-    out["images"] = f"{n} x {H}x{W}, SD geometry (128,256,512,512), random init"
+            torch.cuda.reset_peak_memory_stats()
+            for name, fn, tf in (("encode", lambda: vae.encode_scaled(img, noise), 0.78), ("decode", lambda: vae.decode_to_images(z), 1.76)):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / 3 / n
+                flops = tf * 1e12 * (H * W) / (576 * 320)
+                res[name] = {"ms_per_image": round(ms, 3), "tflops": round(flops / (ms * 1e-3) / 1e12, 1)}
+        res["images"] = f"{n} x {H}x{W}, SD geometry (128,256,512,512), random init"
+        res["peak_device_memory_gib"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
+        return res
+
+    out = measure(8 * LAT_H, 8 * LAT_W, 8)
+    if (LAT_H, LAT_W) != (128, 128):
+        out["1024x1024"] = measure(1024, 1024, 2)
     return out
 
 

@@ -1,0 +1,301 @@
+// Fused feed-forward of a transformer block (level 0 of the UNet): see the comment at the kernel.  Shares the MFMA / epilogue
+// helpers of gemm.hip through gemm_common.h.
+#include "gemm_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Fused feed-forward of a transformer block at C = 320 (level 0 of the UNet; attention.py:129-149: ff(norm3(x)) + x, the
+// GEGLU projection 320 -> 2 x 1280 followed by 1280 -> 320):   out = x + W2 (h * gelu(g)) + b2,  [h | g] = W1 y + b1
+// in ONE launch: the [M, 1280] hidden tensor (236 MB per layer call at CFG batch 32, written and read back by the two-GEMM
+// form) never leaves the chip.
+//
+// A workgroup = 8 waves owns 128 rows: wave (wm, wn) = (wave >> 1, wave & 1) holds rows 32 wm .. 32 wm + 31.
+//   * its y rows live in REGISTERS for the whole launch as MFMA fragments (20 k steps x 4 VGPRs): fetched through the LDS in
+//     whole 128-byte row pieces (DMA, source-side swizzle) like every A tile of this file;
+//   * the output accumulators O[32 rows x 160 columns] (columns 160 wn ..) stay in registers: 5 blocks x 16 VGPRs;
+//   * the hidden axis goes in steps of 32 units.  Step s: (1) S^T[32 x 32] = W1c y^T over K = 320 (20 MFMAs) where W1c holds, for
+//     THIS wave's 16 units 32 s + 16 wn .., the 16 hidden rows and then the 16 gate rows -- with the transposed accumulators
+//     (mfma_t) a lane then has hidden unit u in register e and its gate in register e + 8; (2) GEGLU in registers, 8 values per
+//     lane, rounded to bf16 (the rounding point of the two-GEMM form) and stored to a [128 x 32] tile in LDS, through which
+//     the two waves of a row group exchange their halves; (3) O^T += W2c H^T (10 MFMAs: 5 column blocks x 2 k steps).
+//   * weights stream L2 -> LDS by DMA, double buffered, from a per-step packed copy (ff_prepare_kernel): W1p[s] = 64 rows x
+//     320 (40 KB: rows of wn = 0, then wn = 1), W2p[s] = 320 rows x 32 units (20 KB); every workgroup reads the same 2.4 MB.
+// K order of both products = ascending 16-wide k steps into each accumulator with the bias as the first step, exactly as in
+// the Linear kernels above, and the same gelu: results are BIT-IDENTICAL to gemm(GEGLU) followed by gemm(residual)
+// (tests/opcheck.py ff_fused_*).
+// ------------------------------------------------------------------------------------------------
+constexpr int FF_BM = 128, FF_STEP = 32;
+
+template <int CK>
+__device__ __forceinline__ void ff_fused_body(const GemmParams& p, const u16* __restrict__ W1p, const u16* __restrict__ b1p,
+                                              const u16* __restrict__ W2p, int nsteps) {
+  static_assert(CK % 64 == 0 && (CK / 2) % 32 == 0, "channel count");
+  constexpr int NSLAB = CK / 64, KS1 = CK / 16, NJ = CK / 2 / 32;  // 64-wide K slabs of y / W1, k steps of product 1, column blocks per wave
+  constexpr int W1_BYTES = 64 * CK * 2, W2_BYTES = CK * FF_STEP * 2, WBUF = W1_BYTES + W2_BYTES;
+  constexpr int H_LD = 80, H_OFF = 2 * WBUF, H_BYTES = FF_BM * H_LD;  // H rows: 32 units = 64 B + 16 B pad (conflict-free b128 reads); 2 tiles
+  constexpr int Y_OFF = WBUF, Y_BYTES = FF_BM * CK * 2;                // prologue only: y tile over buffer 1, H and the tail
+  constexpr int SMEM_MAIN = (H_OFF + 2 * H_BYTES) > (Y_OFF + Y_BYTES) ? (H_OFF + 2 * H_BYTES) : (Y_OFF + Y_BYTES);
+  constexpr int SMEM_EPI = 8 * 32 * (EpiGeom<CK / 2>::EPW + 4) * 4;
+  constexpr int SMEM_BYTES = SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI;
+  static_assert(SMEM_BYTES <= 160 * 1024, "does not fit the LDS");
+  __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * FF_BM;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+
+  // ---- weight DMA: lane offsets are loop invariant, the step enters through the uniform base ----
+  // W1p[s]: NSLAB slabs of [64 rows][64 k]; this wave moves rows 8 wave .. 8 wave + 7 of every slab (one 1-KiB instruction each)
+  const int w1_row = wave * 8 + (lane >> 3);
+  const uint32_t w1_voff = (uint32_t)w1_row * (CK * 2) + (uint32_t)((lane & 7) ^ ((w1_row >> 1) & 7)) * 16u;
+  // W2p[s]: [CK rows][32 units] = CK / 16 instructions of 16 rows; this wave moves instructions wave, wave + 8, ...
+  const uint32_t w2_voff = (uint32_t)(lane >> 2) * 64u + (uint32_t)((lane & 3) ^ ((lane >> 4) & 3)) * 16u;
+  auto issue_w1 = [&](int s, int b) {
+    const u16* w1b = W1p + (int64_t)s * (64 * CK);
+    const uint32_t d1 = lds0 + b * WBUF + wave * 1024;
+#pragma unroll
+    for (int t = 0; t < NSLAB; ++t) dma16_sv(w1b + t * 64, w1_voff, d1 + t * 8192);
+  };
+  auto issue_w2 = [&](int s, int b) {
+    const u16* w2b = W2p + (int64_t)s * (CK * FF_STEP);
+    const uint32_t d2 = lds0 + b * WBUF + W1_BYTES;
+#pragma unroll
+    for (int q = 0; q < (CK / 16 + 7) / 8; ++q) {
+      const int inst = wave + 8 * q;
+      if (inst < CK / 16) dma16_sv(w2b + inst * 512, w2_voff, d2 + inst * 1024);
+    }
+  };
+
+  // ---- prologue: y tile -> LDS (5 slabs of [128 rows][64 k]) beside the weights of step 0, then -> registers ----
+  {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = (wave + 8 * h) * 8 + (lane >> 3);
+      int m = m0 + row;
+      if (m > p.M - 1) m = p.M - 1;
+      const uint32_t voff = (uint32_t)m * (uint32_t)(p.lda * 2) + (uint32_t)((lane & 7) ^ ((row >> 1) & 7)) * 16u;
+#pragma unroll
+      for (int t = 0; t < NSLAB; ++t) dma16_sv(p.A + t * 64, voff, lds0 + Y_OFF + t * (FF_BM * 128) + (wave + 8 * h) * 1024);
+    }
+  }
+  issue_w1(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  bf16x8_t xf[KS1];
+  {
+    const int sw = (l31 >> 1) & 7;
+#pragma unroll
+    for (int t = 0; t < NSLAB; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        xf[4 * t + ks] = *reinterpret_cast<const bf16x8_t*>(smem + Y_OFF + t * (FF_BM * 128) + (wm * 32 + l31) * 128 + (((ks * 2 + lh) ^ sw) * 16));
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // every wave has its y rows: buffer 1 and the H tile may be written
+  asm volatile("" ::: "memory");
+
+  f32x16_t acc[1][NJ];
+  acc_init<1, NJ, CK / 2>(p, acc, 0, wn, lane, false);  // b2 as the first k step of product 2
+  f32x16_t zero;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+  const bf16x8_t one0 = k0_fragment(0x3f80, lh);
+
+  // fragment read addresses (bytes from a buffer's start)
+  const int w1_rd = (wn * 32 + l31) * 128, w1_sw = (l31 >> 1) & 7;
+  const int w2_rd = W1_BYTES + (wn * (CK / 2) + l31) * 64, w2_sw = (l31 >> 2) & 3;
+  const int h_row = H_OFF + (wm * 32 + l31) * H_LD;
+
+  // Schedule.  A wave's work per step of 32 hidden units, cut into two intervals by workgroup barriers:
+  //     X_s: S(s) = product 1 (21 MFMAs)           Y_s: GEGLU(s) -> H(s), then product 2 of step s-1 (10 MFMAs)
+  // The second HALF of the workgroup (waves 4-7 = row groups 2-3) runs the same sequence ONE INTERVAL LATE (it passes one extra
+  // barrier before its first interval, the first half one extra after its last).  A workgroup's waves w and w + 4 share a SIMD
+  // (MI355X_MICROARCH.md, LDS section), so in every interval each SIMD holds one wave that streams MFMAs and one that mostly runs
+  // GEGLU on the vector ALU: the pairing in which matrix pipe and vector ALU overlap.  With all eight waves in the same phase
+  // (the first version of this kernel) both waves of a SIMD want the matrix pipe at the same time and then both want the vector
+  // ALU: 2.3x the MFMA time per step, measured.  The H tile is exchanged only between the two waves of a row group, which are in
+  // the same half.  Every wave issues its share of the weight DMA on its OWN schedule -- W1(s+1) in X_s, W2(s) in Y_s -- which
+  // keeps every tile complete one barrier before its first reader (the early half) and intact until its last (the late half):
+  // W1(s+1) replaces W1(s-1), last read by the late half in global interval 2s-1 and first written by the early half in 2s;
+  // W2(s) replaces W2(s-2), last read in global interval 2s, first written in 2s+1; the late half's pieces land by the end of
+  // 2s+1 / 2s+2, the first readers come in 2s+2 / 2s+3 (which is why the very last product 2 waits one idle interval).
+  auto product1 = [&](int s, u16 bias_bits) {
+    const char* wb = smem + (s & 1) * WBUF;
+    f32x16_t sa = mfma_t(one0, k0_fragment(bias_bits, lh), zero);
+#pragma unroll
+    for (int t = 0; t < NSLAB; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(wb + t * 8192 + w1_rd + (((ks * 2 + lh) ^ w1_sw) * 16));
+        sa = mfma_t(xf[4 * t + ks], wf, sa);
+      }
+    asm volatile("" ::"v"(sa));  // every MFMA of the product is issued before what follows (the compiler otherwise sinks some of them
+    return sa;                   // below the interval's barrier, into the interval that belongs to the other half's MFMAs)
+  };
+  auto geglu_store = [&](int s, const f32x16_t& sa) {
+    // register e = hidden unit 4 lh + (e & 3) + 8 (e >> 2) of this wave's 16, register e + 8 = its gate
+    float hv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) hv[e] = sa[e] * gelu_erf_f(sa[e + 8]);
+    uint2 lo, hi;
+    lo.x = pack_bf2(hv[0], hv[1]);
+    lo.y = pack_bf2(hv[2], hv[3]);
+    hi.x = pack_bf2(hv[4], hv[5]);
+    hi.y = pack_bf2(hv[6], hv[7]);
+    char* hp = smem + h_row + (s & 1) * H_BYTES + (16 * wn + 4 * lh) * 2;
+    *reinterpret_cast<uint2*>(hp) = lo;        // units 16 wn + 4 lh + 0..3
+    *reinterpret_cast<uint2*>(hp + 16) = hi;   // units 16 wn + 8 + 4 lh + 0..3
+  };
+  auto product2 = [&](int s) {
+    const char* wb = smem + (s & 1) * WBUF;
+    const char* hb = smem + h_row + (s & 1) * H_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8_t hf = *reinterpret_cast<const bf16x8_t*>(hb + (16 * ks + 8 * lh) * 2);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(wb + w2_rd + j * (32 * 64) + (((ks * 2 + lh) ^ w2_sw) * 16));
+        acc[0][j] = mfma_t(hf, wf, acc[0][j]);
+      }
+    }
+    static_assert(NJ == 5, "the pin below names the five accumulator blocks");
+    asm volatile("" ::"v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[0][2]), "v"(acc[0][3]), "v"(acc[0][4]));
+  };
+  f32x16_t s_cur;
+  auto close_interval = [&]() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed, its LDS reads and stores are done
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  // Bias values (one bf16 per lane and step) are ordinary loads the compiler counts; the DMA statements are not.  A value
+  // loaded in one interval is settled at the top of the interval that uses it, BEFORE that interval's DMA goes out: the wait the
+  // compiler places there finds nothing else in flight (close_interval drained the queue), whereas a wait placed behind the DMA
+  // issue would stall on it.
+  auto settle = [&](uint32_t v) {
+    asm volatile("" : "+v"(v));
+    return (u16)v;
+  };
+  const u16* b1l = b1p + wn * 32 + l31;
+  uint32_t b1v = b1l[0];
+  const bool late = wave >= 4;
+  if (late) close_interval();
+  {  // step 0 (no product 2 yet)
+    const u16 bb = settle(b1v);                    // X_0
+    issue_w1(1, 1);
+    b1v = b1l[64];
+    s_cur = product1(0, bb);
+    close_interval();
+    issue_w2(0, 0);                                // Y_0
+    geglu_store(0, s_cur);
+    close_interval();
+  }
+  for (int s = 1; s + 1 < nsteps; ++s) {
+    const u16 bb = settle(b1v);                    // X_s
+    issue_w1(s + 1, (s + 1) & 1);
+    b1v = b1l[(s + 1) * 64];
+    s_cur = product1(s, bb);
+    close_interval();
+    issue_w2(s, s & 1);                            // Y_s
+    geglu_store(s, s_cur);
+    __builtin_amdgcn_sched_barrier(0);  // GEGLU's registers are dead before product 2's fragments are fetched (register budget);
+    product2(s - 1);                    // the overlap of vector and matrix work comes from the OTHER wave of the SIMD
+    close_interval();
+  }
+  {  // last step, then the product 2 that is still owed
+    const int s = nsteps - 1;
+    const u16 bb = settle(b1v);                    // X_(n-1)
+    s_cur = product1(s, bb);
+    close_interval();
+    issue_w2(s, s & 1);                            // Y_(n-1)
+    geglu_store(s, s_cur);
+    __builtin_amdgcn_sched_barrier(0);
+    product2(s - 1);
+    close_interval();
+    close_interval();                              // X_n: idle -- the other half's pieces of W2(n-1) are still landing
+    product2(s);                                   // Y_n
+    close_interval();
+  }
+  if (!late) close_interval();
+  // everybody's fragment reads are behind a barrier: the epilogue may stage through the same LDS
+  gemm_epilogue<1, NJ, 32, CK / 2, false>(p, acc, reinterpret_cast<float*>(smem), m0, 0, wm, wn, wave, lane);
+}
+
+// (the body is a device function: the host pass instantiates only the stub of a __global__ template, and the register
+// constraints of the asm statements above are device-only)
+template <int CK>
+__global__ __launch_bounds__(512) void ff_fused_kernel(GemmParams p, const u16* __restrict__ W1p, const u16* __restrict__ b1p,
+                                                       const u16* __restrict__ W2p, int nsteps) {
+  ff_fused_body<CK>(p, W1p, b1p, W2p, nsteps);
+}
+
+// Per-step packed copies of the feed-forward weights for ff_fused_kernel (once per layer, at load time):
+//   W1p[s][r][k], r = 32 wn + i: unit u = 32 s + 16 wn + (i & 15); row i < 16 = hidden row u of W1 [2 HID, C], i >= 16 = gate row HID + u
+//   b1p[s][r] the same rows of b1;   W2p[s][n][j] = W2[n][32 s + j]  (W2 [C, HID])
+__global__ __launch_bounds__(256) void ff_prepare_kernel(const u16* W1, const u16* b1, const u16* W2, u16* W1p, u16* b1p, u16* W2p,
+                                                         int C, int HID) {
+  const int64_t n1 = (int64_t)2 * HID * C, n2 = (int64_t)C * HID;
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (id < n1) {
+    const int k = (int)(id % C);
+    const int64_t rr = id / C;
+    const int r = (int)(rr % 64), s = (int)(rr / 64);
+    const int wn = r >> 5, i = r & 31;
+    const int u = 32 * s + 16 * wn + (i & 15);
+    const int src = i < 16 ? u : HID + u;
+    W1p[id] = W1[(int64_t)src * C + k];
+    if (k == 0) b1p[rr] = b1 ? b1[src] : (u16)0;
+  } else if (id < n1 + n2) {
+    const int64_t e = id - n1;
+    const int j = (int)(e % 32);
+    const int64_t t = e / 32;
+    const int n = (int)(t % C), s = (int)(t / C);
+    W2p[e] = W2[(int64_t)n * HID + 32 * s + j];
+  }
+}
+
+int ff_launch_prepare(hipStream_t st, const u16* W1, const u16* b1, const u16* W2, u16* W1p, u16* b1p, u16* W2p, int C, int hidden) {
+  const int64_t total = (int64_t)3 * hidden * C;
+  hipLaunchKernelGGL(ff_prepare_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W1, b1, W2, W1p, b1p, W2p, C, hidden);
+  return dm4d_check_launch("ff_prepare_kernel");
+}
+
+int ff_launch_fused(hipStream_t st, const GemmParams& p, const u16* W1p, const u16* b1p, const u16* W2p, int nsteps) {
+  hipLaunchKernelGGL((ff_fused_kernel<320>), dim3((unsigned)((p.M + FF_BM - 1) / FF_BM)), dim3(512), 0, st, p, W1p, b1p, W2p, nsteps);
+  return dm4d_check_launch("ff_fused_kernel");
+}
+
+}  // namespace
+
+extern "C" int dm4d_ff_geglu_prepare_bf16(void* stream, const void* W1, const void* b1, const void* W2, void* W1p, void* b1p, void* W2p,
+                                          int C, int hidden) {
+  if (!W1 || !W2 || !W1p || !b1p || !W2p || C <= 0 || hidden <= 0)
+    return dm4d_set_error(DM4D_ERR_ARG, "ff_geglu_prepare: null pointer or empty shape");
+  if (hidden % 32 != 0) return dm4d_set_error(DM4D_ERR_ARG, "ff_geglu_prepare: hidden size must be a multiple of 32");
+  return ff_launch_prepare((hipStream_t)stream, (const u16*)W1, (const u16*)b1, (const u16*)W2, (u16*)W1p, (u16*)b1p, (u16*)W2p, C, hidden);
+}
+
+extern "C" int dm4d_ff_geglu_supported(int C, int hidden) { return (C == 320 && hidden >= 64 && hidden % 32 == 0) ? 1 : 0; }
+
+extern "C" int dm4d_ff_geglu_fused_bf16(void* stream, const void* Y, int64_t ldy, const void* W1p, const void* b1p, const void* W2p,
+                                        const void* b2, const void* residual, int64_t ld_res, void* Out, int64_t ldo, int M, int C,
+                                        int hidden) {
+  if (!Y || !W1p || !b1p || !W2p || !Out || M <= 0) return dm4d_set_error(DM4D_ERR_ARG, "ff_geglu_fused: null pointer or empty shape");
+  if (!dm4d_ff_geglu_supported(C, hidden))
+    return dm4d_set_error(DM4D_ERR_ARG, "ff_geglu_fused: built for C = 320 and a hidden size that is a multiple of 32 (use two dm4d_gemm_bf16 calls)");
+  if ((ldy & 7) || (ldo & 7) || (residual && (ld_res & 7)) || ((((uintptr_t)Y) | ((uintptr_t)Out) | ((uintptr_t)W1p) | ((uintptr_t)W2p)) & 15))
+    return dm4d_set_error(DM4D_ERR_ARG, "ff_geglu_fused: row strides must be multiples of 8 elements, pointers 16-byte aligned");
+  if ((uint64_t)M * (uint64_t)ldy * 2u >= (1ull << 32))
+    return dm4d_set_error(DM4D_ERR_ARG, "ff_geglu_fused: input of 4 GiB or more (split the rows)");
+  GemmParams p{};
+  p.A = (const u16*)Y; p.lda = ldy; p.C = (u16*)Out; p.ldc = ldo; p.M = M; p.N = C; p.K = hidden;
+  p.bias = (const u16*)b2; p.res = (const u16*)residual; p.ld_res = ld_res; p.flags = 0; p.out_scale = 1.0f; p.splits = 1;
+  p.rows_per_rb = 1; p.tiles_n = 1;
+  return ff_launch_fused((hipStream_t)stream, p, (const u16*)W1p, (const u16*)b1p, (const u16*)W2p, hidden / FF_STEP);
+}
+

@@ -5,6 +5,8 @@ stream.  Nothing here computes with torch: a tensor on the CPU is an error, not 
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional, Tuple
 
 import torch
@@ -98,6 +100,47 @@ def conv3x3(x: torch.Tensor, wt: torch.Tensor, *, bias=None, rowbias=None, resid
                                            Cout if residual is not None else 0, out_scale, _p(ws), ws_bytes)
     _l.check(rc, "dm4d_conv3x3_nhwc_bf16_ws")
     return y
+
+
+FF_FUSED = os.environ.get("DM4D_FF_FUSED", "1") != "0"  # level-0 feed-forward (C = 320) as one launch; off = the two-GEMM form (A/B, tests)
+
+
+class FeedForward:
+    """ff(n) + residual of a transformer block (attention.py:129-149): GEGLU projection then output projection.  Where the fused
+    kernel is built for the shape (dm4d_ff_geglu_supported: C = 320) the per-step packed weights are made here, at load time
+    (the stream is drained before the object is handed out, as in Upsampler), and the call is ONE launch whose hidden tensor
+    never leaves the chip; other shapes -- and FF_FUSED = False -- run gemm(GEGLU) + gemm(residual).  Both forms are
+    bit-identical (tests/opcheck.py ff_fused_*)."""
+
+    def __init__(self, w1: torch.Tensor, b1: Optional[torch.Tensor], w2: torch.Tensor, b2: Optional[torch.Tensor]):
+        self.w1, self.b1, self.w2, self.b2 = w1, b1, w2, b2
+        self.C, self.hidden = w2.shape[0], w2.shape[1]
+        assert w1.shape == (2 * self.hidden, self.C)
+        self.packed = None
+        lib = _l.load()
+        if w1.is_cuda and lib.dm4d_ff_geglu_supported(self.C, self.hidden):
+            _req(w1, "w1"), _req(w2, "w2")
+            with torch.cuda.device(w1.device):
+                w1p, b1p, w2p = torch.empty_like(w1), torch.empty(2 * self.hidden, dtype=BF16, device=w1.device), torch.empty_like(w2)
+                _l.check(lib.dm4d_ff_geglu_prepare_bf16(_stream(), _p(w1.contiguous()), _p(b1), _p(w2.contiguous()), _p(w1p), _p(b1p),
+                                                        _p(w2p), self.C, self.hidden), "dm4d_ff_geglu_prepare_bf16")
+                torch.cuda.current_stream(w1.device).synchronize()
+            self.packed = (w1p, b1p, w2p)
+
+    def __call__(self, n: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
+        if self.packed is None or not FF_FUSED or n.shape[0] * n.stride(0) * 2 >= (1 << 32):
+            f = gemm(n, self.w1, bias=self.b1, geglu=True)
+            return gemm(f, self.w2, bias=self.b2, residual=residual)
+        lib = _l.load()
+        _req(n, "n"), _req(residual, "residual")
+        M = n.shape[0]
+        out = torch.empty((M, self.C), dtype=BF16, device=n.device)
+        w1p, b1p, w2p = self.packed
+        with _Prof("linear", 2.0 * M * 3 * self.hidden * self.C, "flop"):
+            rc = lib.dm4d_ff_geglu_fused_bf16(_stream(), _p(n), n.stride(0), _p(w1p), _p(b1p), _p(w2p), _p(self.b2), _p(residual),
+                                              residual.stride(0), _p(out), out.stride(0), M, self.C, self.hidden)
+        _l.check(rc, "dm4d_ff_geglu_fused_bf16")
+        return out
 
 
 def conv_up2x_prepare(wt: torch.Tensor) -> torch.Tensor:

@@ -173,8 +173,8 @@ class _TransformerBlock:
         self.qkv = torch.cat([q, k.float(), v.float()], dim=0).to(W.device, BF16).contiguous()  # fused [3C, C], bias-free
         self.ow, self.ob = W.linear(pfx + "attn1.to_out.0.weight"), W.vec(pfx + "attn1.to_out.0.bias")
         self.n3w, self.n3b = W.vec(pfx + "norm3.weight"), W.vec(pfx + "norm3.bias")
-        self.f1w, self.f1b = W.linear(pfx + "ff.net.0.proj.weight"), W.vec(pfx + "ff.net.0.proj.bias")
-        self.f2w, self.f2b = W.linear(pfx + "ff.net.2.weight"), W.vec(pfx + "ff.net.2.bias")
+        self.ff = ops.FeedForward(W.linear(pfx + "ff.net.0.proj.weight"), W.vec(pfx + "ff.net.0.proj.bias"),
+                                  W.linear(pfx + "ff.net.2.weight"), W.vec(pfx + "ff.net.2.bias"))
         if (pfx + "attn2.to_q.weight") in W.sd:
             raise NotImplementedError("cross-attention (attn2) checkpoints are not supported: the reference never "
                                       "passes encoder_hidden_states (SURVEY.md section 0)")
@@ -195,8 +195,7 @@ class _TransformerBlock:
             a = ops.attention(q, kvg[:, :C], kvg[:, C:], batch, self.heads, seq, kv_seq=shard.world * seq, q_scaled=True)
         h = ops.gemm(a, self.ow, bias=self.ob, residual=h)
         n = ops.layernorm(h, self.n3w, self.n3b, 1e-5)
-        f = ops.gemm(n, self.f1w, bias=self.f1b, geglu=True)
-        return ops.gemm(f, self.f2w, bias=self.f2b, residual=h)
+        return self.ff(n, h)  # one launch at C = 320 (level 0), gemm(GEGLU) + gemm(residual) elsewhere
 
 
 class _Transformer:

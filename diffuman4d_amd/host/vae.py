@@ -89,6 +89,7 @@ class _MidAttn:
         # cost 2^-9 |logit| in the exponent at d = 512).  Query rows go in blocks so that the fp32 logits of a block stay
         # below QBLOCK_BYTES whatever the image size: 1024^2 images have L = 16 384, i.e. 1 GB per image unblocked.
         qb = max(32, min(L, (self.QBLOCK_BYTES // (4 * L)) // 32 * 32))
+        self.last_block_bytes = 4 * L * qb  # what the largest logits block of this call occupies (tests assert the bound)
         for b in range(B):
             rows = slice(b * L, (b + 1) * L)
             k, v = qkv[rows, C:2 * C], qkv[rows, 2 * C:]
@@ -167,6 +168,10 @@ class AutoencoderKL:
     @property
     def scale_factor(self) -> int:
         return 2 ** (len(self.config.block_out_channels) - 1)
+
+    def mid_attention_block_bytes(self) -> int:
+        """Bytes of the largest fp32 logits block the two mid-block attentions allocated in their last calls."""
+        return max(getattr(self.e_mid[1], "last_block_bytes", 0), getattr(self.d_mid[1], "last_block_bytes", 0))
 
     def micro_batch(self, height: int, width: int, limit: int = 8) -> int:
         """Images per VAE pass: the reference's 8 (pipeline_diffuman4d.py:47,59), reduced for large images so that the

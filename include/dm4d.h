@@ -206,6 +206,22 @@ int dm4d_plucker_latent_bf16(void* stream, const float* cams, void* Y, int N, in
 /* VaeImageProcessor.postprocess(do_denormalize): (x/2 + 0.5).clamp(0,1), NHWC(ldx) -> NCHW (:282-284)  */
 int dm4d_postprocess_images_bf16(void* stream, const void* X, void* Y, int B, int C, int HW, int ldx);
 
+/* Fused feed-forward of a transformer block (attention.py:129-149 `ff(norm3(x)) + x`; diffusers FeedForward with GEGLU:
+ * Linear(C -> 2 hidden) -> hidden * gelu(gate) -> Linear(hidden -> C)) in ONE launch:
+ *     Out[M, C] = residual + W2 (h * gelu(g)) + b2,   [h | g] = W1 Y + b1,   Y = the LayerNorm output
+ * The [M, hidden] intermediate stays on the chip.  Same products in the same order, same rounding points (the hidden tensor is
+ * rounded to bf16 between the two products) as dm4d_gemm_bf16(GEGLU) followed by dm4d_gemm_bf16(residual): bit-identical.
+ * dm4d_ff_geglu_supported(C, hidden) says whether the kernel is built for the shape (C = 320: level 0 of an SD-class UNet);
+ * dm4d_ff_geglu_prepare_bf16 makes the per-step packed weight copies once per layer from the checkpoint's tensors:
+ *   W1 [2 hidden, C] (rows 0..hidden-1 = hidden half, then the gate half), b1 [2 hidden] or NULL, W2 [C, hidden]
+ *   -> W1p [2 hidden * C], b1p [2 hidden], W2p [C * hidden] (caller-owned, bf16).                                         */
+int dm4d_ff_geglu_supported(int C, int hidden);
+int dm4d_ff_geglu_prepare_bf16(void* stream, const void* W1, const void* b1, const void* W2, void* W1p, void* b1p, void* W2p,
+                               int C, int hidden);
+int dm4d_ff_geglu_fused_bf16(void* stream, const void* Y, int64_t ldy, const void* W1p, const void* b1p, const void* W2p,
+                             const void* b2, const void* residual, int64_t ld_res, void* Out, int64_t ldo, int M, int C,
+                             int hidden);
+
 /* Tuning hook (not part of the operator surface): force one GEMM/conv kernel configuration id for all
  * subsequent launches of this process; 0 restores the built-in heuristic.  Used by tools/gemm_tune.py. */
 int dm4d_tune_set_gemm_config(int id);

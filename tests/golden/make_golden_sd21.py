@@ -2,7 +2,7 @@
 """Golden vectors on the JUDGED configuration (BASELINE.json configs[1..2]): the CPU oracle (oracle/: fp32 restatement
 of the reference path, see its headers) run at full SD-2.1 geometry on 72x40 latents.
 
-    python tests/golden/make_golden_sd21.py [unet16] [unet24] [vae]       (default: all three; ~10 min on 8 cores)
+    python tests/golden/make_golden_sd21.py [unet16] [unet24] [vae] [vae1024]   (default: the first three; ~10 min on 8 cores)
 
 writes tests/golden/sd21_72x40.pt:
   * unet_f16_spatial  -- one spatial window call: F = 16 frames (4 conditioning + 12 targets), CFG batch 32, L3d = 46 080
@@ -11,6 +11,8 @@ writes tests/golden/sd21_72x40.pt:
       reference's own bf16 arithmetic loses), input checksums
   * vae_576x320       -- AutoencoderKL with the SD geometry (128, 256, 512, 512; mid-block attention d = 512, L = 2 880)
       on two 576x320 images: scaled posterior sample and the decoded images, plus their bf16 yardsticks.
+  * vae_1024          -- the same VAE on ONE 1024x1024 image (the reference's native size: mid-block attention L = 16 384):
+      scaled posterior sample (whole) and four 64-row bands of the decoded image, plus bf16 yardsticks (`vae1024`, ~10 min).
 
 Weights are NOT stored: both sides rebuild them with ``random_state_dict(shapes, seed, device="cpu")`` (torch's CPU
 generator is reproducible for one torch build; the fixture carries checksums that the GPU test verifies first).
@@ -131,11 +133,60 @@ def golden_vae(n: int = 2, seed: int = 5):
     return out
 
 
+VAE1024_BANDS = [(0, 64), (320, 384), (480, 544), (960, 1024)]  # image rows kept in the fixture (top edge, two inner bands, bottom edge)
+
+
+def vae1024_inputs(seed: int = 7):
+    """One 1024 x 1024 image (the reference's real size: spatem_dataset.py:27-28) + posterior noise, same recipe as vae_inputs."""
+    g = torch.Generator().manual_seed(seed)
+    H = W = 1024
+    base = torch.nn.functional.interpolate(torch.randn(1, 3, H // 16, W // 16, generator=g), size=(H, W), mode="bilinear")
+    img = (0.6 * base + 0.15 * torch.randn(1, 3, H, W, generator=g)).clamp(-1, 1)
+    ys, xs = torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, W), indexing="ij")
+    inside = ((xs / 0.7) ** 2 + (ys / 0.9) ** 2) < 1.0
+    img = torch.where(inside, img, torch.ones_like(img)).to(BF)
+    noise = torch.randn(1, 4, H // 8, W // 8, generator=g).to(BF)
+    return img, noise
+
+
+def golden_vae_1024(seed: int = 7):
+    """AutoencoderKL (SD geometry) on ONE 1024 x 1024 image: mid-block attention over L = 16 384 tokens at d = 512
+    (pipeline_diffuman4d.py:47-72,553 at the dataset's native size).  Stored: the scaled posterior sample (fp32, whole), the
+    decoded image on four 64-row bands (16-bit fixed point), and the bf16-oracle yardsticks on the same quantities."""
+    from diffuman4d_amd.host.vae import VAEConfig as HC
+    from diffuman4d_amd.host.weights import random_state_dict, vae_param_shapes
+    from oracle.vae import AutoencoderKL, VAEConfig
+    cfg = VAEConfig()
+    sd = random_state_dict(vae_param_shapes(HC()), VAE_SEED, "cpu")
+    v = AutoencoderKL(cfg).eval()
+    res = v.load_state_dict({k: t.float() for k, t in sd.items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    img, noise = vae1024_inputs(seed)
+    bands = lambda x: torch.cat([x[..., a:b, :] for a, b in VAE1024_BANDS], dim=-2)  # noqa: E731
+    with torch.no_grad():
+        t0 = time.time()
+        z = v.sample_posterior(v.moments(img.float()), noise.float()) * cfg.scaling_factor
+        dec = bands((v.decode(z.to(BF).float() / cfg.scaling_factor) / 2 + 0.5).clamp(0, 1))  # decoder fed the bf16-rounded latents
+        t_fp32 = time.time() - t0
+        print(f"vae_1024: fp32 {t_fp32:.1f}s", flush=True)
+        v.to(BF)
+        z_bf = (v.sample_posterior(v.moments(img), noise) * cfg.scaling_factor).float()
+        dec_bf = bands((v.decode(z.to(BF) / cfg.scaling_factor) / 2 + 0.5).clamp(0, 1).float())
+    out = dict(z=z, image_bands_u16=(dec * 65535.0).round().to(torch.int32).to(torch.uint16), bands=VAE1024_BANDS,
+               yard_z=rel_l2(z_bf, z), yard_images=rel_l2(dec_bf, dec), seed=seed, img_checksum=float(img.float().abs().sum()),
+               weights_checksum=float(sum(t.float().abs().sum() for t in sd.values())), config=asdict(cfg), oracle_seconds=t_fp32)
+    print(f"vae_1024: yardsticks z={out['yard_z']:.3e} image bands={out['yard_images']:.3e}", flush=True)
+    return out
+
+
 def main():
     which = set(sys.argv[1:]) or {"unet16", "unet24", "vae"}
     blob = torch.load(OUT) if OUT.exists() else {}
     if "vae" in which:
         blob["vae_576x320"] = golden_vae()
+        torch.save(blob, OUT)
+    if "vae1024" in which:
+        blob["vae_1024"] = golden_vae_1024()
         torch.save(blob, OUT)
     if "unet16" in which:
         blob["unet_f16_spatial"] = golden_unet("unet_f16_spatial", 16, 4, "spatial", 101)

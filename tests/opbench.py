@@ -42,6 +42,19 @@ def bench_gemm(M, N, K, geglu=False, residual=True, tag=""):
     print(f"gemm{tag:10s} M={M:6d} N={N:5d} K={K:5d} geglu={int(geglu)}  {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s", flush=True)
 
 
+def bench_ff(M, C=320, hidden=1280, tag=""):
+    """Level-0 feed-forward: the fused launch vs gemm(GEGLU) + gemm(residual) (+ the LayerNorm both forms follow)."""
+    n, x = rnd(M, C), rnd(M, C)
+    ff = ops.FeedForward(rnd(2 * hidden, C, scale=1 / math.sqrt(C)), rnd(2 * hidden), rnd(C, hidden, scale=1 / math.sqrt(hidden)), rnd(C))
+    fl = 2.0 * M * 3 * hidden * C
+    for rep in range(2):  # alternate the forms: whatever is timed first runs on a colder chip
+        for fused in (True, False):
+            ops.FF_FUSED = fused
+            t = timeit(lambda: ff(n, x))
+            print(f"ff{tag:8s} M={M:6d} C={C} hidden={hidden} {'fused   ' if fused else 'two-gemm'} round {rep}  {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s", flush=True)
+    ops.FF_FUSED = True
+
+
 def bench_conv(B, H, W, Cin, Cout, stride=1, upsample=False, tag=""):
     x = rnd(B, H, W, Cin)
     wt = rnd(Cout, 9 * Cin, scale=1 / math.sqrt(9 * Cin))
@@ -134,6 +147,10 @@ def main():
         bench_conv(B, 36, 20, 1920, 640, tag=" L1 up")
         bench_conv(B, 18, 10, 1280, 1280, tag=" L2")
         bench_conv(B, 9, 5, 1280, 1280, tag=" L3")
+        return
+    if only == "ff":
+        bench_ff(32 * 2880, tag=" L0 F16")
+        bench_ff(48 * 2880, tag=" L0 F24")
         return
     if only == "attn":
         print("attn q_scaled:", QS, flush=True)

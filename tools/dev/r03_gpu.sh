@@ -1,0 +1,56 @@
+#!/bin/bash
+# The GPU calls of round 3, one parameterised script:  gpurun -- 'bash tools/dev/r03_gpu.sh <stage> [args]'
+# Every stage writes under gpurun_out/r03_<stage>*; summaries worth keeping are copied to profiles/ by hand.
+set -u
+stage=${1:-baseline}; shift || true
+out=gpurun_out; mkdir -p $out
+export PYTHONUNBUFFERED=1
+case $stage in
+  baseline)  # GPU test suite on the cleaned tree, the driver's bench command, e2e demo_4d_tiny old vs new host pipeline
+    ( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $out/r03_pytest_gpu.log 2>&1; tail -5 $out/r03_pytest_gpu.log
+    timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/r03_bench_baseline.json 2> $out/r03_bench_baseline.err; tail -c 600 $out/r03_bench_baseline.json
+    timeout 300 python tools/e2e_demo.py --exp demo_4d_tiny --fast-vae --prune --writers 8 --timeline $out/r03_e2e_tiny_old_timeline.json sampler.plucker_on_device=true data.plucker=cameras > $out/r03_e2e_tiny_old.json 2> $out/r03_e2e_tiny_old.err; cat $out/r03_e2e_tiny_old.json
+    timeout 300 python tools/e2e_demo.py --exp demo_4d_tiny --fast-vae --prune --writers 2 --device-results --writer-processes 8 --host-threads 8 --timeline $out/r03_e2e_tiny_new_timeline.json sampler.plucker_on_device=true data.plucker=cameras > $out/r03_e2e_tiny_new.json 2> $out/r03_e2e_tiny_new.err; cat $out/r03_e2e_tiny_new.json
+    ;;
+  e2e)  # the full demo_4d grid (48 x 150, 344 tasks) end to end with the new host pipeline
+    timeout 900 python tools/e2e_demo.py --exp demo_4d --fast-vae --prune --writers 2 --device-results --writer-processes ${1:-12} --host-threads ${2:-8} --depth ${3:-3} --timeline $out/r03_e2e_demo4d_timeline.json sampler.plucker_on_device=true data.plucker=cameras > $out/r03_e2e_demo4d.json 2> $out/r03_e2e_demo4d.err; cat $out/r03_e2e_demo4d.json; tail -3 $out/r03_e2e_demo4d.err
+    ;;
+  check)  # opcheck / modelcheck prefixes given as arguments, e.g.  check "ff_" "unet_sd21"
+    timeout 900 python tests/opcheck.py "${1:-}" > $out/r03_opcheck.log 2>&1; tail -25 $out/r03_opcheck.log
+    if [ -n "${2:-}" ]; then timeout 900 python tests/modelcheck.py "$2" > $out/r03_modelcheck.log 2>&1; tail -8 $out/r03_modelcheck.log; fi
+    ;;
+  ff)  # fused level-0 feed-forward: bit-identity + fp32 parity, per-launch timing, the judged UNet call, a bench step A/B, e2e timers
+    timeout 600 python tests/opcheck.py ff_fused > $out/r03_ff_opcheck.log 2>&1; tail -8 $out/r03_ff_opcheck.log
+    timeout 300 python tests/opbench.py ff > $out/r03_ff_opbench.log 2>&1; cat $out/r03_ff_opbench.log
+    timeout 600 python tests/opcheck.py attn_fp8 > $out/r03_fp8_opcheck.log 2>&1; tail -3 $out/r03_fp8_opcheck.log
+    timeout 900 python tests/modelcheck.py unet_sd21_72x40_f16 demo3d > $out/r03_ff_modelcheck.log 2>&1; tail -6 $out/r03_ff_modelcheck.log
+    for rep in 1 2; do for f in 1 0; do
+      DM4D_FF_FUSED=$f timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-grid-secondary --no-vae > $out/r03_ff_bench_f${f}_$rep.json 2>/dev/null
+      python - <<PY
+import json; d=json.load(open("$out/r03_ff_bench_f${f}_$rep.json")); print("FF_FUSED=$f rep $rep:", d["value"], "lat/s", d["ms_per_step"], "ms; linear", d["kernel_breakdown_one_step"]["linear"], "ln", d["kernel_breakdown_one_step"]["layernorm"])
+PY
+    done; done
+    timeout 300 python tools/e2e_demo.py --exp demo_4d_tiny --fast-vae --prune --writers 2 --device-results --writer-processes 8 --host-threads ${1:-8} --timeline $out/r03_e2e_tiny_new2_timeline.json sampler.plucker_on_device=true data.plucker=cameras > $out/r03_e2e_tiny_new2.json 2> $out/r03_e2e_tiny_new2.err; cat $out/r03_e2e_tiny_new2.json
+    ;;
+  ff2)  # fused feed-forward after a schedule change: parity, per-launch timing, bench A/B
+    timeout 600 python tests/opcheck.py ff_fused > $out/r03_ff_opcheck.log 2>&1; tail -8 $out/r03_ff_opcheck.log
+    timeout 300 python tests/opbench.py ff > $out/r03_ff_opbench.log 2>&1; cat $out/r03_ff_opbench.log
+    for rep in 1 2; do for f in 1 0; do
+      DM4D_FF_FUSED=$f timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-grid-secondary --no-vae > $out/r03_ff_bench_f${f}_$rep.json 2>/dev/null
+      python - <<PY
+import json; d=json.load(open("$out/r03_ff_bench_f${f}_$rep.json")); print("FF_FUSED=$f rep $rep:", d["value"], "lat/s", d["ms_per_step"], "ms; linear", d["kernel_breakdown_one_step"]["linear"])
+PY
+    done; done
+    ;;
+  e2eprof)  # where the GPU time of an end-to-end run goes: kernel-time table of the whole CLI path (torch's kernels included)
+    cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+    rm -rf $out/prof_e2e
+    timeout 600 rocprofv3 --kernel-trace --stats -d $out/prof_e2e -o stats -- python tools/e2e_demo.py --exp demo_4d_tiny --fast-vae --prune --writers 2 --device-results --writer-processes 8 --host-threads 8 sampler.plucker_on_device=true data.plucker=cameras > $out/r03_e2e_tiny_prof.json 2> $out/r03_e2e_tiny_prof.err
+    cat $out/r03_e2e_tiny_prof.json
+    DB=$(find $out/prof_e2e -name "stats*results.db" | head -1)
+    python tools/profile_summary.py "$DB" "rocprofv3 --kernel-trace --stats -- tools/e2e_demo.py --exp demo_4d_tiny (fast VAE, prune, device results)" > $out/r03_e2e_tiny_kernel_stats.txt
+    head -40 $out/r03_e2e_tiny_kernel_stats.txt
+    rm -rf $out/prof_e2e
+    ;;
+  *) echo "unknown stage $stage"; exit 2;;
+esac

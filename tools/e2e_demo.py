@@ -69,7 +69,8 @@ def main():
     torch.cuda.synchronize()
     t_load = time.perf_counter() - t0
 
-    acc, lock = {"load_sample": 0.0, "denoise": 0.0, "save": 0.0}, threading.Lock()
+    from collections import defaultdict
+    acc, lock = defaultdict(float, {"load_sample": 0.0, "denoise": 0.0, "save": 0.0}), threading.Lock()
     events = []  # (stage, start, end, thread name): the timeline of the run
 
     def timed(name, fn):
@@ -84,6 +85,16 @@ def main():
                     events.append((name, t, t1, threading.current_thread().name))
         return w
 
+    if a.timeline:  # finer host-side intervals inside `denoise` (no device synchronisation is added: these are the times the
+        # worker THREAD spends in each part, including whatever blocks it)
+        from diffuman4d_amd.host import results as _res
+        for pipe in pipelines:
+            pipe.prepare_all_latents = timed("d.prepare_all_latents", pipe.prepare_all_latents)
+            pipe.denoise_latents = timed("d.denoise_latents", pipe.denoise_latents)
+            pipe.vae.decode_to_images = timed("d.decode", pipe.vae.decode_to_images)
+            pipe.vae.encode_scaled = timed("d.encode_scaled", pipe.vae.encode_scaled)
+        _res.pack_results_on_device = timed("d.pack", _res.pack_results_on_device)
+        sampler._scatter_cells = timed("d.scatter", sampler._scatter_cells)
     sampler.load_sample = timed("load_sample", sampler.load_sample)
     sampler.denoise = timed("denoise", sampler.denoise)
     if sampler.result_writer is not None:
