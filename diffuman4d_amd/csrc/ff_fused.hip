@@ -111,19 +111,17 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const u16* __
   const int w2_rd = W1_BYTES + (wn * (CK / 2) + l31) * 64, w2_sw = (l31 >> 2) & 3;
   const int h_row = H_OFF + (wm * 32 + l31) * H_LD;
 
-  // Schedule.  A wave's work per step of 32 hidden units, cut into two intervals by workgroup barriers:
-  //     X_s: S(s) = product 1 (21 MFMAs)           Y_s: GEGLU(s) -> H(s), then product 2 of step s-1 (10 MFMAs)
-  // The second HALF of the workgroup (waves 4-7 = row groups 2-3) runs the same sequence ONE INTERVAL LATE (it passes one extra
-  // barrier before its first interval, the first half one extra after its last).  A workgroup's waves w and w + 4 share a SIMD
-  // (MI355X_MICROARCH.md, LDS section), so in every interval each SIMD holds one wave that streams MFMAs and one that mostly runs
-  // GEGLU on the vector ALU: the pairing in which matrix pipe and vector ALU overlap.  With all eight waves in the same phase
-  // (the first version of this kernel) both waves of a SIMD want the matrix pipe at the same time and then both want the vector
-  // ALU: 2.3x the MFMA time per step, measured.  The H tile is exchanged only between the two waves of a row group, which are in
-  // the same half.  Every wave issues its share of the weight DMA on its OWN schedule -- W1(s+1) in X_s, W2(s) in Y_s -- which
-  // keeps every tile complete one barrier before its first reader (the early half) and intact until its last (the late half):
-  // W1(s+1) replaces W1(s-1), last read by the late half in global interval 2s-1 and first written by the early half in 2s;
-  // W2(s) replaces W2(s-2), last read in global interval 2s, first written in 2s+1; the late half's pieces land by the end of
-  // 2s+1 / 2s+2, the first readers come in 2s+2 / 2s+3 (which is why the very last product 2 waits one idle interval).
+  // Schedule: software pipelined by one step, ONE barrier per step.  Body s holds three pieces of work,
+  //     A: GEGLU of S(s) -> H(s)                  (vector ALU, 2 LDS stores)
+  //     B: O^T += W2c(s-1) H(s-1)^T               (10 MFMAs; H(s-1) was stored before the previous barrier)
+  //     C: S(s+1)^T = W1c(s+1) y^T                (21 MFMAs, into the registers A has just read)
+  // and receives W1(s+2) -> the buffer of W1(s) and W2(s) -> the buffer of W2(s-2), both last read in body s-1.
+  // Two other schedules were built and measured on MI355X (profiles/r03_ff_fused_schedules.log), both bit-identical:
+  //  * product 1, GEGLU, barrier, product 2, barrier (two barriers per step): 272-305 us at M = 92 160 against 330-347 us for the
+  //    two-GEMM form; its first version also stalled on the bias load behind the DMA issue (see `settle`);
+  //  * the two halves of the workgroup half a step apart, so that every SIMD pairs one wave in product 1 with one wave in GEGLU:
+  //    305-336 us, SLOWER -- a wave that streams MFMAs starves the vector ALU of the wave it shares the SIMD with (DESIGN.md
+  //    section 4, issue probe): vector work hides only behind a wave's OWN MFMAs, which is what A + B in one block provide.
   auto product1 = [&](int s, u16 bias_bits) {
     const char* wb = smem + (s & 1) * WBUF;
     f32x16_t sa = mfma_t(one0, k0_fragment(bias_bits, lh), zero);
@@ -134,22 +132,27 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const u16* __
         const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(wb + t * 8192 + w1_rd + (((ks * 2 + lh) ^ w1_sw) * 16));
         sa = mfma_t(xf[4 * t + ks], wf, sa);
       }
-    asm volatile("" ::"v"(sa));  // every MFMA of the product is issued before what follows (the compiler otherwise sinks some of them
-    return sa;                   // below the interval's barrier, into the interval that belongs to the other half's MFMAs)
+    return sa;
   };
-  auto geglu_store = [&](int s, const f32x16_t& sa) {
-    // register e = hidden unit 4 lh + (e & 3) + 8 (e >> 2) of this wave's 16, register e + 8 = its gate
+  // GEGLU in registers: register e = hidden unit 4 lh + (e & 3) + 8 (e >> 2) of this wave's 16, register e + 8 = its gate.
+  // The store of the packed result is a separate step: fragment reads cannot be moved above an LDS store they might alias, so the
+  // store comes LAST in a body and the products' reads (and with them their MFMAs) are free to run beside the vector work.
+  struct HPack { uint2 lo, hi; };
+  auto geglu = [&](const f32x16_t& sa) {
     float hv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) hv[e] = sa[e] * gelu_erf_f(sa[e + 8]);
-    uint2 lo, hi;
-    lo.x = pack_bf2(hv[0], hv[1]);
-    lo.y = pack_bf2(hv[2], hv[3]);
-    hi.x = pack_bf2(hv[4], hv[5]);
-    hi.y = pack_bf2(hv[6], hv[7]);
+    HPack h;
+    h.lo.x = pack_bf2(hv[0], hv[1]);
+    h.lo.y = pack_bf2(hv[2], hv[3]);
+    h.hi.x = pack_bf2(hv[4], hv[5]);
+    h.hi.y = pack_bf2(hv[6], hv[7]);
+    return h;
+  };
+  auto h_store = [&](int s, const HPack& h) {
     char* hp = smem + h_row + (s & 1) * H_BYTES + (16 * wn + 4 * lh) * 2;
-    *reinterpret_cast<uint2*>(hp) = lo;        // units 16 wn + 4 lh + 0..3
-    *reinterpret_cast<uint2*>(hp + 16) = hi;   // units 16 wn + 8 + 4 lh + 0..3
+    *reinterpret_cast<uint2*>(hp) = h.lo;        // units 16 wn + 4 lh + 0..3
+    *reinterpret_cast<uint2*>(hp + 16) = h.hi;   // units 16 wn + 8 + 4 lh + 0..3
   };
   auto product2 = [&](int s) {
     const char* wb = smem + (s & 1) * WBUF;
@@ -163,8 +166,6 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const u16* __
         acc[0][j] = mfma_t(hf, wf, acc[0][j]);
       }
     }
-    static_assert(NJ == 5, "the pin below names the five accumulator blocks");
-    asm volatile("" ::"v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[0][2]), "v"(acc[0][3]), "v"(acc[0][4]));
   };
   f32x16_t s_cur;
   auto close_interval = [&]() {
@@ -174,54 +175,59 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const u16* __
   };
 
   // Bias values (one bf16 per lane and step) are ordinary loads the compiler counts; the DMA statements are not.  A value
-  // loaded in one interval is settled at the top of the interval that uses it, BEFORE that interval's DMA goes out: the wait the
-  // compiler places there finds nothing else in flight (close_interval drained the queue), whereas a wait placed behind the DMA
-  // issue would stall on it.
+  // loaded in one body is settled at the top of the body that uses it, BEFORE that body's DMA goes out: the wait the compiler
+  // places there finds nothing else in flight (close_interval drained the queue), whereas a wait placed behind the DMA issue
+  // stalls on the DMA (the first version of this kernel paid that in every step).
   auto settle = [&](uint32_t v) {
     asm volatile("" : "+v"(v));
     return (u16)v;
   };
   const u16* b1l = b1p + wn * 32 + l31;
   uint32_t b1v = b1l[0];
-  const bool late = wave >= 4;
-  if (late) close_interval();
-  {  // step 0 (no product 2 yet)
-    const u16 bb = settle(b1v);                    // X_0
+  // prologue of the pipeline: W1(1) (over the y tile's first 40 KB: every wave holds its rows by now), then S(0)
+  {
+    const u16 b0 = settle(b1v);
     issue_w1(1, 1);
     b1v = b1l[64];
-    s_cur = product1(0, bb);
+    s_cur = product1(0, b0);
     close_interval();
-    issue_w2(0, 0);                                // Y_0
-    geglu_store(0, s_cur);
+  }
+  {  // body 0: no product 2 yet
+    const u16 bb = settle(b1v);
+    const int s2 = 2 < nsteps ? 2 : nsteps - 1;  // past the end: the last slab once more, into a buffer nobody reads again
+    issue_w1(s2, 0);                             // (unconditional issue keeps the body one basic block)
+    issue_w2(0, 0);
+    b1v = b1l[s2 * 64];
+    const HPack h = geglu(s_cur);
+    s_cur = product1(1, bb);
+    h_store(0, h);
     close_interval();
   }
   for (int s = 1; s + 1 < nsteps; ++s) {
-    const u16 bb = settle(b1v);                    // X_s
-    issue_w1(s + 1, (s + 1) & 1);
-    b1v = b1l[(s + 1) * 64];
-    s_cur = product1(s, bb);
-    close_interval();
-    issue_w2(s, s & 1);                            // Y_s
-    geglu_store(s, s_cur);
-    __builtin_amdgcn_sched_barrier(0);  // GEGLU's registers are dead before product 2's fragments are fetched (register budget);
-    product2(s - 1);                    // the overlap of vector and matrix work comes from the OTHER wave of the SIMD
-    close_interval();
-  }
-  {  // last step, then the product 2 that is still owed
-    const int s = nsteps - 1;
-    const u16 bb = settle(b1v);                    // X_(n-1)
-    s_cur = product1(s, bb);
-    close_interval();
-    issue_w2(s, s & 1);                            // Y_(n-1)
-    geglu_store(s, s_cur);
-    __builtin_amdgcn_sched_barrier(0);
+    const u16 bb = settle(b1v);
+    const int s2 = s + 2 < nsteps ? s + 2 : nsteps - 1;
+    issue_w1(s2, s & 1);
+    issue_w2(s, s & 1);
+    b1v = b1l[s2 * 64];
+    __builtin_amdgcn_sched_barrier(0);  // the bias load stays up here (the scheduler otherwise sinks it to the end of the body, in
+                                        // front of close_interval's vmcnt(0): one L2 round trip exposed per step)
+    const HPack h = geglu(s_cur);
     product2(s - 1);
-    close_interval();
-    close_interval();                              // X_n: idle -- the other half's pieces of W2(n-1) are still landing
-    product2(s);                                   // Y_n
+    s_cur = product1(s + 1, bb);
+    h_store(s, h);
+    asm volatile("" ::"v"(s_cur), "v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[0][2]), "v"(acc[0][3]), "v"(acc[0][4]));
     close_interval();
   }
-  if (!late) close_interval();
+  {  // last body, then the product 2 that is still owed
+    const int s = nsteps - 1;
+    issue_w2(s, s & 1);
+    const HPack h = geglu(s_cur);
+    product2(s - 1);
+    h_store(s, h);
+    close_interval();
+    product2(s);
+    close_interval();
+  }
   // everybody's fragment reads are behind a barrier: the epilogue may stage through the same LDS
   gemm_epilogue<1, NJ, 32, CK / 2, false>(p, acc, reinterpret_cast<float*>(smem), m0, 0, wm, wn, wave, lane);
 }

@@ -218,15 +218,27 @@ class AutoencoderKL:
             for k, i in enumerate(idx):
                 fresh[i] = m[k]
         if cache is not None:
+            on_gpu = self.device.type == "cuda"
+            cur = torch.cuda.current_stream(self.device) if on_gpu else None
             if fresh:
+                # The cache is shared by the runner's task streams (gpu_streams > 1): an entry may be read by another stream as
+                # soon as it is in the dict.  It is published together with an EVENT recorded behind the kernels that write it;
+                # a reader on another stream makes its stream wait for that event.  (Round 2 drained the writing stream on the
+                # host instead: one host-side stall per task of the first alternation round, with the GPU idling behind it.)
+                ev = None
                 clones = {i: m.clone() for i, m in fresh.items()}
-                # The cache is shared by the runner's task streams (gpu_streams > 1): an entry may be read by another
-                # stream as soon as it is in the dict, so it is published only once the kernels that write it are done.
-                if self.device.type == "cuda":
-                    torch.cuda.current_stream(self.device).synchronize()
+                if on_gpu:
+                    ev = torch.cuda.Event()
+                    ev.record(cur)
                 for i, c in clones.items():
-                    cache[keys[i]] = c
-            rows = [cache[keys[i]] for i in range(n)]
+                    cache[keys[i]] = (c, ev, cur)
+            rows, waited = [], set()
+            for i in range(n):
+                c, ev, st = cache[keys[i]]
+                if ev is not None and st != cur and id(ev) not in waited:  # written on another stream: order this stream behind it
+                    cur.wait_event(ev)
+                    waited.add(id(ev))
+                rows.append(c)
         else:
             rows = [fresh[i] for i in range(n)]
         outs = []
