@@ -52,5 +52,22 @@ PY
     head -40 $out/r03_e2e_tiny_kernel_stats.txt
     rm -rf $out/prof_e2e
     ;;
+  final)  # the records that go to profiles/: GPU test suite, the driver's bench command, rocprofv3 stats + PMC, extension lines
+    ( time timeout 1800 python -m pytest tests -m gpu -q ) > $out/r03_pytest_gpu.log 2>&1; tail -6 $out/r03_pytest_gpu.log
+    timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/r03_bench.json 2> $out/r03_bench.err; tail -c 400 $out/r03_bench.json
+    bash tools/profile_bench.sh r03
+    # copyBuffer attribution: the same command with 6 timed steps instead of 2 -- launches that do not scale with the step count are init
+    cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+    rm -rf $out/prof_r03b
+    rocprofv3 --kernel-trace --stats -d $out/prof_r03b -o stats -- python bench.py --steps 6 --warmup 1 --no-cpu-baseline --task-streams 1 --no-grid-secondary --no-vae > /dev/null 2> $out/prof_r03b.err
+    DB=$(find $out/prof_r03b -name "stats*results.db" | head -1)
+    python tools/profile_summary.py "$DB" "same command with --steps 6 --no-vae --no-grid-secondary" | grep -E "total kernel|copyBuffer|fillBuffer|attn_kernel" > $out/r03_copybuffer_steps6.txt
+    grep -E "total kernel|copyBuffer|fillBuffer|attn_kernel" $out/r03_kernel_stats.txt > $out/r03_copybuffer_steps2.txt
+    cat $out/r03_copybuffer_steps2.txt $out/r03_copybuffer_steps6.txt
+    rm -rf $out/prof_r03 $out/prof_r03b
+    timeout 600 python bench.py --latent 128x128 --steps 4 --warmup 1 --no-cpu-baseline --no-grid-secondary > $out/r03_bench_latent128.json 2>/dev/null; tail -c 300 $out/r03_bench_latent128.json
+    timeout 300 python bench.py --config5 --steps 8 --warmup 2 --no-grid-secondary --no-vae > $out/r03_bench_config5_bf16.json 2>/dev/null; python -c "import json; d=json.load(open('$out/r03_bench_config5_bf16.json')); print('config5 bf16', d['value'], d['ms_per_step'])"
+    timeout 300 python bench.py --config5 --attention fp8 --steps 8 --warmup 2 --no-grid-secondary --no-vae > $out/r03_bench_config5_fp8.json 2>/dev/null; python -c "import json; d=json.load(open('$out/r03_bench_config5_fp8.json')); print('config5 fp8', d['value'], d['ms_per_step'])"
+    ;;
   *) echo "unknown stage $stage"; exit 2;;
 esac
