@@ -165,3 +165,26 @@ def test_imgwrite_imports_without_torch():
     from pathlib import Path
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(Path(__file__).resolve().parent.parent))
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr
+
+
+def test_writer_pool_writes_packages_in_processes_and_surfaces_errors(tmp_path):
+    """imgwrite.WriterPool: plain subprocesses fed pickled uint8 packages over pipes; results and worker exceptions come back as
+    futures on the submitting side."""
+    from diffuman4d_amd.host.imgwrite import WriterPool
+    rng = np.random.default_rng(0)
+    with WriterPool(2) as pool:
+        futs = []
+        for k in range(5):
+            pkg = {"grid": (str(tmp_path / "grids" / f"g{k}.webp"), rng.integers(0, 255, (40, 300, 3), dtype=np.uint8)),
+                   "images": [(str(tmp_path / "images" / f"{k:02d}" / f"{i:06d}.jpg"), rng.integers(0, 255, (64, 40, 3), dtype=np.uint8),
+                               (2, 3, 50, 30, 70, 44)) for i in range(3)],
+                   "crops": [(str(tmp_path / "crops" / f"{k:02d}" / "000000.json"), (2, 3, 50, 30, 70, 44))], "quality": 90}
+            futs.append(pool.submit(pkg))
+        assert [f.result(timeout=120) for f in futs] == [3] * 5
+        bad = pool.submit({"grid": ("/proc/definitely/not/writable.webp", np.zeros((4, 4, 3), np.uint8))})
+        with pytest.raises(RuntimeError, match="writer process"):
+            bad.result(timeout=120)
+        again = pool.submit({"images": [(str(tmp_path / "images" / "00" / "000000.jpg"), np.zeros((8, 8, 3), np.uint8), None)]})
+        assert again.result(timeout=120) == 0  # exists already: skipped, and the pool survived the failed package
+    assert len(list(tmp_path.rglob("*.jpg"))) == 15 and len(list(tmp_path.rglob("*.webp"))) == 5
+    assert Image.open(tmp_path / "images" / "03" / "000001.jpg").size == (44, 70)  # crop undone onto the (w, h) canvas

@@ -10,7 +10,7 @@ TAG=${1:-r01}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 # one task in flight: the bench's roofline figures come from its one-task-at-a-time pass, and with two task streams the
 # kernel intervals of different tasks overlap in the trace
-BENCH="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --task-streams 1"
+BENCH="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --task-streams 1 --no-grid-secondary --no-vae"
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"
