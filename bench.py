@@ -17,7 +17,7 @@ Modes (--mode; default `auto` = `task` at --gpus 1, `grid` at --gpus N > 1):
          tasks, one per frame), temporal round (44 tasks, one per target camera), spatial round, executed by the
          product's DistributedSamplingRunner -- round-robin task partition, loader / GPU-stream pipelining per rank,
          barrier + RCCL cell exchange at both round boundaries -- on a latents-only pipeline adapter.  Every task runs
-         the first c window calls of its sweep (spatial c_s = max(1, K // 10), temporal c_t = round(3.41 c_s): the
+         the first c window calls of its sweep (spatial c_s = max(1, K // 5), temporal c_t = round(3.41 c_s): the
          2 : 1 call mix), so wave quantisation (150 and 44 tasks over N GPUs), the exchange and host contention are
          in the number; --steps K sets that depth and `value` counts the latent-steps actually executed / 18.
   frame-shard  every window split over all ranks with RCCL K/V all-gathers (latency mode, BASELINE config 4).
@@ -227,9 +227,11 @@ class LatentGridPipeline:
 
 
 def grid_depth(steps: int):
-    """Window calls per task from --steps: spatial c_s = max(1, K // 10), temporal c_t = round(3.41 c_s) keeps the full
-    run's 6600 : 3300 call mix over 300 spatial and 44 temporal tasks (K = 20 -> 2 and 7; the full sweeps are 22 and 75)."""
-    cs = max(1, steps // 10)
+    """Window calls per task from --steps: spatial c_s = max(1, K // 5), temporal c_t = round(3.41 c_s) keeps the full
+    run's 6600 : 3300 call mix over 300 spatial and 44 temporal tasks (K = 20 -> 4 and 14 = 1 816 calls, 18 % of the run; the full
+    sweeps are 22 and 75).  Round 2 used K // 10: at 8 GPUs a rank then ran for about 3 s per pass, too little against the fixed
+    costs of a pass (runner start-up, two barriers, two exchanges)."""
+    cs = max(1, steps // 5)
     return {"spatial": min(cs, 22), "temporal": min(max(1, round(2 * N_FRAMES * cs / (2 * 44))), 75)}
 
 

@@ -36,8 +36,9 @@ def small_latents(monkeypatch):
 
 
 def test_grid_depth_keeps_the_call_mix():
-    assert bench.grid_depth(20) == {"spatial": 2, "temporal": 7}
+    assert bench.grid_depth(20) == {"spatial": 4, "temporal": 14}
     assert bench.grid_depth(4) == {"spatial": 1, "temporal": 3}
+    assert bench.grid_depth(1) == {"spatial": 1, "temporal": 3}
     assert bench.grid_depth(10 ** 4) == {"spatial": 22, "temporal": 75}  # never deeper than the real sweeps
     d = bench.grid_depth(20)
     assert abs((300 * d["spatial"]) / (44 * d["temporal"]) - 2.0) < 0.1  # 6600 : 3300 in the full run
