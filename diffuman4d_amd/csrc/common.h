@@ -74,6 +74,42 @@ __device__ __forceinline__ float gelu_fit_f(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * q));
 }
 
+// LayerNorm statistics of ONE row held by one wave: lane l carries the 16-byte vectors l, l + 64, ... of the row (v[i] = vector
+// l + 64 i, on[i] = that vector exists), two-pass mean / variance in fp32, butterfly over the 64 lanes.  The one definition both
+// ln_kernel (norm.hip) and the in-LDS LayerNorm of the row-register kernels (ff_fused.hip) use, so that a fused LayerNorm gives the
+// bits of the stand-alone launch.
+template <int NV>
+__device__ __forceinline__ void ln_row_stats(const float (&v)[NV][8], const bool (&on)[NV], int C, float eps, float& mu, float& rs) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (on[i]) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e];
+    }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  mu = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (on[i]) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[i][e] - mu;
+        q += d * d;
+      }
+    }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+  rs = rsqrtf(q / (float)C + eps);
+}
+// ... and the affine step on one vector: y = (v - mu) rs gamma + beta
+__device__ __forceinline__ void ln_row_apply(const float (&v)[8], float mu, float rs, const float (&g)[8], const float (&bt)[8], float (&y)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) y[e] = (v[e] - mu) * rs * g[e] + bt[e];
+}
+
 // XCD-aware block remap (8 XCDs, block b runs on XCD b % 8): give each XCD a contiguous range of
 // logical tiles so neighbouring tiles share one L2.  Bijective for any grid size.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

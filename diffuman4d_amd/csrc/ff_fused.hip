@@ -1,8 +1,80 @@
-// Fused feed-forward of a transformer block (level 0 of the UNet): see the comment at the kernel.  Shares the MFMA / epilogue
-// helpers of gemm.hip through gemm_common.h.
+// Fused feed-forward of a transformer block (level 0 of the UNet, C = 320), with the LayerNorm in front of it (norm3) folded in: a
+// kernel that keeps its ACTIVATION ROWS IN REGISTERS for the whole launch.  Shares the MFMA / epilogue helpers of gemm.hip through
+// gemm_common.h.  (The same row-register structure was built for the K = 320 Linear layers -- QKV with norm1 folded in, output
+// projection, proj_in / proj_out -- bit-identical and SLOWER than layernorm + gemm on every shape, 217 vs 118 us for QKV: one
+// workgroup per CU has nothing to overlap its tile fetch, LayerNorm and epilogue with.  profiles/r03_lin320_rowreg_ab.log; removed.)
 #include "gemm_common.h"
 
 namespace {
+
+constexpr int FF_BM = 128, FF_STEP = 32;
+
+// ------------------------------------------------------------------------------------------------
+// A tile of FF_BM rows x CK channels: HBM -> LDS by DMA as CK / 64 slabs of [FF_BM rows][64 k] (128-byte row pieces, the 16-byte
+// chunks of a row XOR-permuted on the source side like every A tile of gemm.hip), optionally LayerNorm'ed IN PLACE, then read
+// into registers as the MFMA fragments of the wave's 32 rows (CK / 16 k steps x 4 VGPRs).
+// ------------------------------------------------------------------------------------------------
+struct LnArgs {
+  const u16* gamma;  // nullptr: the rows are used as they are
+  const u16* beta;
+  float eps;
+};
+
+template <int CK>
+__device__ __forceinline__ void rows_issue(const u16* X, int64_t ldx, int M, int m0, uint32_t lds_tile, int wave, int lane) {
+#pragma unroll
+  for (int h = 0; h < FF_BM / 64; ++h) {
+    const int row = (wave + 8 * h) * 8 + (lane >> 3);
+    int m = m0 + row;
+    if (m > M - 1) m = M - 1;
+    const uint32_t voff = (uint32_t)m * (uint32_t)(ldx * 2) + (uint32_t)((lane & 7) ^ ((row >> 1) & 7)) * 16u;
+#pragma unroll
+    for (int t = 0; t < CK / 64; ++t) dma16_sv(X + t * 64, voff, lds_tile + t * (FF_BM * 128) + (wave + 8 * h) * 1024);
+  }
+}
+
+// LayerNorm of the tile in the LDS, in place: wave w normalises rows 16 w .. 16 w + 15 one after the other with lane l on the
+// row's 16-byte vector l -- the arrangement and the arithmetic of ln_kernel<1> (ln_row_stats / ln_row_apply), so the result is the
+// stand-alone LayerNorm launch bit for bit.  The caller puts a barrier on either side.
+template <int CK>
+__device__ __forceinline__ void rows_layernorm(char* tile, const LnArgs& ln, int wave, int lane) {
+  static_assert(CK / 8 <= 64, "one vector per lane");
+  const bool on[1] = {lane < CK / 8};
+  float g[8], bt[8];
+  if (on[0]) {
+    unpack8(ldg16(ln.gamma + lane * 8), g);
+    unpack8(ldg16(ln.beta + lane * 8), bt);
+  }
+  const int t = lane >> 3, c = lane & 7;
+  for (int i = 0; i < FF_BM / 8; ++i) {
+    const int r = wave * (FF_BM / 8) + i;
+    char* a = tile + t * (FF_BM * 128) + r * 128 + ((c ^ ((r >> 1) & 7)) << 4);
+    float v[1][8];
+    if (on[0]) {
+      unpack8(*reinterpret_cast<const U4*>(a), v[0]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[0][e] = 0.f;
+    }
+    float mu, rs;
+    ln_row_stats<1>(v, on, CK, ln.eps, mu, rs);
+    if (on[0]) {
+      float y[8];
+      ln_row_apply(v[0], mu, rs, g, bt, y);
+      *reinterpret_cast<U4*>(a) = pack8(y);
+    }
+  }
+}
+
+template <int CK>
+__device__ __forceinline__ void rows_fragments(const char* tile, int wm, int lane, bf16x8_t (&xf)[CK / 16]) {
+  const int l31 = lane & 31, lh = lane >> 5, sw = (l31 >> 1) & 7;
+#pragma unroll
+  for (int t = 0; t < CK / 64; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      xf[4 * t + ks] = *reinterpret_cast<const bf16x8_t*>(tile + t * (FF_BM * 128) + (wm * 32 + l31) * 128 + (((ks * 2 + lh) ^ sw) * 16));
+}
 
 // ------------------------------------------------------------------------------------------------
 // Fused feed-forward of a transformer block at C = 320 (level 0 of the UNet; attention.py:129-149: ff(norm3(x)) + x, the
@@ -25,11 +97,9 @@ namespace {
 // the Linear kernels above, and the same gelu: results are BIT-IDENTICAL to gemm(GEGLU) followed by gemm(residual)
 // (tests/opcheck.py ff_fused_*).
 // ------------------------------------------------------------------------------------------------
-constexpr int FF_BM = 128, FF_STEP = 32;
-
 template <int CK>
-__device__ __forceinline__ void ff_fused_body(const GemmParams& p, const u16* __restrict__ W1p, const u16* __restrict__ b1p,
-                                              const u16* __restrict__ W2p, int nsteps) {
+__device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs& ln, const u16* __restrict__ W1p,
+                                              const u16* __restrict__ b1p, const u16* __restrict__ W2p, int nsteps) {
   static_assert(CK % 64 == 0 && (CK / 2) % 32 == 0, "channel count");
   constexpr int NSLAB = CK / 64, KS1 = CK / 16, NJ = CK / 2 / 32;  // 64-wide K slabs of y / W1, k steps of product 1, column blocks per wave
   constexpr int W1_BYTES = 64 * CK * 2, W2_BYTES = CK * FF_STEP * 2, WBUF = W1_BYTES + W2_BYTES;
@@ -71,30 +141,19 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const u16* __
   };
 
   // ---- prologue: y tile -> LDS (5 slabs of [128 rows][64 k]) beside the weights of step 0, then -> registers ----
-  {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int row = (wave + 8 * h) * 8 + (lane >> 3);
-      int m = m0 + row;
-      if (m > p.M - 1) m = p.M - 1;
-      const uint32_t voff = (uint32_t)m * (uint32_t)(p.lda * 2) + (uint32_t)((lane & 7) ^ ((row >> 1) & 7)) * 16u;
-#pragma unroll
-      for (int t = 0; t < NSLAB; ++t) dma16_sv(p.A + t * 64, voff, lds0 + Y_OFF + t * (FF_BM * 128) + (wave + 8 * h) * 1024);
-    }
-  }
+  rows_issue<CK>(p.A, p.lda, p.M, m0, lds0 + Y_OFF, wave, lane);
   issue_w1(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  bf16x8_t xf[KS1];
-  {
-    const int sw = (l31 >> 1) & 7;
-#pragma unroll
-    for (int t = 0; t < NSLAB; ++t)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-        xf[4 * t + ks] = *reinterpret_cast<const bf16x8_t*>(smem + Y_OFF + t * (FF_BM * 128) + (wm * 32 + l31) * 128 + (((ks * 2 + lh) ^ sw) * 16));
+  if (ln.gamma) {  // norm3 folded in: the tile holds x, not LayerNorm(x) (bit-identical to the stand-alone launch, rows_layernorm)
+    rows_layernorm<CK>(smem + Y_OFF, ln, wave, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
   }
+  bf16x8_t xf[KS1];
+  rows_fragments<CK>(smem + Y_OFF, wm, lane, xf);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // every wave has its y rows: buffer 1 and the H tile may be written
   asm volatile("" ::: "memory");
@@ -235,9 +294,9 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const u16* __
 // (the body is a device function: the host pass instantiates only the stub of a __global__ template, and the register
 // constraints of the asm statements above are device-only)
 template <int CK>
-__global__ __launch_bounds__(512) void ff_fused_kernel(GemmParams p, const u16* __restrict__ W1p, const u16* __restrict__ b1p,
-                                                       const u16* __restrict__ W2p, int nsteps) {
-  ff_fused_body<CK>(p, W1p, b1p, W2p, nsteps);
+__global__ __launch_bounds__(512) void ff_fused_kernel(GemmParams p, LnArgs ln, const u16* __restrict__ W1p,
+                                                       const u16* __restrict__ b1p, const u16* __restrict__ W2p, int nsteps) {
+  ff_fused_body<CK>(p, ln, W1p, b1p, W2p, nsteps);
 }
 
 // Per-step packed copies of the feed-forward weights for ff_fused_kernel (once per layer, at load time):
@@ -271,8 +330,8 @@ int ff_launch_prepare(hipStream_t st, const u16* W1, const u16* b1, const u16* W
   return dm4d_check_launch("ff_prepare_kernel");
 }
 
-int ff_launch_fused(hipStream_t st, const GemmParams& p, const u16* W1p, const u16* b1p, const u16* W2p, int nsteps) {
-  hipLaunchKernelGGL((ff_fused_kernel<320>), dim3((unsigned)((p.M + FF_BM - 1) / FF_BM)), dim3(512), 0, st, p, W1p, b1p, W2p, nsteps);
+int ff_launch_fused(hipStream_t st, const GemmParams& p, const LnArgs& ln, const u16* W1p, const u16* b1p, const u16* W2p, int nsteps) {
+  hipLaunchKernelGGL((ff_fused_kernel<320>), dim3((unsigned)((p.M + FF_BM - 1) / FF_BM)), dim3(512), 0, st, p, ln, W1p, b1p, W2p, nsteps);
   return dm4d_check_launch("ff_fused_kernel");
 }
 
@@ -288,9 +347,9 @@ extern "C" int dm4d_ff_geglu_prepare_bf16(void* stream, const void* W1, const vo
 
 extern "C" int dm4d_ff_geglu_supported(int C, int hidden) { return (C == 320 && hidden >= 64 && hidden % 32 == 0) ? 1 : 0; }
 
-extern "C" int dm4d_ff_geglu_fused_bf16(void* stream, const void* Y, int64_t ldy, const void* W1p, const void* b1p, const void* W2p,
-                                        const void* b2, const void* residual, int64_t ld_res, void* Out, int64_t ldo, int M, int C,
-                                        int hidden) {
+extern "C" int dm4d_ff_geglu_fused_bf16(void* stream, const void* Y, int64_t ldy, const void* ln_gamma, const void* ln_beta, float ln_eps,
+                                        const void* W1p, const void* b1p, const void* W2p, const void* b2, const void* residual,
+                                        int64_t ld_res, void* Out, int64_t ldo, int M, int C, int hidden) {
   if (!Y || !W1p || !b1p || !W2p || !Out || M <= 0) return dm4d_set_error(DM4D_ERR_ARG, "ff_geglu_fused: null pointer or empty shape");
   if (!dm4d_ff_geglu_supported(C, hidden))
     return dm4d_set_error(DM4D_ERR_ARG, "ff_geglu_fused: built for C = 320 and a hidden size that is a multiple of 32 (use two dm4d_gemm_bf16 calls)");
@@ -298,10 +357,12 @@ extern "C" int dm4d_ff_geglu_fused_bf16(void* stream, const void* Y, int64_t ldy
     return dm4d_set_error(DM4D_ERR_ARG, "ff_geglu_fused: row strides must be multiples of 8 elements, pointers 16-byte aligned");
   if ((uint64_t)M * (uint64_t)ldy * 2u >= (1ull << 32))
     return dm4d_set_error(DM4D_ERR_ARG, "ff_geglu_fused: input of 4 GiB or more (split the rows)");
+  if ((ln_gamma == nullptr) != (ln_beta == nullptr)) return dm4d_set_error(DM4D_ERR_ARG, "ff_geglu_fused: LayerNorm needs both gamma and beta");
   GemmParams p{};
   p.A = (const u16*)Y; p.lda = ldy; p.C = (u16*)Out; p.ldc = ldo; p.M = M; p.N = C; p.K = hidden;
   p.bias = (const u16*)b2; p.res = (const u16*)residual; p.ld_res = ld_res; p.flags = 0; p.out_scale = 1.0f; p.splits = 1;
   p.rows_per_rb = 1; p.tiles_n = 1;
-  return ff_launch_fused((hipStream_t)stream, p, (const u16*)W1p, (const u16*)b1p, (const u16*)W2p, hidden / FF_STEP);
+  const LnArgs ln{(const u16*)ln_gamma, (const u16*)ln_beta, ln_eps};
+  return ff_launch_fused((hipStream_t)stream, p, ln, (const u16*)W1p, (const u16*)b1p, (const u16*)W2p, hidden / FF_STEP);
 }
 

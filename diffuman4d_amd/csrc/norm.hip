@@ -359,46 +359,28 @@ __global__ __launch_bounds__(256) void ln_kernel(const u16* X, int64_t ldx, cons
   if (row >= M) return;
   const int CV = C / 8;
   float v[NV][8];
-  float s = 0.f;
+  bool on[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int cv = lane + 64 * i;
-    if (cv < CV) {
+    on[i] = cv < CV;
+    if (on[i]) {
       unpack8(ldg16(X + (int64_t)row * ldx + cv * 8), v[i]);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) s += v[i][e];
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
     }
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-  const float mu = s / (float)C;
-  float q = 0.f;
+  float mu, rs;
+  ln_row_stats<NV>(v, on, C, eps, mu, rs);
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int cv = lane + 64 * i;
-    if (cv < CV) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float d = v[i][e] - mu;
-        q += d * d;
-      }
-    }
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
-  const float rs = rsqrtf(q / (float)C + eps);
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int cv = lane + 64 * i;
-    if (cv < CV) {
+    if (on[i]) {
       float g[8], bt[8], y[8];
       unpack8(ldg16(gamma + cv * 8), g);
       unpack8(ldg16(beta + cv * 8), bt);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) y[e] = (v[i][e] - mu) * rs * g[e] + bt[e];
+      ln_row_apply(v[i], mu, rs, g, bt, y);
       stg16(Y + (int64_t)row * ldy + cv * 8, pack8(y));
     }
   }

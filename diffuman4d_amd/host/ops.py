@@ -127,18 +127,26 @@ class FeedForward:
                 torch.cuda.current_stream(w1.device).synchronize()
             self.packed = (w1p, b1p, w2p)
 
-    def __call__(self, n: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
+    def __call__(self, n: torch.Tensor, residual: torch.Tensor, ln=None) -> torch.Tensor:
+        """ln = (gamma, beta, eps): `n` is the un-normalised input and the LayerNorm in front of the feed-forward (norm3) is applied
+        here -- inside the fused launch, or as its own launch in the two-GEMM form."""
         if self.packed is None or not FF_FUSED or n.shape[0] * n.stride(0) * 2 >= (1 << 32):
+            if ln is not None:
+                n = layernorm(n, ln[0], ln[1], ln[2])
             f = gemm(n, self.w1, bias=self.b1, geglu=True)
             return gemm(f, self.w2, bias=self.b2, residual=residual)
         lib = _l.load()
         _req(n, "n"), _req(residual, "residual")
+        if ln is not None:
+            _req(ln[0], "gamma"), _req(ln[1], "beta")
         M = n.shape[0]
         out = torch.empty((M, self.C), dtype=BF16, device=n.device)
         w1p, b1p, w2p = self.packed
         with _Prof("linear", 2.0 * M * 3 * self.hidden * self.C, "flop"):
-            rc = lib.dm4d_ff_geglu_fused_bf16(_stream(), _p(n), n.stride(0), _p(w1p), _p(b1p), _p(w2p), _p(self.b2), _p(residual),
-                                              residual.stride(0), _p(out), out.stride(0), M, self.C, self.hidden)
+            rc = lib.dm4d_ff_geglu_fused_bf16(_stream(), _p(n), n.stride(0), _p(ln[0]) if ln is not None else None,
+                                              _p(ln[1]) if ln is not None else None, float(ln[2]) if ln is not None else 0.0, _p(w1p),
+                                              _p(b1p), _p(w2p), _p(self.b2), _p(residual), residual.stride(0), _p(out), out.stride(0), M,
+                                              self.C, self.hidden)
         _l.check(rc, "dm4d_ff_geglu_fused_bf16")
         return out
 

@@ -194,8 +194,8 @@ class _TransformerBlock:
             kvg = shard.gather_kv_finish(pending).view(batch * shard.world * seq, 2 * C)
             a = ops.attention(q, kvg[:, :C], kvg[:, C:], batch, self.heads, seq, kv_seq=shard.world * seq, q_scaled=True)
         h = ops.gemm(a, self.ow, bias=self.ob, residual=h)
-        n = ops.layernorm(h, self.n3w, self.n3b, 1e-5)
-        return self.ff(n, h)  # one launch at C = 320 (level 0), gemm(GEGLU) + gemm(residual) elsewhere
+        # norm3 + feed-forward + residual: one launch at C = 320 (level 0), layernorm + gemm(GEGLU) + gemm(residual) elsewhere
+        return self.ff(h, h, ln=(self.n3w, self.n3b, 1e-5))
 
 
 class _Transformer:

@@ -208,7 +208,8 @@ int dm4d_postprocess_images_bf16(void* stream, const void* X, void* Y, int B, in
 
 /* Fused feed-forward of a transformer block (attention.py:129-149 `ff(norm3(x)) + x`; diffusers FeedForward with GEGLU:
  * Linear(C -> 2 hidden) -> hidden * gelu(gate) -> Linear(hidden -> C)) in ONE launch:
- *     Out[M, C] = residual + W2 (h * gelu(g)) + b2,   [h | g] = W1 Y + b1,   Y = the LayerNorm output
+ *     Out[M, C] = residual + W2 (h * gelu(g)) + b2,   [h | g] = W1 Y' + b1,   Y' = LayerNorm(Y) when ln_gamma / ln_beta are given
+ *     (norm3 folded in: Y is then the block's residual stream itself), Y' = Y when both are NULL.
  * The [M, hidden] intermediate stays on the chip.  Same products in the same order, same rounding points (the hidden tensor is
  * rounded to bf16 between the two products) as dm4d_gemm_bf16(GEGLU) followed by dm4d_gemm_bf16(residual): bit-identical.
  * dm4d_ff_geglu_supported(C, hidden) says whether the kernel is built for the shape (C = 320: level 0 of an SD-class UNet);
@@ -218,9 +219,9 @@ int dm4d_postprocess_images_bf16(void* stream, const void* X, void* Y, int B, in
 int dm4d_ff_geglu_supported(int C, int hidden);
 int dm4d_ff_geglu_prepare_bf16(void* stream, const void* W1, const void* b1, const void* W2, void* W1p, void* b1p, void* W2p,
                                int C, int hidden);
-int dm4d_ff_geglu_fused_bf16(void* stream, const void* Y, int64_t ldy, const void* W1p, const void* b1p, const void* W2p,
-                             const void* b2, const void* residual, int64_t ld_res, void* Out, int64_t ldo, int M, int C,
-                             int hidden);
+int dm4d_ff_geglu_fused_bf16(void* stream, const void* Y, int64_t ldy, const void* ln_gamma, const void* ln_beta, float ln_eps,
+                             const void* W1p, const void* b1p, const void* W2p, const void* b2, const void* residual,
+                             int64_t ld_res, void* Out, int64_t ldo, int M, int C, int hidden);
 
 /* Tuning hook (not part of the operator surface): force one GEMM/conv kernel configuration id for all
  * subsequent launches of this process; 0 restores the built-in heuristic.  Used by tools/gemm_tune.py. */

@@ -47,11 +47,12 @@ def bench_ff(M, C=320, hidden=1280, tag=""):
     n, x = rnd(M, C), rnd(M, C)
     ff = ops.FeedForward(rnd(2 * hidden, C, scale=1 / math.sqrt(C)), rnd(2 * hidden), rnd(C, hidden, scale=1 / math.sqrt(hidden)), rnd(C))
     fl = 2.0 * M * 3 * hidden * C
+    lnp = (rnd(C), rnd(C), 1e-5)  # norm3 in front of the feed-forward: folded into the fused launch, its own launch otherwise
     for rep in range(2):  # alternate the forms: whatever is timed first runs on a colder chip
         for fused in (True, False):
             ops.FF_FUSED = fused
-            t = timeit(lambda: ff(n, x))
-            print(f"ff{tag:8s} M={M:6d} C={C} hidden={hidden} {'fused   ' if fused else 'two-gemm'} round {rep}  {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s", flush=True)
+            t = timeit(lambda: ff(n, x, ln=lnp))
+            print(f"ff{tag:8s} M={M:6d} C={C} hidden={hidden} {'fused+ln   ' if fused else 'ln+two-gemm'} round {rep}  {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s", flush=True)
     ops.FF_FUSED = True
 
 

@@ -64,7 +64,7 @@ def case_gemm(M, N, K, bias=True, rowbias=False, residual=False, geglu=False, si
     return rel_l2(out, ref), float((out.float().cpu() - ref).abs().max())
 
 
-def case_ff_fused(M, C=320, hidden=1280, bias=True, seed=0, strided=False):
+def case_ff_fused(M, C=320, hidden=1280, bias=True, seed=0, strided=False, ln=False):
     """ops.FeedForward: the fused one-launch feed-forward (LayerNorm output -> GEGLU projection -> output projection + residual)
     against (a) the two-GEMM form on the same inputs -- required BIT-IDENTICAL: same products in the same order, same rounding
     of the hidden tensor -- and (b) the fp32 reference of attention.py:129-149's `ff(n) + x`."""
@@ -74,7 +74,9 @@ def case_ff_fused(M, C=320, hidden=1280, bias=True, seed=0, strided=False):
     x = _rnd((M, C), g)
     w1, w2 = _rnd((2 * hidden, C), g, 1.0 / math.sqrt(C)), _rnd((C, hidden), g, 1.0 / math.sqrt(hidden))
     b1, b2 = (_rnd((2 * hidden,), g, 0.5), _rnd((C,), g, 0.5)) if bias else (None, None)
-    pre = n.float() @ w1.float().t() + (b1.float() if bias else 0.0)
+    gam, bet = (1.0 + 0.1 * torch.randn(C, generator=g)).to(BF), (0.1 * torch.randn(C, generator=g)).to(BF)
+    nn_ = F.layer_norm(n.float(), (C,), gam.float(), bet.float(), 1e-5).to(BF).float() if ln else n.float()  # norm3 folded in
+    pre = nn_ @ w1.float().t() + (b1.float() if bias else 0.0)
     h, gate = pre.chunk(2, dim=-1)
     hid = (h * F.gelu(gate)).to(BF).float()  # the hidden tensor is bf16 between the two products in both forms
     ref = hid @ w2.float().t() + (b2.float() if bias else 0.0) + x.float()
@@ -86,12 +88,13 @@ def case_ff_fused(M, C=320, hidden=1280, bias=True, seed=0, strided=False):
     if strided:  # row-strided views (column slices of wider tensors), as the model may pass
         nd = torch.cat([nd, nd], dim=1)[:, :C]
         xd = torch.cat([xd, xd], dim=1)[:, C:]
+    lnp = (dev(gam), dev(bet), 1e-5) if ln else None
     old = ops.FF_FUSED
     try:
         ops.FF_FUSED = True
-        fused = ff(nd, xd)
+        fused = ff(nd, xd, ln=lnp)
         ops.FF_FUSED = False
-        two = ff(nd, xd)
+        two = ff(nd, xd, ln=lnp)
     finally:
         ops.FF_FUSED = old
     worst = float((fused.float() - two.float()).abs().max())
@@ -582,6 +585,8 @@ CASES = {
     "ff_fused_nobias": (case_ff_fused, dict(M=640, bias=False, seed=3)),
     "ff_fused_strided": (case_ff_fused, dict(M=384, strided=True, seed=4)),
     "ff_fused_judged": (case_ff_fused, dict(M=32 * 2880, seed=5)),
+    "ff_fused_ln_tail": (case_ff_fused, dict(M=300, ln=True, seed=6)),
+    "ff_fused_ln_judged": (case_ff_fused, dict(M=32 * 2880, ln=True, seed=7)),
     "attn_small": (case_attention, dict(batch=2, heads=2, L=128)),
     "attn_tail45": (case_attention, dict(batch=3, heads=1, L=45)),
     # tile-count edge cases of the software-pipelined loop (64-key tiles, look-ahead, tail mask on the last one)
