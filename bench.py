@@ -611,6 +611,15 @@ def main():
             traffic = int((2 * t["FETCH_SIZE"]["avg_kb"] + t["WRITE_SIZE"]["avg_kb"]) * 1024)
             traffic_file = tf.name
         break
+    # MFMA-busy fraction of the same kernel from its own PMC pass (SQ_VALU_MFMA_BUSY_CYCLES against GRBM_GUI_ACTIVE, i.e. at
+    # the clock the chip actually ran under this load; tools/mfma_busy_summary.py -> profiles/*attn_mfma_busy_pmc.json)
+    mfma_busy = None
+    for mf in sorted((ROOT / "profiles").glob("r*_attn_mfma_busy_pmc.json"), reverse=True):
+        if (LAT_H, LAT_W) == (72, 40):
+            m = json.loads(mf.read_text())
+            mfma_busy = {"busy_frac_at_actual_clock": m.get("mfma_busy"), "clock_ghz": m.get("clock_ghz"),
+                         "frac_of_nominal_peak": m.get("frac_of_nominal_peak"), "source": f"profiles/{mf.name}"}
+        break
     attn_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in timer)
     attn_fl = sum(f for _, f, _, _ in timer)
     achieved = attn_fl / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
@@ -668,6 +677,7 @@ def main():
                 "measured_in": f"a separate pass of {k_roof} units (2 spatial + 1 temporal window calls each) with one task in flight "
                                f"({dt_single / max(1, k_roof) * 1e3:.1f} ms per unit), HIP events on the launch stream",
                 "share_of_step_time": round(attn_ms * 1e-3 / dt_single, 4),
+                "mfma_busy_pmc": None if fp8 else mfma_busy,
             },
         }
         if grid_info is not None:

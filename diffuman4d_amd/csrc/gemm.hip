@@ -250,7 +250,7 @@ __device__ __forceinline__ void sched_mfma_reload() {
 // multiply-adds of the fused gather the first round shipped.  Same strip machinery: tap (dy, dx) of phase (py, px) reads
 // pixel (y + dy - 1 + py, x + dx - 1 + px); the grid carries the phase in its slowest dimension.
 template <int BM, int BN, int WM, int WN, int KT = 3>
-__global__ __launch_bounds__(WM* WN * 64) void conv_strip2_kernel(GemmParams p_in) {
+__global__ __launch_bounds__(WM* WN * 64, (BN % 64 != 0 ? 2 : 1)) void conv_strip2_kernel(GemmParams p_in) {
   static_assert(KT == 2 || KT == 3, "3x3 taps, or the 2x2 taps of one upsampling phase");
   constexpr int BK = 64, ROWB = BK * 2;  // bytes per LDS row
   constexpr int NW = WM * WN;
@@ -258,7 +258,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip2_kernel(GemmParams p_i
   constexpr int NA = (BM + 8) / 8;  // 1-KiB DMA instructions per strip (BM + 2 rows needed, 8 rows per instruction)
   constexpr int SR = BM + 16;       // rows per A buffer: the strip, then the zero row at BM + 8
   constexpr int ZROW = BM + 8;
-  constexpr int AW = (NA + NW - 1) / NW, BW = BN / (8 * NW);
+  constexpr int NB = BN / 8;  // 1-KiB DMA instructions per weight slab; a last round may be partial (BN = 160 on 8 waves)
+  constexpr int AW = (NA + NW - 1) / NW, BW = (NB + NW - 1) / NW;
   constexpr int A_BYTES = SR * ROWB, B_BYTES = BN * ROWB;
   constexpr int SMEM_MAIN = 2 * (A_BYTES + B_BYTES);
   constexpr int SMEM_EPI = NW * 32 * (EpiGeom<TN>::EPW + 4) * 4;
@@ -362,7 +363,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip2_kernel(GemmParams p_i
 
   // ---- the K walk: ky (kernel row) > cs (64-channel slab) > kx (tap column); one DMA'd step ahead -------------------
   const int nci = p.Cin / BK;
-  const int ky0 = (KT == 3 && p.splits > 1) ? split : 0, ky1 = (KT == 3 && p.splits > 1) ? split + 1 : KT;
+  // (the 160-wide tiles never run split: with a split index -- the result of an integer division, i.e. of the vector ALU -- in
+  // the weight pointer, the compiler built that pointer in VGPRs for those instantiations, which the DMA's scalar base cannot take)
+  constexpr bool SPLITTABLE = KT == 3 && BN % 64 == 0;
+  const int ky0 = (SPLITTABLE && p.splits > 1) ? split : 0, ky1 = (SPLITTABLE && p.splits > 1) ? split + 1 : KT;
   const int nstrips = (ky1 - ky0) * nci;
   // DMA issue, statically laid out per tap column (no per-step bookkeeping branches): a weight slab is 8 * NW rows per
   // instruction round, the A strip NA pieces of 8 rows of which the last round is partial
@@ -370,7 +374,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_strip2_kernel(GemmParams p_i
   auto issue_b = [&](const u16* wbase, int par) {  // slab at wbase -> B buffer `par`
     const uint32_t dst = b_dst0 + (par ? B_BYTES : 0);
 #pragma unroll
-    for (int i = 0; i < BW; ++i) dma16_sv(wbase, w_voff[i], dst + NW * i * 1024);
+    for (int i = 0; i < BW; ++i) {
+      if (NW * (i + 1) <= NB) {
+        dma16_sv(wbase, w_voff[i], dst + NW * i * 1024);
+      } else if (wave < NB - NW * i) {
+        dma16_sv(wbase, w_voff[i], dst + NW * i * 1024);
+      }
+    }
   };
   auto issue_a = [&](const u16* abase, int par) {  // strip at abase (+ a_voff) -> A buffer `par`
     const uint32_t dst = a_dst0 + (par ? A_BYTES : 0);
@@ -1056,6 +1066,7 @@ __host__ inline bool strip2_ok(const GemmParams& p) {
 template <int BM, int BN, int WM, int WN>
 int launch_strip2(hipStream_t st, GemmParams& p) {
   if (!strip2_ok(p)) return DM4D_ERR_ARG;  // 4 GiB or more of input or weights: the gather kernels take such a launch
+  if (BN % 64 != 0 && p.splits > 1) return DM4D_ERR_ARG;
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   if (p.splits < 1) p.splits = 1;
@@ -1119,7 +1130,7 @@ int launch_by_id(int id, hipStream_t st, GemmParams& p) {
     // 320-wide tile (see id 35), K-slab 64, 2 stages = 144 KB; per-wave tile 64 x 160 = 5 column blocks: no GEGLU pairing
     case 46: return (k64 && !geglu) ? launch_pipe<256, 320, 4, 2, 2, CONV, 64>(st, p) : DM4D_ERR_ARG;
     // stride-1 3x3 convolutions on the strip kernel (same K order on every tile, so the choice never changes a result)
-    case 31: case 32: case 33: case 34: case 35:
+    case 31: case 32: case 33: case 34: case 35: case 36: case 37:
       if constexpr (CONV) {
         if (!(k64 && p.stride == 1 && p.pad == 1 && !p.upsample && p.Ho == p.H && p.Wo == p.W)) return DM4D_ERR_ARG;
         if (id == 31) return launch_strip2<128, 128, 2, 2>(st, p);
@@ -1128,6 +1139,9 @@ int launch_by_id(int id, hipStream_t st, GemmParams& p) {
         // every channel count of an SD-class UNet is a multiple of 320: a 320-wide tile reads the A strip once per
         // kernel row for N = 320 (level 0) and feeds 40 MFMAs per wave between two barriers
         if (id == 35) return launch_strip2<256, 320, 4, 2>(st, p);
+        // 160-wide tiles for N = 320 (two column tiles, no padding): 4 waves x (32 x 160) at 78 KB = two workgroups per CU, or 8 waves
+        if (id == 36) return launch_strip2<128, 160, 4, 1>(st, p);
+        if (id == 37) return launch_strip2<256, 160, 8, 1>(st, p);
         return launch_strip2<256, 256, 2, 4>(st, p);
       } else {
         return DM4D_ERR_ARG;
@@ -1135,13 +1149,17 @@ int launch_by_id(int id, hipStream_t st, GemmParams& p) {
     // Linear layers on gemm_lin2_kernel: 61 = 256x128, 8 waves, K-slab 64, 3 stages; 62 = 256x320, 2 stages, no GEGLU; 63 = 128x128
     // with 4 waves (2 workgroups per CU); 64 = 128x128 with 8 waves; 65 = 256x128, 8 waves, K-slab 32, 3 stages = 74 KB (two
     // workgroups per CU); 67 = 256x256 on eight waves (128x64 per wave), K-slab 64, 2 stages = 128 KB
-    case 61: case 62: case 63: case 64: case 65: case 67:
+    case 61: case 62: case 63: case 64: case 65: case 67: case 68: case 69:
       if constexpr (!CONV) {
         if (!lin2_ok(p)) return DM4D_ERR_ARG;
         if (id == 67) return launch_lin2<256, 256, 2, 4, 2>(st, p);
         if (id == 65) return launch_lin2<256, 128, 4, 2, 3, 32>(st, p);
         if (id == 61) return launch_lin2<256, 128, 4, 2, 3>(st, p);
         if (id == 62) return geglu ? DM4D_ERR_ARG : launch_lin2<256, 320, 4, 2, 2>(st, p);
+        // N = 320 / 960 without column padding on 128-row tiles (2.8 rounds of 256 at CFG batch 32 instead of 1.4): 128x320 on 8 waves
+        // (32 x 160 per wave), 128x160 on 4 waves at 74 KB = two workgroups per CU
+        if (id == 68) return geglu ? DM4D_ERR_ARG : launch_lin2<128, 320, 4, 2, 2>(st, p);
+        if (id == 69) return geglu ? DM4D_ERR_ARG : launch_lin2<128, 160, 4, 1, 2>(st, p);
         if (id == 63) return launch_lin2<128, 128, 2, 2, 2>(st, p);
         return launch_lin2<128, 128, 4, 2, 3>(st, p);
       } else {
@@ -1217,12 +1235,21 @@ int choose_cfg(const GemmParams& p) {
     // stride-1 convs: the strip kernels stage A once per kernel row (profiles/r01_conv_strip.log)
     if (p.stride == 1 && p.pad == 1 && !p.upsample && p.Ho == p.H && p.Wo == p.W && strip2_ok(p)) {
       if (!n128) {
-        // N = 320 (level 0) with Cin >= 640 (the up path's concatenated inputs): the 320-wide strip tile (-5..-6 % at CFG
-        // batch 32, even at 48); same K order as every strip kernel, so the choice never changes a result
-        if (p.N == 320 && p.Cin >= 640 && tm256 >= 256) return 35;
+        // N = 320 on a tall problem (level 0 of the UNet): two 160-wide column tiles, no padded columns and a third of the A re-reads
+        // of the 64-wide tile -- 8 waves on 256 rows when the last round of 256 workgroups is at least half full, else 4 waves on
+        // 128 rows with two workgroups per CU (-6..-12 % per launch against ids 33 / 35 at CFG batch 32 and 48, cold-cache sweep
+        // profiles/r03_strip_160_tiles.log); same K order as every strip kernel, so the choice never changes a result
+        if (p.N == 320 && tm256 >= 256) {
+          const long t2 = tm256 * 2, last = t2 % 256;
+          return (last == 0 || last >= 128) ? 37 : 36;
+        }
         if (tm128 * ((p.N + 63) / 64) >= 256) return 33;
       } else {
         const long t = tm256 * tn;
+        // N = 640 (level 1) when two 320-wide column tiles make ONE nearly full round of 256 workgroups (CFG batch 32: 180): the A strip
+        // is read twice instead of five times, -3..-9 % per launch in both cold sweeps (r02_strip_cold.log, r03_strip_160_tiles.log);
+        // at batch 48 the same tile needs a second, nearly empty round and loses 20 %
+        if (p.N == 640 && p.Cin >= 640 && tm256 * 2 >= 160 && tm256 * 2 <= 256) return 35;
         if (p.N % 256 == 0 && tm256 * (p.N / 256) >= 160) return 34;
         if (t >= 200 && 5 * t >= 4 * ((t + 255) / 256) * 256) return 32;
         if (tm128 * tn >= 256) return 31;

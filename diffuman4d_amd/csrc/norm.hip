@@ -79,16 +79,28 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(GNParams p) {
       ld = p.C2;
       c = (cv - CV1) * 8;
     }
-    for (int px = p0 + prow; px < p1; px += PPB) {
+    // two loads in flight per thread (a chunk is only a few passes long: one load per pass leaves the kernel waiting on a
+    // memory round trip per pass; four cost 92 registers and three of the eight resident workgroups); the sums still run
+    // pixel by pixel in ascending order
+    auto add = [&](const U4& r) {
       float v[8];
-      unpack8(ldg16(src + (int64_t)px * ld + c), v);
+      unpack8(r, v);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float d = v[e] - sh[e];
         s[e] += d;
         q[e] += d * d;
       }
+    };
+    int px = p0 + prow;
+#pragma nounroll
+    for (; px + PPB < p1; px += 2 * PPB) {
+      const u16* a = src + (int64_t)px * ld + c;
+      const U4 r0 = ldg16(a), r1 = ldg16(a + (int64_t)PPB * ld);
+      add(r0);
+      add(r1);
     }
+    for (; px < p1; px += PPB) add(ldg16(src + (int64_t)px * ld + c));
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       sm[(prow * C + cv * 8 + e) * 2 + 0] = s[e];
@@ -182,17 +194,27 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GNParams p) {
       ld = p.C2;
     }
     u16* dst = p.Y + (int64_t)b * p.HW * C + cv * 8;
-#pragma unroll 2
-    for (int px = p0 + prow; px < p1; px += PPB) {
+    auto put = [&](const U4& r, int px) {
       float v[8];
-      unpack8(ldg16(src + (int64_t)px * ld), v);
+      unpack8(r, v);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float y = v[e] * a[e] + sft[e];
         v[e] = p.silu ? silu_f(y) : y;
       }
       stg16(dst + (int64_t)px * C, pack8(v));
+    };
+    int px = p0 + prow;
+#pragma nounroll
+    for (; px + 3 * PPB < p1; px += 4 * PPB) {  // four loads in flight per thread, as in the statistics pass
+      const u16* s0 = src + (int64_t)px * ld;
+      const U4 r0 = ldg16(s0), r1 = ldg16(s0 + (int64_t)PPB * ld), r2 = ldg16(s0 + (int64_t)2 * PPB * ld), r3 = ldg16(s0 + (int64_t)3 * PPB * ld);
+      put(r0, px);
+      put(r1, px + PPB);
+      put(r2, px + 2 * PPB);
+      put(r3, px + 3 * PPB);
     }
+    for (; px < p1; px += PPB) put(ldg16(src + (int64_t)px * ld), px);
   }
 }
 

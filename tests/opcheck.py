@@ -565,6 +565,9 @@ CASES = {
     "conv_strip_128x128": (case_conv, dict(B=11, H=36, W=20, Cin=128, Cout=640, rowbias=True, residual=True)),
     "conv_strip_w1": (case_conv, dict(B=2, H=5800, W=1, Cin=64, Cout=640)),
     # split over the three kernel rows (small image, deep K: the 9x5 level) + reduce/epilogue launch
+    # the 160-wide strip tiles of level 0 (N = 320 on a tall problem): 128x160 with a ragged last row tile, 256x160 likewise
+    "conv_strip_128x160": (case_conv, dict(B=23, H=72, W=40, Cin=64, Cout=320, rowbias=True, residual=True)),
+    "conv_strip_256x160": (case_conv, dict(B=31, H=72, W=40, Cin=128, Cout=320, residual=True)),
     "conv_splitk": (case_conv, dict(B=5, H=9, W=5, Cin=512, Cout=320, rowbias=True, residual=True)),
     "conv_splitk_ragged": (case_conv, dict(B=3, H=9, W=5, Cin=640, Cout=200)),
     "conv_splitk_8x8": (case_conv, dict(B=9, H=8, W=8, Cin=512, Cout=128, residual=True)),

@@ -2,7 +2,7 @@
 then the activation operand is re-touched the way its producer kernel would leave it (weights, bias, residual and the output
 stay cold).  A timing loop that repeats one launch keeps weights and output lines hot and flatters big single-workgroup tiles;
 inside a UNet pass a layer meets cold weights.  Median of 7 single launches per (shape, id); ids are bit-identical.
-python tools/dev/lin_cold.py"""
+python tools/dev/lin_cold.py [--ids=61,65,68] [--levels=0,1] [--batches=32]"""
 import math
 import statistics
 import sys
@@ -14,7 +14,12 @@ from diffuman4d_amd.host import lib as L, ops  # noqa: E402
 
 BF = torch.bfloat16
 lib = L.load()
-IDS = (1, 5, 12, 14, 19, 41, 42, 43, 44, 46, 61, 62, 63, 64, 65, 67)
+IDS = (1, 14, 46, 61, 62, 63, 64, 65, 67, 68, 69)
+for a in sys.argv[1:]:  # --ids=61,65,68  --levels=0,1  --batches=32
+    if a.startswith("--ids="):
+        IDS = tuple(int(x) for x in a[6:].split(","))
+LEVELS = next((tuple(int(x) for x in a[9:].split(",")) for a in sys.argv[1:] if a.startswith("--levels=")), (0, 1, 2, 3))
+BATCHES = next((tuple(int(x) for x in a[10:].split(",")) for a in sys.argv[1:] if a.startswith("--batches=")), (32, 48))
 FLUSH = torch.empty(1 << 28, dtype=torch.float32, device="cuda")  # 1 GiB > L2 + Infinity Cache
 
 
@@ -67,9 +72,11 @@ def run(tag, fn, a, flops, cnt, tot):
 
 
 tot = {"auto": 0.0, "best": 0.0}
-for B in (32, 48):
+for B in BATCHES:
     print(f"===== B = {B} (cold weights / output, producer-warm A) =====")
     for lvl, (h, w, c) in enumerate([(72, 40, 320), (36, 20, 640), (18, 10, 1280), (9, 5, 1280)]):
+        if lvl not in LEVELS:
+            continue
         M = B * h * w
         for tag, N, K, geglu, res in (("proj/out", c, c, False, True), ("qkv", 3 * c, c, False, False),
                                       ("ff1", 4 * c, c, True, False), ("ff2", c, 4 * c, False, True)):

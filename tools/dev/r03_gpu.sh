@@ -52,6 +52,47 @@ PY
     head -40 $out/r03_e2e_tiny_kernel_stats.txt
     rm -rf $out/prof_e2e
     ;;
+  micro)  # GroupNorm loads in flight + 160-wide strip tiles: parity, per-launch A/B (tools/dev/libdm4d_gnbase.so = the tree before), bench A/B, MFMA-busy PMC
+    timeout 600 python tests/opcheck.py gn > $out/r03_micro_opcheck_gn.log 2>&1; tail -4 $out/r03_micro_opcheck_gn.log
+    timeout 600 python tests/opcheck.py conv > $out/r03_micro_opcheck_conv.log 2>&1; tail -4 $out/r03_micro_opcheck_conv.log
+    cp diffuman4d_amd/libdm4d.so tools/dev/libdm4d_new.so
+    TAGS="gnbase new gnbase new" bash tools/dev/abn.sh timeout 300 python tests/opbench.py gn > $out/r03_micro_gn_ab.log 2>&1; cat $out/r03_micro_gn_ab.log
+    timeout 600 python tools/dev/strip_tune.py --cold > $out/r03_micro_strip_tune_cold.log 2>&1; cat $out/r03_micro_strip_tune_cold.log
+    for rep in 1 2; do for v in gnbase new; do
+      cp tools/dev/libdm4d_$v.so diffuman4d_amd/libdm4d.so
+      timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-grid-secondary --no-vae > $out/r03_micro_bench_${v}_$rep.json 2>/dev/null
+      python - <<PY
+import json; d=json.load(open("$out/r03_micro_bench_${v}_$rep.json")); k=d["kernel_breakdown_one_step"]; print("$v rep $rep:", d["value"], "lat/s", d["ms_per_step"], "ms; gn", k["groupnorm"]["ms"], "conv", k["conv3x3"]["ms"], "linear", k["linear"]["ms"])
+PY
+    done; done
+    cp tools/dev/libdm4d_new.so diffuman4d_amd/libdm4d.so
+    timeout 300 python bench.py --steps 8 --warmup 2 --task-streams 3 --no-cpu-baseline --no-grid-secondary --no-vae > $out/r03_micro_bench_streams3.json 2>/dev/null; python -c "import json; d=json.load(open('$out/r03_micro_bench_streams3.json')); print('streams 3:', d['value'], d['ms_per_step'])"
+    bash tools/profile_bench.sh r03m
+    rm -rf $out/prof_r03m
+    ;;
+  verify)  # after the 160-wide tiles were wired: parity first (abort on failure), Linear 160 / 320-wide tiles cold, bench A/B, then the `final` records
+    timeout 300 python tests/opcheck.py conv_s > $out/r03_verify_opcheck.log 2>&1; tail -3 $out/r03_verify_opcheck.log
+    grep -q "opcheck: \([0-9]*\)/\1 passed" $out/r03_verify_opcheck.log || { echo "PARITY FAILED - stopping"; exit 1; }
+    timeout 240 python tools/dev/lin_cold.py --ids=61,62,63,65,68,69 --levels=0,1 > $out/r03_verify_lin_cold.log 2>&1; cat $out/r03_verify_lin_cold.log
+    cp diffuman4d_amd/libdm4d.so tools/dev/libdm4d_new.so
+    for rep in 1 2; do for v in gnbase new; do
+      cp tools/dev/libdm4d_$v.so diffuman4d_amd/libdm4d.so
+      timeout 200 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-grid-secondary --no-vae --no-parity-bf16 > $out/r03_verify_bench_${v}_$rep.json 2>/dev/null
+      python - <<PY
+import json
+try:
+    d=json.load(open("$out/r03_verify_bench_${v}_$rep.json")); k=d["kernel_breakdown_one_step"]; print("$v rep $rep:", d["value"], "lat/s", d["ms_per_step"], "ms; gn", k["groupnorm"]["ms"], "conv", k["conv3x3"]["ms"], "linear", k["linear"]["ms"])
+except Exception as e:
+    print("$v rep $rep: FAILED", e)
+PY
+    done; done
+    cp tools/dev/libdm4d_new.so diffuman4d_amd/libdm4d.so
+    ( time timeout 900 python -m pytest tests -m gpu -q -x ) > $out/r03_pytest_gpu.log 2>&1; tail -6 $out/r03_pytest_gpu.log
+    grep -q " passed" $out/r03_pytest_gpu.log && ! grep -q " failed" $out/r03_pytest_gpu.log || { echo "GPU SUITE FAILED - stopping"; exit 1; }
+    timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/r03_bench.json 2> $out/r03_bench.err; tail -c 400 $out/r03_bench.json
+    bash tools/profile_bench.sh r03
+    rm -rf $out/prof_r03
+    ;;
   final)  # the records that go to profiles/: GPU test suite, the driver's bench command, rocprofv3 stats + PMC, extension lines
     ( time timeout 1800 python -m pytest tests -m gpu -q ) > $out/r03_pytest_gpu.log 2>&1; tail -6 $out/r03_pytest_gpu.log
     timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/r03_bench.json 2> $out/r03_bench.err; tail -c 400 $out/r03_bench.json

@@ -1,4 +1,4 @@
-"""Tile choice for the stride-1 strip convolution (form 2) on the UNet / VAE shapes: forced ids 31-35 vs the heuristic.
+"""Tile choice for the stride-1 strip convolution (form 2) on the UNet / VAE shapes: forced ids 31-37 vs the heuristic.
 python tools/dev/strip_tune.py [--cold]
 --cold: every timed launch is a single one after a 1 GiB cache flush and a re-touch of the input (the state a layer meets
 inside a UNet pass: producer-warm activations, cold weights and output); median of 7."""
@@ -13,8 +13,8 @@ from diffuman4d_amd.host import lib as L, ops  # noqa: E402
 
 BF = torch.bfloat16
 lib = L.load()
-IDS = (31, 32, 33, 34, 35)
-NAMES = {31: "128x128", 32: "256x128", 33: "128x64", 34: "256x256", 35: "256x320"}
+IDS = (31, 32, 33, 34, 35, 36, 37)
+NAMES = {31: "128x128", 32: "256x128", 33: "128x64", 34: "256x256", 35: "256x320", 36: "128x160", 37: "256x160"}
 
 
 def rnd(*s, scale=1.0):

@@ -4,8 +4,11 @@
 # 1. rocprofv3 --kernel-trace --stats      -> gpurun_out/<tag>_kernel_stats.txt   (per-kernel time table)
 # 2. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel trace only, as MI355X_MICROARCH.md's HBM section
 #    prescribes)                            -> gpurun_out/<tag>_attn_traffic_pmc.json (per-launch averages for attn_kernel)
-# Copy the two files into profiles/ to have them judged.
+# 3. rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -> gpurun_out/<tag>_attn_mfma_busy_pmc.json (MFMA-busy fraction at the
+#    clock the chip ran, that clock, and their product against the nominal peak) + the same for the conv / Linear kernels
+# Copy the files into profiles/ to have them judged.
 set -u
+# every rocprofv3 run is under `timeout`: after a fault in the profiled process the tool waits for ever (23 GPU-minutes lost once)
 TAG=${1:-r01}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 # one task in flight: the bench's roofline figures come from its one-task-at-a-time pass, and with two task streams the
@@ -14,14 +17,19 @@ BENCH="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --task-streams 1 -
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"
-rocprofv3 --kernel-trace --stats -d "$OUT" -o stats -- $BENCH > "$OUT.bench.log" 2> "$OUT.stats.err"
+timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT" -o stats -- $BENCH > "$OUT.bench.log" 2> "$OUT.stats.err"
 DB=$(find "$OUT" -name "stats*results.db" | head -1)
 python tools/profile_summary.py "$DB" "rocprofv3 --kernel-trace --stats -- $BENCH ($TAG; 1 warm-up + 2 timed + 2 roofline-pass + 1 breakdown units, plus weight-init kernels)" \
   > gpurun_out/${TAG}_kernel_stats.txt
 tail -1 "$OUT.bench.log" > gpurun_out/${TAG}_bench_under_rocprof.json
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C -d "$OUT" -o pmc_$C -- $BENCH > /dev/null 2> "$OUT.pmc_$C.err"
+  timeout 300 rocprofv3 --kernel-trace --pmc $C -d "$OUT" -o pmc_$C -- $BENCH > /dev/null 2> "$OUT.pmc_$C.err"
 done
 python tools/pmc_summary.py "$OUT" attn_kernel FETCH_SIZE WRITE_SIZE > gpurun_out/${TAG}_attn_traffic_pmc.json
+# 3. MFMA-busy cycles of the attention kernel against the cycles the chip actually clocked (its own pass, kernel trace only)
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT" -o pmc_MFMA -- $BENCH > /dev/null 2> "$OUT.pmc_MFMA.err"
+DBM=$(find "$OUT" -name "pmc_MFMA*results.db" | head -1)
+python tools/mfma_busy_summary.py "$DBM" attn_kernel > gpurun_out/${TAG}_attn_mfma_busy_pmc.json
+for K in conv_strip2_kernel gemm_lin2_kernel ff_fused_kernel; do python tools/mfma_busy_summary.py "$DBM" $K; done > gpurun_out/${TAG}_other_mfma_busy_pmc.txt
 head -12 gpurun_out/${TAG}_kernel_stats.txt
-cat gpurun_out/${TAG}_attn_traffic_pmc.json
+cat gpurun_out/${TAG}_attn_traffic_pmc.json gpurun_out/${TAG}_attn_mfma_busy_pmc.json gpurun_out/${TAG}_other_mfma_busy_pmc.txt
