@@ -1146,19 +1146,17 @@ int launch_by_id(int id, hipStream_t st, GemmParams& p) {
       } else {
         return DM4D_ERR_ARG;
       }
-    // Linear layers on gemm_lin2_kernel: 61 = 256x128, 8 waves, K-slab 64, 3 stages; 62 = 256x320, 2 stages, no GEGLU; 63 = 128x128
+    // Linear layers on gemm_lin2_kernel: 61 = 256x128, 8 waves, K-slab 64, 3 stages; 63 = 128x128
     // with 4 waves (2 workgroups per CU); 64 = 128x128 with 8 waves; 65 = 256x128, 8 waves, K-slab 32, 3 stages = 74 KB (two
     // workgroups per CU); 67 = 256x256 on eight waves (128x64 per wave), K-slab 64, 2 stages = 128 KB
-    case 61: case 62: case 63: case 64: case 65: case 67: case 68: case 69:
+    case 61: case 63: case 64: case 65: case 67: case 69:
       if constexpr (!CONV) {
         if (!lin2_ok(p)) return DM4D_ERR_ARG;
         if (id == 67) return launch_lin2<256, 256, 2, 4, 2>(st, p);
         if (id == 65) return launch_lin2<256, 128, 4, 2, 3, 32>(st, p);
         if (id == 61) return launch_lin2<256, 128, 4, 2, 3>(st, p);
-        if (id == 62) return geglu ? DM4D_ERR_ARG : launch_lin2<256, 320, 4, 2, 2>(st, p);
-        // N = 320 / 960 without column padding on 128-row tiles (2.8 rounds of 256 at CFG batch 32 instead of 1.4): 128x320 on 8 waves
-        // (32 x 160 per wave), 128x160 on 4 waves at 74 KB = two workgroups per CU
-        if (id == 68) return geglu ? DM4D_ERR_ARG : launch_lin2<128, 320, 4, 2, 2>(st, p);
+        // N = 320 on a tall problem (level 0: proj_in, attention output, proj_out) without padded columns: 128x160 on 4 waves
+        // (32 x 160 per wave) at 74 KB = two workgroups per CU
         if (id == 69) return geglu ? DM4D_ERR_ARG : launch_lin2<128, 160, 4, 1, 2>(st, p);
         if (id == 63) return launch_lin2<128, 128, 2, 2, 2>(st, p);
         return launch_lin2<128, 128, 4, 2, 3>(st, p);
@@ -1187,10 +1185,14 @@ int choose_cfg(const GemmParams& p) {
   const int bn = geglu ? 64 : 128;  // output columns of a 128-wide B tile
   const long tm256 = (p.M + 255) / 256, tm128 = (p.M + 127) / 128, tn = (p.N + bn - 1) / bn;
   if (!CONV) {
-    // N = 320 with a deep K (the level-0 feed-forward output projection): one 320-wide tile reads A once instead of three
-    // times (profiles/r02_gemm_tune_wide.log: 130 vs 146 us at CFG batch 32, 190 vs 207 at 48)
-    // (the second form of that tile, id 62, is another 3-5 % ahead: 123.0 vs 128.9 us / 182.1 vs 187.1, r02_lin_tiles_256.log)
-    if (!geglu && p.N == 320 && p.K >= 1024 && tm256 >= 256) return lin2_ok(p) ? 62 : 46;
+    // N = 320 on a tall problem (level 0: proj_in, attention output projection, proj_out; the feed-forward's output projection when
+    // the fused kernel is off): two 160-wide column tiles, no padded third tile -- cold-cache sweep profiles/r03_lin_160_tiles.log:
+    // 59.2 vs 70.0 us at K = 320 and CFG batch 32, 85.6 vs 92.8 at 48; 126 vs 141 / 197 vs 200 at K = 1280 (where the 320-wide
+    // tiles, ids 46 / 62 of round 2, used to be ahead; 46 stays for inputs the second form's 32-bit offsets cannot address)
+    if (!geglu && p.N == 320 && tm256 >= 256) {
+      if (lin2_ok(p)) return 69;
+      if (p.K >= 1024) return 46;
+    }
     // deep-K layers (K >= 1280): the second form (gemm_lin2_kernel), bit-identical, -4..-17 % per launch
     // (profiles/r02_lin2_ab.log): 128x128 tiles with two workgroups per CU wherever they fill the chip, the 8-wave
     // 3-stage 128x128 tile for the few-row, very deep output projections of the deepest level, and the 256x128 K-slab-64
@@ -1251,6 +1253,9 @@ int choose_cfg(const GemmParams& p) {
         // at batch 48 the same tile needs a second, nearly empty round and loses 20 %
         if (p.N == 640 && p.Cin >= 640 && tm256 * 2 >= 160 && tm256 * 2 <= 256) return 35;
         if (p.N % 256 == 0 && tm256 * (p.N / 256) >= 160) return 34;
+        // one partial round of 256x128 tiles against a nearly full round of 128x128 tiles at two workgroups per CU (level 2 at CFG
+        // batch 32: 230 vs 450 of 512): the small tile is 4-6 % ahead in both cold-cache sweeps (r02_strip_cold.log, r03_strip_160_tiles.log)
+        if (t <= 256 && tm128 * tn >= 384 && tm128 * tn <= 512) return 31;
         if (t >= 200 && 5 * t >= 4 * ((t + 255) / 256) * 256) return 32;
         if (tm128 * tn >= 256) return 31;
       }

@@ -533,6 +533,9 @@ CASES = {
     "gemm_256x128_plain": (case_gemm, dict(M=1024, N=256, K=320)),
     "gemm_big_tiles": (case_gemm, dict(M=4096 * 3, N=1280, K=640, residual=True)),
     "gemm_n64_tiles": (case_gemm, dict(M=4096 * 6 + 40, N=320, K=320, residual=True)),
+    # N = 320 on a tall problem: the 128x160 tiles (two workgroups per CU), ragged last row tile; split A on the same tile
+    "gemm_n320_tall": (case_gemm, dict(M=256 * 257 + 40, N=320, K=320, residual=True)),
+    "gemm_n320_tall_rowbias_k1280": (case_gemm, dict(M=256 * 256 + 8, N=320, K=1280, rowbias=True)),
     "gemm_small": (case_gemm, dict(M=77, N=320, K=64)),
     "gemm_mtail_ntail": (case_gemm, dict(M=333, N=200, K=96, residual=True, rowbias=True)),
     "gemm_n4": (case_gemm, dict(M=500, N=4, K=288, bias=True)),

@@ -1,0 +1,24 @@
+"""Which kernels of a source file changed between two builds?  No GPU needed.
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Idiffuman4d_amd/csrc -S --cuda-device-only <old>.hip -o old.s   (same for new.s)
+    python tools/dev/isa_diff.py old.s new.s
+Prints SAME / DIFF per kernel (labels, comments and blank space normalised) and NEW for kernels only the second listing has.  Used in
+round 3 to show that adding the 160-wide tiles left the ISA of all 42 shipped GEMM / convolution kernels untouched."""
+import re
+import sys
+
+
+def kernels(path):
+    text = open(path).read()
+    out = {}
+    for m in re.finditer(r'^(_Z\w+):[^\n]*\n(.*?)\n\s*s_endpgm', text, re.S | re.M):
+        body = re.sub(r';.*', '', m.group(2))
+        body = re.sub(r'\.LBB\d+_', '.LBB_', body)
+        out[m.group(1)] = re.sub(r'[ \t]+', ' ', body)
+    return out
+
+
+a, b = kernels(sys.argv[1]), kernels(sys.argv[2])
+for n in sorted(a):
+    print(("SAME " if a[n] == b[n] else "DIFF ") if n in b else "GONE ", n[:120])
+for n in sorted(set(b) - set(a)):
+    print("NEW  ", n[:120])

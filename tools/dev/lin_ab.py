@@ -10,7 +10,7 @@ from diffuman4d_amd.host import lib as L, ops  # noqa: E402
 
 BF = torch.bfloat16
 lib = L.load()
-IDS = (61, 62, 63, 64, 65, 66, 67)
+IDS = (61, 63, 64, 65, 67, 69)
 
 
 def rnd(*s, scale=1.0):

@@ -14,7 +14,7 @@ from diffuman4d_amd.host import lib as L, ops  # noqa: E402
 
 BF = torch.bfloat16
 lib = L.load()
-IDS = (1, 14, 46, 61, 62, 63, 64, 65, 67, 68, 69)
+IDS = (1, 14, 46, 61, 63, 64, 65, 67, 69)
 for a in sys.argv[1:]:  # --ids=61,65,68  --levels=0,1  --batches=32
     if a.startswith("--ids="):
         IDS = tuple(int(x) for x in a[6:].split(","))

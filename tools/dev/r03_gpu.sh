@@ -93,6 +93,17 @@ PY
     bash tools/profile_bench.sh r03
     rm -rf $out/prof_r03
     ;;
+  final2)  # last call of round 3: parity of the new Linear tile first (abort on failure), GPU suite, the driver's bench command, profiles, a 3-stream line
+    timeout 300 python tests/opcheck.py gemm_n > $out/r03_final2_opcheck.log 2>&1; tail -4 $out/r03_final2_opcheck.log
+    grep -q "opcheck: \([0-9]*\)/\1 passed" $out/r03_final2_opcheck.log || { echo "PARITY FAILED - stopping"; exit 1; }
+    ( time timeout 900 python -m pytest tests -m gpu -q -x ) > $out/r03_pytest_gpu.log 2>&1; tail -6 $out/r03_pytest_gpu.log
+    grep -q " passed" $out/r03_pytest_gpu.log && ! grep -q " failed" $out/r03_pytest_gpu.log || { echo "GPU SUITE FAILED - stopping"; exit 1; }
+    timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/r03_bench.json 2> $out/r03_bench.err; tail -c 300 $out/r03_bench.json
+    timeout 200 python bench.py --steps 8 --warmup 2 --task-streams 3 --no-cpu-baseline --no-grid-secondary --no-vae --no-parity-bf16 > $out/r03_bench_streams3.json 2>/dev/null; python -c "import json; d=json.load(open('$out/r03_bench_streams3.json')); print('streams 3:', d['value'], d['ms_per_step'])"
+    timeout 200 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-grid-secondary --no-vae --no-parity-bf16 > $out/r03_bench_streams2.json 2>/dev/null; python -c "import json; d=json.load(open('$out/r03_bench_streams2.json')); print('streams 2:', d['value'], d['ms_per_step'], d['kernel_breakdown_one_step'])"
+    bash tools/profile_bench.sh r03
+    rm -rf $out/prof_r03
+    ;;
   final)  # the records that go to profiles/: GPU test suite, the driver's bench command, rocprofv3 stats + PMC, extension lines
     ( time timeout 1800 python -m pytest tests -m gpu -q ) > $out/r03_pytest_gpu.log 2>&1; tail -6 $out/r03_pytest_gpu.log
     timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/r03_bench.json 2> $out/r03_bench.err; tail -c 400 $out/r03_bench.json
