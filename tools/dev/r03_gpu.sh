@@ -104,6 +104,20 @@ PY
     bash tools/profile_bench.sh r03
     rm -rf $out/prof_r03
     ;;
+  ab3)  # bench A/B of three builds inside one call: gnbase = tree at the start of this series, prev = with the 160-wide strip tiles + GroupNorm loads, new = + Linear 128x160 + level-2 rule
+    for rep in 1 2; do for v in gnbase prev new; do
+      cp tools/dev/libdm4d_$v.so diffuman4d_amd/libdm4d.so
+      timeout 200 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-grid-secondary --no-vae --no-parity-bf16 > $out/r03_ab3_${v}_$rep.json 2>/dev/null
+      python - <<PY
+import json
+try:
+    d=json.load(open("$out/r03_ab3_${v}_$rep.json")); k=d["kernel_breakdown_one_step"]; print("$v rep $rep:", d["value"], "lat/s", d["ms_per_step"], "ms; gn", k["groupnorm"]["ms"], "conv", k["conv3x3"]["ms"], "linear", k["linear"]["ms"], "attn", k["attention"]["ms"])
+except Exception as e:
+    print("$v rep $rep: FAILED", e)
+PY
+    done; done
+    cp tools/dev/libdm4d_new.so diffuman4d_amd/libdm4d.so
+    ;;
   final)  # the records that go to profiles/: GPU test suite, the driver's bench command, rocprofv3 stats + PMC, extension lines
     ( time timeout 1800 python -m pytest tests -m gpu -q ) > $out/r03_pytest_gpu.log 2>&1; tail -6 $out/r03_pytest_gpu.log
     timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/r03_bench.json 2> $out/r03_bench.err; tail -c 400 $out/r03_bench.json
