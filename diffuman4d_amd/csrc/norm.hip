@@ -435,16 +435,21 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const u16* S, int64_t
 }
 
 // the same for fp32 logits (VAE mid-block attention, d = 512: SDPA keeps its logits in fp32; rounding them to bf16 first
-// costs up to 2^-9 * |logit| in the exponent).  Rows are read as float4 (N % 4 == 0, 16-byte aligned rows); the second
-// and third pass of a row hit L2.
+// costs up to 2^-9 * |logit| in the exponent).  Rows are read as float4 (16-byte aligned rows: lds % 4 == 0) with a scalar
+// tail of N % 4 columns (threads 0..2), so a row may be LONGER than N: the caller pads the key axis to the GEMM's K
+// granularity and the columns behind N are neither read nor written.  The second and third pass of a row hit L2.
 __global__ __launch_bounds__(256) void softmax_rows_f32_kernel(const float* S, int64_t lds, u16* P, int64_t ldp, int N,
                                                                float scale) {
   __shared__ float red[8];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const f32x4_t* s = reinterpret_cast<const f32x4_t*>(S + (int64_t)row * lds);
-  uint2* o = reinterpret_cast<uint2*>(P + (int64_t)row * ldp);
+  const float* srow = S + (int64_t)row * lds;
+  u16* prow = P + (int64_t)row * ldp;
+  const f32x4_t* s = reinterpret_cast<const f32x4_t*>(srow);
+  uint2* o = reinterpret_cast<uint2*>(prow);
   const int n4 = N >> 2;
-  float mx = -3.0e38f;
+  const bool tail = tid < (N & 3);  // this thread also owns column 4 n4 + tid
+  const float st = tail ? srow[4 * n4 + tid] : 0.f;
+  float mx = tail ? st : -3.0e38f;
   for (int i = tid; i < n4; i += 256) {
     const f32x4_t v = s[i];
     mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
@@ -456,12 +461,14 @@ __global__ __launch_bounds__(256) void softmax_rows_f32_kernel(const float* S, i
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   const float c = scale * 1.4426950408889634f;
   const float mc = mx * c;
+  const float et = tail ? __builtin_amdgcn_exp2f(fmaf(st, c, -mc)) : 0.f;
   float sum = 0.f;
   for (int i = tid; i < n4; i += 256) {
     const f32x4_t v = s[i];
     sum += (__builtin_amdgcn_exp2f(fmaf(v[0], c, -mc)) + __builtin_amdgcn_exp2f(fmaf(v[1], c, -mc))) +
            (__builtin_amdgcn_exp2f(fmaf(v[2], c, -mc)) + __builtin_amdgcn_exp2f(fmaf(v[3], c, -mc)));
   }
+  sum += et;  // (after the vector part: rows with N % 4 == 0 sum exactly as before)
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
   if (lane == 0) red[4 + wave] = sum;
@@ -475,6 +482,7 @@ __global__ __launch_bounds__(256) void softmax_rows_f32_kernel(const float* S, i
     w.y = pack_bf2(__builtin_amdgcn_exp2f(fmaf(v[2], c, -mc)) * inv, __builtin_amdgcn_exp2f(fmaf(v[3], c, -mc)) * inv);
     o[i] = w;
   }
+  if (tail) prow[4 * n4 + tid] = f2bf(et * inv);
 }
 
 }  // namespace
@@ -549,8 +557,8 @@ extern "C" int dm4d_softmax_rows_bf16(void* stream, const void* S, int64_t lds, 
 extern "C" int dm4d_softmax_rows_f32in_bf16(void* stream, const float* S, int64_t lds, void* P, int64_t ldp, int M, int N,
                                             float scale) {
   if (!S || !P || M <= 0 || N <= 0) return dm4d_set_error(DM4D_ERR_ARG, "softmax: null pointer or empty shape");
-  if ((N & 3) || (lds & 3) || (ldp & 3) || (((uintptr_t)S) & 15) || (((uintptr_t)P) & 7))
-    return dm4d_set_error(DM4D_ERR_ARG, "softmax (fp32 logits): N and the row strides must be multiples of 4, rows 16-byte aligned");
+  if ((lds & 3) || (ldp & 3) || lds < N || ldp < N || (((uintptr_t)S) & 15) || (((uintptr_t)P) & 7))
+    return dm4d_set_error(DM4D_ERR_ARG, "softmax (fp32 logits): row strides must be multiples of 4 and >= N, rows 16-byte aligned");
   hipLaunchKernelGGL(softmax_rows_f32_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, S, lds, (u16*)P, ldp, N, scale);
   return dm4d_check_launch("softmax_rows_f32_kernel");
 }

@@ -98,6 +98,7 @@ class WriterPool:
         env.setdefault("OMP_NUM_THREADS", "1")
         self._q: "queue.Queue" = queue.Queue()
         self._procs, self._threads = [], []
+        self._lock, self._alive = threading.Lock(), max(1, int(processes))
         for _ in range(max(1, int(processes))):
             p = subprocess.Popen([sys.executable, "-m", "diffuman4d_amd.host.imgwrite"], stdin=subprocess.PIPE,
                                  stdout=subprocess.PIPE, env=env, cwd=root)
@@ -127,6 +128,16 @@ class WriterPool:
                                                    f"writer process exited with code {p.poll()}"))
             except BaseException as e:  # noqa: BLE001
                 fut.set_exception(e)
+            if p.poll() is not None:  # the worker is gone (killed, out of memory): stop feeding it; the others take the queue
+                with self._lock:
+                    self._alive -= 1
+                    last = self._alive == 0
+                while last:  # nobody left to write: fail what is queued instead of leaving its futures pending for ever
+                    item = self._q.get()
+                    if item is None:
+                        return
+                    item[1].set_exception(RuntimeError(f"all writer processes have exited (last code {p.poll()})"))
+                return
 
     def submit(self, pkg: Dict[str, Any]):
         from concurrent.futures import Future

@@ -365,14 +365,21 @@ class _Prof:
         return False
 
 
-def softmax_rows(s: torch.Tensor, scale: float) -> torch.Tensor:
-    """P = softmax(s * scale) per row, bf16; s bf16 or fp32 (logits from gemm(out_f32=True))."""
+def softmax_rows(s: torch.Tensor, scale: float, n: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """P = softmax(s * scale) per row, bf16; s bf16 or fp32 (logits from gemm(out_f32=True)).
+    n (fp32 logits only): softmax over the first n columns of every row -- a key axis padded to the GEMM's K granularity; `out`
+    (same shape as s) then keeps whatever it holds behind column n (the caller's zeros)."""
     lib = _l.load()
     f32 = s.dtype == torch.float32
     _req(s, "s", torch.float32 if f32 else BF16)
-    p = torch.empty(s.shape, dtype=BF16, device=s.device)
+    if n is not None and not f32:
+        raise _l.Dm4dError("softmax_rows: a column count below the row length needs fp32 logits")
+    p = torch.empty(s.shape, dtype=BF16, device=s.device) if out is None else out
+    _req(p, "out", BF16)
+    if p.shape != s.shape:
+        raise _l.Dm4dError(f"softmax_rows: out has shape {tuple(p.shape)}, the logits {tuple(s.shape)}")
     fn = lib.dm4d_softmax_rows_f32in_bf16 if f32 else lib.dm4d_softmax_rows_bf16
-    rc = fn(_stream(), _p(s), s.stride(0), _p(p), p.stride(0), s.shape[0], s.shape[1], scale)
+    rc = fn(_stream(), _p(s), s.stride(0), _p(p), p.stride(0), s.shape[0], s.shape[1] if n is None else int(n), scale)
     _l.check(rc, "dm4d_softmax_rows_f32in_bf16" if f32 else "dm4d_softmax_rows_bf16")
     return p
 

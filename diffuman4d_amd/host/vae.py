@@ -79,8 +79,7 @@ class _MidAttn:
     def __call__(self, x):
         B, H, Wd, C = x.shape
         L = H * Wd
-        if L % 32 != 0:
-            raise ValueError(f"VAE mid-block attention needs H*W % 32 == 0 at latent resolution (got {H}x{Wd})")
+        Lp = (L + 31) // 32 * 32  # key axis padded to the GEMM's K granularity (images whose latent area is not a multiple of 32)
         n = ops.groupnorm(x, self.nw, self.nb, self.g, 1e-6, silu=False)
         qkv = ops.gemm(n.view(B * L, C), self.qkv_w, bias=self.qkv_b)  # [B*L, 3C]
         o = torch.empty((B * L, C), dtype=BF16, device=x.device)
@@ -88,16 +87,30 @@ class _MidAttn:
         # S = q k^T stays in fp32 from the MFMA accumulator to the softmax (SDPA's logits are fp32; a bf16 round trip would
         # cost 2^-9 |logit| in the exponent at d = 512).  Query rows go in blocks so that the fp32 logits of a block stay
         # below QBLOCK_BYTES whatever the image size: 1024^2 images have L = 16 384, i.e. 1 GB per image unblocked.
-        qb = max(32, min(L, (self.QBLOCK_BYTES // (4 * L)) // 32 * 32))
-        self.last_block_bytes = 4 * L * qb  # what the largest logits block of this call occupies (tests assert the bound)
+        qb = max(32, min(L, (self.QBLOCK_BYTES // (4 * Lp)) // 32 * 32))
+        self.last_block_bytes = 4 * Lp * qb  # what the largest logits block of this call occupies (tests assert the bound)
+        if Lp != L:
+            # padded keys: zero rows behind L in K (their logits are never read: the softmax stops at column L) and zero
+            # columns behind L in P and V^T (they add 0 to P V); the buffers are made once per call
+            kp = torch.zeros((Lp, C), dtype=BF16, device=x.device)
+            vtp = torch.zeros((C, Lp), dtype=BF16, device=x.device)
+            pp = torch.zeros((qb, Lp), dtype=BF16, device=x.device)
         for b in range(B):
             rows = slice(b * L, (b + 1) * L)
             k, v = qkv[rows, C:2 * C], qkv[rows, 2 * C:]
             vt = _transpose(v, C)  # [C, L]
+            if Lp != L:
+                kp[:L].copy_(k)
+                vtp[:, :L].copy_(vt)
+                k, vt = kp, vtp
             for q0 in range(0, L, qb):
                 q1 = min(L, q0 + qb)
-                s = ops.gemm(qkv[b * L + q0: b * L + q1, :C], k, out_f32=True)  # [q1 - q0, L] fp32
-                ops.gemm(ops.softmax_rows(s, scale), vt, out=o[b * L + q0: b * L + q1])
+                s = ops.gemm(qkv[b * L + q0: b * L + q1, :C], k, out_f32=True)  # [q1 - q0, Lp] fp32
+                if Lp != L:
+                    p = ops.softmax_rows(s, scale, n=L, out=pp[: q1 - q0])
+                else:
+                    p = ops.softmax_rows(s, scale)
+                ops.gemm(p, vt, out=o[b * L + q0: b * L + q1])
         return ops.gemm(o, self.ow, bias=self.ob, residual=x.view(B * L, C)).view(B, H, Wd, C)
 
 

@@ -142,8 +142,8 @@ int dm4d_attention_fp8_kv_bf16(void* stream, const void* Q, const void* K, const
 
 /* Generic-head-dim attention pieces for the VAE mid block (AutoencoderKL mid_block.attentions.0: single head, d = 512,
  *   reached from pipeline_diffuman4d.py:52,65): P = softmax(S * scale) per row, P in bf16.  The f32in form takes the
- *   logits as dm4d_gemm_bf16(..., DM4D_EPI_F32OUT) leaves them (SDPA keeps its logits in fp32);
- *   N, lds, ldp multiples of 4 there.                                                                              */
+ *   logits as dm4d_gemm_bf16(..., DM4D_EPI_F32OUT) leaves them (SDPA keeps its logits in fp32); lds, ldp multiples
+ *   of 4 and >= N there, any N: columns behind N of a padded row are neither read nor written.                      */
 int dm4d_softmax_rows_bf16(void* stream, const void* S, int64_t lds, void* P, int64_t ldp, int M, int N, float scale);
 int dm4d_softmax_rows_f32in_bf16(void* stream, const float* S, int64_t lds, void* P, int64_t ldp, int M, int N, float scale);
 

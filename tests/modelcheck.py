@@ -638,6 +638,8 @@ CASES = {
     "pipeline_prune_cond_rows_temporal": (case_pipeline_prune, dict(domain="temporal")),
     "pipeline_plucker_on_device": (case_pipeline_plucker_on_device, dict()),
     "vae": (case_vae, dict()),
+    # an image whose latent area (33 x 41 = 1353) is not a multiple of 32, nor of 4: padded key axis in the mid-block attention
+    "vae_odd_latent_area": (case_vae, dict(h=264, w=328)),
     "resize": (case_resize, dict()),
     # stateful scheduler: DPM-Solver++ 2M (first-order first / final steps, second order in between), two denoising steps per
     # window so that latents carry history inside a window and across windows

@@ -396,6 +396,26 @@ def case_logits_softmax_f32(M, N, K, seed=0):
     return (e_p if e_logits <= 2e-6 else 1.0), e_logits
 
 
+def case_logits_softmax_f32_padded(M, L, K, seed=0):
+    """The same pieces for a key count that is not a multiple of 32 (VAE images whose latent area is odd): keys padded with zero
+    rows to the GEMM's K granularity, softmax over the first L columns only, the probabilities behind L left at the caller's zeros."""
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    q, k = _rnd((M, K), g), _rnd((L, K), g)
+    Lp = (L + 31) // 32 * 32
+    kp = torch.zeros(Lp, K, dtype=torch.bfloat16)
+    kp[:L] = k
+    ref_s = q.float() @ k.float().t()
+    s = ops.gemm(q.cuda(), kp.cuda(), out_f32=True)
+    e_logits = rel_l2(s[:, :L], ref_s)
+    scale = K ** -0.5
+    out = torch.zeros(M, Lp, dtype=torch.bfloat16, device="cuda")
+    p = ops.softmax_rows(s, scale, n=L, out=out)
+    assert p.data_ptr() == out.data_ptr() and float(p[:, L:].float().abs().max()) == 0.0
+    e_p = rel_l2(p[:, :L], torch.softmax(ref_s * scale, dim=-1))
+    return (e_p if e_logits <= 2e-6 else 1.0), e_logits
+
+
 def case_plucker(n, H, W, h, w, seed=0):
     """Pluecker maps at latent resolution from the cameras (one launch) vs the reference path restated in
     oracle/plucker.py: full-resolution fp32 maps on the CPU -> F.interpolate(bilinear) -> bf16.  Both round the same
@@ -675,6 +695,8 @@ CASES = {
     "softmax": (case_softmax, dict(M=50, N=2880)),
     "logits_softmax_f32": (case_logits_softmax_f32, dict(M=320, N=2880, K=512)),
     "logits_softmax_f32_ragged": (case_logits_softmax_f32, dict(M=77, N=200, K=64)),
+    "logits_softmax_f32_padded_odd": (case_logits_softmax_f32_padded, dict(M=70, L=1353, K=128)),
+    "logits_softmax_f32_padded_mod4_2": (case_logits_softmax_f32_padded, dict(M=33, L=1030, K=64)),
     # --- conditioning prep on the device ---------------------------------------------
     "plucker_576x320": (case_plucker, dict(n=6, H=576, W=320, h=72, w=40)),
     "plucker_odd_ratio": (case_plucker, dict(n=3, H=100, W=60, h=7, w=5, seed=2)),

@@ -188,3 +188,34 @@ def test_writer_pool_writes_packages_in_processes_and_surfaces_errors(tmp_path):
         assert again.result(timeout=120) == 0  # exists already: skipped, and the pool survived the failed package
     assert len(list(tmp_path.rglob("*.jpg"))) == 15 and len(list(tmp_path.rglob("*.webp"))) == 5
     assert Image.open(tmp_path / "images" / "03" / "000001.jpg").size == (44, 70)  # crop undone onto the (w, h) canvas
+
+
+def test_writer_pool_survives_a_dead_worker_and_fails_loudly_when_all_are_gone(tmp_path):
+    """A writer process that is killed takes at most the package it was writing with it: the remaining processes serve the queue; with
+    no process left, submitted packages fail instead of waiting for ever."""
+    from diffuman4d_amd.host.imgwrite import WriterPool
+    pkg = lambda k: {"images": [(str(tmp_path / "images" / f"{k:02d}" / "000000.jpg"), np.full((16, 16, 3), k, np.uint8), None)]}  # noqa: E731
+    pool = WriterPool(2)
+    try:
+        assert pool.submit(pkg(0)).result(timeout=120) == 1
+        pool._procs[0].kill()
+        pool._procs[0].wait(timeout=30)
+        outcomes = []
+        for k in range(1, 7):  # whichever feeder takes a package: the dead worker's fails once, then the live one serves the rest
+            f = pool.submit(pkg(k))
+            try:
+                outcomes.append(f.result(timeout=120))
+            except Exception:  # noqa: BLE001
+                outcomes.append("failed")
+        assert outcomes.count("failed") <= 1 and outcomes.count(1) >= 5
+        pool._procs[1].kill()
+        pool._procs[1].wait(timeout=30)
+        tail = []
+        for k in range(7, 10):
+            f = pool.submit(pkg(k))
+            with pytest.raises(Exception):
+                f.result(timeout=120)
+            tail.append(f)
+        assert all(f.done() for f in tail)
+    finally:
+        pool.shutdown()

@@ -118,6 +118,10 @@ PY
     done; done
     cp tools/dev/libdm4d_new.so diffuman4d_amd/libdm4d.so
     ;;
+  vaeodd)  # VAE mid-block attention with a padded key axis (latent areas that are not multiples of 32): softmax tail + odd-size VAE parity
+    timeout 200 python tests/opcheck.py logits_softmax > $out/r03_vaeodd_opcheck.log 2>&1; tail -6 $out/r03_vaeodd_opcheck.log
+    timeout 300 python tests/modelcheck.py vae > $out/r03_vaeodd_modelcheck.log 2>&1; tail -8 $out/r03_vaeodd_modelcheck.log
+    ;;
   final)  # the records that go to profiles/: GPU test suite, the driver's bench command, rocprofv3 stats + PMC, extension lines
     ( time timeout 1800 python -m pytest tests -m gpu -q ) > $out/r03_pytest_gpu.log 2>&1; tail -6 $out/r03_pytest_gpu.log
     timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/r03_bench.json 2> $out/r03_bench.err; tail -c 400 $out/r03_bench.json
