@@ -20,6 +20,17 @@ struct LnArgs {
   float eps;
 };
 
+// The attention output projection in front of it all (ff_proj_fused_kernel): h = A0 Wo^T + bo + X is formed by the same workgroup,
+// written once to the output buffer (the block's new residual stream) and left in the LDS tile norm3 reads.
+struct ProjArgs {
+  const u16* A0;  // attention output rows [M, CK]
+  int64_t lda0;
+  const u16* Wo;  // [CK, CK] row-major (attn1.to_out.0.weight)
+  const u16* bo;  // [CK] or nullptr
+  const u16* X;   // residual of the projection [M, CK] (the block's input)
+  int64_t ldx;
+};
+
 template <int CK>
 __device__ __forceinline__ void rows_issue(const u16* X, int64_t ldx, int M, int m0, uint32_t lds_tile, int wave, int lane) {
 #pragma unroll
@@ -36,8 +47,10 @@ __device__ __forceinline__ void rows_issue(const u16* X, int64_t ldx, int M, int
 // LayerNorm of the tile in the LDS, in place: wave w normalises rows 16 w .. 16 w + 15 one after the other with lane l on the
 // row's 16-byte vector l -- the arrangement and the arithmetic of ln_kernel<1> (ln_row_stats / ln_row_apply), so the result is the
 // stand-alone LayerNorm launch bit for bit.  The caller puts a barrier on either side.
-template <int CK>
-__device__ __forceinline__ void rows_layernorm(char* tile, const LnArgs& ln, int wave, int lane) {
+// raw (ff_proj_fused_kernel): the un-normalised rows are also written to `raw` (row stride ldraw) on the way -- rows_valid of them.
+template <int CK, bool RAW = false>
+__device__ __forceinline__ void rows_layernorm(char* tile, const LnArgs& ln, int wave, int lane, u16* raw = nullptr, int64_t ldraw = 0,
+                                               int rows_valid = FF_BM) {
   static_assert(CK / 8 <= 64, "one vector per lane");
   const bool on[1] = {lane < CK / 8};
   float g[8], bt[8];
@@ -51,7 +64,11 @@ __device__ __forceinline__ void rows_layernorm(char* tile, const LnArgs& ln, int
     char* a = tile + t * (FF_BM * 128) + r * 128 + ((c ^ ((r >> 1) & 7)) << 4);
     float v[1][8];
     if (on[0]) {
-      unpack8(*reinterpret_cast<const U4*>(a), v[0]);
+      const U4 rawv = *reinterpret_cast<const U4*>(a);
+      if constexpr (RAW) {
+        if (r < rows_valid) stg16(raw + (int64_t)r * ldraw + lane * 8, rawv);
+      }
+      unpack8(rawv, v[0]);
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[0][e] = 0.f;
@@ -97,8 +114,8 @@ __device__ __forceinline__ void rows_fragments(const char* tile, int wm, int lan
 // the Linear kernels above, and the same gelu: results are BIT-IDENTICAL to gemm(GEGLU) followed by gemm(residual)
 // (tests/opcheck.py ff_fused_*).
 // ------------------------------------------------------------------------------------------------
-template <int CK>
-__device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs& ln, const u16* __restrict__ W1p,
+template <int CK, bool PROJ>
+__device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs& ln, const ProjArgs& proj, const u16* __restrict__ W1p,
                                               const u16* __restrict__ b1p, const u16* __restrict__ W2p, int nsteps) {
   static_assert(CK % 64 == 0 && (CK / 2) % 32 == 0, "channel count");
   constexpr int NSLAB = CK / 64, KS1 = CK / 16, NJ = CK / 2 / 32;  // 64-wide K slabs of y / W1, k steps of product 1, column blocks per wave
@@ -107,7 +124,10 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs&
   constexpr int Y_OFF = WBUF, Y_BYTES = FF_BM * CK * 2;                // prologue only: y tile over buffer 1, H and the tail
   constexpr int SMEM_MAIN = (H_OFF + 2 * H_BYTES) > (Y_OFF + Y_BYTES) ? (H_OFF + 2 * H_BYTES) : (Y_OFF + Y_BYTES);
   constexpr int SMEM_EPI = 8 * 32 * (EpiGeom<CK / 2>::EPW + 4) * 4;
-  constexpr int SMEM_BYTES = SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI;
+  // projection prologue (PROJ): two Wo slabs of [CK rows][64 k] in front, the attention rows tile behind them -- all of the LDS
+  constexpr int WO_SLAB = CK * 128, A0_OFF = 2 * WO_SLAB, SMEM_PROJ = PROJ ? A0_OFF + Y_BYTES : 0;
+  constexpr int SMEM_1 = SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI;
+  constexpr int SMEM_BYTES = SMEM_1 > SMEM_PROJ ? SMEM_1 : SMEM_PROJ;
   static_assert(SMEM_BYTES <= 160 * 1024, "does not fit the LDS");
   __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
 
@@ -140,19 +160,100 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs&
     }
   };
 
-  // ---- prologue: y tile -> LDS (5 slabs of [128 rows][64 k]) beside the weights of step 0, then -> registers ----
-  rows_issue<CK>(p.A, p.lda, p.M, m0, lds0 + Y_OFF, wave, lane);
-  issue_w1(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
+  bf16x8_t xf[KS1];
+  if constexpr (PROJ) {
+    // ---- projection prologue: h = A0 Wo^T + bo + X for this workgroup's 128 rows, into the LDS tile at Y_OFF (and, from
+    // rows_layernorm, out to p.C: the epilogue's residual).  The products and their order are those of gemm(A0, Wo, bias, residual):
+    // bias as the first k step, ascending 16-wide k steps, the residual added to the fp32 sum, one rounding to bf16 -- bit-identical
+    // to that launch.  A0 rows -> LDS behind the two Wo buffers -> registers; Wo streams as NSLAB slabs of [CK rows][64 k] = 40 KB
+    // straight from its row-major layout (128-byte row pieces, source-side swizzle), double buffered.
+    uint32_t wo_voff[CK / 64];
+#pragma unroll
+    for (int i = 0; i < CK / 64; ++i) {
+      const int row = (wave + 8 * i) * 8 + (lane >> 3);
+      wo_voff[i] = (uint32_t)row * (CK * 2) + (uint32_t)((lane & 7) ^ ((row >> 1) & 7)) * 16u;
+    }
+    auto issue_wo = [&](int t, int b) {
+#pragma unroll
+      for (int i = 0; i < CK / 64; ++i) dma16_sv(proj.Wo + t * 64, wo_voff[i], lds0 + b * WO_SLAB + (wave + 8 * i) * 1024);
+    };
+    rows_issue<CK>(proj.A0, proj.lda0, p.M, m0, lds0 + A0_OFF, wave, lane);
+    issue_wo(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    rows_fragments<CK>(smem + A0_OFF, wm, lane, xf);
+    f32x16_t hacc[1][NJ];
+    {
+      GemmParams pb = p;
+      pb.bias = proj.bo;
+      acc_init<1, NJ, CK / 2>(pb, hacc, 0, wn, lane, false);
+    }
+    const int wo_rd = (wn * (CK / 2) + l31) * 128, wo_sw = (l31 >> 1) & 7;
+#pragma unroll
+    for (int t = 0; t < NSLAB; ++t) {
+      if (t + 1 < NSLAB) issue_wo(t + 1, (t + 1) & 1);  // its buffer was last read in slab t - 1, a barrier ago
+      const char* wb = smem + (t & 1) * WO_SLAB;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(wb + wo_rd + j * (32 * 128) + (((ks * 2 + lh) ^ wo_sw) * 16));
+          hacc[0][j] = mfma_t(xf[4 * t + ks], wf, hacc[0][j]);
+        }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    // residual in the accumulators' own layout (lane: row l31 of its 32, runs of four columns): 8-byte loads, all issued first
+    issue_w1(0, 0);  // buffer 0 (Wo slab NSLAB - 1 was its last reader, behind the barrier above); lands while h is formed
+    {
+      int m = m0 + wm * 32 + l31;
+      if (m > p.M - 1) m = p.M - 1;
+      const u16* xr = proj.X + (int64_t)m * proj.ldx + wn * (CK / 2) + 4 * lh;
+      uint2 rx[NJ][4];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rx[j][q] = *reinterpret_cast<const uint2*>(xr + 32 * j + 8 * q);
+      const int r = wm * 32 + l31, key = (r >> 1) & 7;
+      char* trow = smem + Y_OFF + r * 128 + 8 * lh;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float v0 = hacc[0][j][4 * q + 0] + bf2f((u16)(rx[j][q].x & 0xffffu));
+          const float v1 = hacc[0][j][4 * q + 1] + bf2f((u16)(rx[j][q].x >> 16));
+          const float v2 = hacc[0][j][4 * q + 2] + bf2f((u16)(rx[j][q].y & 0xffffu));
+          const float v3 = hacc[0][j][4 * q + 3] + bf2f((u16)(rx[j][q].y >> 16));
+          uint2 pk;
+          pk.x = pack_bf2(v0, v1);
+          pk.y = pack_bf2(v2, v3);
+          const int n = wn * (CK / 2) + 32 * j + 8 * q;  // first of the four columns, before the + 4 lh
+          *reinterpret_cast<uint2*>(trow + (n >> 6) * (FF_BM * 128) + ((((n & 63) >> 3) ^ key) << 4)) = pk;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // W1(0) and the residual loads landed, the h tile is stored
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  } else {
+    // ---- prologue: y tile -> LDS (5 slabs of [128 rows][64 k]) beside the weights of step 0, then -> registers ----
+    rows_issue<CK>(p.A, p.lda, p.M, m0, lds0 + Y_OFF, wave, lane);
+    issue_w1(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
   if (ln.gamma) {  // norm3 folded in: the tile holds x, not LayerNorm(x) (bit-identical to the stand-alone launch, rows_layernorm)
-    rows_layernorm<CK>(smem + Y_OFF, ln, wave, lane);
+    if constexpr (PROJ) {
+      rows_layernorm<CK, true>(smem + Y_OFF, ln, wave, lane, p.C + (int64_t)m0 * p.ldc, p.ldc, p.M - m0);
+    } else {
+      rows_layernorm<CK>(smem + Y_OFF, ln, wave, lane);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }
-  bf16x8_t xf[KS1];
   rows_fragments<CK>(smem + Y_OFF, wm, lane, xf);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // every wave has its y rows: buffer 1 and the H tile may be written
@@ -296,7 +397,16 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs&
 template <int CK>
 __global__ __launch_bounds__(512) void ff_fused_kernel(GemmParams p, LnArgs ln, const u16* __restrict__ W1p,
                                                        const u16* __restrict__ b1p, const u16* __restrict__ W2p, int nsteps) {
-  ff_fused_body<CK>(p, ln, W1p, b1p, W2p, nsteps);
+  ff_fused_body<CK, false>(p, ln, ProjArgs{}, W1p, b1p, W2p, nsteps);
+}
+
+// The tail of a transformer block in one launch: attention output projection + residual, norm3, feed-forward + residual
+// (attention.py:88-90 and :129-149).  p.res == p.C: the projection's result goes out once through rows_layernorm and comes back as
+// the epilogue's residual, element by element through the lane that overwrites it.
+template <int CK>
+__global__ __launch_bounds__(512) void ff_proj_fused_kernel(GemmParams p, LnArgs ln, ProjArgs proj, const u16* __restrict__ W1p,
+                                                            const u16* __restrict__ b1p, const u16* __restrict__ W2p, int nsteps) {
+  ff_fused_body<CK, true>(p, ln, proj, W1p, b1p, W2p, nsteps);
 }
 
 // Per-step packed copies of the feed-forward weights for ff_fused_kernel (once per layer, at load time):
@@ -335,6 +445,13 @@ int ff_launch_fused(hipStream_t st, const GemmParams& p, const LnArgs& ln, const
   return dm4d_check_launch("ff_fused_kernel");
 }
 
+int ff_launch_proj_fused(hipStream_t st, const GemmParams& p, const LnArgs& ln, const ProjArgs& proj, const u16* W1p, const u16* b1p,
+                         const u16* W2p, int nsteps) {
+  hipLaunchKernelGGL((ff_proj_fused_kernel<320>), dim3((unsigned)((p.M + FF_BM - 1) / FF_BM)), dim3(512), 0, st, p, ln, proj, W1p, b1p,
+                     W2p, nsteps);
+  return dm4d_check_launch("ff_proj_fused_kernel");
+}
+
 }  // namespace
 
 extern "C" int dm4d_ff_geglu_prepare_bf16(void* stream, const void* W1, const void* b1, const void* W2, void* W1p, void* b1p, void* W2p,
@@ -366,3 +483,26 @@ extern "C" int dm4d_ff_geglu_fused_bf16(void* stream, const void* Y, int64_t ldy
   return ff_launch_fused((hipStream_t)stream, p, ln, (const u16*)W1p, (const u16*)b1p, (const u16*)W2p, hidden / FF_STEP);
 }
 
+
+extern "C" int dm4d_attn_out_ff_geglu_fused_bf16(void* stream, const void* A0, int64_t lda0, const void* Wo, const void* bo, const void* X,
+                                                 int64_t ldx, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* W1p,
+                                                 const void* b1p, const void* W2p, const void* b2, void* Out, int64_t ldo, int M, int C,
+                                                 int hidden) {
+  if (!A0 || !Wo || !X || !ln_gamma || !ln_beta || !W1p || !b1p || !W2p || !Out || M <= 0)
+    return dm4d_set_error(DM4D_ERR_ARG, "attn_out_ff_geglu_fused: null pointer or empty shape");
+  if (!dm4d_ff_geglu_supported(C, hidden))
+    return dm4d_set_error(DM4D_ERR_ARG, "attn_out_ff_geglu_fused: built for C = 320 and a hidden size that is a multiple of 32");
+  if ((lda0 & 7) || (ldx & 7) || (ldo & 7) ||
+      ((((uintptr_t)A0) | ((uintptr_t)Wo) | ((uintptr_t)X) | ((uintptr_t)Out) | ((uintptr_t)W1p) | ((uintptr_t)W2p)) & 15))
+    return dm4d_set_error(DM4D_ERR_ARG, "attn_out_ff_geglu_fused: row strides must be multiples of 8 elements, pointers 16-byte aligned");
+  if ((uint64_t)M * (uint64_t)lda0 * 2u >= (1ull << 32))
+    return dm4d_set_error(DM4D_ERR_ARG, "attn_out_ff_geglu_fused: input of 4 GiB or more (split the rows)");
+  if (Out == A0 || Out == X) return dm4d_set_error(DM4D_ERR_ARG, "attn_out_ff_geglu_fused: the output may not alias an input");
+  GemmParams p{};
+  p.A = (const u16*)A0; p.lda = lda0; p.C = (u16*)Out; p.ldc = ldo; p.M = M; p.N = C; p.K = hidden;
+  p.bias = (const u16*)b2; p.res = (const u16*)Out; p.ld_res = ldo; p.flags = 0; p.out_scale = 1.0f; p.splits = 1;
+  p.rows_per_rb = 1; p.tiles_n = 1;
+  const LnArgs ln{(const u16*)ln_gamma, (const u16*)ln_beta, ln_eps};
+  const ProjArgs proj{(const u16*)A0, lda0, (const u16*)Wo, (const u16*)bo, (const u16*)X, ldx};
+  return ff_launch_proj_fused((hipStream_t)stream, p, ln, proj, (const u16*)W1p, (const u16*)b1p, (const u16*)W2p, hidden / FF_STEP);
+}

@@ -103,6 +103,8 @@ def conv3x3(x: torch.Tensor, wt: torch.Tensor, *, bias=None, rowbias=None, resid
 
 
 FF_FUSED = os.environ.get("DM4D_FF_FUSED", "1") != "0"  # level-0 feed-forward (C = 320) as one launch; off = the two-GEMM form (A/B, tests)
+# the attention output projection + residual as a prologue of that launch (FeedForward.after_attention); off = its own GEMM (A/B, tests)
+FF_PROJ_FUSED = os.environ.get("DM4D_FF_PROJ_FUSED", "1") != "0"
 
 
 class FeedForward:
@@ -148,6 +150,26 @@ class FeedForward:
                                               _p(b1p), _p(w2p), _p(self.b2), _p(residual), residual.stride(0), _p(out), out.stride(0), M,
                                               self.C, self.hidden)
         _l.check(rc, "dm4d_ff_geglu_fused_bf16")
+        return out
+
+
+    def after_attention(self, a: torch.Tensor, wo: torch.Tensor, bo: Optional[torch.Tensor], x: torch.Tensor, ln) -> torch.Tensor:
+        """The tail of a transformer block: h = a wo^T + bo + x (attention output projection + residual), then ff(LayerNorm(h)) + h.
+        One launch where the fused kernel is built for the shape (FF_PROJ_FUSED), gemm + __call__ otherwise; bit-identical."""
+        if (self.packed is None or not FF_FUSED or not FF_PROJ_FUSED or a.shape[0] * a.stride(0) * 2 >= (1 << 32)
+                or wo.shape != (self.C, self.C) or not wo.is_contiguous()):
+            h = gemm(a, wo, bias=bo, residual=x)
+            return self(h, h, ln=ln)
+        lib = _l.load()
+        _req(a, "a"), _req(wo, "wo"), _req(x, "x"), _req(ln[0], "gamma"), _req(ln[1], "beta")
+        M = a.shape[0]
+        out = torch.empty((M, self.C), dtype=BF16, device=a.device)
+        w1p, b1p, w2p = self.packed
+        with _Prof("linear", 2.0 * M * (3 * self.hidden + self.C) * self.C, "flop"):
+            rc = lib.dm4d_attn_out_ff_geglu_fused_bf16(_stream(), _p(a), a.stride(0), _p(wo), _p(bo), _p(x), x.stride(0), _p(ln[0]),
+                                                       _p(ln[1]), float(ln[2]), _p(w1p), _p(b1p), _p(w2p), _p(self.b2), _p(out),
+                                                       out.stride(0), M, self.C, self.hidden)
+        _l.check(rc, "dm4d_attn_out_ff_geglu_fused_bf16")
         return out
 
 

@@ -193,9 +193,9 @@ class _TransformerBlock:
             q = ops.gemm(n, self.qkv[:C])  # runs while the K|V blocks travel
             kvg = shard.gather_kv_finish(pending).view(batch * shard.world * seq, 2 * C)
             a = ops.attention(q, kvg[:, :C], kvg[:, C:], batch, self.heads, seq, kv_seq=shard.world * seq, q_scaled=True)
-        h = ops.gemm(a, self.ow, bias=self.ob, residual=h)
-        # norm3 + feed-forward + residual: one launch at C = 320 (level 0), layernorm + gemm(GEGLU) + gemm(residual) elsewhere
-        return self.ff(h, h, ln=(self.n3w, self.n3b, 1e-5))
+        # attention output projection + residual, norm3, feed-forward + residual: one launch at C = 320 (level 0); gemm(residual),
+        # layernorm, gemm(GEGLU), gemm(residual) elsewhere
+        return self.ff.after_attention(a, self.ow, self.ob, h, (self.n3w, self.n3b, 1e-5))
 
 
 class _Transformer:

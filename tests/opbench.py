@@ -56,6 +56,22 @@ def bench_ff(M, C=320, hidden=1280, tag=""):
     ops.FF_FUSED = True
 
 
+def bench_ff_proj(M, C=320, hidden=1280, tag=""):
+    """Tail of a level-0 transformer block: attention output projection + residual + norm3 + feed-forward + residual in one launch
+    vs gemm(residual) + the fused LayerNorm / feed-forward launch."""
+    a, x = rnd(M, C), rnd(M, C)
+    wo, bo = rnd(C, C, scale=1 / math.sqrt(C)), rnd(C)
+    ff = ops.FeedForward(rnd(2 * hidden, C, scale=1 / math.sqrt(C)), rnd(2 * hidden), rnd(C, hidden, scale=1 / math.sqrt(hidden)), rnd(C))
+    fl = 2.0 * M * (3 * hidden + C) * C
+    lnp = (rnd(C), rnd(C), 1e-5)
+    for rep in range(2):
+        for fused in (True, False):
+            ops.FF_PROJ_FUSED = fused
+            t = timeit(lambda: ff.after_attention(a, wo, bo, x, lnp))
+            print(f"ffproj{tag:8s} M={M:6d} C={C} hidden={hidden} {'one launch      ' if fused else 'gemm + fused ff '} round {rep}  {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s", flush=True)
+    ops.FF_PROJ_FUSED = True
+
+
 def bench_conv(B, H, W, Cin, Cout, stride=1, upsample=False, tag=""):
     x = rnd(B, H, W, Cin)
     wt = rnd(Cout, 9 * Cin, scale=1 / math.sqrt(9 * Cin))
@@ -152,6 +168,10 @@ def main():
     if only == "ff":
         bench_ff(32 * 2880, tag=" L0 F16")
         bench_ff(48 * 2880, tag=" L0 F24")
+        return
+    if only == "ffproj":
+        bench_ff_proj(32 * 2880, tag=" L0 F16")
+        bench_ff_proj(48 * 2880, tag=" L0 F24")
         return
     if only == "attn":
         print("attn q_scaled:", QS, flush=True)

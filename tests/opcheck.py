@@ -102,6 +102,45 @@ def case_ff_fused(M, C=320, hidden=1280, bias=True, seed=0, strided=False, ln=Fa
     return rel_l2(fused, ref), float((fused.float().cpu() - ref).abs().max())
 
 
+def case_ff_proj_fused(M, C=320, hidden=1280, bias=True, seed=0, strided=False):
+    """FeedForward.after_attention: attention output projection + residual, norm3, feed-forward + residual in ONE launch against
+    (a) the launches it replaces -- gemm(residual), then the fused LayerNorm + feed-forward -- required BIT-IDENTICAL, and (b) the
+    fp32 reference of attention.py:88-90 + :129-149 with the same two bf16 roundings (h, the hidden tensor)."""
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    a, x = _rnd((M, C), g), _rnd((M, C), g)
+    wo = _rnd((C, C), g, 1.0 / math.sqrt(C))
+    w1, w2 = _rnd((2 * hidden, C), g, 1.0 / math.sqrt(C)), _rnd((C, hidden), g, 1.0 / math.sqrt(hidden))
+    bo, b1, b2 = (_rnd((C,), g, 0.5), _rnd((2 * hidden,), g, 0.5), _rnd((C,), g, 0.5)) if bias else (None, None, None)
+    gam, bet = (1.0 + 0.1 * torch.randn(C, generator=g)).to(BF), (0.1 * torch.randn(C, generator=g)).to(BF)
+    h = (a.float() @ wo.float().t() + (bo.float() if bias else 0.0) + x.float()).to(BF).float()
+    nn_ = F.layer_norm(h, (C,), gam.float(), bet.float(), 1e-5).to(BF).float()
+    pre = nn_ @ w1.float().t() + (b1.float() if bias else 0.0)
+    u, gate = pre.chunk(2, dim=-1)
+    hid = (u * F.gelu(gate)).to(BF).float()
+    ref = hid @ w2.float().t() + (b2.float() if bias else 0.0) + h
+    d = "cuda"
+    dev = lambda t: None if t is None else t.to(d)  # noqa: E731
+    ff = ops.FeedForward(dev(w1), dev(b1), dev(w2), dev(b2))
+    assert ff.packed is not None, "fused feed-forward not built for this shape"
+    ad, xd = dev(a), dev(x)
+    if strided:  # row-strided views, as the model passes them (the attention output is a plain tensor, the residual may be a view)
+        ad = torch.cat([ad, ad], dim=1)[:, :C]
+        xd = torch.cat([xd, xd], dim=1)[:, C:]
+    lnp = (dev(gam), dev(bet), 1e-5)
+    old = ops.FF_PROJ_FUSED
+    try:
+        ops.FF_PROJ_FUSED = True
+        one = ff.after_attention(ad, dev(wo), dev(bo), xd, lnp)
+        ops.FF_PROJ_FUSED = False
+        three = ff.after_attention(ad, dev(wo), dev(bo), xd, lnp)
+    finally:
+        ops.FF_PROJ_FUSED = old
+    worst = float((one.float() - three.float()).abs().max())
+    assert torch.equal(one, three), f"projection-fused launch differs from gemm + fused feed-forward (max abs {worst:.3e})"
+    return rel_l2(one, ref), float((one.float().cpu() - ref).abs().max())
+
+
 def case_conv(B, H, W, Cin, Cout, stride=1, pad=1, pad_hi=None, upsample=False, rowbias=False, residual=False, seed=0):
     from diffuman4d_amd.host import ops
     g = torch.Generator().manual_seed(seed)
@@ -613,6 +652,12 @@ CASES = {
     "ff_fused_judged": (case_ff_fused, dict(M=32 * 2880, seed=5)),
     "ff_fused_ln_tail": (case_ff_fused, dict(M=300, ln=True, seed=6)),
     "ff_fused_ln_judged": (case_ff_fused, dict(M=32 * 2880, ln=True, seed=7)),
+    # the same launch with the attention output projection + residual in front (the whole tail of a transformer block)
+    "ff_proj_fused_128": (case_ff_proj_fused, dict(M=128)),
+    "ff_proj_fused_tail": (case_ff_proj_fused, dict(M=300, seed=1)),
+    "ff_proj_fused_nobias_small_hidden": (case_ff_proj_fused, dict(M=257, hidden=96, bias=False, seed=2)),
+    "ff_proj_fused_strided": (case_ff_proj_fused, dict(M=384, strided=True, seed=4)),
+    "ff_proj_fused_judged": (case_ff_proj_fused, dict(M=32 * 2880, seed=5)),
     "attn_small": (case_attention, dict(batch=2, heads=2, L=128)),
     "attn_tail45": (case_attention, dict(batch=3, heads=1, L=45)),
     # tile-count edge cases of the software-pipelined loop (64-key tiles, look-ahead, tail mask on the last one)

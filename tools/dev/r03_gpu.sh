@@ -122,6 +122,24 @@ PY
     timeout 200 python tests/opcheck.py logits_softmax > $out/r03_vaeodd_opcheck.log 2>&1; tail -6 $out/r03_vaeodd_opcheck.log
     timeout 300 python tests/modelcheck.py vae > $out/r03_vaeodd_modelcheck.log 2>&1; tail -8 $out/r03_vaeodd_modelcheck.log
     ;;
+  ffproj)  # attention output projection as a prologue of the fused feed-forward: bit-identity + fp32 parity, per-launch timing, the judged UNet calls, bench A/B
+    timeout 200 python tests/opcheck.py ff_ > $out/r03_ffproj_opcheck.log 2>&1; tail -15 $out/r03_ffproj_opcheck.log
+    grep -q "opcheck: \([0-9]*\)/\1 passed" $out/r03_ffproj_opcheck.log || { echo "PARITY FAILED - stopping"; exit 1; }
+    timeout 200 python tests/opbench.py ffproj > $out/r03_ffproj_opbench.log 2>&1; cat $out/r03_ffproj_opbench.log
+    if [ "${1:-}" = "full" ]; then
+      timeout 300 python tests/modelcheck.py unet_sd21 > $out/r03_ffproj_modelcheck.log 2>&1; tail -4 $out/r03_ffproj_modelcheck.log
+      for rep in 1 2; do for f in 1 0; do
+        DM4D_FF_PROJ_FUSED=$f timeout 200 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-grid-secondary --no-vae --no-parity-bf16 > $out/r03_ffproj_bench_f${f}_$rep.json 2>/dev/null
+        python - <<PY
+import json
+try:
+    d=json.load(open("$out/r03_ffproj_bench_f${f}_$rep.json")); k=d["kernel_breakdown_one_step"]; print("FF_PROJ_FUSED=$f rep $rep:", d["value"], "lat/s", d["ms_per_step"], "ms; linear", k["linear"])
+except Exception as e:
+    print("FF_PROJ_FUSED=$f rep $rep: FAILED", e)
+PY
+      done; done
+    fi
+    ;;
   final)  # the records that go to profiles/: GPU test suite, the driver's bench command, rocprofv3 stats + PMC, extension lines
     ( time timeout 1800 python -m pytest tests -m gpu -q ) > $out/r03_pytest_gpu.log 2>&1; tail -6 $out/r03_pytest_gpu.log
     timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/r03_bench.json 2> $out/r03_bench.err; tail -c 400 $out/r03_bench.json
