@@ -127,7 +127,8 @@ PY
     grep -q "opcheck: \([0-9]*\)/\1 passed" $out/r03_ffproj_opcheck.log || { echo "PARITY FAILED - stopping"; exit 1; }
     timeout 200 python tests/opbench.py ffproj > $out/r03_ffproj_opbench.log 2>&1; cat $out/r03_ffproj_opbench.log
     if [ "${1:-}" = "full" ]; then
-      timeout 300 python tests/modelcheck.py unet_sd21 > $out/r03_ffproj_modelcheck.log 2>&1; tail -4 $out/r03_ffproj_modelcheck.log
+      timeout 300 python tests/modelcheck.py unet_sd21 demo3d > $out/r03_ffproj_modelcheck.log 2>&1; tail -5 $out/r03_ffproj_modelcheck.log
+      grep -q "modelcheck: \([0-9]*\)/\1 passed" $out/r03_ffproj_modelcheck.log || { echo "MODEL PARITY FAILED - stopping"; exit 1; }
       for rep in 1 2; do for f in 1 0; do
         DM4D_FF_PROJ_FUSED=$f timeout 200 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-grid-secondary --no-vae --no-parity-bf16 > $out/r03_ffproj_bench_f${f}_$rep.json 2>/dev/null
         python - <<PY
