@@ -29,11 +29,6 @@ struct ProjArgs {
   const u16* bo;  // [CK] or nullptr
   const u16* X;   // residual of the projection [M, CK] (the block's input)
   int64_t ldx;
-  // POST (ff_tail_fused_kernel): a second square projection behind the feed-forward, Out = (ff result) Wp^T + bp + R
-  const u16* Wp;  // [CK, CK] row-major (the transformer's proj_out.weight)
-  const u16* bp;  // [CK] or nullptr
-  const u16* R;   // its residual [M, CK] (the transformer's input)
-  int64_t ldr;
 };
 
 template <int CK>
@@ -99,93 +94,6 @@ __device__ __forceinline__ void rows_fragments(const char* tile, int wm, int lan
 }
 
 // ------------------------------------------------------------------------------------------------
-// Square projections in front of / behind the feed-forward (ff_proj_fused_kernel, ff_tail_fused_kernel): [128 rows x CK] x W^T,
-// W [CK, CK] row-major, for a wave's 32 x (CK / 2) block.  The rows come as MFMA fragments; W streams as CK / 64 slabs of
-// [CK rows][64 k] = 40 KB straight from its row-major layout (128-byte row pieces, source-side swizzle) into two buffers at the start
-// of the LDS.  Products and order are those of dm4d_gemm_bf16 -- bias as the first k step, ascending 16-wide k steps -- and with the
-// residual added to the fp32 sums and ONE rounding (sq_tile_store, or the staged epilogue) the result is that launch's, bit for bit.
-// (Free functions, not lambdas of the kernel body: the instantiation without projections must not change by a register.)
-// ------------------------------------------------------------------------------------------------
-template <int CK>
-__device__ __forceinline__ void sq_lane_offsets(int wave, int lane, uint32_t (&voff)[CK / 64]) {
-#pragma unroll
-  for (int i = 0; i < CK / 64; ++i) {
-    const int row = (wave + 8 * i) * 8 + (lane >> 3);
-    voff[i] = (uint32_t)row * (CK * 2) + (uint32_t)((lane & 7) ^ ((row >> 1) & 7)) * 16u;
-  }
-}
-
-template <int CK>
-__device__ __forceinline__ void sq_issue_slab(const u16* Wsq, int t, int b, const uint32_t (&voff)[CK / 64], uint32_t lds0, int wave) {
-#pragma unroll
-  for (int i = 0; i < CK / 64; ++i) dma16_sv(Wsq + t * 64, voff[i], lds0 + b * (CK * 128) + (wave + 8 * i) * 1024);
-}
-
-// precondition: slab 0 of Wsq has landed in buffer 0 (wait + barrier passed); ends behind a barrier
-template <int CK>
-__device__ __forceinline__ void sq_product(const GemmParams& p, const u16* Wsq, const u16* bias, const bf16x8_t (&xf)[CK / 16],
-                                           f32x16_t (&hacc)[1][CK / 2 / 32], const char* smem, uint32_t lds0,
-                                           const uint32_t (&voff)[CK / 64], int wave, int wn, int lane) {
-  constexpr int NJ = CK / 2 / 32, NSLAB = CK / 64, WO_SLAB = CK * 128;
-  const int l31 = lane & 31, lh = lane >> 5;
-  {
-    GemmParams pb = p;
-    pb.bias = bias;
-    acc_init<1, NJ, CK / 2>(pb, hacc, 0, wn, lane, false);
-  }
-  const int rd = (wn * (CK / 2) + l31) * 128, sw = (l31 >> 1) & 7;
-#pragma unroll
-  for (int t = 0; t < NSLAB; ++t) {
-    if (t + 1 < NSLAB) sq_issue_slab<CK>(Wsq, t + 1, (t + 1) & 1, voff, lds0, wave);  // that buffer was last read in slab t - 1, a barrier ago
-    const char* wb = smem + (t & 1) * WO_SLAB;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(wb + rd + j * (32 * 128) + (((ks * 2 + lh) ^ sw) * 16));
-        hacc[0][j] = mfma_t(xf[4 * t + ks], wf, hacc[0][j]);
-      }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  }
-}
-
-// (fp32 block + residual rows) -> bf16 -> a rows tile in the LDS, in the layout rows_issue leaves (what rows_layernorm and
-// rows_fragments read).  The residual comes in the accumulators' own layout (lane: row l31 of its 32, runs of four columns):
-// 8-byte loads, all issued first.  resid = the residual matrix's element (0, 0), row stride ldres.
-template <int CK>
-__device__ __forceinline__ void sq_tile_store(const GemmParams& p, const f32x16_t (&hacc)[1][CK / 2 / 32], const u16* resid, int64_t ldres,
-                                              char* tile, int m0, int wm, int wn, int lane) {
-  constexpr int NJ = CK / 2 / 32;
-  const int l31 = lane & 31, lh = lane >> 5;
-  int m = m0 + wm * 32 + l31;
-  if (m > p.M - 1) m = p.M - 1;
-  const u16* xr = resid + (int64_t)m * ldres + wn * (CK / 2) + 4 * lh;
-  uint2 rx[NJ][4];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) rx[j][q] = *reinterpret_cast<const uint2*>(xr + 32 * j + 8 * q);
-  const int r = wm * 32 + l31, key = (r >> 1) & 7;
-  char* trow = tile + r * 128 + 8 * lh;
-#pragma unroll
-  for (int j = 0; j < NJ; ++j)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float v0 = hacc[0][j][4 * q + 0] + bf2f((u16)(rx[j][q].x & 0xffffu));
-      const float v1 = hacc[0][j][4 * q + 1] + bf2f((u16)(rx[j][q].x >> 16));
-      const float v2 = hacc[0][j][4 * q + 2] + bf2f((u16)(rx[j][q].y & 0xffffu));
-      const float v3 = hacc[0][j][4 * q + 3] + bf2f((u16)(rx[j][q].y >> 16));
-      uint2 pk;
-      pk.x = pack_bf2(v0, v1);
-      pk.y = pack_bf2(v2, v3);
-      const int n = wn * (CK / 2) + 32 * j + 8 * q;  // first of the four columns, before the + 4 lh
-      *reinterpret_cast<uint2*>(trow + (n >> 6) * (FF_BM * 128) + ((((n & 63) >> 3) ^ key) << 4)) = pk;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Fused feed-forward of a transformer block at C = 320 (level 0 of the UNet; attention.py:129-149: ff(norm3(x)) + x, the
 // GEGLU projection 320 -> 2 x 1280 followed by 1280 -> 320):   out = x + W2 (h * gelu(g)) + b2,  [h | g] = W1 y + b1
 // in ONE launch: the [M, 1280] hidden tensor (236 MB per layer call at CFG batch 32, written and read back by the two-GEMM
@@ -206,11 +114,10 @@ __device__ __forceinline__ void sq_tile_store(const GemmParams& p, const f32x16_
 // the Linear kernels above, and the same gelu: results are BIT-IDENTICAL to gemm(GEGLU) followed by gemm(residual)
 // (tests/opcheck.py ff_fused_*).
 // ------------------------------------------------------------------------------------------------
-template <int CK, bool PROJ, bool POST = false>
+template <int CK, bool PROJ>
 __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs& ln, const ProjArgs& proj, const u16* __restrict__ W1p,
                                               const u16* __restrict__ b1p, const u16* __restrict__ W2p, int nsteps) {
   static_assert(CK % 64 == 0 && (CK / 2) % 32 == 0, "channel count");
-  static_assert(PROJ || !POST, "the post-projection uses the projection prologue's LDS layout");
   constexpr int NSLAB = CK / 64, KS1 = CK / 16, NJ = CK / 2 / 32;  // 64-wide K slabs of y / W1, k steps of product 1, column blocks per wave
   constexpr int W1_BYTES = 64 * CK * 2, W2_BYTES = CK * FF_STEP * 2, WBUF = W1_BYTES + W2_BYTES;
   constexpr int H_LD = 80, H_OFF = 2 * WBUF, H_BYTES = FF_BM * H_LD;  // H rows: 32 units = 64 B + 16 B pad (conflict-free b128 reads); 2 tiles
@@ -256,19 +163,76 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs&
   bf16x8_t xf[KS1];
   if constexpr (PROJ) {
     // ---- projection prologue: h = A0 Wo^T + bo + X for this workgroup's 128 rows, into the LDS tile at Y_OFF (and, from
-    // rows_layernorm, out to p.C: the epilogue's residual).  A0 rows -> LDS behind the two weight buffers -> registers.
-    uint32_t wsq_voff[CK / 64];
-    sq_lane_offsets<CK>(wave, lane, wsq_voff);
+    // rows_layernorm, out to p.C: the epilogue's residual).  The products and their order are those of gemm(A0, Wo, bias, residual):
+    // bias as the first k step, ascending 16-wide k steps, the residual added to the fp32 sum, one rounding to bf16 -- bit-identical
+    // to that launch.  A0 rows -> LDS behind the two Wo buffers -> registers; Wo streams as NSLAB slabs of [CK rows][64 k] = 40 KB
+    // straight from its row-major layout (128-byte row pieces, source-side swizzle), double buffered.
+    uint32_t wo_voff[CK / 64];
+#pragma unroll
+    for (int i = 0; i < CK / 64; ++i) {
+      const int row = (wave + 8 * i) * 8 + (lane >> 3);
+      wo_voff[i] = (uint32_t)row * (CK * 2) + (uint32_t)((lane & 7) ^ ((row >> 1) & 7)) * 16u;
+    }
+    auto issue_wo = [&](int t, int b) {
+#pragma unroll
+      for (int i = 0; i < CK / 64; ++i) dma16_sv(proj.Wo + t * 64, wo_voff[i], lds0 + b * WO_SLAB + (wave + 8 * i) * 1024);
+    };
     rows_issue<CK>(proj.A0, proj.lda0, p.M, m0, lds0 + A0_OFF, wave, lane);
-    sq_issue_slab<CK>(proj.Wo, 0, 0, wsq_voff, lds0, wave);
+    issue_wo(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     rows_fragments<CK>(smem + A0_OFF, wm, lane, xf);
     f32x16_t hacc[1][NJ];
-    sq_product<CK>(p, proj.Wo, proj.bo, xf, hacc, smem, lds0, wsq_voff, wave, wn, lane);
-    issue_w1(0, 0);  // buffer 0 (the last weight slab was its last reader, behind the barrier above); lands while h is formed
-    sq_tile_store<CK>(p, hacc, proj.X, proj.ldx, smem + Y_OFF, m0, wm, wn, lane);
+    {
+      GemmParams pb = p;
+      pb.bias = proj.bo;
+      acc_init<1, NJ, CK / 2>(pb, hacc, 0, wn, lane, false);
+    }
+    const int wo_rd = (wn * (CK / 2) + l31) * 128, wo_sw = (l31 >> 1) & 7;
+#pragma unroll
+    for (int t = 0; t < NSLAB; ++t) {
+      if (t + 1 < NSLAB) issue_wo(t + 1, (t + 1) & 1);  // its buffer was last read in slab t - 1, a barrier ago
+      const char* wb = smem + (t & 1) * WO_SLAB;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(wb + wo_rd + j * (32 * 128) + (((ks * 2 + lh) ^ wo_sw) * 16));
+          hacc[0][j] = mfma_t(xf[4 * t + ks], wf, hacc[0][j]);
+        }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    // residual in the accumulators' own layout (lane: row l31 of its 32, runs of four columns): 8-byte loads, all issued first
+    issue_w1(0, 0);  // buffer 0 (Wo slab NSLAB - 1 was its last reader, behind the barrier above); lands while h is formed
+    {
+      int m = m0 + wm * 32 + l31;
+      if (m > p.M - 1) m = p.M - 1;
+      const u16* xr = proj.X + (int64_t)m * proj.ldx + wn * (CK / 2) + 4 * lh;
+      uint2 rx[NJ][4];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rx[j][q] = *reinterpret_cast<const uint2*>(xr + 32 * j + 8 * q);
+      const int r = wm * 32 + l31, key = (r >> 1) & 7;
+      char* trow = smem + Y_OFF + r * 128 + 8 * lh;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float v0 = hacc[0][j][4 * q + 0] + bf2f((u16)(rx[j][q].x & 0xffffu));
+          const float v1 = hacc[0][j][4 * q + 1] + bf2f((u16)(rx[j][q].x >> 16));
+          const float v2 = hacc[0][j][4 * q + 2] + bf2f((u16)(rx[j][q].y & 0xffffu));
+          const float v3 = hacc[0][j][4 * q + 3] + bf2f((u16)(rx[j][q].y >> 16));
+          uint2 pk;
+          pk.x = pack_bf2(v0, v1);
+          pk.y = pack_bf2(v2, v3);
+          const int n = wn * (CK / 2) + 32 * j + 8 * q;  // first of the four columns, before the + 4 lh
+          *reinterpret_cast<uint2*>(trow + (n >> 6) * (FF_BM * 128) + ((((n & 63) >> 3) ^ key) << 4)) = pk;
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // W1(0) and the residual loads landed, the h tile is stored
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -425,27 +389,7 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs&
     close_interval();
   }
   // everybody's fragment reads are behind a barrier: the epilogue may stage through the same LDS
-  if constexpr (POST) {
-    // ---- post-projection: (feed-forward result + h) -> bf16 rows tile (the rounding point of the feed-forward's own launch; h is
-    // read back from p.C in the accumulators' layout) -> fragments -> x Wp^T + bp, then the staged epilogue adds R and writes p.C
-    // over h.  Every read of h by this workgroup is behind the barrier below, every write of p.C in front of it is rows_layernorm's.
-    uint32_t wsq_voff[CK / 64];
-    sq_lane_offsets<CK>(wave, lane, wsq_voff);
-    sq_issue_slab<CK>(proj.Wp, 0, 0, wsq_voff, lds0, wave);
-    sq_tile_store<CK>(p, acc, p.C, p.ldc, smem + A0_OFF, m0, wm, wn, lane);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    rows_fragments<CK>(smem + A0_OFF, wm, lane, xf);
-    f32x16_t oacc[1][NJ];
-    sq_product<CK>(p, proj.Wp, proj.bp, xf, oacc, smem, lds0, wsq_voff, wave, wn, lane);
-    GemmParams pp = p;
-    pp.res = proj.R;
-    pp.ld_res = proj.ldr;
-    gemm_epilogue<1, NJ, 32, CK / 2, false>(pp, oacc, reinterpret_cast<float*>(smem), m0, 0, wm, wn, wave, lane);
-  } else {
-    gemm_epilogue<1, NJ, 32, CK / 2, false>(p, acc, reinterpret_cast<float*>(smem), m0, 0, wm, wn, wave, lane);
-  }
+  gemm_epilogue<1, NJ, 32, CK / 2, false>(p, acc, reinterpret_cast<float*>(smem), m0, 0, wm, wn, wave, lane);
 }
 
 // (the body is a device function: the host pass instantiates only the stub of a __global__ template, and the register
@@ -463,14 +407,6 @@ template <int CK>
 __global__ __launch_bounds__(512) void ff_proj_fused_kernel(GemmParams p, LnArgs ln, ProjArgs proj, const u16* __restrict__ W1p,
                                                             const u16* __restrict__ b1p, const u16* __restrict__ W2p, int nsteps) {
   ff_fused_body<CK, true>(p, ln, proj, W1p, b1p, W2p, nsteps);
-}
-
-// ... and with the transformer's proj_out + residual behind it (transformer_multiview.py:209-232 for a one-block transformer): the
-// launch takes the attention output and returns the transformer's output.
-template <int CK>
-__global__ __launch_bounds__(512) void ff_tail_fused_kernel(GemmParams p, LnArgs ln, ProjArgs proj, const u16* __restrict__ W1p,
-                                                            const u16* __restrict__ b1p, const u16* __restrict__ W2p, int nsteps) {
-  ff_fused_body<CK, true, true>(p, ln, proj, W1p, b1p, W2p, nsteps);
 }
 
 // Per-step packed copies of the feed-forward weights for ff_fused_kernel (once per layer, at load time):
@@ -511,11 +447,6 @@ int ff_launch_fused(hipStream_t st, const GemmParams& p, const LnArgs& ln, const
 
 int ff_launch_proj_fused(hipStream_t st, const GemmParams& p, const LnArgs& ln, const ProjArgs& proj, const u16* W1p, const u16* b1p,
                          const u16* W2p, int nsteps) {
-  if (proj.Wp != nullptr) {
-    hipLaunchKernelGGL((ff_tail_fused_kernel<320>), dim3((unsigned)((p.M + FF_BM - 1) / FF_BM)), dim3(512), 0, st, p, ln, proj, W1p, b1p,
-                       W2p, nsteps);
-    return dm4d_check_launch("ff_tail_fused_kernel");
-  }
   hipLaunchKernelGGL((ff_proj_fused_kernel<320>), dim3((unsigned)((p.M + FF_BM - 1) / FF_BM)), dim3(512), 0, st, p, ln, proj, W1p, b1p,
                      W2p, nsteps);
   return dm4d_check_launch("ff_proj_fused_kernel");
@@ -553,55 +484,25 @@ extern "C" int dm4d_ff_geglu_fused_bf16(void* stream, const void* Y, int64_t ldy
 }
 
 
-static int attn_out_ff_impl(const char* who, void* stream, const void* A0, int64_t lda0, const void* Wo, const void* bo, const void* X,
-                            int64_t ldx, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* W1p, const void* b1p,
-                            const void* W2p, const void* b2, const void* Wp, const void* bp, const void* R, int64_t ldr, void* Out,
-                            int64_t ldo, int M, int C, int hidden, bool post) {
-  char msg[160];
-  if (!A0 || !Wo || !X || !ln_gamma || !ln_beta || !W1p || !b1p || !W2p || !Out || M <= 0 || (post && (!Wp || !R))) {
-    snprintf(msg, sizeof msg, "%s: null pointer or empty shape", who);
-    return dm4d_set_error(DM4D_ERR_ARG, msg);
-  }
-  if (!dm4d_ff_geglu_supported(C, hidden)) {
-    snprintf(msg, sizeof msg, "%s: built for C = 320 and a hidden size that is a multiple of 32", who);
-    return dm4d_set_error(DM4D_ERR_ARG, msg);
-  }
-  if ((lda0 & 7) || (ldx & 7) || (ldo & 7) || (post && (ldr & 7)) ||
-      ((((uintptr_t)A0) | ((uintptr_t)Wo) | ((uintptr_t)X) | ((uintptr_t)Out) | ((uintptr_t)W1p) | ((uintptr_t)W2p) |
-        (post ? (((uintptr_t)Wp) | ((uintptr_t)R)) : 0)) & 15)) {
-    snprintf(msg, sizeof msg, "%s: row strides must be multiples of 8 elements, pointers 16-byte aligned", who);
-    return dm4d_set_error(DM4D_ERR_ARG, msg);
-  }
-  if ((uint64_t)M * (uint64_t)lda0 * 2u >= (1ull << 32)) {
-    snprintf(msg, sizeof msg, "%s: input of 4 GiB or more (split the rows)", who);
-    return dm4d_set_error(DM4D_ERR_ARG, msg);
-  }
-  if (Out == A0 || Out == X || (post && Out == R)) {
-    snprintf(msg, sizeof msg, "%s: the output may not alias an input", who);
-    return dm4d_set_error(DM4D_ERR_ARG, msg);
-  }
+extern "C" int dm4d_attn_out_ff_geglu_fused_bf16(void* stream, const void* A0, int64_t lda0, const void* Wo, const void* bo, const void* X,
+                                                 int64_t ldx, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* W1p,
+                                                 const void* b1p, const void* W2p, const void* b2, void* Out, int64_t ldo, int M, int C,
+                                                 int hidden) {
+  if (!A0 || !Wo || !X || !ln_gamma || !ln_beta || !W1p || !b1p || !W2p || !Out || M <= 0)
+    return dm4d_set_error(DM4D_ERR_ARG, "attn_out_ff_geglu_fused: null pointer or empty shape");
+  if (!dm4d_ff_geglu_supported(C, hidden))
+    return dm4d_set_error(DM4D_ERR_ARG, "attn_out_ff_geglu_fused: built for C = 320 and a hidden size that is a multiple of 32");
+  if ((lda0 & 7) || (ldx & 7) || (ldo & 7) ||
+      ((((uintptr_t)A0) | ((uintptr_t)Wo) | ((uintptr_t)X) | ((uintptr_t)Out) | ((uintptr_t)W1p) | ((uintptr_t)W2p)) & 15))
+    return dm4d_set_error(DM4D_ERR_ARG, "attn_out_ff_geglu_fused: row strides must be multiples of 8 elements, pointers 16-byte aligned");
+  if ((uint64_t)M * (uint64_t)lda0 * 2u >= (1ull << 32))
+    return dm4d_set_error(DM4D_ERR_ARG, "attn_out_ff_geglu_fused: input of 4 GiB or more (split the rows)");
+  if (Out == A0 || Out == X) return dm4d_set_error(DM4D_ERR_ARG, "attn_out_ff_geglu_fused: the output may not alias an input");
   GemmParams p{};
   p.A = (const u16*)A0; p.lda = lda0; p.C = (u16*)Out; p.ldc = ldo; p.M = M; p.N = C; p.K = hidden;
   p.bias = (const u16*)b2; p.res = (const u16*)Out; p.ld_res = ldo; p.flags = 0; p.out_scale = 1.0f; p.splits = 1;
   p.rows_per_rb = 1; p.tiles_n = 1;
   const LnArgs ln{(const u16*)ln_gamma, (const u16*)ln_beta, ln_eps};
-  const ProjArgs proj{(const u16*)A0, lda0, (const u16*)Wo, (const u16*)bo, (const u16*)X, ldx,
-                      post ? (const u16*)Wp : nullptr, post ? (const u16*)bp : nullptr, post ? (const u16*)R : nullptr, post ? ldr : 0};
+  const ProjArgs proj{(const u16*)A0, lda0, (const u16*)Wo, (const u16*)bo, (const u16*)X, ldx};
   return ff_launch_proj_fused((hipStream_t)stream, p, ln, proj, (const u16*)W1p, (const u16*)b1p, (const u16*)W2p, hidden / FF_STEP);
-}
-
-extern "C" int dm4d_attn_out_ff_geglu_fused_bf16(void* stream, const void* A0, int64_t lda0, const void* Wo, const void* bo, const void* X,
-                                                 int64_t ldx, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* W1p,
-                                                 const void* b1p, const void* W2p, const void* b2, void* Out, int64_t ldo, int M, int C,
-                                                 int hidden) {
-  return attn_out_ff_impl("attn_out_ff_geglu_fused", stream, A0, lda0, Wo, bo, X, ldx, ln_gamma, ln_beta, ln_eps, W1p, b1p, W2p, b2, nullptr,
-                          nullptr, nullptr, 0, Out, ldo, M, C, hidden, false);
-}
-
-extern "C" int dm4d_transformer_tail_fused_bf16(void* stream, const void* A0, int64_t lda0, const void* Wo, const void* bo, const void* X,
-                                                int64_t ldx, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* W1p,
-                                                const void* b1p, const void* W2p, const void* b2, const void* Wp, const void* bp,
-                                                const void* R, int64_t ldr, void* Out, int64_t ldo, int M, int C, int hidden) {
-  return attn_out_ff_impl("transformer_tail_fused", stream, A0, lda0, Wo, bo, X, ldx, ln_gamma, ln_beta, ln_eps, W1p, b1p, W2p, b2, Wp, bp,
-                          R, ldr, Out, ldo, M, C, hidden, true);
 }

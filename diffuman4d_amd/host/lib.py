@@ -53,8 +53,6 @@ SIGNATURES = {
     "dm4d_ff_geglu_fused_bf16": (_i, [_vp, _vp, _i64, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i]),
     "dm4d_attn_out_ff_geglu_fused_bf16": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i,
                                                 _i]),
-    "dm4d_transformer_tail_fused_bf16": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
-                                               _vp, _i64, _i, _i, _i]),
     "dm4d_tune_set_gemm_config": (_i, [_i]),
     "dm4d_tune_set_groupnorm_resident": (_i, [_i]),
     "dm4d_nchw_to_nhwc_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),

@@ -153,38 +153,23 @@ class FeedForward:
         return out
 
 
-    def after_attention(self, a: torch.Tensor, wo: torch.Tensor, bo: Optional[torch.Tensor], x: torch.Tensor, ln, post=None) -> torch.Tensor:
-        """The tail of a transformer block: h = a wo^T + bo + x (attention output projection + residual), then f = ff(LayerNorm(h)) + h;
-        with post = (wp, bp, r) also the transformer's proj_out: f wp^T + bp + r.  One launch where the fused kernel is built for the
-        shape (FF_PROJ_FUSED), the separate launches otherwise; bit-identical."""
-        fused = (self.packed is not None and FF_FUSED and FF_PROJ_FUSED and a.shape[0] * a.stride(0) * 2 < (1 << 32)
-                 and wo.shape == (self.C, self.C) and wo.is_contiguous())
-        if fused and post is not None and not (post[0].shape == (self.C, self.C) and post[0].is_contiguous()):
-            fused = False
-        if not fused:
+    def after_attention(self, a: torch.Tensor, wo: torch.Tensor, bo: Optional[torch.Tensor], x: torch.Tensor, ln) -> torch.Tensor:
+        """The tail of a transformer block: h = a wo^T + bo + x (attention output projection + residual), then ff(LayerNorm(h)) + h.
+        One launch where the fused kernel is built for the shape (FF_PROJ_FUSED), gemm + __call__ otherwise; bit-identical."""
+        if (self.packed is None or not FF_FUSED or not FF_PROJ_FUSED or a.shape[0] * a.stride(0) * 2 >= (1 << 32)
+                or wo.shape != (self.C, self.C) or not wo.is_contiguous()):
             h = gemm(a, wo, bias=bo, residual=x)
-            f = self(h, h, ln=ln)
-            return f if post is None else gemm(f, post[0], bias=post[1], residual=post[2])
+            return self(h, h, ln=ln)
         lib = _l.load()
         _req(a, "a"), _req(wo, "wo"), _req(x, "x"), _req(ln[0], "gamma"), _req(ln[1], "beta")
         M = a.shape[0]
         out = torch.empty((M, self.C), dtype=BF16, device=a.device)
         w1p, b1p, w2p = self.packed
-        nsq = 1 if post is None else 2
-        with _Prof("linear", 2.0 * M * (3 * self.hidden + nsq * self.C) * self.C, "flop"):
-            if post is None:
-                rc = lib.dm4d_attn_out_ff_geglu_fused_bf16(_stream(), _p(a), a.stride(0), _p(wo), _p(bo), _p(x), x.stride(0), _p(ln[0]),
-                                                           _p(ln[1]), float(ln[2]), _p(w1p), _p(b1p), _p(w2p), _p(self.b2), _p(out),
-                                                           out.stride(0), M, self.C, self.hidden)
-                name = "dm4d_attn_out_ff_geglu_fused_bf16"
-            else:
-                wp, bp, r = post
-                _req(wp, "wp"), _req(r, "r")
-                rc = lib.dm4d_transformer_tail_fused_bf16(_stream(), _p(a), a.stride(0), _p(wo), _p(bo), _p(x), x.stride(0), _p(ln[0]),
-                                                          _p(ln[1]), float(ln[2]), _p(w1p), _p(b1p), _p(w2p), _p(self.b2), _p(wp), _p(bp),
-                                                          _p(r), r.stride(0), _p(out), out.stride(0), M, self.C, self.hidden)
-                name = "dm4d_transformer_tail_fused_bf16"
-        _l.check(rc, name)
+        with _Prof("linear", 2.0 * M * (3 * self.hidden + self.C) * self.C, "flop"):
+            rc = lib.dm4d_attn_out_ff_geglu_fused_bf16(_stream(), _p(a), a.stride(0), _p(wo), _p(bo), _p(x), x.stride(0), _p(ln[0]),
+                                                       _p(ln[1]), float(ln[2]), _p(w1p), _p(b1p), _p(w2p), _p(self.b2), _p(out),
+                                                       out.stride(0), M, self.C, self.hidden)
+        _l.check(rc, "dm4d_attn_out_ff_geglu_fused_bf16")
         return out
 
 

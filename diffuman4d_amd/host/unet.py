@@ -179,11 +179,9 @@ class _TransformerBlock:
             raise NotImplementedError("cross-attention (attn2) checkpoints are not supported: the reference never "
                                       "passes encoder_hidden_states (SURVEY.md section 0)")
 
-    def __call__(self, h: torch.Tensor, batch: int, seq: int, shard=None, post=None) -> torch.Tensor:
+    def __call__(self, h: torch.Tensor, batch: int, seq: int, shard=None) -> torch.Tensor:
         """h [M, C] token-major; attention over `batch` sequences of `seq` tokens (attention.py:68-90).
-        shard (parallel.FrameShard): `seq` is this rank's share of the frame-folded sequence; K/V are all-gathered.
-        post = (proj_out weight, bias, residual): the enclosing transformer's output projection, applied to this block's result
-        (the last block of a transformer; at C = 320 it rides in the same launch as the block's tail)."""
+        shard (parallel.FrameShard): `seq` is this rank's share of the frame-folded sequence; K/V are all-gathered."""
         C = h.shape[1]
         n = ops.layernorm(h, self.n1w, self.n1b, 1e-5)
         if shard is None:
@@ -197,7 +195,7 @@ class _TransformerBlock:
             a = ops.attention(q, kvg[:, :C], kvg[:, C:], batch, self.heads, seq, kv_seq=shard.world * seq, q_scaled=True)
         # attention output projection + residual, norm3, feed-forward + residual: one launch at C = 320 (level 0); gemm(residual),
         # layernorm, gemm(GEGLU), gemm(residual) elsewhere
-        return self.ff.after_attention(a, self.ow, self.ob, h, (self.n3w, self.n3b, 1e-5), post=post)
+        return self.ff.after_attention(a, self.ow, self.ob, h, (self.n3w, self.n3b, 1e-5))
 
 
 class _Transformer:
@@ -221,12 +219,9 @@ class _Transformer:
         M, HW = B * H * Wd, H * Wd
         n = ops.groupnorm(x, self.nw, self.nb, self.groups, 1e-6, silu=False)  # eps 1e-6: transformer_multiview.py:43-45
         h = ops.gemm(n.view(M, C), self.piw, bias=self.pib)
-        post = (self.pow, self.pob, x.view(M, C))  # proj_out + residual: handed to the last block (one launch with its tail at C = 320)
-        for i, blk in enumerate(self.blocks):
-            h = blk(h, B // num_frames, num_frames * HW, shard, post=post if i == len(self.blocks) - 1 else None)
-        if not self.blocks:
-            h = ops.gemm(h, self.pow, bias=self.pob, residual=x.view(M, C))
-        return h.view(B, H, Wd, C)
+        for blk in self.blocks:
+            h = blk(h, B // num_frames, num_frames * HW, shard)
+        return ops.gemm(h, self.pow, bias=self.pob, residual=x.view(M, C)).view(B, H, Wd, C)
 
 
 class UNetMultiviewConditionModel:

@@ -232,15 +232,6 @@ int dm4d_attn_out_ff_geglu_fused_bf16(void* stream, const void* A0, int64_t lda0
                                       int64_t ldx, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* W1p,
                                       const void* b1p, const void* W2p, const void* b2, void* Out, int64_t ldo, int M, int C,
                                       int hidden);
-/* ... and with one more square projection behind it -- a one-block transformer's proj_out + residual
- * (transformer_multiview.py:209-232), so that the launch takes the attention output and returns the transformer's output:
- *     Out = f Wp^T + bp + R,   f = the result above rounded to bf16 (its own launch's rounding point),   Wp [C, C], bp [C] or NULL,
- *     R [M, C] = the transformer's input.  Bit-identical to dm4d_attn_out_ff_geglu_fused_bf16 followed by
- *     dm4d_gemm_bf16(f, Wp, bias, residual).  Out may not alias A0, X or R.                                                       */
-int dm4d_transformer_tail_fused_bf16(void* stream, const void* A0, int64_t lda0, const void* Wo, const void* bo, const void* X,
-                                     int64_t ldx, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* W1p,
-                                     const void* b1p, const void* W2p, const void* b2, const void* Wp, const void* bp, const void* R,
-                                     int64_t ldr, void* Out, int64_t ldo, int M, int C, int hidden);
 
 /* Tuning hook (not part of the operator surface): force one GEMM/conv kernel configuration id for all
  * subsequent launches of this process; 0 restores the built-in heuristic.  Used by tools/gemm_tune.py. */

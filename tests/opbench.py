@@ -56,20 +56,19 @@ def bench_ff(M, C=320, hidden=1280, tag=""):
     ops.FF_FUSED = True
 
 
-def bench_ff_proj(M, C=320, hidden=1280, tag="", post=False):
+def bench_ff_proj(M, C=320, hidden=1280, tag=""):
     """Tail of a level-0 transformer block: attention output projection + residual + norm3 + feed-forward + residual in one launch
     vs gemm(residual) + the fused LayerNorm / feed-forward launch."""
     a, x = rnd(M, C), rnd(M, C)
     wo, bo = rnd(C, C, scale=1 / math.sqrt(C)), rnd(C)
     ff = ops.FeedForward(rnd(2 * hidden, C, scale=1 / math.sqrt(C)), rnd(2 * hidden), rnd(C, hidden, scale=1 / math.sqrt(hidden)), rnd(C))
-    fl = 2.0 * M * (3 * hidden + (2 if post else 1) * C) * C
+    fl = 2.0 * M * (3 * hidden + C) * C
     lnp = (rnd(C), rnd(C), 1e-5)
-    pst = (rnd(C, C, scale=1 / math.sqrt(C)), rnd(C), rnd(M, C)) if post else None
     for rep in range(2):
         for fused in (True, False):
             ops.FF_PROJ_FUSED = fused
-            t = timeit(lambda: ff.after_attention(a, wo, bo, x, lnp, post=pst))
-            print(f"{'fftail' if post else 'ffproj'}{tag:8s} M={M:6d} C={C} hidden={hidden} {'one launch      ' if fused else 'separate gemms  '} round {rep}  {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s", flush=True)
+            t = timeit(lambda: ff.after_attention(a, wo, bo, x, lnp))
+            print(f"ffproj{tag:8s} M={M:6d} C={C} hidden={hidden} {'one launch      ' if fused else 'gemm + fused ff '} round {rep}  {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s", flush=True)
     ops.FF_PROJ_FUSED = True
 
 
@@ -173,8 +172,6 @@ def main():
     if only == "ffproj":
         bench_ff_proj(32 * 2880, tag=" L0 F16")
         bench_ff_proj(48 * 2880, tag=" L0 F24")
-        bench_ff_proj(32 * 2880, tag=" L0 F16", post=True)
-        bench_ff_proj(48 * 2880, tag=" L0 F24", post=True)
         return
     if only == "attn":
         print("attn q_scaled:", QS, flush=True)
