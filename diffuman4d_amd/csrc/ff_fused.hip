@@ -1,6 +1,8 @@
-// Fused feed-forward of a transformer block (level 0 of the UNet, C = 320), with the LayerNorm in front of it (norm3) folded in: a
-// kernel that keeps its ACTIVATION ROWS IN REGISTERS for the whole launch.  Shares the MFMA / epilogue helpers of gemm.hip through
-// gemm_common.h.  (The same row-register structure was built for the K = 320 Linear layers -- QKV with norm1 folded in, output
+// Fused feed-forward of a transformer block (level 0 of the UNet, C = 320), with the LayerNorm in front of it (norm3) folded in and,
+// in the form the UNet calls (ff_proj_fused_kernel), the attention output projection + residual in front of that: a kernel that keeps
+// its ACTIVATION ROWS IN REGISTERS for the whole launch.  Shares the MFMA / epilogue helpers of gemm.hip through gemm_common.h.
+// (The transformer's proj_out as a post-projection of the same launch was built as well: bit-identical, no gain in a bench step,
+// removed -- profiles/r03_ff_proj_fused.log.  The same row-register structure was built for the K = 320 Linear layers -- QKV with norm1 folded in, output
 // projection, proj_in / proj_out -- bit-identical and SLOWER than layernorm + gemm on every shape, 217 vs 118 us for QKV: one
 // workgroup per CU has nothing to overlap its tile fetch, LayerNorm and epilogue with.  profiles/r03_lin320_rowreg_ab.log; removed.)
 #include "gemm_common.h"
