@@ -156,8 +156,11 @@ class FeedForward:
     def after_attention(self, a: torch.Tensor, wo: torch.Tensor, bo: Optional[torch.Tensor], x: torch.Tensor, ln) -> torch.Tensor:
         """The tail of a transformer block: h = a wo^T + bo + x (attention output projection + residual), then ff(LayerNorm(h)) + h.
         One launch where the fused kernel is built for the shape (FF_PROJ_FUSED), gemm + __call__ otherwise; bit-identical."""
-        if (self.packed is None or not FF_FUSED or not FF_PROJ_FUSED or a.shape[0] * a.stride(0) * 2 >= (1 << 32)
-                or wo.shape != (self.C, self.C) or not wo.is_contiguous()):
+        # the one-launch form wants 16-byte aligned rows (row strides in multiples of 8 elements) and a contiguous square weight; a
+        # column view of a wider tensor as `a` or `x` takes the separate launches, which accept any 8-element-aligned view
+        aligned = all(t.data_ptr() % 16 == 0 and t.stride(0) % 8 == 0 for t in (a, x)) and wo.data_ptr() % 16 == 0
+        if (self.packed is None or not FF_FUSED or not FF_PROJ_FUSED or ln is None or not aligned
+                or a.shape[0] * a.stride(0) * 2 >= (1 << 32) or wo.shape != (self.C, self.C) or not wo.is_contiguous()):
             h = gemm(a, wo, bias=bo, residual=x)
             return self(h, h, ln=ln)
         lib = _l.load()
