@@ -13,7 +13,7 @@ def kernels(path):
     for m in re.finditer(r'^(_Z\w+):[^\n]*\n(.*?)\n\s*s_endpgm', text, re.S | re.M):
         body = re.sub(r';.*', '', m.group(2))
         body = re.sub(r'\.LBB\d+_', '.LBB_', body)
-        out[m.group(1)] = re.sub(r'[ \t]+', ' ', body)
+        out[m.group(1)] = '\n'.join(line.strip() for line in re.sub(r'[ \t]+', ' ', body).splitlines())
     return out
 
 
