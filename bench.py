@@ -81,12 +81,9 @@ def parse():
     ap.add_argument("--grid-frames", type=int, default=N_FRAMES, help="grid mode: frames of the (48 camera x T frame) grid")
     ap.add_argument("--config5", action="store_true",
                     help="BASELINE.json configs[4]: 48 x 225 grid, sliding_default (window 12, stride 1, 3 rounds = 36 steps per "
-                         "latent); task mode, 1 GPU.  An EXTENSION line.  Attention runs the bf16 kernel unless --attention fp8 is "
-                         "given: the fp8 (e4m3) kernel is EXPERIMENTAL -- it measured 0.92-1.10x the bf16 kernel including its "
-                         "pack kernels (profiles/r02_bench_config5_fp8.json), has no reference parity target and its own "
-                         "tolerance (tests/opcheck.py attn_fp8_*)")
-    ap.add_argument("--attention", choices=["bf16", "fp8"], default=None,
-                    help="attention kernel: bf16 (default, also under --config5) or the experimental fp8 (e4m3) one")
+                         "latent); task mode, 1 GPU.  An EXTENSION line.  Attention runs the bf16 kernel: the fp8 (e4m3) kernel of "
+                         "rounds 2-3 measured 0.92-1.10x of it including its pack kernels (profiles/r02_bench_config5_fp8.json) "
+                         "and was removed in round 4 (DESIGN.md section 0)")
     ap.add_argument("--prune-cond-rows", action="store_true",
                     help="opt-in extension, NOT the judged configuration: skip the per-frame tail of the UNet (after the last "
                          "3-D attention) for conditioning frames, whose noise prediction the reference discards")
@@ -370,8 +367,8 @@ def vae_secondary(dev):
 
 
 def apply_workload_flags(args) -> bool:
-    """--config5 / --attention: switch the module's workload constants to BASELINE.json configs[4] (48 x 225, sliding_default)
-    and return whether the fp8 attention extension is on.  The default line is untouched."""
+    """--config5: switch the module's workload constants to BASELINE.json configs[4] (48 x 225, sliding_default).  The default
+    line is untouched."""
     global N_FRAMES, STRIDE, STEPS_PER_LATENT, LATENTS_PER_UNIT
     if args.config5:
         if args.gpus != 1 or args.mode not in ("auto", "task"):
@@ -380,13 +377,12 @@ def apply_workload_flags(args) -> bool:
         STEPS_PER_LATENT = WINDOW // STRIDE * ROUNDS  # 36
         LATENTS_PER_UNIT = 3 * WINDOW / STEPS_PER_LATENT  # 1.0
         args.no_cpu_baseline = True  # the CPU sample and the parity object belong to the judged (bf16) line
-    return (args.attention or "bf16") == "fp8"
 
 
 def main():
     global LAT_H, LAT_W
     args = parse()
-    fp8 = apply_workload_flags(args)
+    apply_workload_flags(args)
     LAT_H, LAT_W = (int(v) for v in args.latent.lower().split("x"))
     if LAT_H % 8 or LAT_W % 8:
         raise SystemExit("--latent: both sides must be multiples of 8 (three UNet down-samplings)")
@@ -433,7 +429,6 @@ def main():
     from diffuman4d_amd.host.unet import UNetConfig, UNetMultiviewConditionModel
     from diffuman4d_amd.host.weights import random_state_dict, unet_param_shapes
 
-    ops.ATTENTION_FP8 = fp8
     cfg = UNetConfig()
     state_dict = random_state_dict(unet_param_shapes(cfg), 0, dev)
     unet = UNetMultiviewConditionModel(cfg, state_dict, dev)
@@ -640,7 +635,7 @@ def main():
                     f"CFG 2.0, {LAT_H}x{LAT_W}x4 latents; ")
         if args.config5:
             workload = ("EXTENSION (BASELINE.json configs[4]): 44cam x 225fr, sliding_default (window 12, stride 1, 3 rounds, 36 "
-                        f"steps/latent), {'experimental fp8 e4m3' if fp8 else 'bf16'} attention, CFG 2.0, {LAT_H}x{LAT_W}x4 latents; ")
+                        f"steps/latent), bf16 attention, CFG 2.0, {LAT_H}x{LAT_W}x4 latents; ")
         if mode == "grid":
             workload += (f"ONE pass over the 48 x {args.grid_frames} grid job: {2 * args.grid_frames} spatial + 44 temporal tasks, "
                          f"first {grid_info['depth']['spatial']} / {grid_info['depth']['temporal']} window calls of every task's 22 / 75; "
@@ -649,14 +644,14 @@ def main():
             workload += (f"step = 2 spatial (F=16) + 1 temporal (F=24) window calls = {LATENTS_PER_UNIT:g} denoised "
                          f"latent{'s' if LATENTS_PER_UNIT != 1 else ''}; VAE excluded")
         out = {
-            "metric": (f"denoised view-frame latents/sec (44cam x 225fr grid, sliding_default{', fp8 attention' if fp8 else ''})" if args.config5
+            "metric": (f"denoised view-frame latents/sec (44cam x 225fr grid, sliding_default)" if args.config5
                        else "denoised view-frame latents/sec (44cam x 150fr grid)"),
             "value": round(value, 4),
             "unit": "latents/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak" if mode == "task" else "strong", "vs_baseline": None,
-            "dtype": "bf16 (attention operands fp8 e4m3)" if fp8 else "bf16", "data": "synthetic",
+            "dtype": "bf16", "data": "synthetic",
             "config": {
                 "workload": workload,
                 "mode": mode,
@@ -664,20 +659,20 @@ def main():
                 "parallelism": par,
                 "task_streams": S, "task_batch": kb,
                 "finite_outputs": finite,
-                "extensions": (["prune_cond_rows"] if args.prune_cond_rows else []) + (["fp8_attention"] if fp8 else []),
+                "extensions": (["prune_cond_rows"] if args.prune_cond_rows else []),
             },
             "roofline": {
-                "kernel": ("attn_fp8_kernel + its pack kernels" if fp8 else "attn_kernel") +
+                "kernel": "attn_kernel" +
                           " (2-D + 3-D view/time attention, all 48 launches of a step)",
-                "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS * (2 if fp8 else 1), "unit": "TFLOP/s",
-                "frac": round(achieved / (MFMA_PEAK_TFLOPS * (2 if fp8 else 1)), 4), "traffic": None if fp8 else traffic,
+                "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                 "traffic_note": f"avg HBM bytes per attn launch, PMC (2*FETCH_SIZE+WRITE_SIZE), profiles/{traffic_file}; "
                                 "algorithmic Q+K+V+O bytes average 152e6 per launch",
                 "avg_launch_ms": round(attn_ms / max(1, len(timer)), 4), "launches": len(timer),
                 "measured_in": f"a separate pass of {k_roof} units (2 spatial + 1 temporal window calls each) with one task in flight "
                                f"({dt_single / max(1, k_roof) * 1e3:.1f} ms per unit), HIP events on the launch stream",
                 "share_of_step_time": round(attn_ms * 1e-3 / dt_single, 4),
-                "mfma_busy_pmc": None if fp8 else mfma_busy,
+                "mfma_busy_pmc": mfma_busy,
             },
         }
         if grid_info is not None:

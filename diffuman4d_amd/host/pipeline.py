@@ -27,6 +27,7 @@ from .scheduler import DDIMScheduler
 from .unet import UNetMultiviewConditionModel
 
 BF16 = torch.bfloat16
+F32 = torch.float32
 
 
 def _identity_tqdm(it, **kw):
@@ -46,7 +47,13 @@ class Diffuman4DPipeline:
         if dev.type == "cuda" and dev.index is None:
             dev = torch.device("cuda", torch.cuda.current_device())
         self._device = dev
-        self.dtype = BF16
+        # precision of the arithmetic (include/dm4d.h "Parity precision"): "fast" = bf16 tensors and MFMA operands; "parity" = fp32
+        # tensors between kernels and two-term bf16 operands, within north_star's 1e-3 of the fp32 reference path on decoded RGB
+        self.parity = bool(getattr(unet, "parity", False))
+        if vae is not None and bool(getattr(vae, "parity", False)) != self.parity:
+            raise ValueError("the UNet and the VAE of a pipeline must be built with the same precision")
+        self.precision = "parity" if self.parity else "fast"
+        self.dtype = F32 if self.parity else BF16
         self.vae_scale_factor = vae.scale_factor if vae is not None else 8
         self._vae_cache: Dict[str, dict] = {"pixel": {}, "skeleton": {}}  # encoder moments by caller-supplied key
         # extension (off = compute what the reference computes): after the last 3-D attention layer run only the rows
@@ -62,12 +69,14 @@ class Diffuman4DPipeline:
 
     # ------------------------------------------------------------------------------------------
     @classmethod
-    def from_pretrained(cls, model_dir, torch_dtype=BF16, device="cuda") -> "Diffuman4DPipeline":
+    def from_pretrained(cls, model_dir, torch_dtype=BF16, device="cuda", precision: str = "fast") -> "Diffuman4DPipeline":
         """diffusers checkpoint directory (sampling_utils.py:28-46): model_index.json, unet/, vae/, scheduler/.
         ``torch_dtype`` bf16 | fp16 selects the checkpoint FILES the way the reference does (``*model.safetensors`` vs
         ``*model.fp16.safetensors``, :28-33).  The arithmetic is bf16 MFMA with fp32 accumulation in both cases: gfx950's
         matrix pipe runs both 16-bit formats at the same rate and the kernels are written for bf16, so fp16 weights are
-        converted once at load (their 10-bit mantissas are rounded to 7; no SD-class weight leaves bf16's range)."""
+        converted once at load (their 10-bit mantissas are rounded to 7; no SD-class weight leaves bf16's range).
+        ``precision="parity"`` (extension; configs/model/diffuman4d_mi355x.yaml ``precision``): fp32 tensors between kernels and
+        two-term bf16 activation operands -- the arithmetic that meets north_star's 1e-3 against the fp32 reference path."""
         from .vae import AutoencoderKL
         if torch_dtype in (BF16, "bf16"):
             variant = None
@@ -78,12 +87,12 @@ class Diffuman4DPipeline:
         model_dir = Path(model_dir)
         if (model_dir / "model_index.json").exists():
             json.loads((model_dir / "model_index.json").read_text())  # class names only; import paths are ignored
-        unet = UNetMultiviewConditionModel.from_pretrained(model_dir / "unet", device, variant)
-        vae = AutoencoderKL.from_pretrained(model_dir / "vae", device, variant)
+        unet = UNetMultiviewConditionModel.from_pretrained(model_dir / "unet", device, variant, precision)
+        vae = AutoencoderKL.from_pretrained(model_dir / "vae", device, variant, precision)
         sched = DDIMScheduler.from_pretrained(model_dir / "scheduler")
         pipe = cls(vae, unet, sched, device)
         pipe.checkpoint_variant = variant
-        pipe._source = (str(model_dir), torch_dtype)
+        pipe._source = (str(model_dir), torch_dtype, precision)
         return pipe
 
     def to(self, device):
@@ -97,7 +106,7 @@ class Diffuman4DPipeline:
         src = getattr(self, "_source", None)
         if src is None:
             raise NotImplementedError("this pipeline was assembled from in-memory components; build it on the target device")
-        moved = type(self).from_pretrained(src[0], torch_dtype=src[1], device=dev)
+        moved = type(self).from_pretrained(src[0], torch_dtype=src[1], device=dev, precision=src[2] if len(src) > 2 else "fast")
         moved.prune_cond_rows = self.prune_cond_rows
         self.__dict__.update(moved.__dict__)
         return self
@@ -107,7 +116,10 @@ class Diffuman4DPipeline:
 
     # ------------------------------------------------------------------------------------------
     def _to_dev_nhwc(self, x: torch.Tensor, cpad: Optional[int] = None) -> torch.Tensor:
-        """CPU/GPU NCHW (any float dtype) -> device NHWC bf16 via the layout kernel."""
+        """CPU/GPU NCHW (any float dtype) -> device NHWC bf16 via the layout kernel (parity precision: fp32, permuted where it lies)."""
+        if self.parity:
+            assert cpad is None
+            return x.float().permute(0, 2, 3, 1).contiguous().to(self._device)
         x = x.to(device=self._device, dtype=BF16).contiguous()
         return ops.nchw_to_nhwc(x, cpad)
 
@@ -127,7 +139,8 @@ class Diffuman4DPipeline:
         if plucker_embeds is not None:
             pl_lat = self.vae.resize_to_nhwc(plucker_embeds, (h, w), "bilinear")
         elif cameras is not None:
-            pl_lat = ops.plucker_latents(cameras["Ks"], cameras["poses"], tuple(cameras["image_size"]), (h, w), self._device)
+            pl_lat = ops.plucker_latents(cameras["Ks"], cameras["poses"], tuple(cameras["image_size"]), (h, w), self._device,
+                                         out_f32=self.parity)
         else:
             raise ValueError("plucker_embeds is None and no cameras were given")
         if self.unet.config.enable_pose_encoder:
@@ -160,6 +173,8 @@ class Diffuman4DPipeline:
         GroupNorm, per-(batch, head) attention; every tile choice is bit-identical)."""
         if copies > 1 and (shard is not None or rows_per_task <= 0):
             raise ValueError("task batching needs rows_per_task and is not combined with frame sharding")
+        if shard is not None and self.parity:
+            raise NotImplementedError("precision='parity' runs unsharded")
         ts = self.scheduler.set_timesteps(plan.num_inference_steps)
         cfg = 2 if guidance_scale > 1 else 1
         win = np.stack(plan.windows).astype(np.int32)              # [calls, F]
@@ -237,7 +252,7 @@ class Diffuman4DPipeline:
         fpg = tb.get("frames_per_group", F)  # < F when several tasks share the call (upload_plan copies)
         if len(domains) * fpg != tb["cfg"] * F:
             domains = list(domains[:1]) * (tb["cfg"] * F // fpg)
-        eps = self.unet(x.view(tb["cfg"] * F, h, w, self.unet.IN_PAD), tb["t"][i], domains=domains, num_frames=fpg, shard=shard,
+        eps = self.unet(x.view(tb["cfg"] * F, h, w, -1), tb["t"][i], domains=domains, num_frames=fpg, shard=shard,
                         pose_features=pose, keep_rows=keep)
         if keep is not None:  # back to one row per CFG-batch entry; the rows left at zero are never read by the step kernel
             full = torch.zeros((tb["cfg"] * F,) + tuple(eps.shape[1:]), dtype=eps.dtype, device=eps.device)

@@ -66,11 +66,20 @@ def _round_up(x: int, m: int) -> int:
 
 
 class _Weights:
-    """Converts a diffusers-style state_dict into kernel layouts on the device."""
+    """Converts a diffusers-style state_dict into kernel layouts on the device.
+    parity (precision="parity", include/dm4d.h "Parity precision"): matrices are duplicated along K -- [W | W] per convolution
+    tap -- to meet two-term activation operands [hi | lo]; vectors (biases, norm scales) are the same bf16 tensors."""
 
-    def __init__(self, sd: Dict[str, torch.Tensor], device):
-        self.sd, self.device = sd, device
+    def __init__(self, sd: Dict[str, torch.Tensor], device, parity: bool = False):
+        self.sd, self.device, self.parity = sd, device, parity
         self.used = set()
+
+    def mat(self, w: torch.Tensor, taps: int = 1) -> torch.Tensor:
+        """fp32 / bf16 host matrix [N, taps * C] -> device bf16, duplicated along K in parity precision."""
+        w = w.to(BF16)
+        if self.parity:
+            w = ops.dup_k(w, taps)
+        return w.to(self.device).contiguous()
 
     def get(self, key: str) -> torch.Tensor:
         if key not in self.sd:
@@ -85,7 +94,7 @@ class _Weights:
         w = self.get(key)
         if w.ndim == 4:  # 1x1 conv used as a linear
             w = w.reshape(w.shape[0], w.shape[1])
-        return w.to(self.device, BF16).contiguous()
+        return self.mat(w)
 
     def conv3(self, key: str, cin_pad: Optional[int] = None, cout_pad: Optional[int] = None) -> torch.Tensor:
         """[Cout, Cin, 3, 3] -> [Cout, 9*Cin] with K ordered (ky, kx, ci); optional zero padding."""
@@ -94,7 +103,7 @@ class _Weights:
         cin_pad, cout_pad = cin_pad or ci, cout_pad or co
         wp = torch.zeros(cout_pad, 3, 3, cin_pad)
         wp[:co, :, :, :ci] = w.permute(0, 2, 3, 1)
-        return wp.reshape(cout_pad, 9 * cin_pad).to(self.device, BF16).contiguous()
+        return self.mat(wp.reshape(cout_pad, 9 * cin_pad), taps=9)
 
 
 class _PoseEncoder:
@@ -134,7 +143,7 @@ class _PoseEncoder:
 
 class _Resnet:
     def __init__(self, W: _Weights, pfx: str, groups: int, eps: float, scale: float, temb_list: List):
-        self.groups, self.eps, self.scale = groups, eps, scale
+        self.groups, self.eps, self.scale, self.parity = groups, eps, scale, W.parity
         self.n1w, self.n1b = W.vec(pfx + "norm1.weight"), W.vec(pfx + "norm1.bias")
         self.c1w, self.c1b = W.conv3(pfx + "conv1.weight"), W.vec(pfx + "conv1.bias")
         self.n2w, self.n2b = W.vec(pfx + "norm2.weight"), W.vec(pfx + "norm2.bias")
@@ -148,33 +157,43 @@ class _Resnet:
         temb_list.append((W.get(pfx + "time_emb_proj.weight"), W.get(pfx + "time_emb_proj.bias")))
 
     def __call__(self, x: torch.Tensor, tproj: torch.Tensor, skip: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Fast precision: bf16 tensors throughout.  Parity precision: x, skip, tproj and the result are fp32; the GroupNorm
+        outputs are two-term operands (ops.groupnorm dispatches on the dtype), the convolutions take them against duplicated weights."""
+        P = self.parity
         B, H, Wd = x.shape[:3]
         h = ops.groupnorm(x, self.n1w, self.n1b, self.groups, self.eps, x2=skip, silu=True)
-        h = ops.conv3x3(h, self.c1w, bias=self.c1b, rowbias=tproj[:, self.t_off:self.t_off + self.cout])
+        h = ops.conv3x3(h, self.c1w, bias=self.c1b, rowbias=tproj[:, self.t_off:self.t_off + self.cout], out_f32=P)
         h = ops.groupnorm(h, self.n2w, self.n2b, self.groups, self.eps, silu=True)
         if self.has_sc:
             M = B * H * Wd
-            sc = ops.gemm(x.view(M, -1), self.scw, a2=skip.view(M, -1) if skip is not None else None, bias=self.scb)
+            if P:
+                sc = ops.gemm(ops.split(x.view(M, -1), skip.view(M, -1) if skip is not None else None), self.scw, bias=self.scb, out_f32=True)
+            else:
+                sc = ops.gemm(x.view(M, -1), self.scw, a2=skip.view(M, -1) if skip is not None else None, bias=self.scb)
             sc = sc.view(B, H, Wd, self.cout)
         else:
             assert skip is None
             sc = x
-        return ops.conv3x3(h, self.c2w, bias=self.c2b, residual=sc, out_scale=1.0 / self.scale)
+        return ops.conv3x3(h, self.c2w, bias=self.c2b, residual=sc, out_scale=1.0 / self.scale, out_f32=P)
 
 
 class _TransformerBlock:
     def __init__(self, W: _Weights, pfx: str, heads: int):
-        self.heads = heads
+        self.heads, self.parity = heads, W.parity
         self.n1w, self.n1b = W.vec(pfx + "norm1.weight"), W.vec(pfx + "norm1.bias")
         q, k, v = (W.get(pfx + f"attn1.to_{n}.weight") for n in "qkv")
-        # SDPA's q * scale (and the exp -> exp2 factor) folded into the bias-free to_q rows in fp32, before the single
-        # bf16 rounding: the attention kernel then needs no per-score multiply (dm4d_attention_qscaled_kv_bf16)
-        q = q.float() * ((q.shape[0] // heads) ** -0.5 * ops.LOG2E)
-        self.qkv = torch.cat([q, k.float(), v.float()], dim=0).to(W.device, BF16).contiguous()  # fused [3C, C], bias-free
+        self.scale = (q.shape[0] // heads) ** -0.5
+        if not W.parity:
+            # SDPA's q * scale (and the exp -> exp2 factor) folded into the bias-free to_q rows in fp32, before the single
+            # bf16 rounding: the attention kernel then needs no per-score multiply (dm4d_attention_qscaled_kv_bf16).
+            # Parity precision keeps the checkpoint's rows (exact in bf16) and scales the fp32 scores in the kernel.
+            q = q.float() * (self.scale * ops.LOG2E)
+        self.qkv = W.mat(torch.cat([q.float(), k.float(), v.float()], dim=0))  # fused [3C, C], bias-free
         self.ow, self.ob = W.linear(pfx + "attn1.to_out.0.weight"), W.vec(pfx + "attn1.to_out.0.bias")
         self.n3w, self.n3b = W.vec(pfx + "norm3.weight"), W.vec(pfx + "norm3.bias")
-        self.ff = ops.FeedForward(W.linear(pfx + "ff.net.0.proj.weight"), W.vec(pfx + "ff.net.0.proj.bias"),
-                                  W.linear(pfx + "ff.net.2.weight"), W.vec(pfx + "ff.net.2.bias"))
+        w1, b1 = W.linear(pfx + "ff.net.0.proj.weight"), W.vec(pfx + "ff.net.0.proj.bias")
+        w2, b2 = W.linear(pfx + "ff.net.2.weight"), W.vec(pfx + "ff.net.2.bias")
+        self.ff = (w1, b1, w2, b2) if W.parity else ops.FeedForward(w1, b1, w2, b2)
         if (pfx + "attn2.to_q.weight") in W.sd:
             raise NotImplementedError("cross-attention (attn2) checkpoints are not supported: the reference never "
                                       "passes encoder_hidden_states (SURVEY.md section 0)")
@@ -182,6 +201,8 @@ class _TransformerBlock:
     def __call__(self, h: torch.Tensor, batch: int, seq: int, shard=None) -> torch.Tensor:
         """h [M, C] token-major; attention over `batch` sequences of `seq` tokens (attention.py:68-90).
         shard (parallel.FrameShard): `seq` is this rank's share of the frame-folded sequence; K/V are all-gathered."""
+        if self.parity:
+            return self._call_parity(h, batch, seq, shard)
         C = h.shape[1]
         n = ops.layernorm(h, self.n1w, self.n1b, 1e-5)
         if shard is None:
@@ -197,12 +218,25 @@ class _TransformerBlock:
         # layernorm, gemm(GEGLU), gemm(residual) elsewhere
         return self.ff.after_attention(a, self.ow, self.ob, h, (self.n3w, self.n3b, 1e-5))
 
+    def _call_parity(self, h: torch.Tensor, batch: int, seq: int, shard=None) -> torch.Tensor:
+        """The same block on an fp32 residual stream: LayerNorm -> operand; QKV projection -> hi / lo planes; attention with three
+        MFMA terms per product -> operand; output projection + fp32 residual; LayerNorm; GEGLU -> operand; projection + residual."""
+        if shard is not None:
+            raise NotImplementedError("precision='parity' runs unsharded")
+        w1, b1, w2, b2 = self.ff
+        n = ops.layernorm(h, self.n1w, self.n1b, 1e-5)
+        qkv = ops.gemm(n, self.qkv, split_out=True)  # [M, 6C]
+        a = ops.attention_split(qkv, batch, self.heads, seq, self.scale)
+        h = ops.gemm(a, self.ow, bias=self.ob, residual=h, out_f32=True)
+        f = ops.gemm(ops.layernorm(h, self.n3w, self.n3b, 1e-5), w1, bias=b1, geglu=True, split_out=True)
+        return ops.gemm(f, w2, bias=b2, residual=h, out_f32=True)
+
 
 class _Transformer:
     """TransformerMultiviewModel (transformer_multiview.py:34-232), continuous input."""
 
     def __init__(self, W: _Weights, pfx: str, heads: int, groups: int):
-        self.groups = groups
+        self.groups, self.parity = groups, W.parity
         self.nw, self.nb = W.vec(pfx + "norm.weight"), W.vec(pfx + "norm.bias")
         self.piw, self.pib = W.linear(pfx + "proj_in.weight"), W.vec(pfx + "proj_in.bias")
         self.pow, self.pob = W.linear(pfx + "proj_out.weight"), W.vec(pfx + "proj_out.bias")
@@ -211,17 +245,18 @@ class _Transformer:
         while (pfx + f"transformer_blocks.{i}.norm1.weight") in W.sd:
             self.blocks.append(_TransformerBlock(W, pfx + f"transformer_blocks.{i}.", heads))
             i += 1
-        if (self.piw.shape[0] // heads) != 64:
+        if (self.pob.shape[0] // heads) != 64:
             raise NotImplementedError("the HIP attention kernel is specialised for head_dim 64")
 
     def __call__(self, x: torch.Tensor, num_frames: int, shard=None) -> torch.Tensor:
         B, H, Wd, C = x.shape
         M, HW = B * H * Wd, H * Wd
+        P = self.parity
         n = ops.groupnorm(x, self.nw, self.nb, self.groups, 1e-6, silu=False)  # eps 1e-6: transformer_multiview.py:43-45
-        h = ops.gemm(n.view(M, C), self.piw, bias=self.pib)
+        h = ops.gemm(n.view(M, -1), self.piw, bias=self.pib, out_f32=P)
         for blk in self.blocks:
             h = blk(h, B // num_frames, num_frames * HW, shard)
-        return ops.gemm(h, self.pow, bias=self.pob, residual=x.view(M, C)).view(B, H, Wd, C)
+        return ops.gemm(ops.split(h) if P else h, self.pow, bias=self.pob, residual=x.view(M, C), out_f32=P).view(B, H, Wd, C)
 
 
 class UNetMultiviewConditionModel:
@@ -229,14 +264,21 @@ class UNetMultiviewConditionModel:
 
     IN_PAD = 32  # conv_in input channels are zero-padded to one 32-wide K slab
 
-    def __init__(self, config: UNetConfig, state_dict: Dict[str, torch.Tensor], device="cuda"):
+    def __init__(self, config: UNetConfig, state_dict: Dict[str, torch.Tensor], device="cuda", precision: str = "fast"):
+        """precision: "fast" (bf16 tensors, bf16 MFMA operands) or "parity" (fp32 tensors between kernels, two-term bf16
+        operands: meets north_star's 1e-3 on decoded RGB against the fp32 reference path; include/dm4d.h "Parity precision")."""
         cfg = self.config = config
         self.device = torch.device(device)
+        if precision not in ("fast", "parity"):
+            raise ValueError(f"Unsupported precision: {precision}. Supported values are 'fast' and 'parity'.")
+        self.precision, self.parity = precision, precision == "parity"
         if cfg.cross_attention_dim is not None:
             raise NotImplementedError("cross_attention_dim must be None (SURVEY.md section 0)")
         if cfg.in_channels > self.IN_PAD:
             raise NotImplementedError("in_channels > 32")
-        W = _Weights(state_dict, self.device)
+        if self.parity and cfg.enable_pose_encoder:
+            raise NotImplementedError("precision='parity' does not cover enable_pose_encoder checkpoints")
+        W = _Weights(state_dict, self.device, self.parity)
         boc = cfg.block_out_channels
         g, eps = cfg.norm_num_groups, cfg.norm_eps
         temb_list: List = []
@@ -273,12 +315,12 @@ class UNetMultiviewConditionModel:
             att = [_Transformer(W, p + f"attentions.{j}.", cfg.heads(len(boc) - 1 - i), g) for j in range(n)] if has_attn else None
             us = None
             if i != len(boc) - 1:
-                us = ops.Upsampler(W.conv3(p + "upsamplers.0.conv.weight"), W.vec(p + "upsamplers.0.conv.bias"))
+                us = ops.Upsampler(W.conv3(p + "upsamplers.0.conv.weight"), W.vec(p + "upsamplers.0.conv.bias"), parity=self.parity)
             self.up.append((res, att, us))
         self.no_w, self.no_b = W.vec("conv_norm_out.weight"), W.vec("conv_norm_out.bias")
         self.conv_out_w, self.conv_out_b = W.conv3("conv_out.weight"), W.vec("conv_out.bias")
         # one [sum(Cout), 4*C0] weight for all time_emb_proj layers
-        self.tproj_w = torch.cat([t[0] for t in temb_list], dim=0).to(self.device, BF16).contiguous()
+        self.tproj_w = W.mat(torch.cat([t[0] for t in temb_list], dim=0))
         self.tproj_b = torch.cat([t[1] for t in temb_list], dim=0).to(self.device, BF16).contiguous()
         unused = [k for k in state_dict if k not in W.used and not k.startswith("time_proj")
                   and "time_emb_proj" not in k and ".attn1.to_" not in k]
@@ -287,20 +329,21 @@ class UNetMultiviewConditionModel:
 
     # -- loading --------------------------------------------------------------------------------
     @classmethod
-    def from_pretrained(cls, path, device="cuda", variant: Optional[str] = None) -> "UNetMultiviewConditionModel":
+    def from_pretrained(cls, path, device="cuda", variant: Optional[str] = None, precision: str = "fast") -> "UNetMultiviewConditionModel":
         """``path`` = the ``unet/`` folder of a diffusers checkpoint directory; ``variant="fp16"`` reads the
         ``*.fp16.safetensors`` file (weights are converted to bf16 either way)."""
         from .weights import load_component_state_dict
         path = Path(path)
         cfg = UNetConfig.from_dict(json.loads((path / "config.json").read_text()))
-        return cls(cfg, load_component_state_dict(path, variant), device)
+        return cls(cfg, load_component_state_dict(path, variant), device, precision)
 
     # -- forward --------------------------------------------------------------------------------
     def _temb(self, timestep: torch.Tensor, domains: Sequence[str], num_frames: int, shard=None) -> torch.Tensor:
-        cfg = self.config
+        cfg, P = self.config, self.parity
         c0 = cfg.block_out_channels[0]
-        t_emb = ops.timestep_embedding(timestep.to(self.device, torch.float32), c0, cfg.flip_sin_to_cos, float(cfg.freq_shift))
-        emb = ops.gemm(ops.gemm(t_emb, self.te[0], bias=self.te[1], silu=True), self.te[2], bias=self.te[3])
+        op = (lambda t, **kw: ops.split(t, **kw)) if P else (lambda t, silu=False: ops.silu(t) if silu else t)  # fp32 -> operand
+        t_emb = ops.timestep_embedding(timestep.to(self.device, torch.float32), c0, cfg.flip_sin_to_cos, float(cfg.freq_shift), out_f32=P)
+        emb = ops.gemm(ops.gemm(op(t_emb), self.te[0], bias=self.te[1], silu=True, split_out=P), self.te[2], bias=self.te[3], out_f32=P)
         if self.tpe is not None:  # unet_multiview_condition.py:523-546
             if len(domains) * num_frames != emb.shape[0]:
                 raise ValueError(f"num_frames: {num_frames} * len(domains): {len(domains)} != len(emb): {emb.shape[0]}")
@@ -314,25 +357,29 @@ class UNetMultiviewConditionModel:
                 else:
                     raise ValueError(f"Invalid domain for temporal embedding: {d}")
                 idx.append(full if shard is None else full[shard.local_frames(num_frames * world)])
-            f_emb = ops.timestep_embedding(torch.cat(idx).to(self.device), c0, True, 0.0)
-            emb = ops.gemm(ops.gemm(f_emb, self.tpe[0], bias=self.tpe[1], silu=True), self.tpe[2], bias=self.tpe[3],
-                           residual=emb)
-        return ops.gemm(ops.silu(emb), self.tproj_w, bias=self.tproj_b)  # [B, sum Cout]
+            f_emb = ops.timestep_embedding(torch.cat(idx).to(self.device), c0, True, 0.0, out_f32=P)
+            emb = ops.gemm(ops.gemm(op(f_emb), self.tpe[0], bias=self.tpe[1], silu=True, split_out=P), self.tpe[2], bias=self.tpe[3],
+                           residual=emb, out_f32=P)
+        return ops.gemm(op(emb, silu=True), self.tproj_w, bias=self.tproj_b, out_f32=P)  # [B, sum Cout]
 
     @torch.no_grad()
     def forward(self, sample: torch.Tensor, timestep: torch.Tensor, skeletons=None, domains: Sequence[str] = ("spatial",),
                 num_frames: int = 1, shard=None, pose_features: Optional[torch.Tensor] = None,
                 keep_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
         """sample [B, h, w, 32] NHWC bf16 (channels beyond in_channels zero); timestep [B]; -> [B, h, w, out_channels].
+        precision "parity": sample is the two-term operand [B, h, w, 64] = [hi(32) | lo(32)] (ops.pack_model_input / ops.split of an
+        fp32 sample), the result is fp32.
         keep_rows (int64 [R], optional extension): batch rows whose output is wanted.  Every layer after the last 3-D
         attention is per-frame, so from there on only these rows are computed and the result has R rows (the pipeline
         discards the noise prediction of conditioning rows, pipeline_diffuman4d.py:413-421).
         With `shard` (parallel.FrameShard) sample/timestep hold this rank's frames and num_frames is the LOCAL count.
         enable_pose_encoder checkpoints (:551-552): pass `skeletons` [B, 8h, 8w, 4] NHWC (encoded here, as the
         reference does on every call) or `pose_features` [B, h, w, C0] computed once with ``self.pose_encoder``."""
-        cfg = self.config
-        if sample.shape[-1] != self.IN_PAD:
-            raise ValueError(f"sample must be NHWC with {self.IN_PAD} (padded) channels")
+        cfg, P = self.config, self.parity
+        if sample.shape[-1] != (2 * self.IN_PAD if P else self.IN_PAD):
+            raise ValueError(f"sample must be NHWC with {self.IN_PAD} (padded) channels" + (" as a two-term operand [hi | lo]" if P else ""))
+        if P and shard is not None:
+            raise NotImplementedError("precision='parity' runs unsharded")
         if sample.shape[0] % num_frames != 0:
             raise ValueError("batch must be a multiple of num_frames")
         tproj = self._temb(timestep, domains, num_frames, shard)
@@ -346,7 +393,7 @@ class UNetMultiviewConditionModel:
             pose_features = pose_features.contiguous()
         else:
             pose_features = None
-        x = ops.conv3x3(sample, self.conv_in_w, bias=self.conv_in_b, residual=pose_features)
+        x = ops.conv3x3(sample, self.conv_in_w, bias=self.conv_in_b, residual=pose_features, out_f32=P)
         skips = [x]
         nd = len(self.down)
         for i, (res, att, ds) in enumerate(self.down):
@@ -357,7 +404,7 @@ class UNetMultiviewConditionModel:
                     x = att[j](x, num_frames if is3d else 1, shard if is3d else None)
                 skips.append(x)
             if ds is not None:
-                x = ops.conv3x3(x, ds[0], bias=ds[1], stride=2, pad=1)
+                x = ops.conv3x3(ops.split(x) if P else x, ds[0], bias=ds[1], stride=2, pad=1, out_f32=P)
                 skips.append(x)
         x = self.mid[0][0](x, tproj)
         x = self.mid[1](x, num_frames, shard)  # :570
@@ -380,6 +427,6 @@ class UNetMultiviewConditionModel:
             if us is not None:
                 x = us(x)
         x = ops.groupnorm(x, self.no_w, self.no_b, cfg.norm_num_groups, cfg.norm_eps, silu=True)
-        return ops.conv3x3(x, self.conv_out_w, bias=self.conv_out_b)
+        return ops.conv3x3(x, self.conv_out_w, bias=self.conv_out_b, out_f32=P)
 
     __call__ = forward

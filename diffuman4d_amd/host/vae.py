@@ -18,6 +18,7 @@ from . import ops
 from .unet import _Weights
 
 BF16 = torch.bfloat16
+F32 = torch.float32
 PAD = 32
 
 
@@ -41,7 +42,7 @@ class _Res:
     """ResnetBlock2D without time embedding, eps 1e-6."""
 
     def __init__(self, W: _Weights, pfx: str, groups: int):
-        self.g = groups
+        self.g, self.parity = groups, W.parity
         self.n1w, self.n1b = W.vec(pfx + "norm1.weight"), W.vec(pfx + "norm1.bias")
         self.c1w, self.c1b = W.conv3(pfx + "conv1.weight"), W.vec(pfx + "conv1.bias")
         self.n2w, self.n2b = W.vec(pfx + "norm2.weight"), W.vec(pfx + "norm2.bias")
@@ -51,14 +52,15 @@ class _Res:
             self.scw, self.scb = W.linear(pfx + "conv_shortcut.weight"), W.vec(pfx + "conv_shortcut.bias")
 
     def __call__(self, x):
+        P = self.parity  # fp32 tensors, two-term operands out of the GroupNorms (ops dispatches on the dtype)
         B, H, Wd, C = x.shape
         h = ops.groupnorm(x, self.n1w, self.n1b, self.g, 1e-6, silu=True)
-        h = ops.conv3x3(h, self.c1w, bias=self.c1b)
+        h = ops.conv3x3(h, self.c1w, bias=self.c1b, out_f32=P)
         h = ops.groupnorm(h, self.n2w, self.n2b, self.g, 1e-6, silu=True)
         sc = x
         if self.has_sc:
-            sc = ops.gemm(x.view(-1, C), self.scw, bias=self.scb).view(B, H, Wd, -1)
-        return ops.conv3x3(h, self.c2w, bias=self.c2b, residual=sc)
+            sc = ops.gemm(ops.split(x.view(-1, C)) if P else x.view(-1, C), self.scw, bias=self.scb, out_f32=P).view(B, H, Wd, -1)
+        return ops.conv3x3(h, self.c2w, bias=self.c2b, residual=sc, out_f32=P)
 
 
 class _MidAttn:
@@ -67,16 +69,43 @@ class _MidAttn:
     QBLOCK_BYTES = 128 << 20  # fp32 logits of one query block
 
     def __init__(self, W: _Weights, pfx: str, groups: int):
-        self.g = groups
+        self.g, self.parity = groups, W.parity
         self.nw, self.nb = W.vec(pfx + "group_norm.weight"), W.vec(pfx + "group_norm.bias")
         ws = [W.get(pfx + f"to_{n}.weight") for n in "qkv"]
         bs = [W.get(pfx + f"to_{n}.bias") for n in "qkv"]
         ws = [w.reshape(w.shape[0], w.shape[1]) for w in ws]  # legacy checkpoints store 1x1 convs
-        self.qkv_w = torch.cat(ws, 0).to(W.device, BF16).contiguous()
+        self.qkv_w = W.mat(torch.cat(ws, 0))
         self.qkv_b = torch.cat(bs, 0).to(W.device, BF16).contiguous()
         self.ow, self.ob = W.linear(pfx + "to_out.0.weight"), W.vec(pfx + "to_out.0.bias")
 
+    def _call_parity(self, x):
+        """fp32 in / out.  Both factors of q k^T and of p v are activations, so each product takes three bf16 terms,
+        hi hi + lo hi + hi lo: the left factor as planes [hi | lo | hi], the right one as [hi | hi | lo] (ops.split patterns 1 / 2)."""
+        B, H, Wd, C = x.shape
+        L = H * Wd
+        Lp = (L + 31) // 32 * 32
+        n = ops.groupnorm(x, self.nw, self.nb, self.g, 1e-6, silu=False)
+        qkv = ops.gemm(n.view(B * L, 2 * C), self.qkv_w, bias=self.qkv_b, out_f32=True)  # [B*L, 3C] fp32
+        o = torch.empty((B * L, C), dtype=F32, device=x.device)
+        scale = float(C) ** -0.5
+        qb = max(32, min(L, (self.QBLOCK_BYTES // (4 * Lp)) // 32 * 32))
+        self.last_block_bytes = 4 * Lp * qb
+        s = torch.empty((qb, Lp), dtype=F32, device=x.device)
+        for b in range(B):
+            rows = slice(b * L, (b + 1) * L)
+            k3 = ops.split(qkv[rows, C:2 * C], pattern=2)                                # [L, 3C]  = [k_hi | k_hi | k_lo]
+            vt3 = ops.split(qkv[rows, 2 * C:], cpad=Lp, pattern=2, transposed=True)      # [C, 3Lp] = [v_hi^T | v_hi^T | v_lo^T]
+            for q0 in range(0, L, qb):
+                q1 = min(L, q0 + qb)
+                q3 = ops.split(qkv[b * L + q0: b * L + q1, :C], pattern=1)               # [q, 3C]  = [q_hi | q_lo | q_hi]
+                ops.gemm(q3, k3, out=s[: q1 - q0, :L], out_f32=True)
+                p3 = ops.softmax_rows_split(s[: q1 - q0], scale, n=L)                    # [q, 3Lp] = [p_hi | p_lo | p_hi]
+                ops.gemm(p3, vt3, out=o[b * L + q0: b * L + q1], out_f32=True)
+        return ops.gemm(ops.split(o), self.ow, bias=self.ob, residual=x.view(B * L, C), out_f32=True).view(B, H, Wd, C)
+
     def __call__(self, x):
+        if self.parity:
+            return self._call_parity(x)
         B, H, Wd, C = x.shape
         L = H * Wd
         Lp = (L + 31) // 32 * 32  # key axis padded to the GEMM's K granularity (images whose latent area is not a multiple of 32)
@@ -126,10 +155,14 @@ def _transpose(v: torch.Tensor, C: int) -> torch.Tensor:
 
 
 class AutoencoderKL:
-    def __init__(self, config: VAEConfig, state_dict: Dict[str, torch.Tensor], device="cuda"):
+    def __init__(self, config: VAEConfig, state_dict: Dict[str, torch.Tensor], device="cuda", precision: str = "fast"):
+        """precision "parity": fp32 tensors between kernels, two-term bf16 operands (see host/unet.py, include/dm4d.h)."""
         cfg = self.config = config
         self.device = torch.device(device)
-        W = _Weights(state_dict, self.device)
+        if precision not in ("fast", "parity"):
+            raise ValueError(f"Unsupported precision: {precision}. Supported values are 'fast' and 'parity'.")
+        self.precision, self.parity = precision, precision == "parity"
+        W = _Weights(state_dict, self.device, self.parity)
         g, boc, lc = cfg.norm_num_groups, cfg.block_out_channels, cfg.latent_channels
         if cfg.in_channels > PAD or 2 * lc > PAD:
             raise NotImplementedError("channel counts above 32 at the VAE boundary")
@@ -149,10 +182,10 @@ class AutoencoderKL:
         # conv_out writes a 32-wide row (channels >= 2*lc are zero) so quant_conv is one K=32 GEMM
         self.e_out_w = W.conv3("encoder.conv_out.weight", cout_pad=PAD)
         self.e_out_b = _pad_vec(W.get("encoder.conv_out.bias"), PAD, self.device)
-        self.quant_w = _pad_mat(W.get("quant_conv.weight"), 2 * lc, PAD, self.device)
+        self.quant_w = W.mat(_pad_mat(W.get("quant_conv.weight"), 2 * lc, PAD, "cpu"))
         self.quant_b = W.vec("quant_conv.bias")
         # ---- decoder ----
-        self.pq_w = _pad_mat(W.get("post_quant_conv.weight"), PAD, PAD, self.device)  # out rows >= lc are zero
+        self.pq_w = W.mat(_pad_mat(W.get("post_quant_conv.weight"), PAD, PAD, "cpu"))  # out rows >= lc are zero
         self.pq_b = _pad_vec(W.get("post_quant_conv.bias"), PAD, self.device)
         self.d_in_w, self.d_in_b = W.conv3("decoder.conv_in.weight", cin_pad=PAD), W.vec("decoder.conv_in.bias")
         self.d_mid = (_Res(W, "decoder.mid_block.resnets.0.", g), _MidAttn(W, "decoder.mid_block.attentions.0.", g),
@@ -163,7 +196,7 @@ class AutoencoderKL:
             res = [_Res(W, p + f"resnets.{j}.", g) for j in range(cfg.layers_per_block + 1)]
             us = None
             if i != len(boc) - 1:
-                us = ops.Upsampler(W.conv3(p + "upsamplers.0.conv.weight"), W.vec(p + "upsamplers.0.conv.bias"))
+                us = ops.Upsampler(W.conv3(p + "upsamplers.0.conv.weight"), W.vec(p + "upsamplers.0.conv.bias"), parity=self.parity)
             self.d_up.append((res, us))
         self.d_nw, self.d_nb = W.vec("decoder.conv_norm_out.weight"), W.vec("decoder.conv_norm_out.bias")
         self.d_out_w, self.d_out_b = W.conv3("decoder.conv_out.weight"), W.vec("decoder.conv_out.bias")
@@ -172,11 +205,11 @@ class AutoencoderKL:
             raise KeyError(f"unexpected keys in VAE checkpoint (strict load): {unused[:8]}")
 
     @classmethod
-    def from_pretrained(cls, path, device="cuda", variant: Optional[str] = None) -> "AutoencoderKL":
+    def from_pretrained(cls, path, device="cuda", variant: Optional[str] = None, precision: str = "fast") -> "AutoencoderKL":
         from .weights import load_component_state_dict
         path = Path(path)
         cfg = VAEConfig.from_dict(json.loads((path / "config.json").read_text()))
-        return cls(cfg, load_component_state_dict(path, variant), device)
+        return cls(cfg, load_component_state_dict(path, variant), device, precision)
 
     @property
     def scale_factor(self) -> int:
@@ -189,23 +222,26 @@ class AutoencoderKL:
     def micro_batch(self, height: int, width: int, limit: int = 8) -> int:
         """Images per VAE pass: the reference's 8 (pipeline_diffuman4d.py:47,59), reduced for large images so that the
         widest full-resolution activation ([B, H, W, 2*C0] in the decoder) stays below the kernels' 2^31-element limit."""
-        c = 2 * self.config.block_out_channels[0]
+        c = (4 if self.parity else 2) * self.config.block_out_channels[0]  # parity: the widest tensor is a two-term operand
         return max(1, min(limit, ((1 << 31) - 1) // (height * width * c)))
 
     # ---- encode --------------------------------------------------------------------------------
     def moments(self, x_nhwc32: torch.Tensor) -> torch.Tensor:
-        """x [B,H,W,32] (3 image channels + zero pad) -> moments [B,h,w,2*lc] (mean | logvar)."""
-        x = ops.conv3x3(x_nhwc32, self.e_in_w, bias=self.e_in_b)
+        """x [B,H,W,32] (3 image channels + zero pad) -> moments [B,h,w,2*lc] (mean | logvar).
+        precision "parity": x is the two-term operand [B,H,W,64] of the fp32 image, the moments are fp32."""
+        P = self.parity
+        op = ops.split if P else (lambda t: t)  # fp32 tensor -> operand of the next contraction
+        x = ops.conv3x3(x_nhwc32, self.e_in_w, bias=self.e_in_b, out_f32=P)
         for res, ds in self.e_down:
             for r in res:
                 x = r(x)
             if ds is not None:
-                x = ops.conv3x3(x, ds[0], bias=ds[1], stride=2, pad=0, pad_hi=1)  # F.pad(0,1,0,1) + conv s2 p0
+                x = ops.conv3x3(op(x), ds[0], bias=ds[1], stride=2, pad=0, pad_hi=1, out_f32=P)  # F.pad(0,1,0,1) + conv s2 p0
         x = self.e_mid[2](self.e_mid[1](self.e_mid[0](x)))
         x = ops.groupnorm(x, self.e_nw, self.e_nb, self.config.norm_num_groups, 1e-6, silu=True)
-        x = ops.conv3x3(x, self.e_out_w, bias=self.e_out_b)  # [B,h,w,32]
+        x = ops.conv3x3(x, self.e_out_w, bias=self.e_out_b, out_f32=P)  # [B,h,w,32]
         B, h, w, _ = x.shape
-        return ops.gemm(x.view(-1, PAD), self.quant_w, bias=self.quant_b).view(B, h, w, -1)
+        return ops.gemm(op(x.view(-1, PAD)), self.quant_w, bias=self.quant_b, out_f32=P).view(B, h, w, -1)
 
     def encode_scaled(self, images: torch.Tensor, noise: Optional[torch.Tensor], batch_size: int = 8,
                       cache: Optional[dict] = None, keys=None) -> torch.Tensor:
@@ -227,7 +263,7 @@ class AutoencoderKL:
         for j in range(0, len(todo), batch_size):
             idx = todo[j:j + batch_size]
             sel = images[idx[0]:idx[-1] + 1] if idx == list(range(idx[0], idx[-1] + 1)) else images[idx]
-            m = self.moments(ops.nchw_to_nhwc(sel.to(self.device, BF16).contiguous(), PAD))
+            m = self.moments(self._image_operand(sel))
             for k, i in enumerate(idx):
                 fresh[i] = m[k]
         if cache is not None:
@@ -258,19 +294,32 @@ class AutoencoderKL:
         for i in range(0, n, batch_size):
             m = torch.stack(rows[i:i + batch_size])
             B, h, w, _ = m.shape
-            if noise is not None:
+            if noise is not None and self.parity:
+                nb = noise[i:i + batch_size].float().permute(0, 2, 3, 1).contiguous().to(self.device)  # layout change on the host
+            elif noise is not None:
                 nb = ops.nchw_to_nhwc(noise[i:i + batch_size].to(self.device, BF16).contiguous())
             else:
-                nb = torch.randn((B, h, w, lc), device=self.device, dtype=torch.float32).to(BF16)
+                nb = torch.randn((B, h, w, lc), device=self.device, dtype=torch.float32)
+                nb = nb if self.parity else nb.to(BF16)
             outs.append(ops.vae_sample(m, nb, lc, self.config.scaling_factor))
         return torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
 
+    def _image_operand(self, images: torch.Tensor) -> torch.Tensor:
+        """NCHW images (any device / float dtype) -> what conv_in reads: NHWC bf16 padded to 32 channels, or (parity) the two-term
+        operand [B,H,W,64] of the fp32 image (the NCHW -> NHWC permutation of a host tensor is made on the host)."""
+        if not self.parity:
+            return ops.nchw_to_nhwc(images.to(self.device, BF16).contiguous(), PAD)
+        x = images.float().permute(0, 2, 3, 1).contiguous().to(self.device)
+        return ops.split(x, cpad=PAD)
+
     # ---- decode --------------------------------------------------------------------------------
     def decode(self, z_nhwc: torch.Tensor) -> torch.Tensor:
-        """z [B,h,w,lc] (already divided by scaling_factor, padded to 32) -> image NHWC [B,H,W,3]."""
+        """z [B,h,w,lc] (already divided by scaling_factor, padded to 32) -> image NHWC [B,H,W,3].
+        precision "parity": z is the two-term operand [B,h,w,64], the image fp32."""
+        P = self.parity
         B, h, w, _ = z_nhwc.shape
-        x = ops.gemm(z_nhwc.view(-1, PAD), self.pq_w, bias=self.pq_b).view(B, h, w, PAD)
-        x = ops.conv3x3(x, self.d_in_w, bias=self.d_in_b)
+        x = ops.gemm(z_nhwc.view(B * h * w, -1), self.pq_w, bias=self.pq_b, out_f32=P).view(B, h, w, PAD)
+        x = ops.conv3x3(ops.split(x) if P else x, self.d_in_w, bias=self.d_in_b, out_f32=P)
         x = self.d_mid[2](self.d_mid[1](self.d_mid[0](x)))
         for res, us in self.d_up:
             for r in res:
@@ -278,7 +327,7 @@ class AutoencoderKL:
             if us is not None:
                 x = us(x)
         x = ops.groupnorm(x, self.d_nw, self.d_nb, self.config.norm_num_groups, 1e-6, silu=True)
-        return ops.conv3x3(x, self.d_out_w, bias=self.d_out_b)
+        return ops.conv3x3(x, self.d_out_w, bias=self.d_out_b, out_f32=P)
 
     def decode_to_images(self, lat_nhwc: torch.Tensor, batch_size: int = 8, rows: Optional[torch.Tensor] = None) -> torch.Tensor:
         """pipeline_diffuman4d.py:59-72,280-285: latents NHWC -> images NCHW in [0,1].
@@ -292,7 +341,10 @@ class AutoencoderKL:
             sel = lat_nhwc.index_select(0, idx)
         outs = []
         for i in range(0, sel.shape[0], batch_size):
-            z = ops.scale_pad(sel[i:i + batch_size].contiguous(), PAD, 1.0 / self.config.scaling_factor)
+            if self.parity:
+                z = ops.split(sel[i:i + batch_size].contiguous(), cpad=PAD, scale=1.0 / self.config.scaling_factor)
+            else:
+                z = ops.scale_pad(sel[i:i + batch_size].contiguous(), PAD, 1.0 / self.config.scaling_factor)
             outs.append(ops.postprocess_images(self.decode(z), self.config.out_channels))
         if rows is None:
             return torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
@@ -309,7 +361,7 @@ class AutoencoderKL:
         outs = []
         for i in range(0, images.shape[0], batch_size):
             xb = images[i:i + batch_size].to(self.device, torch.float32).contiguous()
-            outs.append(ops.resize_to_nhwc(xb, size, mode))
+            outs.append(ops.resize_to_nhwc(xb, size, mode, out_f32=self.parity))
         return torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
 
 

@@ -32,7 +32,10 @@ extern "C" {
 /* gemm / conv epilogue flags */
 #define DM4D_EPI_GEGLU 1u /* W holds [2*N, K]: out = (x W_h^T + b_h) * gelu(x W_g^T + b_g)   */
 #define DM4D_EPI_SILU 2u  /* out = silu(acc + bias ...) (time embedding MLP)                 */
-#define DM4D_EPI_F32OUT 4u /* dm4d_gemm_bf16 only: C is float* [M, ldc] (ldc in floats): the result is stored unrounded */
+#define DM4D_EPI_F32OUT 4u /* C is float* [M, ldc] (ldc in floats): the result is stored unrounded */
+/* parity-precision launches (two-term bf16 operands, fp32 tensors between kernels; see "Parity precision" below) */
+#define DM4D_EPI_F32SIDE 8u   /* rowbias and residual are float* (their strides in floats) */
+#define DM4D_EPI_SPLITOUT 16u /* C is bf16 [M, ldc >= 2 N]: hi = bf16(result) at column n, lo = bf16(result - hi) at column N + n */
 
 int dm4d_version(void);
 const char* dm4d_last_error(void);
@@ -73,6 +76,13 @@ int dm4d_conv3x3_nhwc_bf16_ws(void* stream, const void* X, int B, int H, int W, 
                               int Wo, int Cout, int stride, int pad, int upsample, const void* bias, const void* rowbias,
                               int64_t ld_rowbias, const void* residual, int64_t ld_res, float out_scale, void* ws,
                               size_t ws_bytes);
+
+/* The same convolution with epilogue flags (DM4D_EPI_F32OUT: Y is float* [B,Ho,Wo,Cout]; DM4D_EPI_F32SIDE: rowbias / residual are
+ *   float*): the parity-precision form.  X then usually carries two-term operands, [hi(Cin/2) | lo(Cin/2)] per pixel, against weights
+ *   duplicated along Cin; the kernel neither knows nor cares.  Never split over the kernel rows (no workspace).             */
+int dm4d_conv3x3_nhwc_bf16_flags(void* stream, const void* X, int B, int H, int W, int Cin, const void* Wt, void* Y, int Ho,
+                                 int Wo, int Cout, int stride, int pad, int upsample, const void* bias, const void* rowbias,
+                                 int64_t ld_rowbias, const void* residual, int64_t ld_res, float out_scale, unsigned flags);
 
 /* Upsample2D -- third-party: diffusers==0.33.1 (requirements.txt:5), instantiated by the reference at
  * src/diffusers/models/unets/unet_multiview_blocks.py:620 and by the VAE decoder; its published forward is
@@ -128,17 +138,6 @@ int dm4d_attention_kv_bf16(void* stream, const void* Q, const void* K, const voi
 #define DM4D_LOG2E 1.4426950408889634
 int dm4d_attention_qscaled_kv_bf16(void* stream, const void* Q, const void* K, const void* V, void* O, int64_t ldq,
                                    int64_t ldk, int64_t ldv, int64_t ldo, int batch, int heads, int Lq, int Lk);
-
-/* OPT-IN extension (BASELINE.json configs[4], "fp8 MFMA attention"; the reference has no fp8 path): the same
- * attention with Q, K, V and the probabilities in OCP fp8 e4m3 on v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulation and
- * softmax statistics, bf16 output.  Q, K, V are bf16 (same arguments as dm4d_attention_kv_bf16; q_scaled != 0: Q already
- * carries scale * log2(e)); they are converted into `ws` (dm4d_attention_fp8_ws_bytes) by two pack kernels which clamp
- * to +-448 and add the number of clamped elements to *saturated (device int, may be NULL) -- the probabilities cannot
- * saturate by construction (lazy rescaling keeps them <= 2^8).  Tolerance: its own, see tests/opcheck.py attn_fp8_*.    */
-size_t dm4d_attention_fp8_ws_bytes(int batch, int heads, int Lq, int Lk);
-int dm4d_attention_fp8_kv_bf16(void* stream, const void* Q, const void* K, const void* V, void* O, int64_t ldq, int64_t ldk,
-                               int64_t ldv, int64_t ldo, int batch, int heads, int Lq, int Lk, float scale, int q_scaled,
-                               void* ws, size_t ws_bytes, int* saturated);
 
 /* Generic-head-dim attention pieces for the VAE mid block (AutoencoderKL mid_block.attentions.0: single head, d = 512,
  *   reached from pipeline_diffuman4d.py:52,65): P = softmax(S * scale) per row, P in bf16.  The f32in form takes the
@@ -232,6 +231,60 @@ int dm4d_attn_out_ff_geglu_fused_bf16(void* stream, const void* A0, int64_t lda0
                                       int64_t ldx, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* W1p,
                                       const void* b1p, const void* W2p, const void* b2, void* Out, int64_t ldo, int M, int C,
                                       int hidden);
+
+/* ---- Parity precision -------------------------------------------------------------------------------------------------------
+ * north_star (BASELINE.json) asks for decoded RGB within 1e-3 rel-L2 of the reference's fp32 CPU path
+ * (pipeline_diffuman4d.py:439-559 run with fp32 modules).  bf16 MFMA operands alone cost 7e-3 on the judged UNet call, so the
+ * pipeline has a second arithmetic, selected per model object (host: precision="parity"): tensors BETWEEN kernels are fp32 and every
+ * activation that feeds the matrix unit is a TWO-TERM bf16 OPERAND  [hi(C) | lo(C)],  hi = bf16(x), lo = bf16(x - hi)  (16 mantissa
+ * bits), multiplied against the checkpoint's bf16 weights duplicated along K:  x W^T = [hi | lo] [W | W]^T  -- the same GEMM /
+ * convolution kernels with DM4D_EPI_F32OUT / F32SIDE / SPLITOUT.  The entries below produce and consume those operands.        */
+
+/* fp32 -> operand.  Y[m, :] = planes of act(X[m, :]) * scale over Cp >= C1 + C2 columns (columns behind C1 + C2 are zero):
+ *   pattern 0: [hi | lo] (ldy >= 2 Cp)   1: [hi | lo | hi]   2: [hi | hi | lo] (ldy >= 3 Cp; the three-term product of two
+ *   activations, A in pattern 1 against B in pattern 2 = hi hi + lo hi + hi lo: VAE mid-block attention).
+ *   X1 element (m, c) at X1[m * row_stride1 + c * col_stride1] (a transposed read when col_stride1 != 1); X2 (optional second
+ *   source = channel concat of the up-block skip, unet_multiview_blocks.py:667) at X2[m * row_stride2 + c].  act_silu: SiLU first. */
+int dm4d_split_f32(void* stream, const float* X1, int64_t row_stride1, int64_t col_stride1, int C1, const float* X2,
+                   int64_t row_stride2, int C2, void* Y, int64_t ldy, int64_t M, int Cp, int act_silu, float scale, int pattern);
+
+/* GroupNorm (+SiLU) as dm4d_groupnorm_nhwc_bf16, fp32 NHWC in (X2 optional), operand out: Y [B*HW, 2 (C1 + C2)].
+ *   Statistics are summed in fp64; ws: dm4d_groupnorm_f32_ws_bytes(B, HW, groups) bytes.                                          */
+size_t dm4d_groupnorm_f32_ws_bytes(int B, int HW, int groups);
+int dm4d_groupnorm_nhwc_f32_split(void* stream, const float* X1, int C1, const float* X2, int C2, int B, int HW, int groups,
+                                  float eps, const void* gamma, const void* beta, void* Y, int apply_silu, void* ws);
+
+/* LayerNorm as dm4d_layernorm_bf16, fp32 in, operand out: Y [M, ldy >= 2 C].                                                      */
+int dm4d_layernorm_f32_split(void* stream, const float* X, int64_t ldx, const void* gamma, const void* beta, void* Y, int64_t ldy,
+                             int M, int C, float eps);
+
+/* P = softmax(S * scale) per row of fp32 logits -> three planes [p_hi | p_lo | p_hi], each Np >= N columns wide (columns N .. Np-1
+ *   zero: a key axis padded to the GEMM's K granularity), ldp >= 3 Np.                                                           */
+int dm4d_softmax_rows_f32_split(void* stream, const float* S, int64_t lds, void* P, int64_t ldp, int M, int N, int Np, float scale);
+
+/* dm4d_attention_kv_bf16 on two-term Q / K / V: the hi plane at the pointer, the lo plane `*_lo` ELEMENTS behind it (the planes
+ *   dm4d_gemm_bf16(DM4D_EPI_SPLITOUT) leaves for a fused QKV projection).  S = Kh Qh + Kh Ql + Kl Qh, fp32 running-max softmax,
+ *   O = Vh Ph + Vl Ph + Vh Pl; O is written as an operand (hi plane at O, lo plane o_lo elements behind it).  head_dim 64.          */
+int dm4d_attention_split_bf16(void* stream, const void* Q, const void* K, const void* V, void* O, int64_t ldq, int64_t ldk,
+                              int64_t ldv, int64_t ldo, int64_t q_lo, int64_t k_lo, int64_t v_lo, int64_t o_lo, int batch,
+                              int heads, int Lq, int Lk, float scale);
+
+/* fp32-tensor forms of the small kernels around the UNet / VAE calls (same arithmetic, no rounding on the way out):
+ *   dm4d_pack_model_input_f32_split writes the operand of conv_in, rows [hi(cpad) | lo(cpad)].                                    */
+int dm4d_timestep_embedding_f32(void* stream, const float* t, float* out, int B, int dim, int flip_sin_to_cos, float freq_shift);
+int dm4d_pack_model_input_f32_split(void* stream, float* latents, const float* pv_lat, const float* plucker, const float* skel,
+                                    const float* mask, const int32_t* is_cond, const int32_t* frame_idx, void* out, int F, int HW,
+                                    int cpad, int use_cfg);
+int dm4d_cfg_ddim_step_f32(void* stream, float* latents, const float* noise_pred, int64_t ldn, const float* coef,
+                           const int32_t* is_cond, const int32_t* frame_idx, int F, int HW, int use_cfg, float guidance_scale,
+                           int v_prediction);
+int dm4d_cfg_linear_step_f32(void* stream, float* latents, float* x0_prev, const float* noise_pred, int64_t ldn, const float* coef,
+                             const int32_t* is_cond, const int32_t* frame_idx, int F, int HW, int use_cfg, float guidance_scale);
+int dm4d_vae_sample_f32(void* stream, const float* moments, int64_t ldm, const float* noise, float* out, int64_t M, int C, float scale);
+int dm4d_resize_nchw_f32_to_nhwc_f32(void* stream, const float* X, float* Y, int B, int C, int H, int W, int h, int w, int bilinear);
+int dm4d_plucker_latent_f32(void* stream, const float* cams, float* Y, int N, int H, int W, int h, int w);
+int dm4d_postprocess_images_f32(void* stream, const float* X, float* Y, int B, int C, int HW, int ldx);
+int dm4d_nhwc_to_nchw_f32(void* stream, const float* X, float* Y, int B, int C, int HW, int ldx);
 
 /* Tuning hook (not part of the operator surface): force one GEMM/conv kernel configuration id for all
  * subsequent launches of this process; 0 restores the built-in heuristic.  Used by tools/gemm_tune.py. */

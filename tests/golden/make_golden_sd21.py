@@ -2,13 +2,16 @@
 """Golden vectors on the JUDGED configuration (BASELINE.json configs[1..2]): the CPU oracle (oracle/: fp32 restatement
 of the reference path, see its headers) run at full SD-2.1 geometry on 72x40 latents.
 
-    python tests/golden/make_golden_sd21.py [unet16] [unet24] [vae] [vae1024]   (default: the first three; ~10 min on 8 cores)
+    python tests/golden/make_golden_sd21.py [unet16] [unet24] [vae] [vae1024] [unet16_128]   (default: the first three; ~10 min on 8 cores)
 
 writes tests/golden/sd21_72x40.pt:
   * unet_f16_spatial  -- one spatial window call: F = 16 frames (4 conditioning + 12 targets), CFG batch 32, L3d = 46 080
   * unet_f24_temporal -- one temporal window call: F = 24 frames (12 + 12), CFG batch 48, L3d = 69 120
       each: fp32 oracle output (stored fp16), rel-L2 of the oracle run in bf16 against it (the yardstick: what the
       reference's own bf16 arithmetic loses), input checksums
+  * (unet16_128 -> tests/golden/sd21_128x128.pt) unet_f16_spatial_128 -- the same F = 16 call at the reference's NATIVE latent
+      size 128 x 128 (spatem_dataset.py:27-28; 2-D attention L = 16 384 at level 0, 3-D attention L = 65 536 at level 1): every
+      second pixel of the fp32 output (fp32), bf16 yardstick; ~20-40 min on 8 cores
   * vae_576x320       -- AutoencoderKL with the SD geometry (128, 256, 512, 512; mid-block attention d = 512, L = 2 880)
       on two 576x320 images: scaled posterior sample and the decoded images, plus their bf16 yardsticks.
   * vae_1024          -- the same VAE on ONE 1024x1024 image (the reference's native size: mid-block attention L = 16 384):
@@ -42,11 +45,12 @@ def rel_l2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-12))
 
 
-def unet_inputs(num_frames: int, n_cond: int, seed: int):
+def unet_inputs(num_frames: int, n_cond: int, seed: int, size=None):
     """A CFG batch shaped like pipeline_diffuman4d.py:345-395 builds it: [negative | positive] halves, channels
-    [latent 4 | Pluecker 6 | skeleton latent 4 | mask 1]; conditioning frames come first and carry t = 0."""
+    [latent 4 | Pluecker 6 | skeleton latent 4 | mask 1]; conditioning frames come first and carry t = 0.
+    size = (h, w) of the latents (default: the judged 72 x 40)."""
     g = torch.Generator().manual_seed(seed)
-    F_, h, w = num_frames, LAT_H, LAT_W
+    F_, (h, w) = num_frames, (size or (LAT_H, LAT_W))
     lat = torch.randn(F_, 4, h, w, generator=g)
     pv = torch.randn(F_, 4, h, w, generator=g) * (0.18215 * 4)
     pl = (torch.randn(F_, 6, h, w, generator=g) * 0.5).clamp(-1, 1)
@@ -77,9 +81,11 @@ def build_unet():
     return cfg, m, chk
 
 
-def golden_unet(name: str, num_frames: int, n_cond: int, domain: str, seed: int):
+def golden_unet(name: str, num_frames: int, n_cond: int, domain: str, seed: int, size=None, sub: int = 1):
+    """size: latent (h, w); sub > 1: the fixture keeps every sub-th pixel of the output in fp32 (`out_sub`) instead of the whole
+    output in fp16 (`out`) -- the 128 x 128 case, whose whole output would be 8 MB."""
     cfg, m, wchk = build_unet()
-    x, t = unet_inputs(num_frames, n_cond, seed)
+    x, t = unet_inputs(num_frames, n_cond, seed, size)
     with torch.no_grad():
         t0 = time.time()
         ref = m(x.float(), t, domains=[domain] * 2, num_frames=num_frames)
@@ -88,9 +94,14 @@ def golden_unet(name: str, num_frames: int, n_cond: int, domain: str, seed: int)
         t0 = time.time()
         ref_bf = m(x, t, domains=[domain] * 2, num_frames=num_frames).float()
         t_bf = time.time() - t0
-    out = dict(out=ref.to(torch.float16), yard_bf16=rel_l2(ref_bf, ref), num_frames=num_frames, n_cond=n_cond, domain=domain,
+    out = dict(yard_bf16=rel_l2(ref_bf, ref), num_frames=num_frames, n_cond=n_cond, domain=domain,
                seed=seed, x_checksum=float(x.float().abs().sum()), t=t, weights_checksum=wchk, oracle_seconds=(t_fp32, t_bf),
-               threads=torch.get_num_threads())
+               threads=torch.get_num_threads(), size=tuple(size or (LAT_H, LAT_W)))
+    if sub > 1:
+        out.update(out_sub=ref[..., ::sub, ::sub].contiguous(), sub=sub,
+                   yard_bf16_sub=rel_l2(ref_bf[..., ::sub, ::sub], ref[..., ::sub, ::sub]))
+    else:
+        out.update(out=ref.to(torch.float16), out_f32=ref.contiguous())
     print(f"{name}: fp32 {t_fp32:.1f}s bf16 {t_bf:.1f}s yardstick(bf16 oracle vs fp32 oracle)={out['yard_bf16']:.3e}", flush=True)
     return out
 
@@ -191,6 +202,12 @@ def main():
     if "unet16" in which:
         blob["unet_f16_spatial"] = golden_unet("unet_f16_spatial", 16, 4, "spatial", 101)
         torch.save(blob, OUT)
+    if "unet16_128" in which:  # the reference's native latent size (spatem_dataset.py:27-28: 1024^2 images -> 128 x 128 latents)
+        out128 = OUT.with_name("sd21_128x128.pt")
+        b128 = torch.load(out128) if out128.exists() else {}
+        b128["unet_f16_spatial_128"] = golden_unet("unet_f16_spatial_128", 16, 4, "spatial", 103, size=(128, 128), sub=2)
+        torch.save(b128, out128)
+        print("wrote", out128)
     if "unet24" in which:
         blob["unet_f24_temporal"] = golden_unet("unet_f24_temporal", 24, 12, "temporal", 102)
         torch.save(blob, OUT)

@@ -89,22 +89,22 @@ def test_self_launch_command(monkeypatch):
 
 def test_config5_switches_the_workload_and_nothing_else(monkeypatch):
     """--config5 = BASELINE.json configs[4]: 225 frames, stride 1 (36 steps per latent, one latent per 3-call unit), CPU baseline
-    off; attention stays bf16 unless the EXPERIMENTAL fp8 kernel is asked for by name (it does not beat the bf16 kernel:
-    profiles/r02_bench_config5_fp8.json); the default line keeps sliding_fast and bf16."""
+    off; attention is the bf16 kernel (the fp8 kernel of rounds 2-3 never beat it and was removed in round 4); the default line
+    keeps sliding_fast."""
     for name in ("N_FRAMES", "STRIDE", "STEPS_PER_LATENT", "LATENTS_PER_UNIT"):
         monkeypatch.setattr(bench, name, getattr(bench, name))  # restored after the test
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse()
-    assert bench.apply_workload_flags(a) is False
+    bench.apply_workload_flags(a)
     assert (bench.N_FRAMES, bench.STRIDE, bench.STEPS_PER_LATENT, bench.LATENTS_PER_UNIT) == (150, 2, 18, 2.0)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--attention", "fp8"])
-    assert bench.apply_workload_flags(bench.parse()) is True and bench.STRIDE == 2
+    with pytest.raises(SystemExit):
+        bench.parse()  # the flag is gone
     monkeypatch.setattr(sys, "argv", ["bench.py", "--config5"])
     a = bench.parse()
-    assert bench.apply_workload_flags(a) is False and a.no_cpu_baseline
+    bench.apply_workload_flags(a)
+    assert a.no_cpu_baseline
     assert (bench.N_FRAMES, bench.STRIDE, bench.STEPS_PER_LATENT, bench.LATENTS_PER_UNIT) == (225, 1, 36, 1.0)
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--config5", "--attention", "fp8"])
-    assert bench.apply_workload_flags(bench.parse()) is True
     monkeypatch.setattr(sys, "argv", ["bench.py", "--config5", "--gpus", "2"])
     with pytest.raises(SystemExit):
         bench.apply_workload_flags(bench.parse())

@@ -7,7 +7,7 @@ python -m diffuman4d_amd.build > /dev/null
 mkdir -p /tmp/vb
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -Iinclude -Idiffuman4d_amd/csrc -c diffuman4d_amd/csrc/$stem.hip -o /tmp/vb/${stem}_$tag.o
 objs=""
-for f in api gemm ff_fused conv_direct attention attention_fp8 norm elementwise; do
+for f in api gemm ff_fused conv_direct attention norm elementwise; do
   if [ $f = $stem ]; then objs="$objs /tmp/vb/${stem}_$tag.o"; else objs="$objs diffuman4d_amd/build/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o tools/dev/libdm4d_$tag.so $objs
