@@ -252,6 +252,10 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs&
     } else {
       rows_layernorm<CK>(smem + Y_OFF, ln, wave, lane);
     }
+    // PROJ: rows_layernorm<RAW> has just stored h to Out with plain global stores, and the epilogue re-reads those rows as the
+    // residual (p.res == Out) from OTHER waves of this workgroup.  The stores are drained here (vmcnt(0) covers stores on gfx9-class
+    // parts) before the barrier, so that the dependency does not rest on a later interval's wait happening to come first.
+    if constexpr (PROJ) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");

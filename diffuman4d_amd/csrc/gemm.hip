@@ -45,7 +45,7 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // main path: K-slab 64, direct-to-LDS DMA, source-swizzled lane-linear LDS image
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool CONV>
+template <int BM, int BN, int WM, int WN, bool CONV, bool PAR = false>
 __global__ __launch_bounds__(256) void gemm_kernel_glds(GemmParams p) {
   constexpr int BK = 64;
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void gemm_kernel_glds(GemmParams p) {
     }
     __syncthreads();  // all waves done with `buf`; the DMA into buf^1 has landed (vmcnt(0) before the barrier)
   }
-  gemm_epilogue<MI, NI, TM, TN, EpiBudget<WM * WN, MI, NI, SMEM_BYTES>::STRAIGHT>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
+  gemm_epilogue<MI, NI, TM, TN, EpiBudget<WM * WN, MI, NI, SMEM_BYTES>::STRAIGHT, PAR>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -249,7 +249,7 @@ __device__ __forceinline__ void sched_mfma_reload() {
 // input whose weights are sums of the 3x3 taps that land on the same pixel (dm4d_conv_up2x_prepare_bf16) -- 4 / 9 of the
 // multiply-adds of the fused gather the first round shipped.  Same strip machinery: tap (dy, dx) of phase (py, px) reads
 // pixel (y + dy - 1 + py, x + dx - 1 + px); the grid carries the phase in its slowest dimension.
-template <int BM, int BN, int WM, int WN, int KT = 3>
+template <int BM, int BN, int WM, int WN, int KT = 3, bool PAR = false>
 __global__ __launch_bounds__(WM* WN * 64, (BN % 64 != 0 ? 2 : 1)) void conv_strip2_kernel(GemmParams p_in) {
   static_assert(KT == 2 || KT == 3, "3x3 taps, or the 2x2 taps of one upsampling phase");
   constexpr int BK = 64, ROWB = BK * 2;  // bytes per LDS row
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(WM* WN * 64, (BN % 64 != 0 ? 2 : 1)) void conv_stri
     p.bias = p.rowbias = p.res = nullptr;
     p.out_scale = 1.0f;
   }
-  gemm_epilogue<MI, NI, TM, TN, EpiBudget<WM * WN, MI, NI, SMEM_BYTES>::STRAIGHT>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
+  gemm_epilogue<MI, NI, TM, TN, EpiBudget<WM * WN, MI, NI, SMEM_BYTES>::STRAIGHT, PAR>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -851,7 +851,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_lin2_kernel(GemmParams p) {
 // ------------------------------------------------------------------------------------------------
 // fallback: K-slab 32, register staged, padded LDS rows (80 B stride => conflict-free fragment reads)
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool CONV>
+template <int BM, int BN, int WM, int WN, bool CONV, bool PAR = false>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   constexpr int LDK = 40;
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
@@ -966,19 +966,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     if (kt + 1 < nk) store_slab(buf ^ 1);
     __syncthreads();
   }
-  gemm_epilogue<MI, NI, TM, TN, EpiBudget<WM * WN, MI, NI, SMEM_BYTES>::STRAIGHT>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
+  gemm_epilogue<MI, NI, TM, TN, EpiBudget<WM * WN, MI, NI, SMEM_BYTES>::STRAIGHT, PAR>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
 }
 
-template <int BM, int BN, int WM, int WN, bool CONV, bool GLDS>
+template <int BM, int BN, int WM, int WN, bool CONV, bool GLDS, bool PAR = false>
 int launch_cfg(hipStream_t st, GemmParams& p) {
   const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
   const int bn_out = geglu ? BN / 2 : BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + bn_out - 1) / bn_out;
   if constexpr (GLDS) {
-    hipLaunchKernelGGL((gemm_kernel_glds<BM, BN, WM, WN, CONV>), dim3(tiles_m * p.tiles_n), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((gemm_kernel_glds<BM, BN, WM, WN, CONV, PAR>), dim3(tiles_m * p.tiles_n), dim3(256), 0, st, p);
   } else {
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, CONV>), dim3(tiles_m * p.tiles_n), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, CONV, PAR>), dim3(tiles_m * p.tiles_n), dim3(256), 0, st, p);
   }
   return dm4d_check_launch("gemm_kernel");
 }
@@ -1063,14 +1063,14 @@ __host__ inline bool strip2_ok(const GemmParams& p) {
   return (uint64_t)p.M * (uint64_t)p.Cin * 2u < (1ull << 32) && (uint64_t)p.N * (uint64_t)p.ldw * 2u < (1ull << 32);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool PAR = false>
 int launch_strip2(hipStream_t st, GemmParams& p) {
   if (!strip2_ok(p)) return DM4D_ERR_ARG;  // 4 GiB or more of input or weights: the gather kernels take such a launch
   if (BN % 64 != 0 && p.splits > 1) return DM4D_ERR_ARG;
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   if (p.splits < 1) p.splits = 1;
-  hipLaunchKernelGGL((conv_strip2_kernel<BM, BN, WM, WN>), dim3(tiles_m * p.tiles_n * p.splits), dim3(WM * WN * 64), 0, st, p);
+  hipLaunchKernelGGL((conv_strip2_kernel<BM, BN, WM, WN, 3, PAR>), dim3(tiles_m * p.tiles_n * p.splits), dim3(WM * WN * 64), 0, st, p);
   int rc = dm4d_check_launch("conv_strip2_kernel");
   if (rc || p.splits == 1) return rc;
   const int64_t nthreads = (int64_t)p.M * (p.N / 8);
@@ -1278,9 +1278,39 @@ int choose_cfg(const GemmParams& p) {
   return tm256 * ((p.N + 63) / 64) >= 384 ? 2 : 3;
 }
 
+// Parity-precision launches (DM4D_EPI_F32SIDE / DM4D_EPI_SPLITOUT: fp32 side inputs, two-term output) run on their own
+// instantiations of a few tile geometries (PAR = true), chosen by the tail of the heuristic above; every kernel of this file walks
+// K in the same order, so the choice never changes a result.  The fast kernels do not carry that epilogue code.
+template <bool CONV>
+int launch_par(hipStream_t st, GemmParams& p) {
+  const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
+  const bool k64 = CONV ? (p.Cin % 64 == 0) : (p.K % 64 == 0 && (!p.A2 || p.K1 % 64 == 0));
+  const bool n128 = geglu || (p.N % 128 == 0) || (p.N > 1024);
+  const long tm128 = (p.M + 127) / 128, tm256 = (p.M + 255) / 256, tn = (p.N + (geglu ? 63 : 127)) / (geglu ? 64 : 128);
+  if constexpr (CONV) {
+    if (k64 && p.stride == 1 && p.pad == 1 && !p.upsample && p.Ho == p.H && p.Wo == p.W && strip2_ok(p)) {
+      if (!n128) return launch_strip2<128, 64, 4, 1, true>(st, p);
+      if (tm256 * tn >= 200) return launch_strip2<256, 128, 4, 2, true>(st, p);
+      return launch_strip2<128, 128, 2, 2, true>(st, p);
+    }
+    if (!k64) return dm4d_set_error(DM4D_ERR_ARG, "conv3x3: parity-precision launches need Cin % 64 == 0 (a two-term operand of Cin / 2 channels)");
+  } else {
+    if (!k64) {  // K-slab 32, register staged (P V of the VAE mid block: K = 3 Lp with Lp a multiple of 32)
+      if (n128) return launch_cfg<128, 128, 2, 2, false, false, true>(st, p);
+      return launch_cfg<128, 64, 4, 1, false, false, true>(st, p);
+    }
+  }
+  if (n128) {
+    if (tm128 * tn >= 256 || geglu) return launch_cfg<128, 128, 2, 2, CONV, true, true>(st, p);
+    return tm128 * tn >= 200 ? launch_cfg<128, 64, 4, 1, CONV, true, true>(st, p) : launch_cfg<64, 64, 2, 2, CONV, true, true>(st, p);
+  }
+  return launch_cfg<128, 64, 4, 1, CONV, true, true>(st, p);
+}
+
 template <bool CONV>
 int launch(hipStream_t st, GemmParams& p) {
   p.splits = 1;
+  if (p.flags & (DM4D_EPI_F32SIDE | DM4D_EPI_SPLITOUT)) return launch_par<CONV>(st, p);
   if (g_tune_cfg) {
     int rc = launch_by_id<CONV>(g_tune_cfg, st, p);
     if (rc == DM4D_ERR_ARG) return dm4d_set_error(DM4D_ERR_ARG, "gemm: forced configuration does not support this shape");

@@ -148,7 +148,7 @@ __device__ __forceinline__ void acc_init(const GemmParams& p, f32x16_t (&acc)[MI
 // (runtime row stride).  Ablation (profiles/r02_gemm_ablation.log): the epilogue was 39 % of the K = 320 Linear layers'
 // time, the stores only 8 %.  With MODE a template parameter the staging stride, the chunk geometry and the trip counts
 // are constants: the staging stores take immediate offsets and the read-back loop unrolls.
-template <int MI, int NI, int TM, int TN, int MODE, int EPW, int J0, int JN, bool SYNC, bool STRAIGHT>
+template <int MI, int NI, int TM, int TN, int MODE, int EPW, int J0, int JN, bool SYNC, bool STRAIGHT, bool PAR = false>
 __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t (&acc)[MI][NI], float* smem_f, int m0, int n0,
                                                    int wm, int wn, int wave, int lane) {
   // This instance handles output blocks [J0, J0 + JN) of the wave's NJ 32-column blocks (a "column group"): wide per-wave
@@ -172,10 +172,12 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t
   constexpr bool CPR_POW2 = (CPR & (CPR - 1)) == 0;
   constexpr int cshift = CPR >= 16 ? 4 : (CPR >= 8 ? 3 : (CPR >= 4 ? 2 : (CPR >= 2 ? 1 : 0)));
   constexpr int cmask = CPR - 1;
-  // parity-precision launches (host/ops.py precision "parity"): fp32 row bias / residual, result split into two bf16 terms
-  const bool f32side = (p.flags & DM4D_EPI_F32SIDE) != 0, splitout = (p.flags & DM4D_EPI_SPLITOUT) != 0;
+  // PAR instantiations (parity-precision launches, host/ops.py precision "parity") also take fp32 row bias / residual
+  // (DM4D_EPI_F32SIDE) and split the result into two bf16 terms (DM4D_EPI_SPLITOUT).  They are separate kernels: the code below
+  // would otherwise raise the register count of every fast kernel (the 74 KB two-workgroups-per-CU tiles live on 128 registers).
+  const bool f32side = PAR && (p.flags & DM4D_EPI_F32SIDE) != 0, splitout = PAR && (p.flags & DM4D_EPI_SPLITOUT) != 0;
   const bool fast_ok = CPR_POW2 && vec_ok && p.ldc < (1 << 24) && (!p.res || p.ld_res < (1 << 24)) &&
-                       (!p.rowbias || p.rows_per_rb > 0) && !f32out && !f32side && !splitout && p.up_w == 0;
+                       (!p.rowbias || p.rows_per_rb > 0) && !f32out && !(PAR && (f32side || splitout)) && p.up_w == 0;
   // nothing is applied after the staging: round to bf16 first, stage packed halfwords, copy rows out
   const bool plain = fast_ok && !p.res && !p.rowbias && p.out_scale == 1.0f;
   // The staging area is private to a wave and LDS operations of one wave complete in program order, so only one
@@ -354,71 +356,106 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t
       f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(s + 4);
       v[0] = s0[0]; v[1] = s0[1]; v[2] = s0[2]; v[3] = s0[3];
       v[4] = s1[0]; v[5] = s1[1]; v[6] = s1[2]; v[7] = s1[3];
-      if (vec_ok) {
-        if (p.rowbias) {
-          float t[8];
-          if (f32side) {
-            const float* rb = reinterpret_cast<const float*>(p.rowbias) + (int64_t)(m / p.rows_per_rb) * p.ld_rb + n;
-            const f32x4_t t0 = *reinterpret_cast<const f32x4_t*>(rb), t1 = *reinterpret_cast<const f32x4_t*>(rb + 4);
-            t[0] = t0[0]; t[1] = t0[1]; t[2] = t0[2]; t[3] = t0[3];
-            t[4] = t1[0]; t[5] = t1[1]; t[6] = t1[2]; t[7] = t1[3];
-          } else {
-            unpack8(ldg16(p.rowbias + (int64_t)(m / p.rows_per_rb) * p.ld_rb + n), t);
-          }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += t[e];
-        }
-        if (p.res) {
-          float t[8];
-          if (f32side) {
-            const float* rs = reinterpret_cast<const float*>(p.res) + (int64_t)m * p.ld_res + n;
-            const f32x4_t t0 = *reinterpret_cast<const f32x4_t*>(rs), t1 = *reinterpret_cast<const f32x4_t*>(rs + 4);
-            t[0] = t0[0]; t[1] = t0[1]; t[2] = t0[2]; t[3] = t0[3];
-            t[4] = t1[0]; t[5] = t1[1]; t[6] = t1[2]; t[7] = t1[3];
-          } else {
-            unpack8(ldg16(p.res + (int64_t)m * p.ld_res + n), t);
-          }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += t[e];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
-        if (f32out) {
-          float* cf = reinterpret_cast<float*>(p.C) + mo * p.ldc + n;
-          f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-          *reinterpret_cast<f32x4_t*>(cf) = o0;
-          *reinterpret_cast<f32x4_t*>(cf + 4) = o1;
-        } else if (splitout) {  // x = hi + lo + O(2^-17 x): two bf16 planes, columns [0, N) and [N, 2N) of C
-          const U4 hi = pack8(v);
-          float h[8];
-          unpack8(hi, h);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] -= h[e];
-          stg16(p.C + mo * p.ldc + n, hi);
-          stg16(p.C + mo * p.ldc + p.N + n, pack8(v));
-        } else {
-          stg16(p.C + mo * p.ldc + n, pack8(v));
-        }
-      } else {
-        for (int e = 0; e < 8 && n + e < p.N; ++e) {
-          float x = v[e];
+      if constexpr (PAR) {
+        if (vec_ok) {
           if (p.rowbias) {
-            const int64_t o = (int64_t)(m / p.rows_per_rb) * p.ld_rb + n + e;
-            x += f32side ? reinterpret_cast<const float*>(p.rowbias)[o] : bf2f(p.rowbias[o]);
+            float t[8];
+            if (f32side) {
+              const float* rb = reinterpret_cast<const float*>(p.rowbias) + (int64_t)(m / p.rows_per_rb) * p.ld_rb + n;
+              const f32x4_t t0 = *reinterpret_cast<const f32x4_t*>(rb), t1 = *reinterpret_cast<const f32x4_t*>(rb + 4);
+              t[0] = t0[0]; t[1] = t0[1]; t[2] = t0[2]; t[3] = t0[3];
+              t[4] = t1[0]; t[5] = t1[1]; t[6] = t1[2]; t[7] = t1[3];
+            } else {
+              unpack8(ldg16(p.rowbias + (int64_t)(m / p.rows_per_rb) * p.ld_rb + n), t);
+            }
+  #pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += t[e];
           }
           if (p.res) {
-            const int64_t o = (int64_t)m * p.ld_res + n + e;
-            x += f32side ? reinterpret_cast<const float*>(p.res)[o] : bf2f(p.res[o]);
+            float t[8];
+            if (f32side) {
+              const float* rs = reinterpret_cast<const float*>(p.res) + (int64_t)m * p.ld_res + n;
+              const f32x4_t t0 = *reinterpret_cast<const f32x4_t*>(rs), t1 = *reinterpret_cast<const f32x4_t*>(rs + 4);
+              t[0] = t0[0]; t[1] = t0[1]; t[2] = t0[2]; t[3] = t0[3];
+              t[4] = t1[0]; t[5] = t1[1]; t[6] = t1[2]; t[7] = t1[3];
+            } else {
+              unpack8(ldg16(p.res + (int64_t)m * p.ld_res + n), t);
+            }
+  #pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += t[e];
           }
-          x *= p.out_scale;
+  #pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
           if (f32out) {
-            reinterpret_cast<float*>(p.C)[mo * p.ldc + n + e] = x;
-          } else if (splitout) {
-            const u16 hi = f2bf(x);
-            p.C[mo * p.ldc + n + e] = hi;
-            p.C[mo * p.ldc + p.N + n + e] = f2bf(x - bf2f(hi));
+            float* cf = reinterpret_cast<float*>(p.C) + mo * p.ldc + n;
+            f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+            *reinterpret_cast<f32x4_t*>(cf) = o0;
+            *reinterpret_cast<f32x4_t*>(cf + 4) = o1;
+          } else if (splitout) {  // x = hi + lo + O(2^-17 x): two bf16 planes, columns [0, N) and [N, 2N) of C
+            const U4 hi = pack8(v);
+            float h[8];
+            unpack8(hi, h);
+  #pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] -= h[e];
+            stg16(p.C + mo * p.ldc + n, hi);
+            stg16(p.C + mo * p.ldc + p.N + n, pack8(v));
           } else {
-            p.C[mo * p.ldc + n + e] = f2bf(x);
+            stg16(p.C + mo * p.ldc + n, pack8(v));
+          }
+        } else {
+          for (int e = 0; e < 8 && n + e < p.N; ++e) {
+            float x = v[e];
+            if (p.rowbias) {
+              const int64_t o = (int64_t)(m / p.rows_per_rb) * p.ld_rb + n + e;
+              x += f32side ? reinterpret_cast<const float*>(p.rowbias)[o] : bf2f(p.rowbias[o]);
+            }
+            if (p.res) {
+              const int64_t o = (int64_t)m * p.ld_res + n + e;
+              x += f32side ? reinterpret_cast<const float*>(p.res)[o] : bf2f(p.res[o]);
+            }
+            x *= p.out_scale;
+            if (f32out) {
+              reinterpret_cast<float*>(p.C)[mo * p.ldc + n + e] = x;
+            } else if (splitout) {
+              const u16 hi = f2bf(x);
+              p.C[mo * p.ldc + n + e] = hi;
+              p.C[mo * p.ldc + p.N + n + e] = f2bf(x - bf2f(hi));
+            } else {
+              p.C[mo * p.ldc + n + e] = f2bf(x);
+            }
+          }
+        }
+      } else {
+        if (vec_ok) {
+          if (p.rowbias) {
+            float t[8];
+            unpack8(ldg16(p.rowbias + (int64_t)(m / p.rows_per_rb) * p.ld_rb + n), t);
+  #pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += t[e];
+          }
+          if (p.res) {
+            float t[8];
+            unpack8(ldg16(p.res + (int64_t)m * p.ld_res + n), t);
+  #pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += t[e];
+          }
+  #pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+          if (f32out) {
+            float* cf = reinterpret_cast<float*>(p.C) + mo * p.ldc + n;
+            f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+            *reinterpret_cast<f32x4_t*>(cf) = o0;
+            *reinterpret_cast<f32x4_t*>(cf + 4) = o1;
+          } else {
+            stg16(p.C + mo * p.ldc + n, pack8(v));
+          }
+        } else {
+          for (int e = 0; e < 8 && n + e < p.N; ++e) {
+            float x = v[e];
+            if (p.rowbias) x += bf2f(p.rowbias[(int64_t)(m / p.rows_per_rb) * p.ld_rb + n + e]);
+            if (p.res) x += bf2f(p.res[(int64_t)m * p.ld_res + n + e]);
+            if (f32out) reinterpret_cast<float*>(p.C)[mo * p.ldc + n + e] = x * p.out_scale;
+            else p.C[mo * p.ldc + n + e] = f2bf(x * p.out_scale);
           }
         }
       }
@@ -434,18 +471,18 @@ struct EpiGeom {
   static constexpr int EPW = TN <= 128 ? TN : 128;
 };
 
-template <int MI, int NI, int TM, int TN, int MODE, bool STRAIGHT>
+template <int MI, int NI, int TM, int TN, int MODE, bool STRAIGHT, bool PAR = false>
 __device__ __forceinline__ void gemm_epilogue_mode(const GemmParams& p, f32x16_t (&acc)[MI][NI], float* smem_f, int m0, int n0,
                                                    int wm, int wn, int wave, int lane) {
   constexpr int NJ = MODE == 2 ? NI / 2 : NI;
   constexpr int EPW = EpiGeom<TN>::EPW;
   constexpr int G = EPW / 32;  // blocks per full column group
   if constexpr (NJ <= G) {
-    gemm_epilogue_impl<MI, NI, TM, TN, MODE, EPW, 0, NJ, true, STRAIGHT>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
+    gemm_epilogue_impl<MI, NI, TM, TN, MODE, EPW, 0, NJ, true, STRAIGHT, PAR>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
   } else {
     static_assert(NJ <= 2 * G, "at most two column groups");
-    gemm_epilogue_impl<MI, NI, TM, TN, MODE, EPW, 0, G, true, STRAIGHT>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
-    gemm_epilogue_impl<MI, NI, TM, TN, MODE, EPW, G, NJ - G, false, STRAIGHT>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
+    gemm_epilogue_impl<MI, NI, TM, TN, MODE, EPW, 0, G, true, STRAIGHT, PAR>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
+    gemm_epilogue_impl<MI, NI, TM, TN, MODE, EPW, G, NJ - G, false, STRAIGHT, PAR>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
   }
 }
 
@@ -457,18 +494,18 @@ struct EpiBudget {
   static constexpr bool STRAIGHT = NW <= 8 && MI * NI <= 8 && !(NW == 8 && SMEM <= 80 * 1024);
 };
 
-template <int MI, int NI, int TM, int TN, bool STRAIGHT = false>
+template <int MI, int NI, int TM, int TN, bool STRAIGHT = false, bool PAR = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[MI][NI], float* smem_f, int m0, int n0,
                                               int wm, int wn, int wave, int lane) {
   // wave-uniform dispatch; GEGLU pairs hidden block j with gate block j + NI/2 inside the wave, so it needs an even NI
   if constexpr (NI >= 2 && NI % 2 == 0) {
     if (p.flags & DM4D_EPI_GEGLU) {
-      gemm_epilogue_mode<MI, NI, TM, TN, 2, STRAIGHT>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
+      gemm_epilogue_mode<MI, NI, TM, TN, 2, STRAIGHT, PAR>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
       return;
     }
   }
-  if (p.flags & DM4D_EPI_SILU) gemm_epilogue_mode<MI, NI, TM, TN, 1, STRAIGHT>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
-  else gemm_epilogue_mode<MI, NI, TM, TN, 0, STRAIGHT>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
+  if (p.flags & DM4D_EPI_SILU) gemm_epilogue_mode<MI, NI, TM, TN, 1, STRAIGHT, PAR>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
+  else gemm_epilogue_mode<MI, NI, TM, TN, 0, STRAIGHT, PAR>(p, acc, smem_f, m0, n0, wm, wn, wave, lane);
 }
 
 

@@ -101,7 +101,7 @@ class WriterPool:
         self._lock, self._alive = threading.Lock(), max(1, int(processes))
         for _ in range(max(1, int(processes))):
             p = subprocess.Popen([sys.executable, "-m", "diffuman4d_amd.host.imgwrite"], stdin=subprocess.PIPE,
-                                 stdout=subprocess.PIPE, env=env, cwd=root)
+                                 stdout=subprocess.PIPE, env=env)  # the parent's cwd: output paths may be relative to it
             t = threading.Thread(target=self._feed, args=(p,), name="dm4d-writer-feed", daemon=True)
             t.start()
             self._procs.append(p)

@@ -349,8 +349,10 @@ class DistributedSamplingRunner:
         ops_, recv_bufs = [], {}
         for q in range(self.world):
             if send_cells[q]:
-                # one stacked device tensor per peer (cells already live on the exchange device under RCCL: `.to` is a no-op there)
-                buf = torch.stack([s.latents[c][t].to(xdev, non_blocking=True) for c, t in send_cells[q]])
+                # one stacked tensor per peer.  Under RCCL the cells already live on the exchange device (`.to` is a no-op); under gloo
+                # with HIP pipelines the copies are device-to-host and BLOCKING: a non_blocking D2H copy returns before the bytes have
+                # landed, and torch.stack / isend would read them too early
+                buf = torch.stack([s.latents[c][t].to(xdev) for c, t in send_cells[q]])
                 idx = torch.tensor([s.timestep_indices[c][t] for c, t in send_cells[q]], dtype=torch.int64, device=xdev)
                 ops_ += [dist.P2POp(dist.isend, buf, q, self.group), dist.P2POp(dist.isend, idx, q, self.group)]
             if recv_cells[q]:

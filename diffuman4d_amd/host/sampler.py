@@ -70,7 +70,10 @@ class SlidingIterativeSampler:
         # device_results: the arithmetic of the result writer (mosaic, |output - input|, down-scale, uint8 conversion) runs on the GPU
         # inside `denoise` and the task leaves it as a small uint8 package (results.pack_results_on_device); the writer then only
         # encodes files (imgwrite.write_package: in the runner's writer processes, or on the calling thread)
-        self.device_results = bool(device_results)
+        # It applies only to the writer that understands packages: with a caller-supplied writer, or with pipelines that are not on a
+        # HIP device, the sampler keeps the reference's contract (float CPU `images` handed to the writer).
+        on_hip = bool(pipelines) and all(getattr(getattr(p, "device", None), "type", "cpu") == "cuda" for p in pipelines)
+        self.device_results = bool(device_results) and result_writer is None and on_hip and torch.cuda.is_available()
         if result_writer is None:
             if self.device_results:
                 from .results import write_packed_results as result_writer
@@ -202,7 +205,7 @@ class SlidingIterativeSampler:
                                                 **self._pipeline_extensions(sample))
         sample["timestep_indices"] = result["timestep_indices"].cpu()
         sample["fully_denoised"] = result["fully_denoised"].cpu()
-        if self.device_results and on_gpu and self.result_writer is not None:
+        if self.device_results and on_gpu and self.result_writer is not None:  # (device_results is off for caller-supplied writers)
             from .results import pack_results_on_device
             sample["_package"] = pack_results_on_device(sample, result["images"], output_dir=self.output_dir)
             sample["images"] = None  # the float images never leave the device (the package holds what gets written)

@@ -2,7 +2,8 @@
 """Golden vectors on the JUDGED configuration (BASELINE.json configs[1..2]): the CPU oracle (oracle/: fp32 restatement
 of the reference path, see its headers) run at full SD-2.1 geometry on 72x40 latents.
 
-    python tests/golden/make_golden_sd21.py [unet16] [unet24] [vae] [vae1024] [unet16_128]   (default: the first three; ~10 min on 8 cores)
+    python tests/golden/make_golden_sd21.py [unet16] [unet24] [vae] [vae1024] [unet16_128] [matched16] [matched24]
+                                            (default: the first three; ~10 min on 8 cores)
 
 writes tests/golden/sd21_72x40.pt:
   * unet_f16_spatial  -- one spatial window call: F = 16 frames (4 conditioning + 12 targets), CFG batch 32, L3d = 46 080
@@ -106,6 +107,23 @@ def golden_unet(name: str, num_frames: int, n_cond: int, domain: str, seed: int,
     return out
 
 
+def golden_unet_matched(blob: dict, name: str):
+    """The rounding-matched oracle of the fast precision (oracle/matched.py: the fp32 oracle with a bf16 rounding wherever the HIP path
+    stores a tensor, its attention's first-tile row maximum, its pre-scaled to_q rows and summed up-sampling weights) on the inputs
+    of fixture `name`: stored as `matched_out` (bf16) beside the fp32 output, with its own distance to the fp32 oracle."""
+    from oracle import matched
+    g = blob[name]
+    cfg, m, wchk = build_unet()
+    assert wchk == g["weights_checksum"]
+    x, t = unet_inputs(g["num_frames"], g["n_cond"], g["seed"], g.get("size"))
+    t0 = time.time()
+    out = matched.unet_forward(m, x.float(), t, domains=[g["domain"]] * 2, num_frames=g["num_frames"])
+    secs = time.time() - t0
+    ref = g["out_f32"] if "out_f32" in g else g["out"].float()
+    g.update(matched_out=out.to(BF), matched_vs_fp32=rel_l2(out, ref), matched_seconds=secs)
+    print(f"{name}: matched oracle {secs:.1f}s, rel-L2 vs the fp32 oracle {g['matched_vs_fp32']:.3e} (bf16 oracle: {g['yard_bf16']:.3e})", flush=True)
+
+
 def vae_inputs(n: int, seed: int):
     g = torch.Generator().manual_seed(seed)
     H, W = LAT_H * 8, LAT_W * 8
@@ -201,6 +219,12 @@ def main():
         torch.save(blob, OUT)
     if "unet16" in which:
         blob["unet_f16_spatial"] = golden_unet("unet_f16_spatial", 16, 4, "spatial", 101)
+        torch.save(blob, OUT)
+    if "matched16" in which:
+        golden_unet_matched(blob, "unet_f16_spatial")
+        torch.save(blob, OUT)
+    if "matched24" in which:
+        golden_unet_matched(blob, "unet_f24_temporal")
         torch.save(blob, OUT)
     if "unet16_128" in which:  # the reference's native latent size (spatem_dataset.py:27-28: 1024^2 images -> 128 x 128 latents)
         out128 = OUT.with_name("sd21_128x128.pt")

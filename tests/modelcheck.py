@@ -13,7 +13,9 @@ Tolerances (bf16 activations end to end, fp32 accumulation; the fp32 oracle is t
     it would take fp32 activations;
   * cases with their own fixed bound (bitwise equalities, extension-vs-strict comparisons, the golden fixtures whose
     generator did not record a yardstick) keep a TOL entry;
-  * integer bookkeeping (timestep indices, fully_denoised) must be bit-exact.
+  * integer bookkeeping (timestep indices, fully_denoised) must be bit-exact;
+  * `par_*` cases run the same models with precision="parity" and must stay within PARITY_TOL (= north_star's 1e-3) of the fp32
+    oracle on every compared quantity, decoded RGB included.
 """
 from __future__ import annotations
 
@@ -29,7 +31,11 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 
 BF = torch.bfloat16
 YARD_FACTOR = 1.15   # HIP error may exceed the bf16-oracle yardstick by at most 15 %
-NORTH_STAR = 1e-3    # BASELINE.json: decoded RGB within 1e-3 rel-L2 -- reported, not met by any bf16 path (see above)
+NORTH_STAR = 1e-3    # BASELINE.json: decoded RGB within 1e-3 rel-L2 -- not met by any bf16 path (see above); met by precision="parity"
+# precision="parity" (fp32 tensors between kernels, two-term bf16 MFMA operands; include/dm4d.h "Parity precision"): every `par_*`
+# case is judged against a FIXED bound on rel-L2 vs the fp32 oracle -- PARITY_TOL unless PARITY_TOLS names a tighter one.
+PARITY_TOL = 1e-3
+MATCHED_TOL = 2e-3   # HIP fast precision vs the rounding-matched oracle (oracle/matched.py), fixed
 GOLDEN = Path(__file__).resolve().parent / "golden"
 
 
@@ -63,19 +69,28 @@ def make_vae(seed=1):
     return cfg, bf16_weights(v)
 
 
-def hip_unet(cfg, oracle_model):
+def hip_unet(cfg, oracle_model, precision="fast"):
     from dataclasses import asdict
     from diffuman4d_amd.host.unet import UNetConfig, UNetMultiviewConditionModel
-    return UNetMultiviewConditionModel(UNetConfig.from_dict(asdict(cfg)), oracle_model.state_dict(), "cuda")
+    return UNetMultiviewConditionModel(UNetConfig.from_dict(asdict(cfg)), oracle_model.state_dict(), "cuda", precision)
 
 
-def hip_vae(cfg, oracle_model):
+def hip_vae(cfg, oracle_model, precision="fast"):
     from dataclasses import asdict
     from diffuman4d_amd.host.vae import AutoencoderKL, VAEConfig
-    return AutoencoderKL(VAEConfig.from_dict(asdict(cfg)), oracle_model.state_dict(), "cuda")
+    return AutoencoderKL(VAEConfig.from_dict(asdict(cfg)), oracle_model.state_dict(), "cuda", precision)
 
 
-def case_unet(num_frames=4, cfg_batch=2, h=16, w=8, tem=False, domain="spatial", seed=0, pose=False):
+def unet_sample(hm, x):
+    """NCHW input batch (CPU) -> what the HIP UNet's forward takes: NHWC bf16 padded to 32 channels, or (precision "parity") the
+    two-term operand of the fp32 sample."""
+    from diffuman4d_amd.host import ops
+    if hm.parity:
+        return ops.split(x.float().permute(0, 2, 3, 1).contiguous().cuda(), cpad=hm.IN_PAD)
+    return ops.nchw_to_nhwc(x.to(BF).cuda(), hm.IN_PAD)
+
+
+def case_unet(num_frames=4, cfg_batch=2, h=16, w=8, tem=False, domain="spatial", seed=0, pose=False, precision="fast"):
     from diffuman4d_amd.host import ops
     cfg, om = make_unet(seed, enable_tem_embeds=tem, **(dict(enable_pose_encoder=True, in_channels=11) if pose else {}))
     if tem:  # the temporal embedding MLP is zero-initialised in training; randomise it so it is exercised
@@ -83,7 +98,7 @@ def case_unet(num_frames=4, cfg_batch=2, h=16, w=8, tem=False, domain="spatial",
         with torch.no_grad():
             for p in om.temporal_pos_embed.parameters():
                 p.copy_((torch.randn(p.shape, generator=g) * 0.05).to(BF).float())
-    hm = hip_unet(cfg, om)
+    hm = hip_unet(cfg, om, precision)
     g = torch.Generator().manual_seed(seed + 1)
     B = num_frames * cfg_batch
     x = (torch.randn(B, cfg.in_channels, h, w, generator=g)).to(BF)
@@ -95,7 +110,7 @@ def case_unet(num_frames=4, cfg_batch=2, h=16, w=8, tem=False, domain="spatial",
         om_bf = om.to(BF)
         ref_bf = om_bf(x, t, skeletons=sk, domains=domains, num_frames=num_frames).float()
         om.float()
-    xd = ops.nchw_to_nhwc(x.cuda(), hm.IN_PAD)
+    xd = unet_sample(hm, x)
     out = hm(xd, t.float().cuda(), skeletons=ops.nchw_to_nhwc(sk.cuda(), 4) if pose else None, domains=domains,
              num_frames=num_frames)
     out = ops.nhwc_to_nchw(out)
@@ -239,10 +254,18 @@ def case_task_batching(domain="spatial", copies=2, sched="ddim", seed=23):
     return float((stacked.float() - ref.float()).abs().max()), 0.0
 
 
-def case_vae(h=64, w=64, seed=1):
+def latents_nhwc(hv, z):
+    """NCHW latents (CPU) -> the NHWC device tensor decode_to_images takes (bf16, or fp32 under precision "parity")."""
+    from diffuman4d_amd.host import ops
+    if hv.parity:
+        return z.float().permute(0, 2, 3, 1).contiguous().cuda()
+    return ops.nchw_to_nhwc(z.to(BF).contiguous().cuda())
+
+
+def case_vae(h=64, w=64, seed=1, precision="fast"):
     from diffuman4d_amd.host import ops
     cfg, ov = make_vae(seed)
-    hv = hip_vae(cfg, ov)
+    hv = hip_vae(cfg, ov, precision)
     g = torch.Generator().manual_seed(seed + 1)
     img = (torch.rand(3, 3, h, w, generator=g) * 2 - 1).to(BF)
     noise = torch.randn(3, 4, h // 8, w // 8, generator=g).to(BF)
@@ -255,7 +278,7 @@ def case_vae(h=64, w=64, seed=1):
         img_bf = (ov.decode(z_in / cfg.scaling_factor) / 2 + 0.5).clamp(0, 1).float()
         ov.float()
     z = hv.encode_scaled(img, noise)  # NHWC
-    out = hv.decode_to_images(ops.nchw_to_nhwc(z_in.contiguous().cuda()))
+    out = hv.decode_to_images(latents_nhwc(hv, z_in))
     return ({"latents": rel_l2(ops.nhwc_to_nchw(z), z_ref), "images": rel_l2(out, img_ref)},
             {"latents": rel_l2(z_bf, z_ref), "images": rel_l2(img_bf, img_ref)})
 
@@ -266,7 +289,7 @@ def _check_fixture_inputs(what, got, want):
                            "than when tests/golden/sd21_72x40.pt was made; regenerate it (tests/golden/make_golden_sd21.py)")
 
 
-def case_unet_sd21(name):
+def case_unet_sd21(name, precision="fast", fixture="sd21_72x40.pt", matched=False):
     """The JUDGED configuration: full SD-2.1 geometry (320, 640, 1280, 1280; heads 5/10/20/20), 72x40 latents, one spatial
     (F = 16, CFG batch 32, 3-D attention over 46 080 / 11 520 / 2 880 / 720 tokens) or temporal (F = 24, CFG batch 48,
     69 120 / 17 280 / 4 320 / 1 080 tokens) window call, HIP vs the fp32 CPU oracle's output recorded in
@@ -276,23 +299,42 @@ def case_unet_sd21(name):
     from diffuman4d_amd.host.weights import random_state_dict, unet_param_shapes
     sys.path.insert(0, str(GOLDEN))
     import make_golden_sd21 as mk
-    g = torch.load(GOLDEN / "sd21_72x40.pt")[name]
+    g = torch.load(GOLDEN / fixture)[name]
     cfg = UNetConfig()
     sd = random_state_dict(unet_param_shapes(cfg), mk.UNET_SEED, "cpu")
     _check_fixture_inputs("UNet weights", float(sum(v.float().abs().sum() for v in sd.values())), g["weights_checksum"])
-    x, t = mk.unet_inputs(g["num_frames"], g["n_cond"], g["seed"])
+    x, t = mk.unet_inputs(g["num_frames"], g["n_cond"], g["seed"], g.get("size"))
     _check_fixture_inputs("UNet input", float(x.float().abs().sum()), g["x_checksum"])
     assert torch.equal(t, g["t"])
-    hm = UNetMultiviewConditionModel(cfg, sd, "cuda")
+    hm = UNetMultiviewConditionModel(cfg, sd, "cuda", precision)
     del sd
-    out = hm(ops.nchw_to_nhwc(x.cuda(), hm.IN_PAD), t.float().cuda(), domains=[g["domain"]] * 2, num_frames=g["num_frames"])
-    err = rel_l2(ops.nhwc_to_nchw(out), g["out"])
+    torch.cuda.synchronize()
+    t0 = time.time()
+    out = hm(unet_sample(hm, x), t.float().cuda(), domains=[g["domain"]] * 2, num_frames=g["num_frames"])
+    torch.cuda.synchronize()
+    secs = time.time() - t0
+    out = ops.nhwc_to_nchw(out)
+    if matched:
+        # HIP (fast precision) against the ROUNDING-MATCHED oracle (oracle/matched.py: the fp32 oracle rounded to bf16 wherever the HIP
+        # path stores a tensor), under a FIXED bound (MATCHED_TOL): what is left between the two is summation order, the hardware's
+        # exp2 / rcp and the roundings those flip -- a defect worth a few 1e-3 that the yardstick bound lets through fails here
+        err = rel_l2(out, g["matched_out"])
+        print(f"    [{name} fast vs rounding-matched oracle] unet_out rel_l2={err:.3e} (bound {MATCHED_TOL:.1e}; matched oracle vs fp32 oracle "
+              f"{g['matched_vs_fp32']:.3e}, HIP vs fp32 oracle {rel_l2(out, g.get('out_f32', g['out'])):.3e})", flush=True)
+        del hm
+        torch.cuda.empty_cache()
+        return {"unet_out": err}, {"unet_out": 0.0}
+    if "out_sub" in g:  # the 128 x 128 fixture keeps every sub-th pixel of the fp32 output
+        err, yard = rel_l2(out[..., ::g["sub"], ::g["sub"]], g["out_sub"]), g["yard_bf16_sub"]
+    else:  # fp32 copy of the oracle output where the fixture has one (round 4), else the fp16 copy (its own floor: 2.1e-4)
+        err, yard = rel_l2(out, g.get("out_f32", g["out"])), g["yard_bf16"]
+    print(f"    [{name} {precision}, first call incl. allocation {secs * 1e3:.0f} ms] unet_out rel_l2={err:.3e} (oracle-bf16 {yard:.3e})", flush=True)
     del hm
     torch.cuda.empty_cache()
-    return {"unet_out": err}, {"unet_out": g["yard_bf16"]}
+    return {"unet_out": err}, {"unet_out": yard}
 
 
-def case_vae_sd(name="vae_576x320"):
+def case_vae_sd(name="vae_576x320", precision="fast"):
     """AutoencoderKL at the SD geometry (128, 256, 512, 512; mid-block attention d = 512 over 2 880 tokens) on two 576x320
     images vs the fp32 oracle's recorded posterior sample and decoded images (tests/golden/sd21_72x40.pt)."""
     from diffuman4d_amd.host import ops
@@ -306,14 +348,14 @@ def case_vae_sd(name="vae_576x320"):
     _check_fixture_inputs("VAE weights", float(sum(v.float().abs().sum() for v in sd.values())), g["weights_checksum"])
     img, noise = mk.vae_inputs(g["n"], g["seed"])
     _check_fixture_inputs("VAE input", float(img.float().abs().sum()), g["img_checksum"])
-    hv = AutoencoderKL(cfg, sd, "cuda")
+    hv = AutoencoderKL(cfg, sd, "cuda", precision)
     z = hv.encode_scaled(img, noise)
-    out = hv.decode_to_images(ops.nchw_to_nhwc(g["z"].to(BF).contiguous().cuda()))
+    out = hv.decode_to_images(latents_nhwc(hv, g["z"].to(BF)))  # the fixture's decoder was fed the bf16-rounded latents
     return ({"latents": rel_l2(ops.nhwc_to_nchw(z), g["z"]), "images": rel_l2(out, g["images"])},
             {"latents": g["yard_z"], "images": g["yard_images"]})
 
 
-def case_demo3d_sd21():
+def case_demo3d_sd21(precision="fast"):
     """BASELINE.json configs[0] END TO END on the judged geometry: `demo_3d` (configs/exp/demo_3d.yaml:3-10 + sampler/sliding_3d.yaml:
     48 cameras x 1 frame, 4 input cameras, window 12, stride 1, one alternation round => 12 steps per latent, 44 UNet calls of F = 16
     = CFG batch 32) through `sliding_iterative_denoise` (pipeline_diffuman4d.py:439-559) with the SD-2.1 UNet, the SD VAE and 576 x 320
@@ -335,7 +377,8 @@ def case_demo3d_sd21():
         _check_fixture_inputs("demo3d " + k, got[k], want[k])
     for k in noise:
         _check_fixture_inputs("demo3d noise " + k, got["noise"][k], want["noise"][k])
-    hp = Diffuman4DPipeline(AutoencoderKL(VAEConfig(), vsd, "cuda"), UNetMultiviewConditionModel(UNetConfig(), usd, "cuda"), HS(HC()), "cuda")
+    hp = Diffuman4DPipeline(AutoencoderKL(VAEConfig(), vsd, "cuda", precision), UNetMultiviewConditionModel(UNetConfig(), usd, "cuda", precision),
+                            HS(HC()), "cuda")
     del usd, vsd
     t0 = time.time()
     out = hp.sliding_iterative_denoise(pixel_values=pv, plucker_embeds=pl, skeletons=sk, cond_masks=cm, latents=None, domain="spatial",
@@ -350,7 +393,7 @@ def case_demo3d_sd21():
     # yardsticks of the bf16 pass of the generator; until that pass has run the bound falls back to the F = 16 UNet call's yardstick
     fallback = 1.22e-2
     y = {"latents": g.get("yard_latents", fallback), "images": g.get("yard_images", fallback)}
-    print(f"    [demo_3d, SD-2.1 + SD VAE, 72x40, 44 calls, {secs:.1f}s] latents rel_l2={e['latents']:.3e} (targets only {e_t:.3e}; oracle-bf16 "
+    print(f"    [demo_3d {precision}, SD-2.1 + SD VAE, 72x40, 44 calls, {secs:.1f}s] latents rel_l2={e['latents']:.3e} (targets only {e_t:.3e}; oracle-bf16 "
           f"{y['latents']:.3e}) images rel_l2={e['images']:.3e} (oracle-bf16 {y['images']:.3e}; north_star {NORTH_STAR:.0e}: "
           f"{'met' if e['images'] <= NORTH_STAR else 'NOT met'}) bookkeeping_exact={exact}", flush=True)
     del hp
@@ -434,7 +477,7 @@ def synthetic_task(n, H, W, input_rows, seed=7):
 
 
 def case_pipeline(domain="spatial", n_cams=8, T=4, window=4, stride=2, rounds=1, steps=1, bidir=False, gs=2.0,
-                  pred="epsilon", seed=11, pose=False, sched="ddim", sched_kw=None):
+                  pred="epsilon", seed=11, pose=False, sched="ddim", sched_kw=None, precision="fast"):
     """One full task through sliding_iterative_denoise (VAE encode -> window sweep -> VAE decode).
     sched="dpm": DPM-Solver++ multistep -- the oracle keeps one stateful scheduler object per latent as the reference does
     (pipeline_diffuman4d.py:265-271, 420), the HIP path runs its planned coefficient rows (host/scheduler.py)."""
@@ -470,7 +513,7 @@ def case_pipeline(domain="spatial", n_cams=8, T=4, window=4, stride=2, rounds=1,
     op = OraclePipeline(ov, ou, DDIMScheduler(DDIMConfig(prediction_type=pred)), torch.float32)
     noise_f = {k: v.float() for k, v in noise.items()}
     ref = op.sliding_iterative_denoise(pv, pl, sk, cm, None, domain, tidx, noise_f, **kw)
-    hp = Diffuman4DPipeline(hip_vae(cfg_v, ov), hip_unet(cfg_u, ou), HS(HCf(prediction_type=pred)), "cuda")
+    hp = Diffuman4DPipeline(hip_vae(cfg_v, ov, precision), hip_unet(cfg_u, ou, precision), HS(HCf(prediction_type=pred)), "cuda")
     out = hp.sliding_iterative_denoise(pixel_values=pv, plucker_embeds=pl, skeletons=sk, cond_masks=cm, latents=None,
                                        domain=domain, timestep_indices=tidx, noise=noise, **kw)
     exact = bool((out["timestep_indices"].cpu() == ref["timestep_indices"]).all()) and \
@@ -482,7 +525,7 @@ def case_pipeline(domain="spatial", n_cams=8, T=4, window=4, stride=2, rounds=1,
     refb = opb.sliding_iterative_denoise(pv, pl, sk, cm, None, domain, tidx, noise, **kw)
     ov.float(), ou.float()
     y_lat, y_img = rel_l2(refb["latents"], ref["latents"]), rel_l2(refb["images"], ref["images"])
-    print(f"    [pipeline {domain}] latents rel_l2={e_lat:.3e} (oracle-bf16 {y_lat:.3e}) images rel_l2={e_img:.3e} "
+    print(f"    [pipeline {domain} {precision}] latents rel_l2={e_lat:.3e} (oracle-bf16 {y_lat:.3e}) images rel_l2={e_img:.3e} "
           f"(oracle-bf16 {y_img:.3e}; north_star {NORTH_STAR:.0e}: {'met' if e_img <= NORTH_STAR else 'NOT met'}) "
           f"bookkeeping_exact={exact}", flush=True)
     if not exact:
@@ -621,6 +664,65 @@ def case_golden_pipeline(name):
     return {"latents": e_lat, "images": e_img}, {"latents": y_lat, "images": y_img}
 
 
+def case_multiround_sd21(precision="fast"):
+    """A multi-round job THROUGH THE SAMPLER at the judged geometry: 8 cameras x 4 frames, window 4, stride 2, 3 alternation rounds
+    (spatial -> temporal -> spatial: 14 tasks, 36 window calls, 6 steps per latent; sliding_iterative_sampler.py:192-212,
+    sampling_runner.py:18-62) with the SD-2.1 UNet + SD VAE on 576 x 320 images: this repo's SlidingIterativeSampler + SamplingRunner
+    drive the HIP pipeline; the final grid, the decoded RGB of three cells and -- bit for bit -- the timestep grid are compared
+    with what the fp32 CPU oracle pipeline gave under the reference's control flow (tests/golden/multiround_sd21_72x40.pt, made by
+    tests/golden/make_golden_multiround.py; same per-call random draws on both sides)."""
+    from diffuman4d_amd.host.pipeline import Diffuman4DPipeline
+    from diffuman4d_amd.host.runner import SamplingRunner
+    from diffuman4d_amd.host.sampler import SlidingIterativeSampler
+    from diffuman4d_amd.host.scheduler import DDIMConfig as HC, DDIMScheduler as HS
+    from diffuman4d_amd.host.unet import UNetConfig, UNetMultiviewConditionModel
+    from diffuman4d_amd.host.vae import AutoencoderKL, VAEConfig
+    sys.path.insert(0, str(GOLDEN))
+    import make_golden_demo3d as mk3
+    import make_golden_multiround as mk
+    g = torch.load(GOLDEN / "multiround_sd21_72x40.pt")
+    usd, vsd = mk3.state_dicts()
+    f = lambda t: float(t.float().abs().sum())  # noqa: E731
+    _check_fixture_inputs("multiround UNet weights", float(sum(f(v) for v in usd.values())), g["checksums"]["unet_weights"])
+    _check_fixture_inputs("multiround VAE weights", float(sum(f(v) for v in vsd.values())), g["checksums"]["vae_weights"])
+    hp = Diffuman4DPipeline(AutoencoderKL(VAEConfig(), vsd, "cuda", precision), UNetMultiviewConditionModel(UNetConfig(), usd, "cuda", precision),
+                            HS(HC()), "cuda")
+    del usd, vsd
+    own = SlidingIterativeSampler(mk.dataset(), [mk.SeededNoise(hp, oracle=False)], "/tmp/dm4d_multiround_unused", **g["kw"])
+    first = own.dataset.get_item("synthetic", own.spa_labels, [own.tem_labels[0]], own.input_spa_labels)
+    for k, key in (("pixel_values", "pixel_values"), ("plucker", "plucker_embeds"), ("skeletons", "skeletons")):
+        _check_fixture_inputs("multiround dataset " + k, f(first[key]), g["checksums"][k])
+    kept = {}
+
+    def writer(sample, output_dir):
+        if sample["alt"] != g["kw"]["alternation_rounds"]:
+            return
+        for row, (_, c, fr) in enumerate(sample["labels"]):
+            if (c, fr) in [tuple(x) for x in g["image_cells"]]:
+                kept[(c, fr)] = sample["images"][row].float().cpu()
+    own.result_writer = writer
+    t0 = time.time()
+    SamplingRunner(own, prefetch_depth=0, writers=1, gpu_streams=1).inference()  # one task at a time: the draws come in the job's order
+    torch.cuda.synchronize()
+    secs = time.time() - t0
+    lat = torch.stack([torch.stack([own.latents[c][fr].float().cpu() for fr in own.tem_labels]) for c in own.spa_labels])
+    idx = torch.tensor([[own.timestep_indices[c][fr] for fr in own.tem_labels] for c in own.spa_labels])
+    exact = torch.equal(idx, g["timestep_indices"])
+    images = torch.stack([kept[tuple(cell)] for cell in g["image_cells"]])
+    ref_img = g["images_u16"].to(torch.int32).float() / 65535.0
+    tgt = g["timestep_indices"] > 0
+    e = {"latents": rel_l2(lat[tgt], g["latents"][tgt]), "images": rel_l2(images, ref_img)}
+    y = {"latents": g.get("yard_latents_targets", 1.5e-2), "images": g.get("yard_images", 1.5e-2)}
+    print(f"    [multi-round job {precision}: 8 x 4 grid, 3 rounds, 14 tasks / 36 calls through the sampler, {secs:.1f}s] target latents rel_l2="
+          f"{e['latents']:.3e} (oracle-bf16 {y['latents']:.3e}) images rel_l2={e['images']:.3e} (oracle-bf16 {y['images']:.3e}; north_star "
+          f"{NORTH_STAR:.0e}: {'met' if e['images'] <= NORTH_STAR else 'NOT met'}) bookkeeping_exact={exact}", flush=True)
+    del hp, own
+    torch.cuda.empty_cache()
+    if not exact:
+        return {"bookkeeping": 1.0}, {"bookkeeping": 0.0}
+    return e, y
+
+
 CASES = {
     "unet_spatial": (case_unet, dict(num_frames=4, cfg_batch=2)),
     "unet_temporal_temb": (case_unet, dict(num_frames=4, cfg_batch=2, tem=True, domain="temporal")),
@@ -662,17 +764,50 @@ CASES = {
     "unet_sd21_72x40_f24": (case_unet_sd21, dict(name="unet_f24_temporal")),
     "vae_sd_576x320": (case_vae_sd, dict()),
 }
+# precision="parity" on the small configurations (fp32 oracle run on the spot): every layer type, both domains, CFG on / off, DPM
+PAR = dict(precision="parity")
+CASES.update({
+    "par_unet_spatial": (case_unet, dict(num_frames=4, cfg_batch=2, **PAR)),
+    "par_unet_temporal_temb": (case_unet, dict(num_frames=4, cfg_batch=2, tem=True, domain="temporal", **PAR)),
+    "par_unet_2d_only": (case_unet, dict(num_frames=1, cfg_batch=3, h=8, w=8, **PAR)),
+    "par_vae": (case_vae, dict(**PAR)),
+    "par_vae_odd_latent_area": (case_vae, dict(h=264, w=328, **PAR)),
+    "par_pipeline_spatial": (case_pipeline, dict(domain="spatial", **PAR)),
+    "par_pipeline_temporal_v": (case_pipeline, dict(domain="temporal", T=4, window=4, stride=1, pred="v_prediction", **PAR)),
+    "par_pipeline_bidir_nocfg": (case_pipeline, dict(domain="spatial", window=3, stride=3, bidir=True, gs=1.0, steps=2, **PAR)),
+    "par_pipeline_dpm_spatial": (case_pipeline, dict(domain="spatial", sched="dpm", steps=2, window=4, stride=2, bidir=True, **PAR)),
+    # ... and on the judged geometry, against the committed fp32 fixtures
+    "par_unet_sd21_72x40_f16": (case_unet_sd21, dict(name="unet_f16_spatial", **PAR)),
+    "par_vae_sd_576x320": (case_vae_sd, dict(**PAR)),
+})
+# HIP fast precision vs the rounding-matched oracle on the judged UNet calls (make_golden_sd21.py matched16 / matched24)
+_sd21 = torch.load(GOLDEN / "sd21_72x40.pt")
+for _n, _k in (("unet_sd21_72x40_f16_matched", "unet_f16_spatial"), ("unet_sd21_72x40_f24_matched", "unet_f24_temporal")):
+    if "matched_out" in _sd21.get(_k, {}):
+        CASES[_n] = (case_unet_sd21, dict(name=_k, matched=True))
+del _sd21
+# the reference's NATIVE latent size (spatem_dataset.py:27-28: 1024^2 images -> 128 x 128 latents; make_golden_sd21.py unet16_128)
+if (GOLDEN / "sd21_128x128.pt").exists():
+    CASES["unet_sd21_128x128_f16"] = (case_unet_sd21, dict(name="unet_f16_spatial_128", fixture="sd21_128x128.pt"))
+    CASES["par_unet_sd21_128x128_f16"] = (case_unet_sd21, dict(name="unet_f16_spatial_128", fixture="sd21_128x128.pt", **PAR))
+if (GOLDEN / "multiround_sd21_72x40.pt").exists():  # spatial -> temporal -> spatial through the sampler (make_golden_multiround.py)
+    CASES["multiround_sd21_72x40"] = (case_multiround_sd21, dict())
+    CASES["par_multiround_sd21_72x40"] = (case_multiround_sd21, dict(**PAR))
 # BASELINE.json configs[0] end to end at the judged geometry, vs tests/golden/demo3d_sd21_72x40.pt (made by
 # tests/golden/make_golden_demo3d.py: two CPU-hours; the case exists once the fixture does)
 if "vae_1024" in torch.load(GOLDEN / "sd21_72x40.pt"):  # the VAE at the reference's native 1024 x 1024 (make_golden_sd21.py vae1024)
     CASES["vae_sd_1024x1024"] = (case_vae_1024, dict())
 if (GOLDEN / "demo3d_sd21_72x40.pt").exists():
     CASES["demo3d_sd21_72x40"] = (case_demo3d_sd21, dict())
+    CASES["par_demo3d_sd21_72x40"] = (case_demo3d_sd21, dict(**PAR))  # north_star: decoded RGB within 1e-3 of the fp32 reference path
 # Cases with a fixed bound of their own: bitwise equalities (0.0), extension-vs-strict comparisons, exact resampling.
 # Every other case is judged against its bf16-oracle yardstick (YARD_FACTOR, see the module docstring).
 TOL = {"task_batching_spatial": 0.0, "task_batching_temporal_x3": 0.0, "task_batching_dpm": 0.0, "pipeline_shard_rccl_world1": 0.0, "unet_frame_shard_p4": 0.0, "unet_frame_shard_p8": 0.0,
        "pipeline_cache_lazy_decode": 0.0, "pipeline_prune_cond_rows": 5e-3, "pipeline_prune_cond_rows_temporal": 5e-3,
        "pipeline_plucker_on_device": 5e-3, "resize": 4e-3}
+PARITY_TOLS: dict = {}  # tighter fixed bounds of individual par_* cases (name -> bound), from the measurements in DESIGN.md section 3
+TOL.update({n: PARITY_TOLS.get(n, PARITY_TOL) for n in CASES if n.startswith("par_")})
+TOL.update({n: MATCHED_TOL for n in CASES if n.endswith("_matched")})
 
 
 def judge(name, err, yard):

@@ -531,6 +531,245 @@ def case_linear_step(F_, HW, use_cfg, seed=0):
     return err, float((dl.float().cpu() - ref_lat).abs().max())
 
 
+
+# ---- parity precision (include/dm4d.h "Parity precision"): fp32 tensors, two-term bf16 operands -------------------------------------
+# References are computed in fp64 from the SAME fp32 inputs; the bound is what two bf16 terms leave (|x - hi - lo| <= 2^-17 |x|, about
+# 3e-6 rms per operand) plus fp32 accumulation: TOL_PAR.  Attention multiplies two split operands twice: its own bound.
+TOL_PAR = 2e-5
+TOL_PAR_ATTN = 1e-4
+
+
+def _join(op, planes=2):
+    """two-term operand [..., planes * C] -> fp64 value hi + lo (pattern 0)."""
+    C = op.shape[-1] // planes
+    return op[..., :C].double().cpu() + op[..., C:2 * C].double().cpu()
+
+
+def case_par_split(M=300, C1=96, C2=0, cpad=None, silu=False, scale=1.0, pattern=0, transposed=False, seed=0):
+    """ops.split: every plane must hold exactly bf16(x) / bf16(x - bf16(x)) of act(x) * scale in the documented order."""
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, C1, generator=g) * 3
+    x2 = torch.randn(M, C2, generator=g) if C2 else None
+    src = x.t().contiguous() if transposed else x
+    op = ops.split(src.cuda(), x2.cuda() if C2 else None, cpad=cpad, silu=silu, scale=scale, pattern=pattern, transposed=transposed).cpu()
+    Cp = cpad or (C1 + C2)
+    v = torch.cat([x, x2], dim=1) if C2 else x
+    if silu:
+        v = F.silu(v)
+    v = F.pad(v * scale, (0, Cp - v.shape[1]))
+    hi = v.to(BF)
+    lo = (v - hi.float()).to(BF)
+    want = {0: [hi, lo], 1: [hi, lo, hi], 2: [hi, hi, lo]}[pattern]
+    want = torch.cat(want, dim=1)
+    assert op.shape == want.shape, (op.shape, want.shape)
+    # SiLU on the device uses the hardware exp / rcp: compare the recombined value; without it the planes must match bit for bit
+    if not silu:
+        assert torch.equal(op, want), f"planes differ: max abs {float((op.float() - want.float()).abs().max()):.3e}"
+        return 0.0, 0.0
+    rec, ref = op[:, :Cp].double() + op[:, Cp:2 * Cp].double(), v.double()
+    return rel_l2(rec, ref), float((rec - ref).abs().max())
+
+
+def case_par_gemm(M, N, K, bias=True, rowbias=False, residual=False, geglu=False, silu=False, split_out=False, seed=0):
+    """dm4d_gemm_bf16 on a two-term operand against K-duplicated weights, fp32 side inputs, fp32 or two-term output."""
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    a = torch.randn(M, K, generator=g)
+    w = _rnd(((2 * N) if geglu else N, K), g, 1.0 / math.sqrt(K))
+    b = _rnd(((2 * N) if geglu else N,), g, 0.5) if bias else None
+    rpr = 7
+    rb = torch.randn((M + rpr - 1) // rpr, N, generator=g) if rowbias else None
+    res = torch.randn(M, N, generator=g) if residual else None
+    ref = a.double() @ w.double().t()
+    if b is not None:
+        ref = ref + b.double()
+    if geglu:
+        h, gate = ref.chunk(2, dim=-1)
+        ref = h * F.gelu(gate)
+    if silu:
+        ref = F.silu(ref)
+    if rb is not None:
+        ref = ref + rb.double().repeat_interleave(rpr, dim=0)[:M]
+    if res is not None:
+        ref = ref + res.double()
+    d = "cuda"
+    out = ops.gemm(ops.split(a.to(d)), ops.dup_k(w).to(d), bias=b.to(d) if b is not None else None,
+                   rowbias=rb.to(d) if rb is not None else None, rows_per_rowbias=rpr, residual=res.to(d) if res is not None else None,
+                   geglu=geglu, silu=silu, out_f32=not split_out, split_out=split_out)
+    got = _join(out) if split_out else out.double().cpu()
+    return rel_l2(got, ref), float((got - ref).abs().max())
+
+
+def case_par_conv(B, H, W, Cin, Cout, stride=1, pad=1, pad_hi=None, upsample=False, bias=True, rowbias=False, residual=False,
+                  scale=1.0, seed=0):
+    """dm4d_conv3x3_nhwc_bf16_flags on a two-term operand (channels [hi | lo]) against weights duplicated per tap."""
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = _rnd((Cout, Cin, 3, 3), g, 1.0 / math.sqrt(9 * Cin))
+    b = _rnd((Cout,), g, 0.5) if bias else None
+    xi = F.interpolate(x.double(), scale_factor=2, mode="nearest") if upsample else x.double()
+    ph = pad if pad_hi is None else pad_hi
+    ref = F.conv2d(F.pad(xi, (pad, ph, pad, ph)), w.double(), b.double() if bias else None, stride=stride)
+    Ho, Wo = ref.shape[-2:]
+    rb = torch.randn(B, Cout, generator=g) if rowbias else None
+    res = torch.randn(B, Ho, Wo, Cout, generator=g) if residual else None
+    if rb is not None:
+        ref = ref + rb.double()[:, :, None, None]
+    if res is not None:
+        ref = ref + res.double().permute(0, 3, 1, 2)
+    ref = ref * scale
+    d = "cuda"
+    wt = ops.dup_k(w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous(), taps=9).to(d)
+    out = ops.conv3x3(ops.split(x.permute(0, 2, 3, 1).contiguous().to(d)), wt, bias=b.to(d) if bias else None,
+                      rowbias=rb.to(d) if rb is not None else None, residual=res.to(d) if res is not None else None, stride=stride,
+                      pad=pad, pad_hi=pad_hi, upsample=upsample, out_scale=scale, out_f32=True)
+    got = out.double().cpu().permute(0, 3, 1, 2)
+    return rel_l2(got, ref), float((got - ref).abs().max())
+
+
+def case_par_groupnorm(B, HW, C1, C2=0, groups=32, silu=True, eps=1e-5, mean_shift=0.0, seed=0):
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    x1 = torch.randn(B, HW, C1, generator=g) * 2 + mean_shift
+    x2 = torch.randn(B, HW, C2, generator=g) if C2 else None
+    C = C1 + C2
+    gam, bet = (1.0 + 0.1 * torch.randn(C, generator=g)).to(BF), (0.1 * torch.randn(C, generator=g)).to(BF)
+    x = torch.cat([x1, x2], dim=-1) if C2 else x1
+    ref = F.group_norm(x.double().permute(0, 2, 1), groups, gam.double(), bet.double(), eps).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    out = ops.groupnorm(x1.cuda(), gam.cuda(), bet.cuda(), groups, eps, x2=x2.cuda() if C2 else None, silu=silu)
+    got = _join(out)
+    return rel_l2(got, ref), float((got - ref).abs().max())
+
+
+def case_par_layernorm(M, C, seed=0):
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, C, generator=g) * 3 + 0.5
+    gam, bet = (1.0 + 0.1 * torch.randn(C, generator=g)).to(BF), (0.1 * torch.randn(C, generator=g)).to(BF)
+    ref = F.layer_norm(x.double(), (C,), gam.double(), bet.double(), 1e-5)
+    got = _join(ops.layernorm(x.cuda(), gam.cuda(), bet.cuda(), 1e-5))
+    return rel_l2(got, ref), float((got - ref).abs().max())
+
+
+def case_par_softmax(M, N, Np, scale=0.05, seed=0):
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    s = torch.randn(M, Np, generator=g) * 40
+    ref = torch.softmax(s[:, :N].double() * scale, dim=-1)
+    p = ops.softmax_rows_split(s.cuda(), scale, n=N).cpu()
+    assert p.shape == (M, 3 * Np) and torch.equal(p[:, :Np], p[:, 2 * Np:]), "planes [hi | lo | hi]"
+    assert bool((p[:, N:Np] == 0).all()) and bool((p[:, Np + N:2 * Np] == 0).all()), "padded columns must be zero"
+    got = p[:, :N].double() + p[:, Np:Np + N].double()
+    return rel_l2(got, ref), float((got - ref).abs().max())
+
+
+def case_par_attention(batch, heads, L, seed=0, spike=False, qk_scale=1.0):
+    """dm4d_attention_split_bf16 on the hi / lo planes a fused QKV projection leaves ([q_hi | k_hi | v_hi | q_lo | k_lo | v_lo]),
+    against fp64 SDPA on the same two-term values.  spike: one late key dominates every row (forces the lazy rescale)."""
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    C = heads * 64
+    qkv = torch.randn(batch * L, 3 * C, generator=g)
+    qkv[:, :2 * C] *= qk_scale
+    if spike:
+        kk = qkv[:, C:2 * C].view(batch, L, C)
+        qq = qkv[:, :C].view(batch, L, C)
+        kk[:, L - 7] = qq.mean(dim=1) * 6 + kk[:, L - 7]
+    hi = qkv.to(BF)
+    lo = (qkv - hi.float()).to(BF)
+    val = hi.double() + lo.double()
+
+    def hv(t):
+        return t.view(batch, L, heads, 64).transpose(1, 2)
+    q, k, v = (hv(val[:, i * C:(i + 1) * C]) for i in range(3))
+    ref = torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1) @ v
+    ref = ref.transpose(1, 2).reshape(batch * L, C)
+    out = ops.attention_split(torch.cat([hi, lo], dim=1).cuda(), batch, heads, L, 0.125)
+    got = _join(out)
+    return rel_l2(got, ref), float((got - ref).abs().max())
+
+
+def case_par_small_kernels(seed=0):
+    """fp32 forms of the kernels around the UNet / VAE calls: pack (operand of conv_in), CFG + DDIM / linear multistep steps, posterior
+    sample, resize, postprocess, layout, timestep embedding -- each against its torch formula in fp64 (worst rel-L2 returned)."""
+    import numpy as np
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    worst = 0.0
+    N, F_, HW = 6, 4, 48
+    lat, pv, sk = (torch.randn(N, HW, 4, generator=g) for _ in range(3))
+    pl, mask = torch.randn(N, HW, 6, generator=g), torch.ones(N, HW, 1)
+    cond = torch.tensor([1, 0, 0, 1], dtype=torch.int32)
+    widx = torch.tensor([4, 0, 2, 5], dtype=torch.int32)
+    mask[widx.long()[cond.bool()]] = 0.0
+    dlat = lat.clone().cuda()
+    x = ops.pack_model_input(dlat, pv.cuda(), pl.cuda(), sk.cuda(), mask.cuda(), cond.cuda(), 32, True, frame_idx=widx.cuda()).cpu()
+    assert x.shape == (2 * F_, HW, 64)
+    val = x[..., :32].double() + x[..., 32:].double()
+    rows = widx.long()
+    xin = torch.where(cond.bool()[:, None, None], pv[rows], lat[rows])
+    pos = torch.cat([xin, pl[rows], sk[rows], mask[rows]], dim=-1)
+    neg = torch.cat([torch.where(cond.bool()[:, None, None], torch.ones_like(xin), xin), torch.zeros_like(pl[rows]),
+                     -torch.ones_like(sk[rows]), mask[rows]], dim=-1)
+    want = F.pad(torch.cat([neg, pos]), (0, 32 - 15)).double()
+    worst = max(worst, rel_l2(val, want))
+    lat_after = lat.clone()
+    lat_after[rows[cond.bool()]] = pv[rows[cond.bool()]]
+    assert torch.equal(dlat.cpu(), lat_after), "aliasing side effect: cond rows of the latents take the image latents"
+    # CFG + DDIM (epsilon and v prediction) and the linear multistep row
+    eps = torch.randn(2 * F_, HW, 4, generator=g)
+    coef = torch.rand(F_, 4, generator=g) * 0.8 + 0.1
+    for vpred in (False, True):
+        d2 = lat_after.clone().cuda()
+        ops.cfg_ddim_step(d2, eps.cuda(), coef.cuda(), cond.cuda(), True, 2.0, vpred, frame_idx=widx.cuda())
+        e = eps[:F_].double() + 2.0 * (eps[F_:].double() - eps[:F_].double())
+        xx = lat_after[rows].double()
+        sa, sb, sap, sbp = (coef[:, i].double()[:, None, None] for i in range(4))
+        x0, ee = ((sa * xx - sb * e, sa * e + sb * xx) if vpred else ((xx - sb * e) / sa, e))
+        new = sap * x0 + sbp * ee
+        ref = lat_after.clone().double()
+        ref[rows[~cond.bool()]] = new[~cond.bool()]
+        worst = max(worst, rel_l2(d2.cpu().double(), ref))
+    c8 = torch.rand(F_, 8, generator=g)
+    d3, p3 = lat_after.clone().cuda(), torch.randn(N, HW, 4, generator=g)
+    dp = p3.clone().cuda()
+    ops.cfg_linear_step(d3, dp, eps.cuda(), c8.cuda(), cond.cuda(), True, 2.0, frame_idx=widx.cuda())
+    m = eps[:F_].double() + 2.0 * (eps[F_:].double() - eps[:F_].double())
+    a, b, c, dd, ee = (c8[:, i].double()[:, None, None] for i in range(5))
+    xx, pp = lat_after[rows].double(), p3[rows].double()
+    ref_x, ref_p = lat_after.clone().double(), p3.clone().double()
+    ref_x[rows[~cond.bool()]] = (a * xx + b * m + c * pp)[~cond.bool()]
+    ref_p[rows[~cond.bool()]] = (dd * xx + ee * m)[~cond.bool()]
+    worst = max(worst, rel_l2(d3.cpu().double(), ref_x), rel_l2(dp.cpu().double(), ref_p))
+    # posterior sample
+    mom, nz = torch.randn(5, 7, 8, generator=g), torch.randn(5, 7, 4, generator=g)
+    z = ops.vae_sample(mom.cuda(), nz.cuda(), 4, 0.18215).cpu().double()
+    ref = (mom[..., :4].double() + torch.exp(0.5 * mom[..., 4:].double().clamp(-30, 20)) * nz.double()) * 0.18215
+    worst = max(worst, rel_l2(z, ref))
+    # resize (bilinear / nearest), postprocess, layout
+    img = torch.randn(2, 6, 64, 48, generator=g)
+    for mode in ("bilinear", "nearest"):
+        o = ops.resize_to_nhwc(img.cuda(), (8, 6), mode, out_f32=True).cpu().permute(0, 3, 1, 2).double()
+        worst = max(worst, rel_l2(o, F.interpolate(img.double(), size=(8, 6), mode=mode)))
+    y = torch.randn(2, 5, 7, 8, generator=g)
+    worst = max(worst, rel_l2(ops.postprocess_images(y.cuda(), 3).cpu().double(), (y[..., :3].double() / 2 + 0.5).clamp(0, 1).permute(0, 3, 1, 2)))
+    assert torch.equal(ops.nhwc_to_nchw(y.cuda(), 6).cpu(), y[..., :6].permute(0, 3, 1, 2).contiguous())
+    # timestep embedding: fp32 trigonometry of arguments up to 1000 -- the comparison is against the fp64 formula, so the bound is
+    # the argument's fp32 resolution (6e-5 at t = 999), not the output format
+    t = torch.tensor([0.0, 1.0, 37.0, 999.0])
+    emb = ops.timestep_embedding(t.cuda(), 320, True, 0.0, out_f32=True).cpu().double()
+    k = torch.arange(160, dtype=torch.float64)
+    arg = t.double()[:, None] * torch.exp(-math.log(10000.0) * k / 160.0)[None]
+    e_t = rel_l2(emb, torch.cat([torch.cos(arg), torch.sin(arg)], dim=1))
+    assert e_t < 2e-4, e_t
+    del np
+    return worst, e_t
+
+
 CASES = {
     # --- GEMM: every tile config, tails, epilogues -------------------------------------------
     "gemm_256x128_plain": (case_gemm, dict(M=1024, N=256, K=320)),
@@ -687,6 +926,44 @@ CASES = {
     "pack_ddim_cfg_eps": (case_pack_ddim, dict(F_=16, HW=45, use_cfg=True, vpred=False)),
     "pack_ddim_nocfg_v": (case_pack_ddim, dict(F_=8, HW=30, use_cfg=False, vpred=True)),
     "pack_ddim_noskel": (case_pack_ddim, dict(F_=8, HW=30, use_cfg=True, vpred=False, skel=False)),
+    # --- parity precision: fp32 tensors, two-term operands (TOL_PAR) ---------------------------------------------------------
+    "par_split": (case_par_split, dict()),
+    "par_split_concat_pad_scale": (case_par_split, dict(M=77, C1=4, C2=0, cpad=32, scale=1.0 / 0.18215)),
+    "par_split_two_sources": (case_par_split, dict(M=333, C1=64, C2=32)),
+    "par_split_silu": (case_par_split, dict(M=64, C1=320, silu=True)),
+    "par_split_pattern1": (case_par_split, dict(M=100, C1=64, pattern=1)),
+    "par_split_pattern2_transposed_pad": (case_par_split, dict(M=64, C1=45, cpad=64, pattern=2, transposed=True)),
+    "par_gemm_resid": (case_par_gemm, dict(M=1000, N=320, K=320, residual=True)),
+    "par_gemm_rowbias_tails": (case_par_gemm, dict(M=333, N=200, K=96, residual=True, rowbias=True)),
+    "par_gemm_n4": (case_par_gemm, dict(M=500, N=4, K=288)),
+    "par_gemm_geglu_split": (case_par_gemm, dict(M=700, N=1280, K=320, geglu=True, split_out=True)),
+    "par_gemm_silu_split": (case_par_gemm, dict(M=32, N=1280, K=320, silu=True, split_out=True)),
+    "par_gemm_qkv_split": (case_par_gemm, dict(M=2880, N=960, K=320, bias=False, split_out=True)),
+    "par_gemm_tall_n320": (case_par_gemm, dict(M=256 * 257 + 40, N=320, K=320, residual=True)),
+    "par_gemm_deep": (case_par_gemm, dict(M=1440, N=1280, K=5120, residual=True)),
+    "par_conv_l0": (case_par_conv, dict(B=2, H=72, W=40, Cin=320, Cout=320, rowbias=True)),
+    "par_conv_resid_scale": (case_par_conv, dict(B=2, H=36, W=20, Cin=640, Cout=640, residual=True, scale=0.5)),
+    "par_conv_in": (case_par_conv, dict(B=3, H=24, W=16, Cin=32, Cout=320)),
+    "par_conv_out4": (case_par_conv, dict(B=2, H=24, W=16, Cin=320, Cout=4)),
+    "par_conv_9x5_deep": (case_par_conv, dict(B=4, H=9, W=5, Cin=1280, Cout=1280, rowbias=True, residual=True)),
+    "par_conv_stride2": (case_par_conv, dict(B=2, H=36, W=20, Cin=320, Cout=320, stride=2)),
+    "par_conv_stride2_vae_pad": (case_par_conv, dict(B=2, H=32, W=24, Cin=128, Cout=128, stride=2, pad=0, pad_hi=1)),
+    "par_conv_upsample": (case_par_conv, dict(B=2, H=18, W=10, Cin=640, Cout=640, upsample=True)),
+    "par_gn_silu": (case_par_groupnorm, dict(B=3, HW=720, C1=320)),
+    "par_gn_two_sources": (case_par_groupnorm, dict(B=2, HW=180, C1=1280, C2=640)),
+    "par_gn_vae_128ch_eps6": (case_par_groupnorm, dict(B=2, HW=4096, C1=128, eps=1e-6)),
+    "par_gn_mean_200sigma": (case_par_groupnorm, dict(B=2, HW=512, C1=64, groups=8, silu=False, mean_shift=400.0)),
+    "par_gn_nosilu_small": (case_par_groupnorm, dict(B=1, HW=45, C1=1280, silu=False, eps=1e-6)),
+    "par_ln": (case_par_layernorm, dict(M=1000, C=320)),
+    "par_ln_1280": (case_par_layernorm, dict(M=333, C=1280)),
+    "par_softmax": (case_par_softmax, dict(M=96, N=2880, Np=2880)),
+    "par_softmax_padded": (case_par_softmax, dict(M=33, N=1353, Np=1376)),
+    "par_attn_small": (case_par_attention, dict(batch=2, heads=3, L=200)),
+    "par_attn_tail": (case_par_attention, dict(batch=1, heads=2, L=333, seed=1)),
+    "par_attn_spike": (case_par_attention, dict(batch=1, heads=2, L=1000, spike=True, seed=2)),
+    "par_attn_large_logits": (case_par_attention, dict(batch=1, heads=1, L=512, qk_scale=3.0, seed=3)),
+    "par_attn_l0_2d": (case_par_attention, dict(batch=4, heads=5, L=2880, seed=4)),
+    "par_small_kernels": (case_par_small_kernels, dict()),
 }
 
 TOLS = {"plucker_576x320": 2e-3, "plucker_odd_ratio": 2e-3, "plucker_identity_size": 2e-3, "layout": 0.0, "temb": 6e-3, "attn_kv_split": 0.0, "attn_kv_split3": 0.0, "attn_qs_kv_split": 0.0,
@@ -696,7 +973,8 @@ TOLS = {"plucker_576x320": 2e-3, "plucker_odd_ratio": 2e-3, "plucker_identity_si
 def run_case(name):
     fn, kw = CASES[name]
     err, mx = fn(**kw)
-    return err, mx, TOLS.get(name, TOL)
+    default = (TOL_PAR_ATTN if name.startswith("par_attn") else TOL_PAR) if name.startswith("par_") else TOL
+    return err, mx, TOLS.get(name, default)
 
 
 def main():
