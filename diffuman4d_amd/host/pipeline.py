@@ -162,6 +162,13 @@ class Diffuman4DPipeline:
         lat = self._to_dev_nhwc(latents)  # init_noise_sigma == 1 for DDIM
         return pv_lat, pl_lat, sk_lat, cm_lat, lat
 
+    def seeded_noise(self, seed: int, n: int, h: int, w: int, need_latents: bool = True) -> Dict[str, torch.Tensor]:
+        """The task's random draws (VAE posterior samples of the images and the skeleton maps, initial latents) from a generator of
+        this device seeded with `seed`: the same numbers on every rank that passes the same seed (frame-shard groups)."""
+        g = torch.Generator(device=self._device).manual_seed(seed)
+        keys = ("pixel", "skeleton") + (("latents",) if need_latents else ())
+        return {k: torch.randn((n, 4, h, w), generator=g, device=self._device, dtype=torch.float32) for k in keys}
+
     # ------------------------------------------------------------------------------------------
     def upload_plan(self, plan: SweepPlan, guidance_scale: float, shard=None, copies: int = 1, rows_per_task: int = 0):
         """Host plan -> device index / timestep / coefficient tables (one H2D each, no syncs later).
@@ -277,13 +284,16 @@ class Diffuman4DPipeline:
                                   sliding_stride: int = 1, sliding_shift: int = 0, bidirectional: bool = True,
                                   num_denoising_steps: int = 1, alternation_rounds: int = 3, guidance_scale: float = 2.0,
                                   tqdm: Callable = _identity_tqdm, noise: Optional[Dict] = None, cache_keys=None,
-                                  decode: str = "all", cameras: Optional[Dict] = None):
+                                  decode: str = "all", cameras: Optional[Dict] = None, shard=None, noise_seed: Optional[int] = None):
         """Same contract as pipeline_diffuman4d.py:439-559 (inputs are not mutated).
         Extensions, off by default (= the reference's behaviour): `noise` injects the random draws; `cache_keys`
         (one hashable per frame) reuses VAE encoder moments across calls; `decode="denoised"` runs the VAE decoder
         only for fully denoised rows -- the only ones the sampler saves (sampling_utils.py:103-104) -- and returns
         zero images for the rest; `cameras` (with plucker_embeds=None) evaluates the Pluecker maps on the device at latent
-        resolution (see prepare_all_latents)."""
+        resolution (see prepare_all_latents); `shard` (parallel.FrameShard): the ranks of its group run THIS task together, every
+        window call split over them by frames with K/V all-gathers in the 3-D attention layers -- every rank
+        passes the same arguments and gets the same result; `noise_seed`: the random draws come from a device generator seeded
+        with it instead of the global one, so that the ranks of a shard group draw the same numbers."""
         if decode not in ("all", "denoised"):
             raise ValueError("decode must be 'all' or 'denoised'")
         if self.vae is None:
@@ -292,9 +302,12 @@ class Diffuman4DPipeline:
         cond_flags = (cond_masks[:, 0, 0, 0] == 0.0).cpu().numpy()
         plan = plan_sweep(cond_flags, torch.as_tensor(timestep_indices).cpu().numpy(), domain, window_size,
                           sliding_stride, sliding_shift, bidirectional, num_denoising_steps, alternation_rounds)
+        if noise_seed is not None and noise is None:
+            noise = self.seeded_noise(int(noise_seed), pixel_values.shape[0], pixel_values.shape[-2] // self.vae_scale_factor,
+                                      pixel_values.shape[-1] // self.vae_scale_factor, need_latents=latents is None)
         pv_lat, pl_lat, sk_lat, cm_lat, lat = self.prepare_all_latents(pixel_values, plucker_embeds, skeletons,
                                                                        cond_masks, latents, noise, cache_keys, cameras)
-        self.denoise_latents(pv_lat, pl_lat, sk_lat, cm_lat, lat, plan, domain, guidance_scale, tqdm)
+        self.denoise_latents(pv_lat, pl_lat, sk_lat, cm_lat, lat, plan, domain, guidance_scale, tqdm, shard=shard)
         tidx = torch.from_numpy(plan.final_timestep_indices)
         rows = (tidx == plan.num_inference_steps) if decode == "denoised" else None
         images = self.vae.decode_to_images(lat, rows=rows)  # [N,3,H,W] in [0,1]

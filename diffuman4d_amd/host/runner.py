@@ -211,12 +211,29 @@ class DistributedSamplingRunner:
     its next tasks read), so the balance is applied between rounds instead of inside them: every rank measures its task rate,
     the rates are all-gathered at the round boundary and `balance=True` deals the next round's tasks in proportion to them
     (`weighted_deal`: a pure function of the gathered numbers, so the replicated bookkeeping stays in agreement).  Rates within
-    10 % of each other are treated as equal, which reproduces the round-robin deal exactly."""
+    10 % of each other are treated as equal, which reproduces the round-robin deal exactly.
+
+    Modes (``runner.mode`` of inference.py; the scheduling seam is the reference's runner, sampling_runner.py:26-62):
+      * ``task`` (default): every task runs on one rank, as above.
+      * ``frame-shard``: every task runs on ALL ranks together -- each window call split over them by frames, K/V all-gathered inside
+        the 3-D attention layers (parallel.FrameShard; BASELINE.json configs[3]).  The grid stays replicated, the
+        exchange has nothing to send.  The latency mode: one task finishes world times sooner, throughput is lower.
+      * ``hybrid``: full waves of a round run task-parallel; when the LAST wave would leave at least half of the ranks idle
+        (r = tasks mod world, 0 < r <= world / 2 -- the 44-camera temporal round on 8 GPUs: 5 waves + 4 tasks) those r tasks run
+        frame-sharded on r sub-groups of P = world / r ranks (P a power of two dividing the window's frame count) instead of on r
+        single ranks beside world - r idle ones.  Also what a round with fewer tasks than ranks gets.
+    Ranks of a group pass identical arguments (same sample, a task-derived noise seed), the group leader alone writes results."""
+
+    MODES = ("task", "frame-shard", "hybrid")
 
     def __init__(self, sampler: SlidingIterativeSampler, group=None, prefetch_depth: int = 2, writers: int = 2,
-                 gpu_streams: int = 2, balance: bool = True, writer_processes: int = 0):
+                 gpu_streams: int = 2, balance: bool = True, writer_processes: int = 0, mode: str = "task"):
         import torch.distributed as dist
+        if mode not in self.MODES:
+            raise ValueError(f"Unsupported runner mode: {mode}. Supported modes are {', '.join(self.MODES)}.")
         self.dist = dist
+        self.mode = mode
+        self._subgroups: Dict[int, list] = {}  # P -> [(ranks, process group)] in sub-group order
         self.sampler = sampler
         self.prefetch_depth, self.writers, self.gpu_streams = prefetch_depth, writers, gpu_streams
         self.writer_processes = writer_processes
@@ -243,9 +260,62 @@ class DistributedSamplingRunner:
             out[r].append(k)
         return out
 
+    # -- which tasks of a round run alone on a rank ("main") and which on a group of ranks ("tail") ------------------------
+    def _window_frames(self, domain: str) -> int:
+        """Frames of one window call: the quantity a shard group divides (spatial: inputs + window, temporal: 2 x window)."""
+        s = self.sampler
+        return s.sweep.window_size + (len(s.input_spa_labels) if domain == "spatial" else s.sweep.window_size)
+
+    def _split_round(self, round_index: int) -> Tuple[List[dict], List[dict], int]:
+        """(main tasks, tail tasks, ranks per tail task) -- a pure function of the task lists, the world size and the mode."""
+        tasks = self.sampler.all_tasks[round_index]
+        if self.mode == "task" or self.world == 1 or not tasks:
+            return tasks, [], 1
+        frames = self._window_frames(tasks[0]["domain"])
+        if self.mode == "frame-shard":
+            if frames % self.world != 0:
+                raise ValueError(f"runner mode 'frame-shard': a window of {frames} frames cannot be split over {self.world} ranks")
+            return [], tasks, self.world
+        r = len(tasks) % self.world
+        if r == 0 or 2 * r > self.world:
+            return tasks, [], 1
+        width = 1
+        while width * 2 <= self.world // r and self.world % (width * 2) == 0 and frames % (width * 2) == 0:
+            width *= 2
+        if width == 1:
+            return tasks, [], 1
+        return tasks[:len(tasks) - r], tasks[len(tasks) - r:], width
+
+    def _group_ranks(self, width: int, g: int) -> List[int]:
+        return list(range(g * width, (g + 1) * width))
+
+    def tail_of(self, round_index: int) -> List[Tuple[dict, List[int]]]:
+        """(task, ranks that run it together) for the round's tail tasks; tail task k goes to sub-group k mod (world / width)."""
+        _, tail, width = self._split_round(round_index)
+        n_groups = self.world // width
+        return [(t, self._group_ranks(width, k % n_groups)) for k, t in enumerate(tail)]
+
+    def _subgroup(self, ranks: List[int]):
+        """The process group of a set of consecutive ranks.  Groups of one width are created together, by every rank, in sub-group
+        order the first time that width is needed (new_group is collective over the default group)."""
+        width = len(ranks)
+        if width == self.world:
+            return self.group
+        if width not in self._subgroups:
+            base = self.dist.get_process_group_ranks(self.group) if self.group is not None else list(range(self.world))
+            self._subgroups[width] = [(self._group_ranks(width, g), self.dist.new_group([base[r] for r in self._group_ranks(width, g)]))
+                                      for g in range(self.world // width)]
+        return next(grp for rk, grp in self._subgroups[width] if rk == ranks)
+
     def tasks_of(self, round_index: int, rank: int) -> List[dict]:
+        """The tasks `rank` runs ALONE in the round (its share of the main tasks)."""
         a = self._assign.get(round_index)
-        return a[rank] if a is not None else self.sampler.partition(round_index, rank, self.world)
+        if a is not None:
+            return a[rank]
+        main = self._split_round(round_index)[0]
+        if len(main) == len(self.sampler.all_tasks[round_index]):
+            return self.sampler.partition(round_index, rank, self.world)
+        return main[rank::self.world]
 
     def _plan_next_round(self, round_index: int, seconds: float, n_done: int) -> None:
         """Gather (seconds, tasks) of the round that just ran and deal round_index + 1 accordingly."""
@@ -261,7 +331,7 @@ class DistributedSamplingRunner:
             # ranks without a (long enough) round keep their last rate; 10 % steps: noise does not reshuffle the deal
             self.rates = [max(0.1, round((n / t) / mean, 1)) if good else self.rates[q]
                           for q, ((t, n), good) in enumerate(zip(stats, ok))]
-        tasks = self.sampler.all_tasks[nxt]
+        tasks = self._split_round(nxt)[0]  # the tasks that run on single ranks; a tail (hybrid / frame-shard) is dealt to groups
         self._assign[nxt] = [[tasks[k] for k in idx] for idx in self.weighted_deal(len(tasks), self.rates)]
 
     def _input_camera_of(self, target_label: str) -> str:
@@ -285,7 +355,8 @@ class DistributedSamplingRunner:
         as data -- any rank's copy will do.)"""
         s = self.sampler
         cells = []
-        for t in self.tasks_of(round_index, rank):
+        mine = self.tasks_of(round_index, rank) + [t for t, ranks in self.tail_of(round_index) if ranks[0] == rank]  # group leaders own
+        for t in mine:
             if t["domain"] == "spatial":
                 cells += [(c, t["domain_label"]) for c in s.target_spa_labels]
             else:
@@ -300,6 +371,13 @@ class DistributedSamplingRunner:
                     w = self._written.get(cell)
                     if w is None or w[0] < round_index:
                         self._written[cell] = (round_index, r)
+                    self._holds[r][cell] = round_index
+        for t, ranks in self.tail_of(round_index):  # every rank of the group ends the task with the same cells; the leader sends
+            for cell in self._task_cells(t):
+                w = self._written.get(cell)
+                if w is None or w[0] < round_index:
+                    self._written[cell] = (round_index, ranks[0])
+                for r in ranks:
                     self._holds[r][cell] = round_index
 
     def _cell_proto(self):
@@ -332,7 +410,7 @@ class DistributedSamplingRunner:
         recv_cells: Dict[int, list] = {q: [] for q in range(self.world)}
         for q in range(self.world):
             need = set()
-            for t in self.tasks_of(round_index + 1, q):
+            for t in self.tasks_of(round_index + 1, q) + [t for t, ranks in self.tail_of(round_index + 1) if q in ranks]:
                 need.update(self._task_cells(t))
             for cell in sorted(need):  # deterministic cell order on both sides of every pair
                 w = self._written.get(cell)
@@ -371,6 +449,20 @@ class DistributedSamplingRunner:
                 s.latents[c][t] = buf[k]
                 s.timestep_indices[c][t] = int(idx[k])
 
+    def _run_sharded(self, task: dict, ranks: List[int], group) -> None:
+        """One task on the ranks of `group`: same sample and noise seed everywhere, every window call split by frames
+        (parallel.FrameShard), one task at a time (collectives have to be issued in one order); the leader writes the results."""
+        from .parallel import FrameShard
+        s = self.sampler
+        keep = s.result_writer
+        s.frame_shard = FrameShard(group)
+        if self.rank != ranks[0]:
+            s.result_writer = None
+        try:
+            s.execute_one_task(task)
+        finally:
+            s.frame_shard, s.result_writer = None, keep
+
     def inference(self):
         s = self.sampler
         import time
@@ -381,6 +473,10 @@ class DistributedSamplingRunner:
                 t0 = time.perf_counter()
                 run_round_pipelined(s, mine, 0, self.prefetch_depth, self.writers, self.gpu_streams, pool)
                 dt = time.perf_counter() - t0
+                for task, ranks in self.tail_of(ri):  # the round's tail: tasks a group of ranks runs together, frame-sharded
+                    grp = self._subgroup(ranks)       # (collective over all ranks the first time a width is used)
+                    if self.rank in ranks:
+                        self._run_sharded(task, ranks, grp)
                 self._plan_next_round(ri, dt, len(mine))  # before the exchange: it ships what the NEXT deal reads
                 self.dist.barrier(self.group)
                 self.exchange(ri)

@@ -84,6 +84,10 @@ class SlidingIterativeSampler:
             raise ValueError("decode_policy must be 'all' or 'denoised'")
         self.vae_cache, self.decode_policy = bool(vae_cache), decode_policy
         self.plucker_on_device = bool(plucker_on_device)
+        # set by DistributedSamplingRunner (modes "frame-shard" / "hybrid") around the tasks a GROUP of ranks runs together: the
+        # parallel.FrameShard of that group, handed to the pipeline with a task-derived noise seed so that the group draws alike
+        self.frame_shard = None
+        self.noise_base_seed = 0
         if self.vae_cache:  # the cache is keyed by (camera, frame) of ONE scene
             for pipe in pipelines:
                 pipe.clear_vae_cache()
@@ -232,7 +236,14 @@ class SlidingIterativeSampler:
             kw["cache_keys"] = [(spa, tem) for _, spa, tem in sample["labels"]]
         if self.decode_policy != "all":
             kw["decode"] = self.decode_policy
+        if self.frame_shard is not None:
+            kw["shard"] = self.frame_shard
+            kw["noise_seed"] = self.task_noise_seed(sample["alt"], sample["domain"], sample["domain_label"])
         return kw
+
+    def task_noise_seed(self, alt: int, domain: str, domain_label: str) -> int:
+        """A seed every rank derives alike for one task (a pure function of the task's identity and `noise_base_seed`)."""
+        return (int(self.noise_base_seed) * 1000003 + int(alt) * 100003 + (0 if domain == "spatial" else 50021) + int(domain_label)) % (2 ** 31 - 1)
 
     def execute_one_task(self, task: dict, pipe_idx: int = 0) -> dict:
         sample = self.denoise(self.load_sample(**task), pipe_idx=pipe_idx)

@@ -49,7 +49,12 @@ def inference(cfg: dict):
     ht = (cfg.get("runner") or {}).get("host_threads")
     if ht:
         torch.set_num_threads(max(1, int(ht)))
-    runner = DistributedSamplingRunner(sampler, **rk) if distributed else SamplingRunner(sampler, **rk)
+    # runner.mode=task|frame-shard|hybrid (one process per GPU only): how a round's tasks meet the ranks -- one rank per task, all
+    # ranks on every task (in-window frame sharding, RCCL K/V all-gather), or task-parallel waves with a frame-sharded tail
+    mode = str((cfg.get("runner") or {}).get("mode", "task"))
+    if not distributed and mode != "task":
+        raise ValueError(f"runner.mode={mode} needs one process per GPU (torchrun --nproc-per-node N)")
+    runner = DistributedSamplingRunner(sampler, mode=mode, **rk) if distributed else SamplingRunner(sampler, **rk)
     if cfg.get("sampling", True):
         runner.inference()
     if cfg.get("to_nerfstudio") or cfg.get("evaluating"):

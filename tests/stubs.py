@@ -30,3 +30,35 @@ class StubPipeline:
         tidx = torch.from_numpy(plan.final_timestep_indices)
         return {"images": torch.zeros(n, 3, 8 * self.h, 8 * self.w), "latents": lat, "timestep_indices": tidx,
                 "fully_denoised": tidx == plan.num_inference_steps}
+
+
+class ShardStubPipeline(StubPipeline):
+    """StubPipeline that also takes the runner's frame-shard extensions: with `shard` (parallel.FrameShard) every rank of the
+    group updates ITS frames of each window and the rows are all-gathered (a real collective of the test's backend), as
+    Diffuman4DPipeline.denoise_latents does; the result must equal the unsharded stub's on every rank of the group."""
+
+    def sliding_iterative_denoise(self, pixel_values, plucker_embeds, skeletons, cond_masks, latents, domain,
+                                  timestep_indices, window_size, sliding_stride, sliding_shift, bidirectional,
+                                  num_denoising_steps, alternation_rounds, guidance_scale, tqdm=None, shard=None, noise_seed=None):
+        if shard is None:
+            return super().sliding_iterative_denoise(pixel_values, plucker_embeds, skeletons, cond_masks, latents, domain,
+                                                     timestep_indices, window_size, sliding_stride, sliding_shift, bidirectional,
+                                                     num_denoising_steps, alternation_rounds, guidance_scale, tqdm)
+        assert noise_seed is not None, "a shard group must be handed a common noise seed"
+        n = pixel_values.shape[0]
+        cond = (cond_masks[:, 0, 0, 0] == 0).tolist()
+        plan = plan_sweep(cond, timestep_indices.tolist(), domain, window_size, sliding_stride, sliding_shift,
+                          bidirectional, num_denoising_steps, alternation_rounds)
+        self.calls.append({"latents_was_none": latents is None, "domain": domain, "n": n, "sharded": shard.world, "noise_seed": noise_seed,
+                           "cond_rows": [i for i, c in enumerate(cond) if c]})
+        lat = torch.zeros(n, 4, self.h, self.w) if latents is None else latents.clone().float()
+        for w, c in zip(plan.windows, plan.is_cond):
+            sl = shard.local_frames(len(w))
+            wl, cl = torch.as_tensor(w[sl]), torch.as_tensor(c[sl])
+            new = lat[wl].clone()
+            new[cl] = -1.0
+            new[~cl] += 1.0
+            lat[torch.as_tensor(w)] = shard.gather_rows(new)
+        tidx = torch.from_numpy(plan.final_timestep_indices)
+        return {"images": torch.zeros(n, 3, 8 * self.h, 8 * self.w), "latents": lat, "timestep_indices": tidx,
+                "fully_denoised": tidx == plan.num_inference_steps}
