@@ -310,6 +310,47 @@ __global__ void plucker_latent_kernel(const float* cams, T* Y, int N, int H, int
   for (int k = 0; k < 6; ++k) stv(y + k, hy * (hx * a.v[k] + lx * b.v[k]) + ly * (hx * c.v[k] + lx * d.v[k]));
 }
 
+// F.interpolate(x, size=(h, w), mode="bilinear", antialias=True, align_corners=False) on fp32 NCHW planes: the down-scale of the
+// result writer's snapshot mosaic (sampling_utils.py:70-93 resizes the grid with torchvision's antialiased `resize`).  PIL's /
+// ATen's separable triangle filter: output i covers [c - s, c + s) around c = scale (i + 0.5) with support s = max(scale, 1);
+// tap j has weight max(0, 1 - |(j + 0.5 - c) / max(scale, 1)|), normalised per axis.  One thread per output pixel.
+__device__ __forceinline__ void aa_span(int i, float scale, int in_size, int& lo, int& n, float& center, float& inv) {
+  const float support = scale >= 1.0f ? scale : 1.0f;
+  inv = scale >= 1.0f ? 1.0f / scale : 1.0f;
+  center = scale * ((float)i + 0.5f);
+  lo = max((int)(center - support + 0.5f), 0);
+  n = min((int)(center + support + 0.5f), in_size) - lo;
+}
+__device__ __forceinline__ float aa_weight(int j, int lo, float center, float inv) {
+  const float x = fabsf(((float)(j + lo) - center + 0.5f) * inv);
+  return x < 1.0f ? 1.0f - x : 0.0f;
+}
+__global__ void resize_aa_kernel(const float* X, float* Y, int64_t planes, int H, int W, int h, int w) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over planes * h * w
+  if (i >= planes * h * w) return;
+  const int ox = (int)(i % w);
+  const int64_t r = i / w;
+  const int oy = (int)(r % h);
+  const float* src = X + (r / h) * (int64_t)H * W;
+  const float sy = (float)H / (float)h, sx = (float)W / (float)w;
+  int y0, ny, x0, nx;
+  float cy, iy, cx, ix;
+  aa_span(oy, sy, H, y0, ny, cy, iy);
+  aa_span(ox, sx, W, x0, nx, cx, ix);
+  float wy_sum = 0.f, wx_sum = 0.f;
+  for (int j = 0; j < ny; ++j) wy_sum += aa_weight(j, y0, cy, iy);
+  for (int k = 0; k < nx; ++k) wx_sum += aa_weight(k, x0, cx, ix);
+  float acc = 0.f;
+  for (int j = 0; j < ny; ++j) {
+    const float wy = aa_weight(j, y0, cy, iy) / wy_sum;
+    const float* row = src + (int64_t)(y0 + j) * W + x0;
+    float racc = 0.f;
+    for (int k = 0; k < nx; ++k) racc += (aa_weight(k, x0, cx, ix) / wx_sum) * row[k];
+    acc += wy * racc;
+  }
+  Y[i] = acc;
+}
+
 inline dim3 grid1d(int64_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
 
 }  // namespace
@@ -488,4 +529,10 @@ extern "C" int dm4d_plucker_latent_bf16(void* stream, const float* cams, void* Y
 }
 extern "C" int dm4d_plucker_latent_f32(void* stream, const float* cams, float* Y, int N, int H, int W, int h, int w) {
   return plucker_impl<float>(stream, cams, Y, N, H, W, h, w);
+}
+
+extern "C" int dm4d_resize_aa_nchw_f32(void* stream, const float* X, float* Y, int64_t planes, int H, int W, int h, int w) {
+  if (!X || !Y || planes <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0) return dm4d_set_error(DM4D_ERR_ARG, "resize_aa: bad arguments");
+  hipLaunchKernelGGL(resize_aa_kernel, grid1d(planes * h * w, 256), dim3(256), 0, (hipStream_t)stream, X, Y, planes, H, W, h, w);
+  return dm4d_check_launch("resize_aa_kernel");
 }

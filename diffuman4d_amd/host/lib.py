@@ -45,6 +45,7 @@ SIGNATURES = {
     "dm4d_resize_nchw_f32_to_nhwc_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
     "dm4d_plucker_latent_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "dm4d_postprocess_images_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),
+    "dm4d_resize_aa_nchw_f32": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _i]),
     "dm4d_conv_up2x_prepare_bf16": (_i, [_vp, _vp, _vp, _i, _i]),
     "dm4d_conv_up2x_nhwc_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "dm4d_ff_geglu_prepare_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i]),

@@ -73,7 +73,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
     assert out.shape[1] >= ocols or out.stride(0) >= ocols
     flags = ((_l.EPI_GEGLU if geglu else 0) | (_l.EPI_SILU if silu else 0) | (_l.EPI_F32OUT if out_f32 else 0)
              | (_l.EPI_F32SIDE if f32_side else 0) | (_l.EPI_SPLITOUT if split_out else 0))
-    with _Prof("linear", 2.0 * M * w.shape[0] * K, "flop"):
+    with _Prof("linear", 2.0 * M * w.shape[0] * K, "flop", M):
         rc = lib.dm4d_gemm_bf16(_stream(), _p(a), a.stride(0), _p(a2), a2.stride(0) if a2 is not None else 0,
                                 K1 if a2 is not None else 0, _p(w), w.stride(0), _p(out), out.stride(0), M, N, K,
                                 _p(bias), _p(rowbias), rowbias.stride(0) if rowbias is not None else 0,
@@ -112,7 +112,7 @@ def conv3x3(x: torch.Tensor, wt: torch.Tensor, *, bias=None, rowbias=None, resid
         _req(rowbias, "rowbias", side)
         assert rowbias.shape[0] == B
     if out_f32:
-        with _Prof("conv3x3", 2.0 * B * Ho * Wo * 9 * Cin * Cout, "flop"):
+        with _Prof("conv3x3", 2.0 * B * Ho * Wo * 9 * Cin * Cout, "flop", B * Ho * Wo):
             rc = lib.dm4d_conv3x3_nhwc_bf16_flags(_stream(), _p(x), B, H, W, Cin, _p(wt), _p(y), Ho, Wo, Cout, stride, pad,
                                                   1 if upsample else 0, _p(bias), _p(rowbias),
                                                   rowbias.stride(0) if rowbias is not None else 0, _p(residual),
@@ -122,7 +122,7 @@ def conv3x3(x: torch.Tensor, wt: torch.Tensor, *, bias=None, rowbias=None, resid
     # small images with a deep K (the 9x5 level) run split over the three kernel rows and need an fp32 workspace
     ws_bytes = lib.dm4d_conv3x3_ws_bytes(B, H, W, Cin, Ho, Wo, Cout, stride, pad, 1 if upsample else 0)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device) if ws_bytes else None
-    with _Prof("conv3x3", 2.0 * B * Ho * Wo * 9 * Cin * Cout, "flop"):
+    with _Prof("conv3x3", 2.0 * B * Ho * Wo * 9 * Cin * Cout, "flop", B * Ho * Wo):
         rc = lib.dm4d_conv3x3_nhwc_bf16_ws(_stream(), _p(x), B, H, W, Cin, _p(wt), _p(y), Ho, Wo, Cout, stride, pad,
                                            1 if upsample else 0, _p(bias), _p(rowbias),
                                            rowbias.stride(0) if rowbias is not None else 0, _p(residual),
@@ -218,7 +218,7 @@ class FeedForward:
         M = n.shape[0]
         out = torch.empty((M, self.C), dtype=BF16, device=n.device)
         w1p, b1p, w2p = self.packed
-        with _Prof("linear", 2.0 * M * 3 * self.hidden * self.C, "flop"):
+        with _Prof("linear", 2.0 * M * 3 * self.hidden * self.C, "flop", M):
             rc = lib.dm4d_ff_geglu_fused_bf16(_stream(), _p(n), n.stride(0), _p(ln[0]) if ln is not None else None,
                                               _p(ln[1]) if ln is not None else None, float(ln[2]) if ln is not None else 0.0, _p(w1p),
                                               _p(b1p), _p(w2p), _p(self.b2), _p(residual), residual.stride(0), _p(out), out.stride(0), M,
@@ -242,7 +242,7 @@ class FeedForward:
         M = a.shape[0]
         out = torch.empty((M, self.C), dtype=BF16, device=a.device)
         w1p, b1p, w2p = self.packed
-        with _Prof("linear", 2.0 * M * (3 * self.hidden + self.C) * self.C, "flop"):
+        with _Prof("linear", 2.0 * M * (3 * self.hidden + self.C) * self.C, "flop", M):
             rc = lib.dm4d_attn_out_ff_geglu_fused_bf16(_stream(), _p(a), a.stride(0), _p(wo), _p(bo), _p(x), x.stride(0), _p(ln[0]),
                                                        _p(ln[1]), float(ln[2]), _p(w1p), _p(b1p), _p(w2p), _p(self.b2), _p(out),
                                                        out.stride(0), M, self.C, self.hidden)
@@ -306,7 +306,7 @@ def conv_up2x(x: torch.Tensor, wp: torch.Tensor, *, bias=None) -> torch.Tensor:
     assert wp.shape == (4, Cout, 4 * Cin), (wp.shape, Cin)
     y = torch.empty((B, 2 * H, 2 * W, Cout), dtype=BF16, device=x.device)
     # credited with the multiply-adds it executes (4 taps per output pixel), not the 9 of the op it replaces
-    with _Prof("conv3x3", 2.0 * B * 4 * H * W * 4 * Cin * Cout, "flop"):
+    with _Prof("conv3x3", 2.0 * B * 4 * H * W * 4 * Cin * Cout, "flop", B * 4 * H * W):
         rc = lib.dm4d_conv_up2x_nhwc_bf16(_stream(), _p(x), B, H, W, Cin, _p(wp), _p(y), Cout, _p(bias))
     _l.check(rc, "dm4d_conv_up2x_nhwc_bf16")
     return y
@@ -347,7 +347,7 @@ def groupnorm(x1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups:
         C2 = x2.shape[-1]
     y = torch.empty(x1.shape[:-1] + (C1 + C2,), dtype=BF16, device=x1.device)
     ws = torch.empty(lib.dm4d_groupnorm_ws_bytes(B, HW, groups) // 4, dtype=torch.float32, device=x1.device)
-    with _Prof("groupnorm", 2.0 * y.numel() * 2, "byte"):  # ALGORITHMIC bytes: read once + write once; the
+    with _Prof("groupnorm", 2.0 * y.numel() * 2, "byte", B * HW):  # ALGORITHMIC bytes: read once + write once; the
         # statistics pass re-reads the input (mostly from L2 / Infinity Cache), so the device moves up to 1.5x this
         rc = lib.dm4d_groupnorm_nhwc_bf16(_stream(), _p(x1), C1, _p(x2), C2, B, HW, groups, eps, _p(gamma), _p(beta),
                                           _p(y), 1 if silu else 0, _p(ws))
@@ -368,7 +368,7 @@ def _groupnorm_f32(x1, gamma, beta, groups, eps, x2, silu) -> torch.Tensor:
         C2 = x2.shape[-1]
     y = torch.empty(x1.shape[:-1] + (2 * (C1 + C2),), dtype=BF16, device=x1.device)
     ws = torch.empty(lib.dm4d_groupnorm_f32_ws_bytes(B, HW, groups) // 8, dtype=torch.float64, device=x1.device)
-    with _Prof("groupnorm", 6.0 * x1.numel() + (6.0 * x2.numel() if x2 is not None else 0.0), "byte"):  # 4 in + 2 hi + 2 lo... per element
+    with _Prof("groupnorm", 6.0 * x1.numel() + (6.0 * x2.numel() if x2 is not None else 0.0), "byte", B * HW):  # fp32 in + hi + lo out
         rc = lib.dm4d_groupnorm_nhwc_f32_split(_stream(), _p(x1), C1, _p(x2), C2, B, HW, groups, eps, _p(gamma), _p(beta), _p(y),
                                                1 if silu else 0, _p(ws))
     _l.check(rc, "dm4d_groupnorm_nhwc_f32_split")
@@ -383,14 +383,14 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
         x2 = x.reshape(-1, x.shape[-1])
         C = x2.shape[1]
         y = torch.empty((x2.shape[0], 2 * C), dtype=BF16, device=x.device)
-        with _Prof("layernorm", 8.0 * x2.numel(), "byte"):
+        with _Prof("layernorm", 8.0 * x2.numel(), "byte", x2.shape[0]):
             rc = lib.dm4d_layernorm_f32_split(_stream(), _p(x2), x2.stride(0), _p(gamma), _p(beta), _p(y), y.stride(0), x2.shape[0], C, eps)
         _l.check(rc, "dm4d_layernorm_f32_split")
         return y.view(x.shape[:-1] + (2 * C,))
     _req(x, "x"), _req(gamma, "gamma"), _req(beta, "beta")
     x2 = x.reshape(-1, x.shape[-1])
     y = torch.empty_like(x2)
-    with _Prof("layernorm", 2.0 * y.numel() * 2, "byte"):
+    with _Prof("layernorm", 2.0 * y.numel() * 2, "byte", x2.shape[0]):
         rc = lib.dm4d_layernorm_bf16(_stream(), _p(x2), x2.stride(0), _p(gamma), _p(beta), _p(y), y.stride(0), x2.shape[0],
                                      x2.shape[1], eps)
     _l.check(rc, "dm4d_layernorm_bf16")
@@ -419,7 +419,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, hea
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    with _Prof("attention", 4.0 * batch * heads * seq * kv_seq * 64, "flop"):
+    with _Prof("attention", 4.0 * batch * heads * seq * kv_seq * 64, "flop", batch * seq):
         if q_scaled:
             rc = lib.dm4d_attention_qscaled_kv_bf16(_stream(), _p(q), _p(k), _p(v), _p(out), q.stride(0), k.stride(0),
                                                     v.stride(0), out.stride(0), batch, heads, seq, kv_seq)
@@ -442,7 +442,7 @@ def attention_split(qkv: torch.Tensor, batch: int, heads: int, seq: int, scale: 
     C = heads * 64
     assert qkv.shape == (batch * seq, 6 * C), (qkv.shape, batch, seq, heads)
     out = torch.empty((batch * seq, 2 * C), dtype=BF16, device=qkv.device)
-    with _Prof("attention", 3 * 4.0 * batch * heads * seq * seq * 64, "flop"):  # three MFMA terms per product
+    with _Prof("attention", 3 * 4.0 * batch * heads * seq * seq * 64, "flop", batch * seq):  # three MFMA terms per product
         rc = lib.dm4d_attention_split_bf16(_stream(), _p(qkv), qkv.data_ptr() + 2 * C, qkv.data_ptr() + 4 * C, _p(out), qkv.stride(0),
                                            qkv.stride(0), qkv.stride(0), out.stride(0), 3 * C, 3 * C, 3 * C, C, batch, heads, seq, seq,
                                            0.125 if scale is None else scale)
@@ -466,16 +466,17 @@ def softmax_rows_split(s: torch.Tensor, scale: float, n: Optional[int] = None) -
 # bench.py sets this to a list to time individual launches with HIP events on the launch stream:
 # entries are (kernel, algorithmic flops, start_event, end_event).  None = no instrumentation.
 KERNEL_TIMER = None
-# Same idea for every kernel family (bench.py's untimed breakdown pass): entries are (family, work, unit, start, end)
-# with unit "flop" or "byte".  None = no instrumentation.
+# Same idea for every kernel family (bench.py's untimed breakdown pass): entries are (family, work, unit, start, end, rows)
+# with unit "flop" or "byte" and rows = output rows of the launch.  None = no instrumentation.
 PROFILE = None
 
 
 class _Prof:
     """with _Prof(family, work, unit): <one launch>   -- records two events when ops.PROFILE is a list."""
 
-    def __init__(self, family: str, work: float, unit: str):
+    def __init__(self, family: str, work: float, unit: str, rows: int = 0):
         self.args = (family, work, unit)
+        self.rows = int(rows)  # output rows (tokens / pixels) of the launch: bench.py derives the UNet level from it
         self.on = PROFILE is not None
 
     def __enter__(self):
@@ -487,7 +488,7 @@ class _Prof:
     def __exit__(self, *exc):
         if self.on:
             self.e1.record()
-            PROFILE.append(self.args + (self.e0, self.e1))
+            PROFILE.append(self.args + (self.e0, self.e1, self.rows))
         return False
 
 
@@ -649,6 +650,18 @@ def resize_to_nhwc(x: torch.Tensor, size: Tuple[int, int], mode: str, out_f32: b
     y = torch.empty((B, h, w, C), dtype=F32 if out_f32 else BF16, device=x.device)
     rc = (lib.dm4d_resize_nchw_f32_to_nhwc_f32 if out_f32 else lib.dm4d_resize_nchw_f32_to_nhwc_bf16)(_stream(), _p(x), _p(y), B, C, H, W, h, w, 1 if mode == "bilinear" else 0)
     _l.check(rc, "dm4d_resize_nchw_f32_to_nhwc_bf16")
+    return y
+
+
+def resize_aa(x: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
+    """F.interpolate(x, size=size, mode="bilinear", antialias=True) for fp32 NCHW on the device (the result writer's mosaic)."""
+    lib = _l.load()
+    _req(x, "x", F32)
+    assert x.is_contiguous() and x.ndim == 4
+    N, C, H, W = x.shape
+    h, w = size
+    y = torch.empty((N, C, h, w), dtype=F32, device=x.device)
+    _l.check(lib.dm4d_resize_aa_nchw_f32(_stream(), _p(x), _p(y), N * C, H, W, h, w), "dm4d_resize_aa_nchw_f32")
     return y
 
 

@@ -49,6 +49,9 @@ def _resize_smaller_edge(x: torch.Tensor, size: int) -> torch.Tensor:
         nh, nw = size, max(1, int(size * w / h))
     else:
         nh, nw = max(1, int(size * h / w)), size
+    if x.is_cuda:  # on the device: the library's kernel (the same separable triangle filter), no torch operator on the result path
+        from . import ops
+        return ops.resize_aa(x.float().contiguous(), (nh, nw))
     return torch.nn.functional.interpolate(x, size=(nh, nw), mode="bilinear", antialias=True, align_corners=False)
 
 

@@ -202,6 +202,11 @@ int dm4d_resize_nchw_f32_to_nhwc_bf16(void* stream, const float* X, void* Y, int
  *   inverse(camera-to-world pose)[:3]; Y [N, h*w, 6] bf16 = [ray direction | o x direction].                        */
 int dm4d_plucker_latent_bf16(void* stream, const float* cams, void* Y, int N, int H, int W, int h, int w);
 
+/* F.interpolate(size=(h, w), mode="bilinear", antialias=True) on `planes` fp32 H x W planes (NCHW with planes = N * C): the down-scale of
+ *   the result writer's snapshot mosaic (samplers/utils/sampling_utils.py:70-93 -> torchvision's antialiased resize); PIL's separable
+ *   triangle filter of support max(H / h, 1), normalised per axis.                                                            */
+int dm4d_resize_aa_nchw_f32(void* stream, const float* X, float* Y, int64_t planes, int H, int W, int h, int w);
+
 /* VaeImageProcessor.postprocess(do_denormalize): (x/2 + 0.5).clamp(0,1), NHWC(ldx) -> NCHW (:282-284)  */
 int dm4d_postprocess_images_bf16(void* stream, const void* X, void* Y, int B, int C, int HW, int ldx);
 

@@ -693,6 +693,16 @@ def case_par_attention(batch, heads, L, seed=0, spike=False, qk_scale=1.0):
     return rel_l2(got, ref), float((got - ref).abs().max())
 
 
+def case_resize_aa(N=3, C=3, H=576, W=320, h=306, w=170, seed=0):
+    """dm4d_resize_aa_nchw_f32 against F.interpolate(mode="bilinear", antialias=True) on the CPU (fp32 both; summation order differs)."""
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(N, C, H, W, generator=g)
+    ref = F.interpolate(x, size=(h, w), mode="bilinear", antialias=True, align_corners=False)
+    out = ops.resize_aa(x.cuda(), (h, w)).cpu()
+    return rel_l2(out, ref), float((out - ref).abs().max())
+
+
 def case_par_small_kernels(seed=0):
     """fp32 forms of the kernels around the UNet / VAE calls: pack (operand of conv_in), CFG + DDIM / linear multistep steps, posterior
     sample, resize, postprocess, layout, timestep embedding -- each against its torch formula in fp64 (worst rel-L2 returned)."""
@@ -964,9 +974,13 @@ CASES = {
     "par_attn_large_logits": (case_par_attention, dict(batch=1, heads=1, L=512, qk_scale=3.0, seed=3)),
     "par_attn_l0_2d": (case_par_attention, dict(batch=4, heads=5, L=2880, seed=4)),
     "par_small_kernels": (case_par_small_kernels, dict()),
+    # the result writer's antialiased down-scale (mosaic of a 48-view spatial task; of a 300-frame temporal task; an up-scale axis)
+    "resize_aa_spatial_mosaic": (case_resize_aa, dict()),
+    "resize_aa_temporal_mosaic": (case_resize_aa, dict(N=4, H=576, W=320, h=48, w=27)),
+    "resize_aa_mixed": (case_resize_aa, dict(N=2, C=1, H=50, W=30, h=17, w=45)),
 }
 
-TOLS = {"plucker_576x320": 2e-3, "plucker_odd_ratio": 2e-3, "plucker_identity_size": 2e-3, "layout": 0.0, "temb": 6e-3, "attn_kv_split": 0.0, "attn_kv_split3": 0.0, "attn_qs_kv_split": 0.0,
+TOLS = {"resize_aa_spatial_mosaic": 5e-5, "resize_aa_temporal_mosaic": 5e-5, "resize_aa_mixed": 5e-5, "plucker_576x320": 2e-3, "plucker_odd_ratio": 2e-3, "plucker_identity_size": 2e-3, "layout": 0.0, "temb": 6e-3, "attn_kv_split": 0.0, "attn_kv_split3": 0.0, "attn_qs_kv_split": 0.0,
         "conv_batch_invariance_l3": 0.0, "conv_batch_invariance_l2": 0.0}
 
 
