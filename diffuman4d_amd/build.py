@@ -25,12 +25,25 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
+STAMP = ROOT / "libdm4d.so.srchash"  # sha256 of the sources the shipped libdm4d.so was built from (travels with it; git-ignored)
+
+
+def source_hash() -> str:
+    """sha256 over every source, header and compile flag that goes into libdm4d.so."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted([CSRC / s for s in SOURCES] + list(CSRC.glob("*.h")) + list(INCLUDE.glob("*.h"))):
+        h.update(f.name.encode() + b"\0" + f.read_bytes() + b"\0")
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
-    if not LIB.exists():
+    """True unless libdm4d.so exists AND was built from exactly the sources in the tree: the content hash recorded at build time
+    must match (file times do not survive a copy to another machine, and a stale library must never be blessed)."""
+    if not LIB.exists() or not STAMP.exists():
         return True
-    t = LIB.stat().st_mtime
-    deps = [CSRC / s for s in SOURCES] + list(CSRC.glob("*.h")) + list(INCLUDE.glob("*.h"))
-    return any(d.stat().st_mtime > t for d in deps)
+    return STAMP.read_text().strip() != source_hash()
 
 
 def _stale(obj: Path, src: Path, headers) -> bool:
@@ -64,6 +77,10 @@ def build(force: bool = False, verbose: bool = True, defines=()) -> Path:
     with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1) or 1) as ex:
         list(ex.map(run, jobs))
     run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB)] + [str(objdir / (Path(s).stem + ".o")) for s in SOURCES])
+    if not defines:
+        STAMP.write_text(source_hash() + "\n")
+    elif STAMP.exists():
+        STAMP.unlink()  # a tuning build: never mistaken for the shipped library
     return LIB
 
 

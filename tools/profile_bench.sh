@@ -13,7 +13,7 @@ TAG=${1:-r01}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 # one task in flight: the bench's roofline figures come from its one-task-at-a-time pass, and with two task streams the
 # kernel intervals of different tasks overlap in the trace
-BENCH="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --task-streams 1 --no-grid-secondary --no-vae"
+BENCH="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --task-streams 1 --no-grid-secondary --no-vae --no-parity-precision --no-latent128"
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"
@@ -26,10 +26,14 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $C -d "$OUT" -o pmc_$C -- $BENCH > /dev/null 2> "$OUT.pmc_$C.err"
 done
 python tools/pmc_summary.py "$OUT" attn_kernel FETCH_SIZE WRITE_SIZE > gpurun_out/${TAG}_attn_traffic_pmc.json
+# the same HBM-traffic figures for the other MFMA families (strip convolutions, Linear layers, the fused level-0 block tail)
+for K in conv_strip2_kernel gemm_lin2_kernel ff_proj_fused_kernel gn_apply_kernel gn_stats_kernel; do
+  echo "== $K"; python tools/pmc_summary.py "$OUT" $K FETCH_SIZE WRITE_SIZE
+done > gpurun_out/${TAG}_other_traffic_pmc.txt 2>&1
 # 3. MFMA-busy cycles of the attention kernel against the cycles the chip actually clocked (its own pass, kernel trace only)
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT" -o pmc_MFMA -- $BENCH > /dev/null 2> "$OUT.pmc_MFMA.err"
 DBM=$(find "$OUT" -name "pmc_MFMA*results.db" | head -1)
 python tools/mfma_busy_summary.py "$DBM" attn_kernel > gpurun_out/${TAG}_attn_mfma_busy_pmc.json
-for K in conv_strip2_kernel gemm_lin2_kernel ff_fused_kernel; do python tools/mfma_busy_summary.py "$DBM" $K; done > gpurun_out/${TAG}_other_mfma_busy_pmc.txt
+for K in conv_strip2_kernel gemm_lin2_kernel ff_proj_fused_kernel; do python tools/mfma_busy_summary.py "$DBM" $K; done > gpurun_out/${TAG}_other_mfma_busy_pmc.txt
 head -12 gpurun_out/${TAG}_kernel_stats.txt
 cat gpurun_out/${TAG}_attn_traffic_pmc.json gpurun_out/${TAG}_attn_mfma_busy_pmc.json gpurun_out/${TAG}_other_mfma_busy_pmc.txt
