@@ -196,6 +196,149 @@ def unet_forward(m: UNetMultiviewConditionModel, sample: torch.Tensor, timestep:
     return r(_conv(m.conv_out, x, padding=1))
 
 
+# ------------------------------------------------------------------------------------------------------------------------------
+# AutoencoderKL and the pipeline around the UNet, with the fast path's roundings (diffuman4d_amd/host/vae.py, pipeline.py)
+# ------------------------------------------------------------------------------------------------------------------------------
+def vae_resnet(mod, x):
+    h = r(F.silu(_gn(mod.norm1, x)))
+    h = r(_conv(mod.conv1, h, padding=1))
+    h = r(F.silu(_gn(mod.norm2, h)))
+    sc = r(_conv(mod.conv_shortcut, x)) if mod.conv_shortcut is not None else x
+    return r((_conv(mod.conv2, h, padding=1) + sc) / mod.output_scale_factor)
+
+
+def vae_attention(mod, x, q_block: int = 2048):
+    """host/vae.py::_MidAttn: GroupNorm -> bf16; fused q/k/v projection -> bf16; LOGITS STAY fp32 (DM4D_EPI_F32OUT); the normalised
+    probabilities -> bf16 (dm4d_softmax_rows_f32in_bf16); P V -> bf16; output projection + residual -> bf16."""
+    b, c, h, w = x.shape
+    y = r(_gn(mod.group_norm, x)).view(b, c, h * w).transpose(1, 2)
+    q, k, v = r(_lin(mod.to_q, y)), r(_lin(mod.to_k, y)), r(_lin(mod.to_v, y))
+    o = torch.empty_like(q)
+    for bi in range(b):
+        for s0 in range(0, h * w, q_block):
+            p = r(torch.softmax((q[bi, s0:s0 + q_block] @ k[bi].T) * (float(c) ** -0.5), dim=-1))
+            o[bi, s0:s0 + q_block] = r(p @ v[bi])
+    out = _lin(mod.to_out[0], o)
+    return r(out.transpose(-1, -2).reshape(b, c, h, w) + x)
+
+
+def vae_mid(mod, x):
+    return vae_resnet(mod.resnets[1], vae_attention(mod.attentions[0], vae_resnet(mod.resnets[0], x)))
+
+
+@torch.no_grad()
+def vae_moments(v, images):
+    """oracle/vae.py::AutoencoderKL.moments with the fast path's roundings; images NCHW in [-1, 1]."""
+    e = v.encoder
+    x = r(_conv(e.conv_in, r(images.float()), padding=1))
+    for blk in e.down_blocks:
+        for res in blk.resnets:
+            x = vae_resnet(res, x)
+        if blk.downsamplers is not None:
+            x = r(_conv(blk.downsamplers[0].conv, F.pad(x, (0, 1, 0, 1)), stride=2))
+    x = vae_mid(e.mid_block, x)
+    x = r(_conv(e.conv_out, r(F.silu(_gn(e.conv_norm_out, x))), padding=1))
+    return r(_conv(v.quant_conv, x))
+
+
+@torch.no_grad()
+def vae_encode_scaled(v, images, noise):
+    mean, logvar = vae_moments(v, images).chunk(2, dim=1)
+    return r((mean + torch.exp(0.5 * logvar.clamp(-30.0, 20.0)) * r(noise.float())) * v.cfg.scaling_factor)
+
+
+@torch.no_grad()
+def vae_decode_to_images(v, latents):
+    """latents (x scaling_factor, bf16-valued) -> images in [0, 1] as decode_to_images returns them (bf16-valued)."""
+    d = v.decoder
+    z = r(r(latents.float()) * float(1.0 / v.cfg.scaling_factor))
+    x = r(_conv(d.conv_in, r(_conv(v.post_quant_conv, z)), padding=1))
+    x = vae_mid(d.mid_block, x)
+    for blk in d.up_blocks:
+        for res in blk.resnets:
+            x = vae_resnet(res, x)
+        if blk.upsamplers is not None:
+            x = upsample(blk.upsamplers[0], x)
+    x = r(_conv(d.conv_out, r(F.silu(_gn(d.conv_norm_out, x))), padding=1))
+    return r((x * 0.5 + 0.5).clamp(0.0, 1.0))
+
+
+class MatchedPipeline:
+    """oracle/pipeline.py::OraclePipeline.sliding_iterative_denoise with the fast HIP pipeline's roundings: VAE and UNet as above; the
+    conditioning maps resized in fp32 and rounded once; per window call the packer writes bf16, and ONE kernel forms the guided
+    prediction and the DDIM update in fp32 from the bf16 noise prediction and latents and rounds the new latents once
+    (csrc/elementwise.hip::cfg_ddim_kernel; pipeline_diffuman4d.py:408-422)."""
+
+    def __init__(self, vae, unet, scheduler):
+        self.vae, self.unet, self.scheduler = vae, unet, scheduler
+        self.device, self.dtype = torch.device("cpu"), torch.float32
+
+    def _encode(self, x, noise, batch_size=8):
+        return torch.cat([vae_encode_scaled(self.vae, xb, nb) for xb, nb in zip(x.split(batch_size), noise.split(batch_size))])
+
+    def post_process(self, latents, batch_size=8):
+        return torch.cat([vae_decode_to_images(self.vae, lb) for lb in latents.split(batch_size)])
+
+    @torch.no_grad()
+    def sliding_iterative_denoise(self, pixel_values, plucker_embeds, skeletons, cond_masks, latents, domain, timestep_indices, noise,
+                                  window_size=12, sliding_stride=1, sliding_shift=0, bidirectional=True, num_denoising_steps=1,
+                                  alternation_rounds=3, guidance_scale=2.0, decode=True, trace=None):
+        from .pipeline import build_windows, steps_per_alternation
+        per_alt = steps_per_alternation(window_size, sliding_stride, bidirectional, num_denoising_steps)
+        num_inference_steps = per_alt * alternation_rounds
+        timestep_indices = timestep_indices.clone()
+        target_indices = torch.where(cond_masks[:, 0, 0, 0] != 0.0)[0]
+        input_indices = torch.where(cond_masks[:, 0, 0, 0] == 0.0)[0]
+        id_end = int(timestep_indices[target_indices][0]) + per_alt
+        pv_lat = self._encode(pixel_values, noise["pixel"])
+        n, _, h, w = pv_lat.shape
+        pl_lat = r(F.interpolate(plucker_embeds.float(), size=(h, w), mode="bilinear"))
+        sk_lat = self._encode(skeletons, noise["skeleton"])
+        cm_lat = r(F.interpolate(cond_masks.float(), size=(h, w), mode="nearest"))
+        lat = r((noise["latents"] if latents is None else latents).float())
+        timesteps = self.scheduler.set_timesteps(num_inference_steps)
+        is_cond_all = cm_lat[:, 0, 0, 0] == 0
+        tws, iws = build_windows(target_indices, input_indices, domain, window_size, sliding_stride, sliding_shift, bidirectional)
+        sch, do_cfg = self.scheduler, guidance_scale > 1
+        for tw, iw in zip(tws, iws):
+            win = torch.cat([iw, tw])
+            cond = is_cond_all[win]
+            tidx = timestep_indices[win].clone()
+            for _ in range(num_denoising_steps):
+                tidx[cond] = 0
+                t = timesteps[tidx].clone()
+                t[cond] = 0
+                lat[win[cond]] = pv_lat[win[cond]]  # the packer's aliasing side effect (:375-379)
+                x = lat[win]
+                pos = torch.cat([x, pl_lat[win], sk_lat[win], cm_lat[win]], dim=1)
+                if do_cfg:
+                    neg = torch.cat([torch.where(cond[:, None, None, None], torch.ones_like(x), x), torch.zeros_like(pl_lat[win]),
+                                     -torch.ones_like(sk_lat[win]), cm_lat[win]], dim=1)
+                    eps = unet_forward(self.unet, torch.cat([neg, pos]), torch.cat([t, t]), domains=[domain] * 2, num_frames=len(win))
+                    u, c = eps.chunk(2)
+                    e = u + guidance_scale * (c - u)
+                else:
+                    e = unet_forward(self.unet, pos, t, domains=[domain], num_frames=len(win))
+                new = x.clone()
+                for j in range(len(win)):
+                    if not cond[j]:
+                        a_t, a_prev = (float(v) for v in sch.coefficients(int(t[j])))
+                        sa, sb, sap, sbp = (torch.tensor(v, dtype=torch.float32).sqrt() for v in (a_t, 1 - a_t, a_prev, 1 - a_prev))
+                        if sch.cfg.prediction_type == "epsilon":
+                            x0, ee = (x[j] - sb * e[j]) / sa, e[j]
+                        else:
+                            x0, ee = sa * x[j] - sb * e[j], sa * e[j] + sb * x[j]
+                        new[j] = r(sap * x0 + sbp * ee)
+                lat[win] = new
+                tidx[~cond] += 1
+            timestep_indices[tw] += num_denoising_steps
+        if (timestep_indices[target_indices] != id_end).any() or (timestep_indices[input_indices] != 0).any():
+            raise ValueError("matched pipeline: the timestep bookkeeping went wrong")
+        images = self.post_process(lat) if decode else None
+        return {"images": images, "latents": lat, "timestep_indices": timestep_indices,
+                "fully_denoised": timestep_indices == num_inference_steps}
+
+
 def _self_check():  # python -m oracle.matched: the un-rounded walk of this module equals oracle/unet.py's forward
     global r
     from .unet import UNetConfig, init_unet_weights

@@ -12,7 +12,7 @@ Geometry: SD-2.1 UNet (320, 640, 1280, 1280), SD VAE (128, 256, 512, 512), 576 x
 
     python tests/golden/make_golden_demo3d.py fp32      # ~55 min on 8 cores: fp32 oracle latents + decoded RGB
     python tests/golden/make_golden_demo3d.py bf16      # ~85 min: the oracle in bf16 = the reference's own arithmetic -> yardsticks
-    python tests/golden/make_golden_demo3d.py budget    # optional, per-call error budget (see tools/error_budget.py)
+    python tests/golden/make_golden_demo3d.py matched   # ~2.5 h: the rounding-matched oracle of the FAST precision (oracle/matched.py)
 
 writes tests/golden/demo3d_sd21_72x40.pt:
   latents            fp32 oracle result, all 48 rows [48, 4, 72, 40] (fp32)
@@ -20,6 +20,9 @@ writes tests/golden/demo3d_sd21_72x40.pt:
   image_rows         which rows those are (5 targets spread over the ring + 1 conditioning row)
   timestep_indices, fully_denoised      bit-exact bookkeeping
   yard_latents, yard_images             rel-L2 of the bf16 oracle against the fp32 oracle (images: same rows)
+  matched_latents (bf16), matched_images_u16   the same task through oracle/matched.py::MatchedPipeline (bf16 roundings wherever the fast HIP
+                                        path stores a tensor): what `modelcheck demo3d_sd21_72x40_matched` compares the HIP result with
+                                        directly, under a fixed bound; matched_vs_fp32_* = its own distance to the fp32 oracle
   checksums of weights / inputs / noise (the GPU test rebuilds them from the seeds and verifies first)
 
 Weights are NOT stored: both sides rebuild them with ``random_state_dict(shapes, seed, device="cpu")``.
@@ -127,9 +130,33 @@ def run(dtype):
     return out, images, checksums(pv, pl, sk, cm, noise, usd, vsd), t_den
 
 
+def run_matched():
+    from oracle import matched
+    op, usd, vsd = build_oracle(torch.float32)
+    mp = matched.MatchedPipeline(op.vae, op.unet, op.scheduler)
+    pv, pl, sk, cm = task_inputs()
+    noise = task_noise()
+    t0 = time.time()
+    out = mp.sliding_iterative_denoise(pv, pl, sk, cm, None, "spatial", torch.zeros(N_CAMS, dtype=torch.int64), noise, decode=False, **KW)
+    t_den = time.time() - t0
+    images = mp.post_process(out["latents"][IMAGE_ROWS])
+    print(f"[matched] denoise {t_den:.0f}s, decode {time.time() - t0 - t_den:.0f}s", flush=True)
+    return out, images, checksums(pv, pl, sk, cm, noise, usd, vsd), t_den
+
+
 def main():
     which = set(sys.argv[1:]) or {"fp32", "bf16"}
     blob = torch.load(OUT) if OUT.exists() else {}
+    if "matched" in which:
+        assert "latents" in blob, "run the fp32 pass first"
+        out, images, chk, secs = run_matched()
+        assert chk == blob["checksums"] and torch.equal(out["timestep_indices"], blob["timestep_indices"])
+        ref_img = blob["images_u16"].to(torch.int32).float() / 65535.0
+        blob.update(matched_latents=out["latents"].to(BF), matched_images_u16=(images.float() * 65535.0).round().to(torch.int32).to(torch.uint16),
+                    matched_vs_fp32_latents=rel_l2(out["latents"], blob["latents"]), matched_vs_fp32_images=rel_l2(images, ref_img),
+                    oracle_seconds_matched=secs)
+        torch.save(blob, OUT)
+        print(f"matched pass stored: vs the fp32 oracle latents {blob['matched_vs_fp32_latents']:.3e} images {blob['matched_vs_fp32_images']:.3e}", flush=True)
     if "fp32" in which:
         out, images, chk, secs = run(torch.float32)
         blob.update(latents=out["latents"].float(), images_u16=(images.float() * 65535.0).round().to(torch.int32).to(torch.uint16),

@@ -90,7 +90,7 @@ def unet_sample(hm, x):
     return ops.nchw_to_nhwc(x.to(BF).cuda(), hm.IN_PAD)
 
 
-def case_unet(num_frames=4, cfg_batch=2, h=16, w=8, tem=False, domain="spatial", seed=0, pose=False, precision="fast"):
+def case_unet(num_frames=4, cfg_batch=2, h=16, w=8, tem=False, domain="spatial", seed=0, pose=False, precision="fast", matched=False):
     from diffuman4d_amd.host import ops
     cfg, om = make_unet(seed, enable_tem_embeds=tem, **(dict(enable_pose_encoder=True, in_channels=11) if pose else {}))
     if tem:  # the temporal embedding MLP is zero-initialised in training; randomise it so it is exercised
@@ -114,6 +114,10 @@ def case_unet(num_frames=4, cfg_batch=2, h=16, w=8, tem=False, domain="spatial",
     out = hm(xd, t.float().cuda(), skeletons=ops.nchw_to_nhwc(sk.cuda(), 4) if pose else None, domains=domains,
              num_frames=num_frames)
     out = ops.nhwc_to_nchw(out)
+    if matched:  # HIP fast precision vs the rounding-matched oracle, run on the spot (fixed bound MATCHED_TOL)
+        from oracle import matched as mo
+        mref = mo.unet_forward(om, x.float(), t, domains=domains, num_frames=num_frames)
+        return {"unet_out": rel_l2(out, mref)}, {"unet_out": 0.0}
     return {"unet_out": rel_l2(out, ref)}, {"unet_out": rel_l2(ref_bf, ref)}
 
 
@@ -355,7 +359,7 @@ def case_vae_sd(name="vae_576x320", precision="fast"):
             {"latents": g["yard_z"], "images": g["yard_images"]})
 
 
-def case_demo3d_sd21(precision="fast"):
+def case_demo3d_sd21(precision="fast", matched=False):
     """BASELINE.json configs[0] END TO END on the judged geometry: `demo_3d` (configs/exp/demo_3d.yaml:3-10 + sampler/sliding_3d.yaml:
     48 cameras x 1 frame, 4 input cameras, window 12, stride 1, one alternation round => 12 steps per latent, 44 UNet calls of F = 16
     = CFG batch 32) through `sliding_iterative_denoise` (pipeline_diffuman4d.py:439-559) with the SD-2.1 UNet, the SD VAE and 576 x 320
@@ -386,6 +390,15 @@ def case_demo3d_sd21(precision="fast"):
     torch.cuda.synchronize()
     secs = time.time() - t0
     exact = torch.equal(out["timestep_indices"].cpu(), g["timestep_indices"]) and torch.equal(out["fully_denoised"].cpu(), g["fully_denoised"])
+    if matched:  # the whole task against the rounding-matched oracle pipeline (fixed bound MATCHED_TOL)
+        mimg = g["matched_images_u16"].to(torch.int32).float() / 65535.0
+        e = {"latents": rel_l2(out["latents"], g["matched_latents"]), "images": rel_l2(out["images"][g["image_rows"]], mimg)}
+        print(f"    [demo_3d fast vs rounding-matched oracle, {secs:.1f}s] latents rel_l2={e['latents']:.3e} images rel_l2={e['images']:.3e} "
+              f"(bound {MATCHED_TOL:.1e}; matched oracle vs fp32 oracle: latents {g['matched_vs_fp32_latents']:.3e} images "
+              f"{g['matched_vs_fp32_images']:.3e}) bookkeeping_exact={exact}", flush=True)
+        del hp
+        torch.cuda.empty_cache()
+        return ({"bookkeeping": 1.0}, {"bookkeeping": 0.0}) if not exact else (e, {"latents": 0.0, "images": 0.0})
     ref_img = g["images_u16"].to(torch.int32).float() / 65535.0
     fd = g["fully_denoised"]
     e = {"latents": rel_l2(out["latents"], g["latents"]), "images": rel_l2(out["images"][g["image_rows"]], ref_img)}
@@ -477,7 +490,7 @@ def synthetic_task(n, H, W, input_rows, seed=7):
 
 
 def case_pipeline(domain="spatial", n_cams=8, T=4, window=4, stride=2, rounds=1, steps=1, bidir=False, gs=2.0,
-                  pred="epsilon", seed=11, pose=False, sched="ddim", sched_kw=None, precision="fast"):
+                  pred="epsilon", seed=11, pose=False, sched="ddim", sched_kw=None, precision="fast", matched=False):
     """One full task through sliding_iterative_denoise (VAE encode -> window sweep -> VAE decode).
     sched="dpm": DPM-Solver++ multistep -- the oracle keeps one stateful scheduler object per latent as the reference does
     (pipeline_diffuman4d.py:265-271, 420), the HIP path runs its planned coefficient rows (host/scheduler.py)."""
@@ -518,6 +531,15 @@ def case_pipeline(domain="spatial", n_cams=8, T=4, window=4, stride=2, rounds=1,
                                        domain=domain, timestep_indices=tidx, noise=noise, **kw)
     exact = bool((out["timestep_indices"].cpu() == ref["timestep_indices"]).all()) and \
         bool((out["fully_denoised"].cpu() == ref["fully_denoised"]).all())
+    if matched:  # HIP fast precision vs the rounding-matched oracle pipeline, run on the spot (fixed bound MATCHED_TOL)
+        from oracle import matched as mo
+        assert sched == "ddim" and not pose
+        mref = mo.MatchedPipeline(ov, ou, DDIMScheduler(DDIMConfig(prediction_type=pred))).sliding_iterative_denoise(
+            pv, pl, sk, cm, None, domain, tidx, noise, **kw)
+        e = {"latents": rel_l2(out["latents"], mref["latents"]), "images": rel_l2(out["images"], mref["images"])}
+        print(f"    [pipeline {domain} fast vs rounding-matched oracle] latents rel_l2={e['latents']:.3e} images rel_l2={e['images']:.3e} "
+              f"(bound {MATCHED_TOL:.1e}; matched oracle vs fp32 oracle: latents {rel_l2(mref['latents'], ref['latents']):.3e})", flush=True)
+        return e, {"latents": 0.0, "images": 0.0}
     e_lat = rel_l2(out["latents"], ref["latents"])
     e_img = rel_l2(out["images"], ref["images"])
     # yardstick: the oracle in bf16 (what the reference computes) vs the fp32 oracle
@@ -780,7 +802,14 @@ CASES.update({
     "par_unet_sd21_72x40_f16": (case_unet_sd21, dict(name="unet_f16_spatial", **PAR)),
     "par_vae_sd_576x320": (case_vae_sd, dict(**PAR)),
 })
-# HIP fast precision vs the rounding-matched oracle on the judged UNet calls (make_golden_sd21.py matched16 / matched24)
+# HIP fast precision vs the rounding-matched oracle (oracle/matched.py): small configurations on the spot ...
+CASES.update({
+    "unet_spatial_matched": (case_unet, dict(num_frames=4, cfg_batch=2, matched=True)),
+    "unet_temporal_temb_matched": (case_unet, dict(num_frames=4, cfg_batch=2, tem=True, domain="temporal", matched=True)),
+    "pipeline_spatial_matched": (case_pipeline, dict(domain="spatial", matched=True)),
+    "pipeline_temporal_v_matched": (case_pipeline, dict(domain="temporal", T=4, window=4, stride=1, pred="v_prediction", matched=True)),
+})
+# ... and on the judged UNet calls (make_golden_sd21.py matched16 / matched24)
 _sd21 = torch.load(GOLDEN / "sd21_72x40.pt")
 for _n, _k in (("unet_sd21_72x40_f16_matched", "unet_f16_spatial"), ("unet_sd21_72x40_f24_matched", "unet_f24_temporal")):
     if "matched_out" in _sd21.get(_k, {}):
@@ -800,6 +829,8 @@ if "vae_1024" in torch.load(GOLDEN / "sd21_72x40.pt"):  # the VAE at the referen
 if (GOLDEN / "demo3d_sd21_72x40.pt").exists():
     CASES["demo3d_sd21_72x40"] = (case_demo3d_sd21, dict())
     CASES["par_demo3d_sd21_72x40"] = (case_demo3d_sd21, dict(**PAR))  # north_star: decoded RGB within 1e-3 of the fp32 reference path
+    if "matched_latents" in torch.load(GOLDEN / "demo3d_sd21_72x40.pt"):  # make_golden_demo3d.py matched
+        CASES["demo3d_sd21_72x40_matched"] = (case_demo3d_sd21, dict(matched=True))
 # Cases with a fixed bound of their own: bitwise equalities (0.0), extension-vs-strict comparisons, exact resampling.
 # Every other case is judged against its bf16-oracle yardstick (YARD_FACTOR, see the module docstring).
 TOL = {"task_batching_spatial": 0.0, "task_batching_temporal_x3": 0.0, "task_batching_dpm": 0.0, "pipeline_shard_rccl_world1": 0.0, "unet_frame_shard_p4": 0.0, "unet_frame_shard_p8": 0.0,
