@@ -27,6 +27,17 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# tests/modelcheck.py (the *_opreplay cases) sets this to a list: every fast-precision launch then appends (operator name, its
+# inputs as a dict of tensors / scalars, its output tensor), so that each launch of a real model call can be recomputed on the CPU
+# from the very tensors the device was given (oracle/replay.py).  None = no tracing.  The tensors are kept alive by the list.
+TRACE = None
+
+
+def _trace(name: str, out, **inputs) -> None:
+    if TRACE is not None:
+        TRACE.append((name, inputs, out))
+
+
 def _req(t: torch.Tensor, name: str, dtype=BF16):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise _l.Dm4dError(f"{name}: expected a tensor on a HIP device (no CPU fallback in diffuman4d_amd)")
@@ -80,6 +91,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
                                 rows_per_rowbias, _p(residual), residual.stride(0) if residual is not None else 0,
                                 flags, out_scale)
     _l.check(rc, "dm4d_gemm_bf16")
+    _trace("gemm", out, a=a, w=w, a2=a2, bias=bias, rowbias=rowbias, rows_per_rowbias=rows_per_rowbias, residual=residual, geglu=geglu,
+           silu=silu, out_scale=out_scale, out_f32=out_f32, split_out=split_out)
     return out
 
 
@@ -118,6 +131,8 @@ def conv3x3(x: torch.Tensor, wt: torch.Tensor, *, bias=None, rowbias=None, resid
                                                   rowbias.stride(0) if rowbias is not None else 0, _p(residual),
                                                   Cout if residual is not None else 0, out_scale, _l.EPI_F32OUT | _l.EPI_F32SIDE)
         _l.check(rc, "dm4d_conv3x3_nhwc_bf16_flags")
+        _trace("conv3x3", y, x=x, wt=wt, bias=bias, rowbias=rowbias, residual=residual, stride=stride, pad=pad, pad_hi=pad_hi,
+               upsample=upsample, out_scale=out_scale, out_f32=True)
         return y
     # small images with a deep K (the 9x5 level) run split over the three kernel rows and need an fp32 workspace
     ws_bytes = lib.dm4d_conv3x3_ws_bytes(B, H, W, Cin, Ho, Wo, Cout, stride, pad, 1 if upsample else 0)
@@ -128,6 +143,8 @@ def conv3x3(x: torch.Tensor, wt: torch.Tensor, *, bias=None, rowbias=None, resid
                                            rowbias.stride(0) if rowbias is not None else 0, _p(residual),
                                            Cout if residual is not None else 0, out_scale, _p(ws), ws_bytes)
     _l.check(rc, "dm4d_conv3x3_nhwc_bf16_ws")
+    _trace("conv3x3", y, x=x, wt=wt, bias=bias, rowbias=rowbias, residual=residual, stride=stride, pad=pad, pad_hi=pad_hi,
+           upsample=upsample, out_scale=out_scale, out_f32=False)
     return y
 
 
@@ -224,6 +241,7 @@ class FeedForward:
                                               _p(b1p), _p(w2p), _p(self.b2), _p(residual), residual.stride(0), _p(out), out.stride(0), M,
                                               self.C, self.hidden)
         _l.check(rc, "dm4d_ff_geglu_fused_bf16")
+        _trace("ff_fused", out, n=n, residual=residual, ln=ln, w1=self.w1, b1=self.b1, w2=self.w2, b2=self.b2)
         return out
 
 
@@ -247,6 +265,7 @@ class FeedForward:
                                                        _p(ln[1]), float(ln[2]), _p(w1p), _p(b1p), _p(w2p), _p(self.b2), _p(out),
                                                        out.stride(0), M, self.C, self.hidden)
         _l.check(rc, "dm4d_attn_out_ff_geglu_fused_bf16")
+        _trace("attn_out_ff_fused", out, a=a, wo=wo, bo=bo, x=x, ln=ln, w1=self.w1, b1=self.b1, w2=self.w2, b2=self.b2)
         return out
 
 
@@ -309,6 +328,7 @@ def conv_up2x(x: torch.Tensor, wp: torch.Tensor, *, bias=None) -> torch.Tensor:
     with _Prof("conv3x3", 2.0 * B * 4 * H * W * 4 * Cin * Cout, "flop", B * 4 * H * W):
         rc = lib.dm4d_conv_up2x_nhwc_bf16(_stream(), _p(x), B, H, W, Cin, _p(wp), _p(y), Cout, _p(bias))
     _l.check(rc, "dm4d_conv_up2x_nhwc_bf16")
+    _trace("conv_up2x", y, x=x, wp=wp, bias=bias)
     return y
 
 
@@ -352,6 +372,7 @@ def groupnorm(x1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups:
         rc = lib.dm4d_groupnorm_nhwc_bf16(_stream(), _p(x1), C1, _p(x2), C2, B, HW, groups, eps, _p(gamma), _p(beta),
                                           _p(y), 1 if silu else 0, _p(ws))
     _l.check(rc, "dm4d_groupnorm_nhwc_bf16")
+    _trace("groupnorm", y, x1=x1, x2=x2, gamma=gamma, beta=beta, groups=groups, eps=eps, silu=silu)
     return y
 
 
@@ -394,6 +415,7 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
         rc = lib.dm4d_layernorm_bf16(_stream(), _p(x2), x2.stride(0), _p(gamma), _p(beta), _p(y), y.stride(0), x2.shape[0],
                                      x2.shape[1], eps)
     _l.check(rc, "dm4d_layernorm_bf16")
+    _trace("layernorm", y, x=x2, gamma=gamma, beta=beta, eps=eps)
     return y.view(x.shape)
 
 
@@ -430,6 +452,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, hea
         e1.record()
         prof.append(("attn_kernel", 4.0 * batch * heads * seq * kv_seq * 64, e0, e1))
     _l.check(rc, "dm4d_attention_kv_bf16")
+    _trace("attention", out, q=q, k=k, v=v, batch=batch, heads=heads, seq=seq, kv_seq=kv_seq, scale=scale, q_scaled=q_scaled)
     return out
 
 
@@ -508,6 +531,7 @@ def softmax_rows(s: torch.Tensor, scale: float, n: Optional[int] = None, out: Op
     fn = lib.dm4d_softmax_rows_f32in_bf16 if f32 else lib.dm4d_softmax_rows_bf16
     rc = fn(_stream(), _p(s), s.stride(0), _p(p), p.stride(0), s.shape[0], s.shape[1] if n is None else int(n), scale)
     _l.check(rc, "dm4d_softmax_rows_f32in_bf16" if f32 else "dm4d_softmax_rows_bf16")
+    _trace("softmax_rows", p, s=s, scale=scale, n=n)
     return p
 
 
@@ -528,6 +552,7 @@ def silu(x: torch.Tensor) -> torch.Tensor:
     assert x.is_contiguous()
     y = torch.empty_like(x)
     _l.check(lib.dm4d_silu_bf16(_stream(), _p(x), _p(y), x.numel()), "dm4d_silu_bf16")
+    _trace("silu", y, x=x)
     return y
 
 

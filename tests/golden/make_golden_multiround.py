@@ -63,8 +63,9 @@ class SeededNoise:
     """Pipeline wrapper: call k of the job gets its random draws from a CPU generator seeded NOISE_SEED + k (bf16-rounded).
     `oracle` selects the oracle pipeline's positional signature; otherwise the keywords go through as the sampler gave them."""
 
-    def __init__(self, pipe, oracle: bool):
+    def __init__(self, pipe, oracle: bool, keep_images_of=()):
         self.pipe, self.oracle, self.calls, self.device = pipe, oracle, 0, pipe.device
+        self.keep_images_of, self.images = set(keep_images_of), {}  # call index -> the decoded images that call returned
 
     def __getattr__(self, name):  # everything else (prune_cond_rows, vae, ...) is the wrapped pipeline's
         return getattr(self.__dict__["pipe"], name)
@@ -75,7 +76,10 @@ class SeededNoise:
         self.calls += 1
         noise = {k: torch.randn(n, 4, H // 8, W // 8, generator=g).to(BF) for k in ("pixel", "skeleton", "latents")}
         if not self.oracle:
-            return self.pipe.sliding_iterative_denoise(noise=noise, **kw)
+            out = self.pipe.sliding_iterative_denoise(noise=noise, **kw)
+            if self.calls - 1 in self.keep_images_of:
+                self.images[self.calls - 1] = out["images"].float().cpu()
+            return out
         kw.pop("tqdm", None)
         dt = self.pipe.dtype
         lat = kw.pop("latents")

@@ -35,7 +35,21 @@ NORTH_STAR = 1e-3    # BASELINE.json: decoded RGB within 1e-3 rel-L2 -- not met 
 # precision="parity" (fp32 tensors between kernels, two-term bf16 MFMA operands; include/dm4d.h "Parity precision"): every `par_*`
 # case is judged against a FIXED bound on rel-L2 vs the fp32 oracle -- PARITY_TOL unless PARITY_TOLS names a tighter one.
 PARITY_TOL = 1e-3
-MATCHED_TOL = 2e-3   # HIP fast precision vs the rounding-matched oracle (oracle/matched.py), fixed
+# HIP fast precision vs the rounding-matched oracle (oracle/matched.py).  Two bf16 networks decorrelate within a few rounding layers
+# (oracle/replay.py header: measured 1.29e-2 between HIP and the matched oracle, each 1.06e-2 from fp32), so the DIRECT distance cannot be
+# bounded tightly; what the matched oracle predicts sharply is the SIZE of the fast path's error.  A `*_matched` case passes when
+# err(HIP vs fp32) / err(matched vs fp32) lies in MATCHED_BAND (two-sided: fewer roundings than the model of the path is a finding
+# too) and the direct distance stays below sqrt(2) x 1.1 of the larger of the two.
+MATCHED_BAND = (0.85, 1.10)
+
+
+def matched_verdict(err_hip, err_matched, direct):
+    ratio = err_hip / err_matched
+    excess = max(0.0, ratio - MATCHED_BAND[1], MATCHED_BAND[0] - ratio) + max(0.0, direct - 1.1 * math.sqrt(2.0) * max(err_hip, err_matched))
+    return ratio, excess
+# Fast precision, every launch of a model call recomputed in fp64 from the tensors the device was given (oracle/replay.py): what is
+# left is summation order and the hardware's exp2 / rcp, i.e. the bf16 roundings those flip.  Fixed bound per launch.
+REPLAY_TOL = 5e-4
 GOLDEN = Path(__file__).resolve().parent / "golden"
 
 
@@ -114,10 +128,14 @@ def case_unet(num_frames=4, cfg_batch=2, h=16, w=8, tem=False, domain="spatial",
     out = hm(xd, t.float().cuda(), skeletons=ops.nchw_to_nhwc(sk.cuda(), 4) if pose else None, domains=domains,
              num_frames=num_frames)
     out = ops.nhwc_to_nchw(out)
-    if matched:  # HIP fast precision vs the rounding-matched oracle, run on the spot (fixed bound MATCHED_TOL)
+    if matched:  # HIP fast precision vs the rounding-matched oracle, run on the spot (MATCHED_BAND)
         from oracle import matched as mo
         mref = mo.unet_forward(om, x.float(), t, domains=domains, num_frames=num_frames)
-        return {"unet_out": rel_l2(out, mref)}, {"unet_out": 0.0}
+        e_h, e_m, direct = rel_l2(out, ref), rel_l2(mref, ref), rel_l2(out, mref)
+        ratio, excess = matched_verdict(e_h, e_m, direct)
+        print(f"    [unet {domain} fast vs rounding-matched oracle] HIP vs fp32 {e_h:.3e}, matched vs fp32 {e_m:.3e} (ratio {ratio:.3f}, band "
+              f"{MATCHED_BAND}), HIP vs matched {direct:.3e}", flush=True)
+        return {"band_excess": excess}, {"band_excess": 0.0}
     return {"unet_out": rel_l2(out, ref)}, {"unet_out": rel_l2(ref_bf, ref)}
 
 
@@ -319,15 +337,15 @@ def case_unet_sd21(name, precision="fast", fixture="sd21_72x40.pt", matched=Fals
     secs = time.time() - t0
     out = ops.nhwc_to_nchw(out)
     if matched:
-        # HIP (fast precision) against the ROUNDING-MATCHED oracle (oracle/matched.py: the fp32 oracle rounded to bf16 wherever the HIP
-        # path stores a tensor), under a FIXED bound (MATCHED_TOL): what is left between the two is summation order, the hardware's
-        # exp2 / rcp and the roundings those flip -- a defect worth a few 1e-3 that the yardstick bound lets through fails here
-        err = rel_l2(out, g["matched_out"])
-        print(f"    [{name} fast vs rounding-matched oracle] unet_out rel_l2={err:.3e} (bound {MATCHED_TOL:.1e}; matched oracle vs fp32 oracle "
-              f"{g['matched_vs_fp32']:.3e}, HIP vs fp32 oracle {rel_l2(out, g.get('out_f32', g['out'])):.3e})", flush=True)
+        # HIP (fast precision) and the ROUNDING-MATCHED oracle (oracle/matched.py: the fp32 oracle rounded to bf16 wherever the HIP
+        # path stores a tensor): see MATCHED_BAND above for what can and cannot be asserted between two bf16 networks
+        e_h, e_m, direct = rel_l2(out, g.get("out_f32", g["out"])), g["matched_vs_fp32"], rel_l2(out, g["matched_out"])
+        ratio, excess = matched_verdict(e_h, e_m, direct)
+        print(f"    [{name} fast vs rounding-matched oracle] HIP vs fp32 {e_h:.3e}, matched vs fp32 {e_m:.3e} (ratio {ratio:.3f}, band "
+              f"{MATCHED_BAND}), HIP vs matched {direct:.3e}", flush=True)
         del hm
         torch.cuda.empty_cache()
-        return {"unet_out": err}, {"unet_out": 0.0}
+        return {"band_excess": excess}, {"band_excess": 0.0}
     if "out_sub" in g:  # the 128 x 128 fixture keeps every sub-th pixel of the fp32 output
         err, yard = rel_l2(out[..., ::g["sub"], ::g["sub"]], g["out_sub"]), g["yard_bf16_sub"]
     else:  # fp32 copy of the oracle output where the fixture has one (round 4), else the fp16 copy (its own floor: 2.1e-4)
@@ -390,15 +408,19 @@ def case_demo3d_sd21(precision="fast", matched=False):
     torch.cuda.synchronize()
     secs = time.time() - t0
     exact = torch.equal(out["timestep_indices"].cpu(), g["timestep_indices"]) and torch.equal(out["fully_denoised"].cpu(), g["fully_denoised"])
-    if matched:  # the whole task against the rounding-matched oracle pipeline (fixed bound MATCHED_TOL)
+    if matched:  # the whole task against the rounding-matched oracle pipeline (MATCHED_BAND)
         mimg = g["matched_images_u16"].to(torch.int32).float() / 65535.0
-        e = {"latents": rel_l2(out["latents"], g["matched_latents"]), "images": rel_l2(out["images"][g["image_rows"]], mimg)}
-        print(f"    [demo_3d fast vs rounding-matched oracle, {secs:.1f}s] latents rel_l2={e['latents']:.3e} images rel_l2={e['images']:.3e} "
-              f"(bound {MATCHED_TOL:.1e}; matched oracle vs fp32 oracle: latents {g['matched_vs_fp32_latents']:.3e} images "
-              f"{g['matched_vs_fp32_images']:.3e}) bookkeeping_exact={exact}", flush=True)
+        ref_img = g["images_u16"].to(torch.int32).float() / 65535.0
+        res = {}
+        for q, hip_q, ref_q, m_q, e_m in (("latents", out["latents"], g["latents"], g["matched_latents"], g["matched_vs_fp32_latents"]),
+                                          ("images", out["images"][g["image_rows"]], ref_img, mimg, g["matched_vs_fp32_images"])):
+            e_h, direct = rel_l2(hip_q, ref_q), rel_l2(hip_q, m_q)
+            ratio, res[q] = matched_verdict(e_h, e_m, direct)
+            print(f"    [demo_3d fast vs rounding-matched oracle, {q}] HIP vs fp32 {e_h:.3e}, matched vs fp32 {e_m:.3e} (ratio {ratio:.3f}, band "
+                  f"{MATCHED_BAND}), HIP vs matched {direct:.3e} bookkeeping_exact={exact}", flush=True)
         del hp
         torch.cuda.empty_cache()
-        return ({"bookkeeping": 1.0}, {"bookkeeping": 0.0}) if not exact else (e, {"latents": 0.0, "images": 0.0})
+        return ({"bookkeeping": 1.0}, {"bookkeeping": 0.0}) if not exact else (res, {"latents": 0.0, "images": 0.0})
     ref_img = g["images_u16"].to(torch.int32).float() / 65535.0
     fd = g["fully_denoised"]
     e = {"latents": rel_l2(out["latents"], g["latents"]), "images": rel_l2(out["images"][g["image_rows"]], ref_img)}
@@ -531,15 +553,18 @@ def case_pipeline(domain="spatial", n_cams=8, T=4, window=4, stride=2, rounds=1,
                                        domain=domain, timestep_indices=tidx, noise=noise, **kw)
     exact = bool((out["timestep_indices"].cpu() == ref["timestep_indices"]).all()) and \
         bool((out["fully_denoised"].cpu() == ref["fully_denoised"]).all())
-    if matched:  # HIP fast precision vs the rounding-matched oracle pipeline, run on the spot (fixed bound MATCHED_TOL)
+    if matched:  # HIP fast precision vs the rounding-matched oracle pipeline, run on the spot (MATCHED_BAND)
         from oracle import matched as mo
         assert sched == "ddim" and not pose
         mref = mo.MatchedPipeline(ov, ou, DDIMScheduler(DDIMConfig(prediction_type=pred))).sliding_iterative_denoise(
             pv, pl, sk, cm, None, domain, tidx, noise, **kw)
-        e = {"latents": rel_l2(out["latents"], mref["latents"]), "images": rel_l2(out["images"], mref["images"])}
-        print(f"    [pipeline {domain} fast vs rounding-matched oracle] latents rel_l2={e['latents']:.3e} images rel_l2={e['images']:.3e} "
-              f"(bound {MATCHED_TOL:.1e}; matched oracle vs fp32 oracle: latents {rel_l2(mref['latents'], ref['latents']):.3e})", flush=True)
-        return e, {"latents": 0.0, "images": 0.0}
+        res = {}
+        for q in ("latents", "images"):
+            e_h, e_m, direct = rel_l2(out[q], ref[q]), rel_l2(mref[q], ref[q]), rel_l2(out[q], mref[q])
+            ratio, res[q] = matched_verdict(e_h, e_m, direct)
+            print(f"    [pipeline {domain} fast vs rounding-matched oracle, {q}] HIP vs fp32 {e_h:.3e}, matched vs fp32 {e_m:.3e} (ratio "
+                  f"{ratio:.3f}, band {MATCHED_BAND}), HIP vs matched {direct:.3e}", flush=True)
+        return res, {"latents": 0.0, "images": 0.0}
     e_lat = rel_l2(out["latents"], ref["latents"])
     e_img = rel_l2(out["images"], ref["images"])
     # yardstick: the oracle in bf16 (what the reference computes) vs the fp32 oracle
@@ -686,6 +711,105 @@ def case_golden_pipeline(name):
     return {"latents": e_lat, "images": e_img}, {"latents": y_lat, "images": y_img}
 
 
+def _replay_report(tag, trace, secs):
+    from oracle import replay
+    t0 = time.time()
+    stats = replay.replay_trace(trace)
+    unknown = sorted(n for n in stats if n not in replay.REPLAY)
+    worst = max((st["worst"] for st in stats.values()), default=0.0)
+    rows = "; ".join(f"{n} {st['checked']}/{st['launches']} worst {st['worst']:.1e} mean {st['mean']:.1e}" for n, st in sorted(stats.items()))
+    print(f"    [{tag}: {len(trace)} launches traced in {secs * 1e3:.0f} ms, replayed on the CPU in {time.time() - t0:.1f}s] {rows}", flush=True)
+    bad = {n: st["where"] for n, st in stats.items() if st["worst"] > REPLAY_TOL}
+    if bad:
+        print(f"    launches above {REPLAY_TOL:.0e}: {bad}", flush=True)
+    assert not unknown, f"traced operators without a replay function: {unknown}"
+    return worst
+
+
+def case_opreplay_unet(sd21=False, num_frames=4, tem=True, domain="temporal"):
+    """EVERY launch of one HIP UNet call (fast precision) recomputed in fp64 from the tensors the device was given (oracle/replay.py):
+    the tight model-level check of the fast path.  sd21: the judged call (SD-2.1 geometry, 72 x 40, F = 16, CFG batch 32: ~450 launches)."""
+    from diffuman4d_amd.host import ops
+    if sd21:
+        from diffuman4d_amd.host.unet import UNetConfig, UNetMultiviewConditionModel
+        from diffuman4d_amd.host.weights import random_state_dict, unet_param_shapes
+        sys.path.insert(0, str(GOLDEN))
+        import make_golden_sd21 as mk
+        cfg = UNetConfig()
+        hm = UNetMultiviewConditionModel(cfg, random_state_dict(unet_param_shapes(cfg), mk.UNET_SEED, "cpu"), "cuda")
+        x, t = mk.unet_inputs(16, 4, 101)
+        num_frames, domain = 16, "spatial"
+    else:
+        cfg, om = make_unet(0, enable_tem_embeds=tem)
+        hm = hip_unet(cfg, om)
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(2 * num_frames, cfg.in_channels, 16, 8, generator=g).to(BF)
+        t = torch.randint(0, 1000, (2 * num_frames,), generator=g)
+    xin = unet_sample(hm, x)
+    hm(xin, t.float().cuda(), domains=[domain] * 2, num_frames=num_frames)  # warm: allocator, lazily prepared tables
+    torch.cuda.synchronize()
+    ops.TRACE = trace = []
+    try:
+        t0 = time.time()
+        hm(xin, t.float().cuda(), domains=[domain] * 2, num_frames=num_frames)
+        torch.cuda.synchronize()
+        secs = time.time() - t0
+    finally:
+        ops.TRACE = None
+    worst = _replay_report("UNet call, SD-2.1 geometry 72x40 F=16" if sd21 else "UNet call, small geometry", trace, secs)
+    del hm, trace
+    torch.cuda.empty_cache()
+    return worst, 0.0
+
+
+def case_opreplay_pipeline(domain="spatial", seed=11):
+    """The same for a whole task on the small geometry: VAE encode, every window call, VAE decode."""
+    from diffuman4d_amd.host import ops
+    from diffuman4d_amd.host.pipeline import Diffuman4DPipeline
+    from diffuman4d_amd.host.scheduler import DDIMConfig as HC, DDIMScheduler as HS
+    cfg_u, ou = make_unet(seed)
+    cfg_v, ov = make_vae(seed + 1)
+    n, inputs = (8, [1, 5]) if domain == "spatial" else (8, [0, 1, 2, 3])
+    pv, pl, sk, cm = synthetic_task(n, 64, 64, inputs, seed)
+    g = torch.Generator().manual_seed(seed + 2)
+    noise = {k: torch.randn(n, 4, 8, 8, generator=g).to(BF) for k in ("pixel", "skeleton", "latents")}
+    hp = Diffuman4DPipeline(hip_vae(cfg_v, ov), hip_unet(cfg_u, ou), HS(HC()), "cuda")
+    ops.TRACE = trace = []
+    try:
+        t0 = time.time()
+        hp.sliding_iterative_denoise(pixel_values=pv, plucker_embeds=pl, skeletons=sk, cond_masks=cm, latents=None, domain=domain,
+                                     timestep_indices=torch.zeros(n, dtype=torch.int64), noise=noise, window_size=4,
+                                     sliding_stride=2 if domain == "spatial" else 1, sliding_shift=0, bidirectional=False,
+                                     num_denoising_steps=1, alternation_rounds=1, guidance_scale=2.0)
+        torch.cuda.synchronize()
+        secs = time.time() - t0
+    finally:
+        ops.TRACE = None
+    return _replay_report(f"whole {domain} task, small geometry (VAE + window calls)", trace, secs), 0.0
+
+
+def case_opreplay_vae_sd():
+    """SD VAE (128, 256, 512, 512) on one 576 x 320 image: encode + decode, every launch replayed."""
+    from diffuman4d_amd.host import ops
+    from diffuman4d_amd.host.vae import AutoencoderKL, VAEConfig
+    from diffuman4d_amd.host.weights import random_state_dict, vae_param_shapes
+    sys.path.insert(0, str(GOLDEN))
+    import make_golden_sd21 as mk
+    cfg = VAEConfig()
+    hv = AutoencoderKL(cfg, random_state_dict(vae_param_shapes(cfg), mk.VAE_SEED, "cpu"), "cuda")
+    img, noise = mk.vae_inputs(1, 5)
+    ops.TRACE = trace = []
+    try:
+        t0 = time.time()
+        z = hv.encode_scaled(img, noise)
+        hv.decode_to_images(z)
+        torch.cuda.synchronize()
+        secs = time.time() - t0
+    finally:
+        ops.TRACE = None
+    return _replay_report("SD VAE encode + decode of one 576x320 image", trace, secs), 0.0
+
+
 def case_multiround_sd21(precision="fast"):
     """A multi-round job THROUGH THE SAMPLER at the judged geometry: 8 cameras x 4 frames, window 4, stride 2, 3 alternation rounds
     (spatial -> temporal -> spatial: 14 tasks, 36 window calls, 6 steps per latent; sliding_iterative_sampler.py:192-212,
@@ -710,19 +834,15 @@ def case_multiround_sd21(precision="fast"):
     hp = Diffuman4DPipeline(AutoencoderKL(VAEConfig(), vsd, "cuda", precision), UNetMultiviewConditionModel(UNetConfig(), usd, "cuda", precision),
                             HS(HC()), "cuda")
     del usd, vsd
-    own = SlidingIterativeSampler(mk.dataset(), [mk.SeededNoise(hp, oracle=False)], "/tmp/dm4d_multiround_unused", **g["kw"])
+    # tasks run in the sampler's order: 4 spatial (one per frame), 6 temporal, 4 spatial; the kept cells belong to the last round,
+    # whose task of frame f is call 10 + f and whose rows are the cameras in label order
+    cells = [tuple(c) for c in g["image_cells"]]
+    wrapped = mk.SeededNoise(hp, oracle=False, keep_images_of={10 + int(f) for _, f in cells})
+    own = SlidingIterativeSampler(mk.dataset(), [wrapped], "/tmp/dm4d_multiround_unused", **g["kw"])
     first = own.dataset.get_item("synthetic", own.spa_labels, [own.tem_labels[0]], own.input_spa_labels)
     for k, key in (("pixel_values", "pixel_values"), ("plucker", "plucker_embeds"), ("skeletons", "skeletons")):
         _check_fixture_inputs("multiround dataset " + k, f(first[key]), g["checksums"][k])
-    kept = {}
-
-    def writer(sample, output_dir):
-        if sample["alt"] != g["kw"]["alternation_rounds"]:
-            return
-        for row, (_, c, fr) in enumerate(sample["labels"]):
-            if (c, fr) in [tuple(x) for x in g["image_cells"]]:
-                kept[(c, fr)] = sample["images"][row].float().cpu()
-    own.result_writer = writer
+    own.result_writer = None  # nothing is written (and the runner's completeness check of the files is skipped)
     t0 = time.time()
     SamplingRunner(own, prefetch_depth=0, writers=1, gpu_streams=1).inference()  # one task at a time: the draws come in the job's order
     torch.cuda.synchronize()
@@ -730,7 +850,7 @@ def case_multiround_sd21(precision="fast"):
     lat = torch.stack([torch.stack([own.latents[c][fr].float().cpu() for fr in own.tem_labels]) for c in own.spa_labels])
     idx = torch.tensor([[own.timestep_indices[c][fr] for fr in own.tem_labels] for c in own.spa_labels])
     exact = torch.equal(idx, g["timestep_indices"])
-    images = torch.stack([kept[tuple(cell)] for cell in g["image_cells"]])
+    images = torch.stack([wrapped.images[10 + int(fr)][own.spa_labels.index(c)] for c, fr in cells])
     ref_img = g["images_u16"].to(torch.int32).float() / 65535.0
     tgt = g["timestep_indices"] > 0
     e = {"latents": rel_l2(lat[tgt], g["latents"][tgt]), "images": rel_l2(images, ref_img)}
@@ -802,6 +922,13 @@ CASES.update({
     "par_unet_sd21_72x40_f16": (case_unet_sd21, dict(name="unet_f16_spatial", **PAR)),
     "par_vae_sd_576x320": (case_vae_sd, dict(**PAR)),
 })
+# fast precision, launch by launch against fp64 on the device's own tensors (oracle/replay.py): fixed bound REPLAY_TOL
+CASES.update({
+    "opreplay_unet_small": (case_opreplay_unet, dict()),
+    "opreplay_pipeline_small": (case_opreplay_pipeline, dict()),
+    "opreplay_unet_sd21_72x40_f16": (case_opreplay_unet, dict(sd21=True)),
+    "opreplay_vae_sd_576x320": (case_opreplay_vae_sd, dict()),
+})
 # HIP fast precision vs the rounding-matched oracle (oracle/matched.py): small configurations on the spot ...
 CASES.update({
     "unet_spatial_matched": (case_unet, dict(num_frames=4, cfg_batch=2, matched=True)),
@@ -838,7 +965,8 @@ TOL = {"task_batching_spatial": 0.0, "task_batching_temporal_x3": 0.0, "task_bat
        "pipeline_plucker_on_device": 5e-3, "resize": 4e-3}
 PARITY_TOLS: dict = {}  # tighter fixed bounds of individual par_* cases (name -> bound), from the measurements in DESIGN.md section 3
 TOL.update({n: PARITY_TOLS.get(n, PARITY_TOL) for n in CASES if n.startswith("par_")})
-TOL.update({n: MATCHED_TOL for n in CASES if n.endswith("_matched")})
+TOL.update({n: 0.0 for n in CASES if n.endswith("_matched")})  # band_excess must be zero (MATCHED_BAND)
+TOL.update({n: REPLAY_TOL for n in CASES if n.startswith("opreplay_")})
 
 
 def judge(name, err, yard):

@@ -26,5 +26,43 @@ case $stage in
     timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-grid-secondary --no-vae > $out/r04_bench_parity1.json 2> $out/r04_bench_parity1.err
     bench_line $out/r04_bench_parity1.json "fast path after the epilogue change:"
     ;;
+  verify2)  # parity launches on their own kernel instantiations, the matched-oracle / multi-round / 128x128 cases, the new bench line
+    timeout 600 python tests/opcheck.py par_ > $out/r04_v2_opcheck_par.log 2>&1; tail -2 $out/r04_v2_opcheck_par.log
+    timeout 300 python tests/opcheck.py resize_aa > $out/r04_v2_opcheck_resize.log 2>&1; tail -4 $out/r04_v2_opcheck_resize.log
+    timeout 900 python tests/modelcheck.py unet_spatial_matched unet_temporal_temb_matched pipeline_spatial_matched pipeline_temporal_v_matched \
+        unet_sd21_72x40_f16_matched unet_sd21_72x40_f24_matched > $out/r04_v2_modelcheck_matched.log 2>&1; grep -v "^/opt" $out/r04_v2_modelcheck_matched.log | tail -14
+    timeout 900 python tests/modelcheck.py multiround par_multiround par_unet_sd21_72x40 par_demo3d par_vae_sd > $out/r04_v2_modelcheck_par.log 2>&1; grep -v "^/opt" $out/r04_v2_modelcheck_par.log | tail -12
+    ( time timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/r04_v2_bench_default.json 2> $out/r04_v2_bench_default.err ) 2> $out/r04_v2_bench_default.time; tail -3 $out/r04_v2_bench_default.time
+    bench_line $out/r04_v2_bench_default.json "driver command:"
+    python - <<'PY'
+import json
+try:
+    d = json.load(open("gpurun_out/r04_v2_bench_default.json"))
+    print("parity:", json.dumps(d.get("parity", {}).get("modes")), "| parity_precision:", json.dumps(d["secondary"].get("parity_precision")))
+    print("latent128:", json.dumps(d["secondary"].get("latent128")))
+    print("levels:", {k: (v["ms"], v["roofline_frac"]) for k, v in d["kernel_breakdown_one_step"].items() if "." in k})
+    print("cpu_baseline:", d.get("cpu_baseline", {}).get("value"), "grid:", d["secondary"].get("grid", {}).get("latents_per_s"))
+except Exception as e:
+    print("default bench line unreadable:", e)
+PY
+    for rep in 1 2; do for ts in 2 3; do
+      timeout 300 python bench.py --steps 8 --warmup 2 --task-streams $ts --no-cpu-baseline --no-grid-secondary --no-vae --no-parity-precision --no-latent128 > $out/r04_v2_bench_ts${ts}_$rep.json 2>/dev/null
+      bench_line $out/r04_v2_bench_ts${ts}_$rep.json "task streams $ts rep $rep:"
+    done; done
+    timeout 600 python -m pytest tests/test_e2e_gpu.py -m gpu -x -q > $out/r04_v2_pytest_e2e.log 2>&1; tail -3 $out/r04_v2_pytest_e2e.log
+    ;;
+  verify3)  # launch-by-launch replay of the fast precision, the matched-oracle band, the multi-round job; then the whole CLI path twice
+    timeout 900 python tests/modelcheck.py opreplay_ > $out/r04_v3_modelcheck_opreplay.log 2>&1; grep -v "^/opt\|Denoising" $out/r04_v3_modelcheck_opreplay.log | cut -c1-1200 | tail -14
+    timeout 900 python tests/modelcheck.py unet_spatial_matched unet_temporal_temb_matched pipeline_spatial_matched pipeline_temporal_v_matched \
+        unet_sd21_72x40_f16_matched unet_sd21_72x40_f24_matched multiround par_multiround > $out/r04_v3_modelcheck_matched.log 2>&1
+    grep -v "^/opt\|Denoising" $out/r04_v3_modelcheck_matched.log | cut -c1-400 | tail -24
+    for m in strict fast; do
+      if [ $m = fast ]; then fl="--fast-vae --prune"; else fl=""; fi
+      timeout 1200 python tools/e2e_demo.py --exp demo_4d $fl --writers 2 --device-results --writer-processes 12 --host-threads 8 --depth 3 \
+        --timeline $out/r04_e2e_demo4d_${m}_timeline.json sampler.plucker_on_device=true data.plucker=cameras > $out/r04_e2e_demo4d_$m.json 2> $out/r04_e2e_demo4d_$m.err
+      cat $out/r04_e2e_demo4d_$m.json; tail -2 $out/r04_e2e_demo4d_$m.err | cut -c1-300
+    done
+    rm -f $out/r04_e2e_demo4d_*_timeline.json
+    ;;
   *) echo "unknown stage $stage"; exit 2;;
 esac
