@@ -162,6 +162,41 @@ __global__ void cfg_linear_step_kernel(T* latents, T* x0_prev, const T* np, int6
   }
 }
 
+// General linear multistep update with up to three stored tensors per latent (UniPC with its corrector, DEIS of order <= 3): rows of
+// 16 floats planned on the host (host/scheduler.py, block comment above UniPCConfig):
+//   m = guided model output;  conv = k0 x + k1 m;  xc = k2 x + k3 s3 + k4 s1 + k5 s2 + k6 conv;  x' = k7 xc + k8 conv + k9 s1 + k10 s2
+//   s3' = xc, s2' = s1, s1' = conv.   s2 / s3 may be NULL (order-1 / DEIS schedulers keep fewer tensors).  The stored tensors start a
+// call as ZEROS (the host allocates them so): a latent's first steps meet zero coefficients on them.
+template <typename T>
+__global__ void cfg_multistep_kernel(T* latents, T* s1, T* s2, T* s3, const T* np, int64_t ldn, const float* coef, const int32_t* is_cond,
+                                     const int32_t* frame_idx, int F, int HW, int use_cfg, float gs) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // window-local (frame, pixel)
+  if (o >= (int64_t)F * HW) return;
+  const int f = (int)(o / HW);
+  if (is_cond[f] != 0) return;  // "only denoise target latents" (pipeline_diffuman4d.py:418-420)
+  const int64_t i = frame_idx ? (int64_t)frame_idx[f] * HW + (o - (int64_t)f * HW) : o;
+  const float* k = coef + f * 16;
+#pragma unroll
+  for (int ch = 0; ch < 4; ++ch) {
+    float m;
+    if (use_cfg) {
+      const float u = ldv(np + o * ldn + ch);
+      const float cc = ldv(np + ((int64_t)F * HW + o) * ldn + ch);
+      m = u + gs * (cc - u);
+    } else {
+      m = ldv(np + o * ldn + ch);
+    }
+    const float x = ldv(latents + i * 4 + ch);
+    const float p1 = ldv(s1 + i * 4 + ch), p2 = s2 ? ldv(s2 + i * 4 + ch) : 0.f, p3 = s3 ? ldv(s3 + i * 4 + ch) : 0.f;
+    const float conv = k[0] * x + k[1] * m;
+    const float xc = k[2] * x + k[3] * p3 + k[4] * p1 + k[5] * p2 + k[6] * conv;
+    stv(latents + i * 4 + ch, k[7] * xc + k[8] * conv + k[9] * p1 + k[10] * p2);
+    if (s3) stv(s3 + i * 4 + ch, xc);
+    if (s2) stv(s2 + i * 4 + ch, p1);
+    stv(s1 + i * 4 + ch, conv);
+  }
+}
+
 __global__ void nchw_to_nhwc_kernel(const u16* X, u16* Y, int B, int C, int HW, int cpad) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over B*HW*cpad
   if (i >= (int64_t)B * HW * cpad) return;
@@ -535,4 +570,24 @@ extern "C" int dm4d_resize_aa_nchw_f32(void* stream, const float* X, float* Y, i
   if (!X || !Y || planes <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0) return dm4d_set_error(DM4D_ERR_ARG, "resize_aa: bad arguments");
   hipLaunchKernelGGL(resize_aa_kernel, grid1d(planes * h * w, 256), dim3(256), 0, (hipStream_t)stream, X, Y, planes, H, W, h, w);
   return dm4d_check_launch("resize_aa_kernel");
+}
+
+template <typename T>
+static int cfg_multistep_impl(void* stream, void* latents, void* s1, void* s2, void* s3, const void* noise_pred, int64_t ldn, const float* coef,
+                              const int32_t* is_cond, const int32_t* frame_idx, int F, int HW, int use_cfg, float guidance_scale) {
+  if (!latents || !s1 || !noise_pred || !coef || !is_cond || F <= 0 || HW <= 0 || ldn < 4)
+    return dm4d_set_error(DM4D_ERR_ARG, "cfg_multistep_step: bad arguments");
+  hipLaunchKernelGGL(cfg_multistep_kernel<T>, grid1d((int64_t)F * HW, 256), dim3(256), 0, (hipStream_t)stream, (T*)latents, (T*)s1, (T*)s2,
+                     (T*)s3, (const T*)noise_pred, ldn, coef, is_cond, frame_idx, F, HW, use_cfg, guidance_scale);
+  return dm4d_check_launch("cfg_multistep_kernel");
+}
+extern "C" int dm4d_cfg_multistep_step_bf16(void* stream, void* latents, void* s1, void* s2, void* s3, const void* noise_pred, int64_t ldn,
+                                            const float* coef, const int32_t* is_cond, const int32_t* frame_idx, int F, int HW, int use_cfg,
+                                            float guidance_scale) {
+  return cfg_multistep_impl<u16>(stream, latents, s1, s2, s3, noise_pred, ldn, coef, is_cond, frame_idx, F, HW, use_cfg, guidance_scale);
+}
+extern "C" int dm4d_cfg_multistep_step_f32(void* stream, float* latents, float* s1, float* s2, float* s3, const float* noise_pred, int64_t ldn,
+                                           const float* coef, const int32_t* is_cond, const int32_t* frame_idx, int F, int HW, int use_cfg,
+                                           float guidance_scale) {
+  return cfg_multistep_impl<float>(stream, latents, s1, s2, s3, noise_pred, ldn, coef, is_cond, frame_idx, F, HW, use_cfg, guidance_scale);
 }

@@ -40,6 +40,7 @@ SIGNATURES = {
     "dm4d_pack_model_input_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     "dm4d_cfg_ddim_step_bf16": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _f, _i]),
     "dm4d_cfg_linear_step_bf16": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _f]),
+    "dm4d_cfg_multistep_step_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _f]),
     "dm4d_vae_sample_bf16": (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _i, _f]),
     "dm4d_scale_pad_bf16": (_i, [_vp, _vp, _i64, _vp, _i, _i64, _i, _f]),
     "dm4d_resize_nchw_f32_to_nhwc_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
@@ -64,6 +65,7 @@ SIGNATURES = {
     "dm4d_pack_model_input_f32_split": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     "dm4d_cfg_ddim_step_f32": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _f, _i]),
     "dm4d_cfg_linear_step_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _f]),
+    "dm4d_cfg_multistep_step_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _f]),
     "dm4d_vae_sample_f32": (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _i, _f]),
     "dm4d_resize_nchw_f32_to_nhwc_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
     "dm4d_plucker_latent_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i]),

@@ -617,6 +617,29 @@ def cfg_linear_step(latents, x0_prev, noise_pred, coef, is_cond, use_cfg: bool, 
     return latents
 
 
+def cfg_multistep_step(latents, states, noise_pred, coef, is_cond, use_cfg: bool, guidance_scale: float,
+                       frame_idx: Optional[torch.Tensor] = None):
+    """In-place general linear multistep update (UniPC with its corrector, DEIS; dm4d.h: dm4d_cfg_multistep_step_bf16) of rows frame_idx
+    of `latents` and of the stored tensors `states` (a list of 1-3 tensors shaped like latents, zero at the start of a call) from
+    noise_pred [cfg*F, HW, ldn]; coef [F,16] fp32 rows from scheduler.step_rows."""
+    lib = _l.load()
+    dt = F32 if latents.dtype == F32 else BF16
+    _req(latents, "latents", dt), _req(noise_pred, "noise_pred", dt), _req(coef, "coef", torch.float32), _req(is_cond, "is_cond", torch.int32)
+    assert 1 <= len(states) <= 3 and coef.shape[-1] == 16 and coef.is_contiguous()
+    for t in states:
+        _req(t, "state", dt)
+        assert t.shape == latents.shape and t.is_contiguous()
+    F, HW = is_cond.shape[0], latents.shape[1]
+    if frame_idx is not None:
+        _req(frame_idx, "frame_idx", torch.int32)
+    st = list(states) + [None] * (3 - len(states))
+    fn = lib.dm4d_cfg_multistep_step_f32 if dt == F32 else lib.dm4d_cfg_multistep_step_bf16
+    rc = fn(_stream(), _p(latents), _p(st[0]), _p(st[1]), _p(st[2]), _p(noise_pred), noise_pred.stride(-2), _p(coef), _p(is_cond),
+            _p(frame_idx), F, HW, 1 if use_cfg else 0, guidance_scale)
+    _l.check(rc, "dm4d_cfg_multistep_step")
+    return latents
+
+
 def nchw_to_nhwc(x: torch.Tensor, cpad: Optional[int] = None) -> torch.Tensor:
     lib = _l.load()
     _req(x, "x")

@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .schedule import SweepPlan, history_flags, plan_sweep
+from .schedule import SweepPlan, history_counts, history_flags, plan_sweep
 from .scheduler import DDIMScheduler
 from .unet import UNetMultiviewConditionModel
 
@@ -193,8 +193,11 @@ class Diffuman4DPipeline:
             # update a latent gets depends on its step index and on whether it has been stepped before IN THIS CALL -- both known
             # from the plan -- so the objects collapse to one coefficient row per (call, frame)
             tix = np.stack(plan.timestep_index)
-            has_prev = np.stack(history_flags(plan.windows, plan.is_cond))
-            coef = self.scheduler.step_rows(np.where(cond, 0, tix), has_prev)   # [calls, F, 8]
+            if getattr(self.scheduler, "general_rows", False):  # UniPC / DEIS: rows depend on how many steps a latent has taken in this call
+                coef = self.scheduler.step_rows(np.where(cond, 0, tix), np.stack(history_counts(plan.windows, plan.is_cond)))  # [calls, F, 16]
+            else:
+                has_prev = np.stack(history_flags(plan.windows, plan.is_cond))
+                coef = self.scheduler.step_rows(np.where(cond, 0, tix), has_prev)   # [calls, F, 8]
         else:
             coef = self.scheduler.step_coefficients(t)             # [calls, F, 4]
         group = win.shape[1]  # frames folded into one 3-D attention sequence
@@ -237,7 +240,11 @@ class Diffuman4DPipeline:
         F = tb["win"].shape[1]  # frames of a window handled by THIS rank
         domains = [domain] * tb["cfg"]
         # multistep schedulers: the latents' previous x0 predictions, the only state the reference's per-latent scheduler copies carry
-        x0_prev = torch.zeros_like(lat3) if getattr(self.scheduler, "is_multistep", False) else None
+        x0_prev = None
+        if getattr(self.scheduler, "general_rows", False):  # UniPC / DEIS: up to three stored tensors per latent, zero at the start of a call
+            x0_prev = [torch.zeros_like(lat3) for _ in range(self.scheduler.state_slots)]
+        elif getattr(self.scheduler, "is_multistep", False):
+            x0_prev = torch.zeros_like(lat3)
         for i in tqdm(range(tb["calls"]), total=tb["calls"]):
             self.window_call(lat3, pv3, pl3, sk3, cm3, tb, i, h, w, domains, guidance_scale, use_cfg, vpred, shard, x0_prev)
         return lat
@@ -245,7 +252,7 @@ class Diffuman4DPipeline:
     def window_call(self, lat3, pv3, pl3, sk3, cm3, tb, i, h, w, domains, guidance_scale, use_cfg, vpred, shard=None,
                     x0_prev=None):
         """One window: pack -> UNet -> CFG + scheduler step (pipeline_diffuman4d.py:369-423), all on device, no host sync.
-        x0_prev: [N, HW, 4] state of a multistep scheduler (None for DDIM)."""
+        x0_prev: [N, HW, 4] state of a multistep scheduler (None for DDIM; a list of 1-3 such tensors for UniPC / DEIS)."""
         widx, cond = tb["win"][i], tb["cond"][i]
         F, HW = widx.shape[0], h * w
         pose = None
@@ -264,7 +271,10 @@ class Diffuman4DPipeline:
         if keep is not None:  # back to one row per CFG-batch entry; the rows left at zero are never read by the step kernel
             full = torch.zeros((tb["cfg"] * F,) + tuple(eps.shape[1:]), dtype=eps.dtype, device=eps.device)
             eps = full.index_copy_(0, keep, eps)
-        if x0_prev is not None:
+        if isinstance(x0_prev, list):
+            ops.cfg_multistep_step(lat3, x0_prev, eps.view(tb["cfg"] * F, HW, -1), tb["coef"][i], cond, use_cfg, float(guidance_scale),
+                                   frame_idx=widx)
+        elif x0_prev is not None:
             ops.cfg_linear_step(lat3, x0_prev, eps.view(tb["cfg"] * F, HW, -1), tb["coef"][i], cond, use_cfg,
                                 float(guidance_scale), frame_idx=widx)
         else:
@@ -273,9 +283,9 @@ class Diffuman4DPipeline:
         if shard is not None:  # F/P updated rows per rank -> every rank's copy of the task latents (and of the scheduler state)
             rows = shard.gather_rows(lat3.index_select(0, widx.long()))
             lat3.index_copy_(0, tb["win_full"][i], rows)
-            if x0_prev is not None:
-                rows = shard.gather_rows(x0_prev.index_select(0, widx.long()))
-                x0_prev.index_copy_(0, tb["win_full"][i], rows)
+            for st in (x0_prev if isinstance(x0_prev, list) else ([x0_prev] if x0_prev is not None else [])):
+                rows = shard.gather_rows(st.index_select(0, widx.long()))
+                st.index_copy_(0, tb["win_full"][i], rows)
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()

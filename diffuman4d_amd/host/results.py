@@ -82,14 +82,20 @@ def make_image_grid_device(images: torch.Tensor, nrow: int, padding: int = 2) ->
 @torch.no_grad()
 def pack_results_on_device(sample: Dict[str, Any], images: torch.Tensor, output_dir: str = "./results", save_image_grid: bool = True,
                            save_output_image: bool = True, save_crop_param: bool = False, image_ext: str = ".jpg",
-                           image_quality: int = 90, max_image_size: int = 8192) -> Dict[str, Any]:
+                           image_quality: int = 90, max_image_size: int = 8192, device=None) -> Dict[str, Any]:
     """``save_sampling_results`` up to (not including) the file encoding, evaluated on the device `images` lives on.
 
     images: the pipeline's decoded output [N, 3, H, W] in [0, 1], still on the GPU.  ``sample`` as the sampler builds it
     (``pixel_values`` / ``skeletons`` are the host tensors: they are uploaded once more in fp32, which is what the reference's
     arithmetic reads).  Returns the package ``imgwrite.write_package`` consumes: uint8 HWC numpy arrays + paths + crop tuples."""
-    dev = images.device
-    out = images.float()
+    # `device`: where the arithmetic runs (the sampler passes the pipeline's).  With decode_policy "denoised" a task of an early round
+    # returns a zero-stride HOST placeholder for its images (nothing was decoded): the packer must not follow it onto the CPU -- 194 of
+    # the 344 tasks of demo_4d then built their mosaics with host arithmetic, 130 s of a 303 s run (profiles/r04_e2e_demo_4d_fast.json)
+    dev = torch.device(device) if device is not None else images.device
+    if images.device != dev:
+        out = torch.zeros(images.shape, dtype=torch.float32, device=dev) if images.stride(0) == 0 else images.to(dev).float()
+    else:
+        out = images.float()
     input_indices = sample["input_indices"].to(dev)
     target_indices = set(int(i) for i in sample["target_indices"])
     inp = sample["pixel_values"].to(dev, non_blocking=True).float() * 0.5 + 0.5  # denorm_vae_tensor

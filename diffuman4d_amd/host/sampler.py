@@ -211,7 +211,7 @@ class SlidingIterativeSampler:
         sample["fully_denoised"] = result["fully_denoised"].cpu()
         if self.device_results and on_gpu and self.result_writer is not None:  # (device_results is off for caller-supplied writers)
             from .results import pack_results_on_device
-            sample["_package"] = pack_results_on_device(sample, result["images"], output_dir=self.output_dir)
+            sample["_package"] = pack_results_on_device(sample, result["images"], output_dir=self.output_dir, device=pipe.device)
             sample["images"] = None  # the float images never leave the device (the package holds what gets written)
         else:
             sample["images"] = result["images"].float().cpu()

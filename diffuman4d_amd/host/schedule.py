@@ -94,6 +94,20 @@ def plan_sweep(cond_flags: Sequence[bool], timestep_indices: Sequence[int], doma
     return SweepPlan(num_inference_steps, windows, conds, tidx, idx, target_indices, input_indices)
 
 
+def history_counts(windows: Sequence[np.ndarray], is_cond: Sequence[np.ndarray]) -> List[np.ndarray]:
+    """Per call: HOW MANY steps each frame of the window has taken earlier in this plan (0 for conditioning frames) -- what a
+    multistep scheduler of order > 2, or one with a corrector, needs to know about its per-latent object's history
+    (``lower_order_nums`` / ``last_sample`` of a scheduler copy made afresh for the call, pipeline_diffuman4d.py:500-501)."""
+    taken: dict = {}
+    out = []
+    for w, c in zip(windows, is_cond):
+        out.append(np.array([0 if ic else taken.get(int(i), 0) for i, ic in zip(w, c)], dtype=np.int64))
+        for i, ic in zip(w, c):
+            if not ic:
+                taken[int(i)] = taken.get(int(i), 0) + 1
+    return out
+
+
 def history_flags(windows: Sequence[np.ndarray], is_cond: Sequence[np.ndarray]) -> List[np.ndarray]:
     """Per call: which frames of the window have been stepped EARLIER IN THIS PLAN.  The reference makes one fresh scheduler
     object per latent for every sliding_iterative_denoise call (pipeline_diffuman4d.py:500-501), so a multistep scheduler has

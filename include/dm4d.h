@@ -181,6 +181,15 @@ int dm4d_cfg_linear_step_bf16(void* stream, void* latents, void* x0_prev, const 
                               const float* coef, const int32_t* is_cond, const int32_t* frame_idx, int F, int HW, int use_cfg,
                               float guidance_scale);
 
+/* CFG combine + per-latent GENERAL linear multistep step with up to three stored tensors per latent: UniPC (with its corrector) and DEIS,
+ * where the reference keeps one stateful scheduler object per latent (pipeline_diffuman4d.py:265-271, 420, 500-501).  coef [F,16] fp32 rows
+ * (k0..k10, host/scheduler.py::step_rows):   m = u + s (c - u);   conv = k0 x + k1 m;   xc = k2 x + k3 s3 + k4 s1 + k5 s2 + k6 conv;
+ * x <- k7 xc + k8 conv + k9 s1 + k10 s2;   s3 <- xc, s2 <- s1, s1 <- conv   for non-cond rows.  s1 / s2 / s3: same shape and indexing as
+ * latents, ZERO at the start of a sliding_iterative_denoise call (s2, s3 may be NULL).                                                   */
+int dm4d_cfg_multistep_step_bf16(void* stream, void* latents, void* s1, void* s2, void* s3, const void* noise_pred, int64_t ldn,
+                                 const float* coef, const int32_t* is_cond, const int32_t* frame_idx, int F, int HW, int use_cfg,
+                                 float guidance_scale);
+
 /* VAE posterior sample, DiagonalGaussianDistribution.sample() * scaling_factor
  *   (pipeline_diffuman4d.py:52,55): out[m,c] = (mean + exp(0.5*clamp(logvar,-30,20)) * noise[m,c]) * scale
  *   moments rows hold [mean(C) | logvar(C) | ...] with row stride ldm; noise/out are [M, C].          */
@@ -285,6 +294,9 @@ int dm4d_cfg_ddim_step_f32(void* stream, float* latents, const float* noise_pred
                            int v_prediction);
 int dm4d_cfg_linear_step_f32(void* stream, float* latents, float* x0_prev, const float* noise_pred, int64_t ldn, const float* coef,
                              const int32_t* is_cond, const int32_t* frame_idx, int F, int HW, int use_cfg, float guidance_scale);
+int dm4d_cfg_multistep_step_f32(void* stream, float* latents, float* s1, float* s2, float* s3, const float* noise_pred, int64_t ldn,
+                                const float* coef, const int32_t* is_cond, const int32_t* frame_idx, int F, int HW, int use_cfg,
+                                float guidance_scale);
 int dm4d_vae_sample_f32(void* stream, const float* moments, int64_t ldm, const float* noise, float* out, int64_t M, int C, float scale);
 int dm4d_resize_nchw_f32_to_nhwc_f32(void* stream, const float* X, float* Y, int B, int C, int H, int W, int h, int w, int bilinear);
 int dm4d_plucker_latent_f32(void* stream, const float* cams, float* Y, int N, int H, int W, int h, int w);

@@ -394,6 +394,25 @@ class DPMSolverSchedulerAdapter:
         return (self._s.step(model_output, int(timestep), sample),)
 
 
+class StatefulSchedulerAdapter:
+    """diffusers-API adapter over ANY stateful oracle scheduler (oracle/multistep.py: UniPC, DEIS; oracle/dpmsolver.py), deep-copyable:
+    what the reference's "a scheduler for each latent" copies (pipeline_diffuman4d.py:265-271)."""
+
+    def __init__(self, scheduler):
+        self._s = scheduler
+        self.init_noise_sigma = 1.0
+        self.timesteps = None
+
+    def set_timesteps(self, n, device=None):
+        self.timesteps = self._s.set_timesteps(n)
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def step(self, model_output, timestep, sample, return_dict=True, **kw):
+        return (self._s.step(model_output, int(timestep), sample),)
+
+
 class VaeImageProcessor:
     def __init__(self, vae_scale_factor=8, **kw):
         self.vae_scale_factor = vae_scale_factor

@@ -164,6 +164,73 @@ def golden_pipeline_dpm():
     torch.save(out, OUT / "pipeline_dpm.pt")
 
 
+MULTISTEP_CASES = {
+    # UniPC order 2 (bh2) with its corrector: 8 steps per latent in the call (window 4, stride 2, both directions, 2 steps per window)
+    "unipc_spatial_bidir": dict(kind="unipc", domain="spatial", n=8, inputs=[1, 5],
+                                sched=dict(prediction_type="epsilon", beta_schedule="scaled_linear", beta_start=0.00085, beta_end=0.012),
+                                kw=dict(window_size=4, sliding_stride=2, sliding_shift=0, bidirectional=True, num_denoising_steps=2,
+                                        alternation_rounds=1, guidance_scale=2.0)),
+    # UniPC bh1, v-prediction, the corrector switched off at two steps, a second-round call (latents handed back, step index 4)
+    "unipc_temporal_v_bh1_round2": dict(kind="unipc", domain="temporal", n=8, inputs=[0, 1, 2, 3], start_idx=4,
+                                        sched=dict(prediction_type="v_prediction", solver_type="bh1", final_sigmas_type="sigma_min",
+                                                   timestep_spacing="leading", steps_offset=1, disable_corrector=[5, 6],
+                                                   beta_schedule="scaled_linear", beta_start=0.00085, beta_end=0.012),
+                                        kw=dict(window_size=4, sliding_stride=1, sliding_shift=0, bidirectional=False,
+                                                num_denoising_steps=1, alternation_rounds=3, guidance_scale=2.0)),
+    # DEIS order 3: first / second / third-order updates inside one call
+    "deis3_spatial_bidir": dict(kind="deis", domain="spatial", n=8, inputs=[1, 5],
+                                sched=dict(solver_order=3, prediction_type="epsilon", beta_schedule="scaled_linear", beta_start=0.00085,
+                                           beta_end=0.012),
+                                kw=dict(window_size=4, sliding_stride=2, sliding_shift=0, bidirectional=True, num_denoising_steps=2,
+                                        alternation_rounds=1, guidance_scale=2.0)),
+    "deis2_temporal_v_round2": dict(kind="deis", domain="temporal", n=8, inputs=[0, 1, 2, 3], start_idx=4,
+                                    sched=dict(solver_order=2, prediction_type="v_prediction", timestep_spacing="trailing",
+                                               beta_schedule="scaled_linear", beta_start=0.00085, beta_end=0.012),
+                                    kw=dict(window_size=4, sliding_stride=1, sliding_shift=0, bidirectional=False, num_denoising_steps=1,
+                                            alternation_rounds=3, guidance_scale=2.0)),
+}
+
+
+def oracle_multistep(kind, sched):
+    from oracle import multistep as ms
+    return ms.UniPCMultistepScheduler(ms.UniPCConfig(**sched)) if kind == "unipc" else ms.DEISMultistepScheduler(ms.DEISConfig(**sched))
+
+
+def golden_pipeline_multistep():
+    """The reference's own pipeline with STATEFUL UniPC / DEIS scheduler objects (oracle/multistep.py behind the diffusers API), one deep
+    copy per latent made afresh per call (pipeline_diffuman4d.py:265-271, 500-501, 535): pins what the product's planned 16-float rows
+    assume about the reference's control flow (which steps a latent has taken in a call, where the corrector applies)."""
+    out = {}
+    for name, c in MULTISTEP_CASES.items():
+        cfg_u, ou = mc.make_unet(11)
+        cfg_v, ov = mc.make_vae(12)
+        pipe = RefPipeline(vae=refshim.AutoencoderKL(ov), unet=ref_unet_from(cfg_u, ou),
+                           scheduler=refshim.StatefulSchedulerAdapter(oracle_multistep(c["kind"], c["sched"])))
+        n = c["n"]
+        pv, pl, sk, cm = mc.synthetic_task(n, 64, 64, c["inputs"], 11)
+        g = torch.Generator().manual_seed(13)
+        noise = {k: torch.randn(n, 4, 8, 8, generator=g) for k in ("pixel", "skeleton", "latents")}
+        tidx = torch.zeros(n, dtype=torch.int64)
+        latents_in = None
+        refshim.NOISE_QUEUE.clear()
+        refshim.NOISE_QUEUE.extend([noise["pixel"], noise["skeleton"]])
+        if c.get("start_idx"):
+            tidx[[i for i in range(n) if i not in c["inputs"]]] = c["start_idx"]
+            latents_in = torch.randn(n, 4, 8, 8, generator=g)
+        else:
+            refshim.NOISE_QUEUE.append(noise["latents"])
+        res = pipe.sliding_iterative_denoise(pixel_values=pv, plucker_embeds=pl, skeletons=sk, cond_masks=cm,
+                                             latents=latents_in, domain=c["domain"], timestep_indices=tidx.clone(),
+                                             tqdm=lambda it, total=None: it, **c["kw"])
+        assert not refshim.NOISE_QUEUE
+        out[name] = dict(case=c, seeds=dict(unet=11, vae=12, task=11, noise=13), noise=noise, latents_in=latents_in,
+                         timestep_indices_in=tidx, latents=res["latents"], images=res["images"].half(),
+                         timestep_indices=res["timestep_indices"], fully_denoised=res["fully_denoised"])
+        print(f"pipeline_multistep[{name}]: idx {res['timestep_indices'].tolist()} denoised {int(res['fully_denoised'].sum())} "
+              f"finite {bool(torch.isfinite(res['latents']).all())}")
+    torch.save(out, OUT / "pipeline_multistep.pt")
+
+
 def golden_pose():
     """enable_pose_encoder checkpoints (pose_encoder.py; unet_multiview_condition.py:551-552;
     pipeline_diffuman4d.py:229-231,352-353,389-395): the reference UNet and pipeline with raw skeleton images."""
@@ -241,7 +308,7 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     only = sys.argv[1:]  # e.g. `make_golden.py pose` regenerates one fixture file
     for name, fn in (("unet", golden_unet), ("pipeline", golden_pipeline), ("sampler", golden_sampler),
-                     ("pose", golden_pose), ("dpm", golden_pipeline_dpm)):
+                     ("pose", golden_pose), ("dpm", golden_pipeline_dpm), ("multistep", golden_pipeline_multistep)):
         if not only or name in only:
             fn()
     print("golden fixtures written to", OUT)

@@ -668,13 +668,21 @@ def case_pipeline_plucker_on_device(seed=51):
     return (err if exact else 1.0), 0.0
 
 
-def case_golden_pipeline(name):
+def case_golden_pipeline(name, precision="fast"):
     """HIP sliding_iterative_denoise vs the output of the REFERENCE's own pipeline code (committed
     fixture tests/golden/pipeline_sliding.pt, fp32): same seeded weights, task tensors and noise."""
     from diffuman4d_amd.host.pipeline import Diffuman4DPipeline
     gdir = Path(__file__).resolve().parent / "golden"
     dpm = name.startswith("dpm_")  # fixture of the reference pipeline run with one stateful DPM-Solver++ object per latent
-    if dpm:
+    multistep = name.startswith(("unipc", "deis"))  # ... with one stateful UniPC / DEIS object per latent (make_golden.py multistep)
+    if multistep:
+        from diffuman4d_amd.host import scheduler as hs
+        from oracle import multistep as ms
+        g = torch.load(gdir / "pipeline_multistep.pt")[name]
+        sc, kind = g["case"]["sched"], g["case"]["kind"]
+        host_sched = (hs.UniPCMultistepScheduler(hs.UniPCConfig.from_dict(sc)) if kind == "unipc" else hs.DEISMultistepScheduler(hs.DEISConfig.from_dict(sc)))
+        oracle_sched = (lambda: ms.UniPCMultistepScheduler(ms.UniPCConfig(**sc))) if kind == "unipc" else (lambda: ms.DEISMultistepScheduler(ms.DEISConfig(**sc)))
+    elif dpm:
         from diffuman4d_amd.host.scheduler import DPMSolverConfig as HC, DPMSolverMultistepScheduler as HS
         from oracle.dpmsolver import DPMSolverConfig as OC_, DPMSolverMultistepScheduler as OS_
         g = torch.load(gdir / "pipeline_dpm.pt")[name]
@@ -689,19 +697,22 @@ def case_golden_pipeline(name):
     cfg_u, ou = make_unet(seeds["unet"], **g.get("cfg_kw", {}))
     cfg_v, ov = make_vae(seeds["vae"])
     pv, pl, sk, cm = synthetic_task(c["n"], 64, 64, c["inputs"], seeds["task"])
-    hp = Diffuman4DPipeline(hip_vae(cfg_v, ov), hip_unet(cfg_u, ou), host_sched, "cuda")
-    lat_in = g["latents_in"].to(BF) if g["latents_in"] is not None else None
+    hp = Diffuman4DPipeline(hip_vae(cfg_v, ov, precision), hip_unet(cfg_u, ou, precision), host_sched, "cuda")
+    lat_in = g["latents_in"].to(hp.dtype) if g["latents_in"] is not None else None  # parity precision takes the fixture's fp32 draws as they are
     out = hp.sliding_iterative_denoise(pixel_values=pv, plucker_embeds=pl, skeletons=sk, cond_masks=cm, latents=lat_in,
                                        domain=c["domain"], timestep_indices=g["timestep_indices_in"],
-                                       noise={k: v.to(BF) for k, v in g["noise"].items()}, **c["kw"])
+                                       noise={k: v.to(hp.dtype) for k, v in g["noise"].items()}, **c["kw"])
     exact = torch.equal(out["timestep_indices"].cpu(), g["timestep_indices"]) and \
         torch.equal(out["fully_denoised"].cpu(), g["fully_denoised"])
     e_lat, e_img = rel_l2(out["latents"], g["latents"]), rel_l2(out["images"], g["images"])
+    if precision == "parity":  # fixed bound against the reference pipeline's own fp32 output
+        print(f"    [golden {name} parity] latents rel_l2={e_lat:.3e} images rel_l2={e_img:.3e} (fixture images are fp16) bookkeeping_exact={exact}", flush=True)
+        return ({"bookkeeping": 1.0}, {"bookkeeping": 0.0}) if not exact else ({"latents": e_lat, "images": e_img}, {"latents": 0.0, "images": 0.0})
     # yardstick: the oracle run in bf16 on the same task, measured against the same fixture (= the reference's fp32 output)
     from oracle.pipeline import OraclePipeline
     ov.to(BF), ou.to(BF)
     opb = OraclePipeline(ov, ou, oracle_sched(), BF)
-    refb = opb.sliding_iterative_denoise(pv, pl, sk, cm, lat_in, c["domain"], g["timestep_indices_in"],
+    refb = opb.sliding_iterative_denoise(pv, pl, sk, cm, None if lat_in is None else lat_in.to(BF), c["domain"], g["timestep_indices_in"],
                                          {k: v.to(BF) for k, v in g["noise"].items()}, **c["kw"])
     y_lat, y_img = rel_l2(refb["latents"], g["latents"]), rel_l2(refb["images"], g["images"])
     print(f"    [golden {name}] latents rel_l2={e_lat:.3e} (oracle-bf16 {y_lat:.3e}) images rel_l2={e_img:.3e} "
@@ -901,6 +912,11 @@ CASES = {
     "golden_pose_encoder": (case_golden_pipeline, dict(name="pose_encoder")),
     "golden_dpm_spatial_bidir": (case_golden_pipeline, dict(name="dpm_spatial_bidir")),
     "golden_dpm_temporal_v_heun_round2": (case_golden_pipeline, dict(name="dpm_temporal_v_heun_round2")),
+    # UniPC (with its corrector) and DEIS: the reference pipeline with one stateful object per latent vs the planned 16-float rows
+    "golden_unipc_spatial_bidir": (case_golden_pipeline, dict(name="unipc_spatial_bidir")),
+    "golden_unipc_temporal_v_bh1_round2": (case_golden_pipeline, dict(name="unipc_temporal_v_bh1_round2")),
+    "golden_deis3_spatial_bidir": (case_golden_pipeline, dict(name="deis3_spatial_bidir")),
+    "golden_deis2_temporal_v_round2": (case_golden_pipeline, dict(name="deis2_temporal_v_round2")),
     # the judged configuration (BASELINE.json configs[1..2]): SD-2.1 geometry at 72x40, vs tests/golden/sd21_72x40.pt
     "unet_sd21_72x40_f16": (case_unet_sd21, dict(name="unet_f16_spatial")),
     "unet_sd21_72x40_f24": (case_unet_sd21, dict(name="unet_f24_temporal")),
@@ -918,6 +934,14 @@ CASES.update({
     "par_pipeline_temporal_v": (case_pipeline, dict(domain="temporal", T=4, window=4, stride=1, pred="v_prediction", **PAR)),
     "par_pipeline_bidir_nocfg": (case_pipeline, dict(domain="spatial", window=3, stride=3, bidir=True, gs=1.0, steps=2, **PAR)),
     "par_pipeline_dpm_spatial": (case_pipeline, dict(domain="spatial", sched="dpm", steps=2, window=4, stride=2, bidir=True, **PAR)),
+    # parity precision against the fixtures made by the REFERENCE's own pipeline code (fp32): all three scheduler families, both domains
+    "par_golden_spatial": (case_golden_pipeline, dict(name="spatial", **PAR)),
+    "par_golden_temporal_v": (case_golden_pipeline, dict(name="temporal_v", **PAR)),
+    "par_golden_round2_shift": (case_golden_pipeline, dict(name="round2_shift", **PAR)),
+    "par_golden_dpm_temporal_v_heun_round2": (case_golden_pipeline, dict(name="dpm_temporal_v_heun_round2", **PAR)),
+    "par_golden_unipc_temporal_v_bh1_round2": (case_golden_pipeline, dict(name="unipc_temporal_v_bh1_round2", **PAR)),
+    "par_golden_unipc_spatial_bidir": (case_golden_pipeline, dict(name="unipc_spatial_bidir", **PAR)),
+    "par_golden_deis3_spatial_bidir": (case_golden_pipeline, dict(name="deis3_spatial_bidir", **PAR)),
     # ... and on the judged geometry, against the committed fp32 fixtures
     "par_unet_sd21_72x40_f16": (case_unet_sd21, dict(name="unet_f16_spatial", **PAR)),
     "par_vae_sd_576x320": (case_vae_sd, dict(**PAR)),

@@ -693,6 +693,44 @@ def case_par_attention(batch, heads, L, seed=0, spike=False, qk_scale=1.0):
     return rel_l2(got, ref), float((got - ref).abs().max())
 
 
+def case_multistep_step(f32=False, slots=3, seed=0):
+    """dm4d_cfg_multistep_step_*: the general linear multistep update (UniPC with its corrector, DEIS) against its formula in fp64, two
+    consecutive steps so that the stored tensors written by the first are read by the second."""
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    dt = torch.float32 if f32 else BF
+    N, F_, HW = 6, 4, 48
+    lat = torch.randn(N, HW, 4, generator=g).to(dt)
+    cond = torch.tensor([1, 0, 0, 0], dtype=torch.int32)
+    widx = torch.tensor([4, 0, 2, 5], dtype=torch.int32)
+    rows = widx.long()
+    keep = ~cond.bool()
+    states = [torch.zeros(N, HW, 4, dtype=dt) for _ in range(slots)]
+    d_lat, d_st = lat.clone().cuda(), [t.clone().cuda() for t in states]
+    x = lat.double()
+    st = [t.double() for t in states] + [torch.zeros(N, HW, 4, dtype=torch.float64)] * (3 - slots)
+    worst = 0.0
+    for step in range(2):
+        eps = torch.randn(2 * F_, HW, 4, generator=g).to(dt)
+        k = (torch.rand(F_, 16, generator=g) - 0.3).float()
+        ops.cfg_multistep_step(d_lat, d_st, eps.cuda(), k.cuda(), cond.cuda(), True, 2.0, frame_idx=widx.cuda())
+        m = eps[:F_].double() + 2.0 * (eps[F_:].double() - eps[:F_].double())
+        kk = [k[:, j].double()[:, None, None] for j in range(11)]
+        xr, s1, s2, s3 = x[rows], st[0][rows], st[1][rows], st[2][rows]
+        conv = kk[0] * xr + kk[1] * m
+        xc = kk[2] * xr + kk[3] * s3 + kk[4] * s1 + kk[5] * s2 + kk[6] * conv
+        xn = kk[7] * xc + kk[8] * conv + kk[9] * s1 + kk[10] * s2
+        rnd = (lambda t: t.to(dt).double())
+        x[rows[keep]] = rnd(xn)[keep]
+        if slots >= 3:
+            st[2][rows[keep]] = rnd(xc)[keep]
+        if slots >= 2:
+            st[1][rows[keep]] = s1[keep]
+        st[0][rows[keep]] = rnd(conv)[keep]
+        worst = max(worst, rel_l2(d_lat, x), *(rel_l2(d_st[j], st[j]) for j in range(slots)))
+    return worst, 0.0
+
+
 def case_resize_aa(N=3, C=3, H=576, W=320, h=306, w=170, seed=0):
     """dm4d_resize_aa_nchw_f32 against F.interpolate(mode="bilinear", antialias=True) on the CPU (fp32 both; summation order differs)."""
     from diffuman4d_amd.host import ops
@@ -974,13 +1012,16 @@ CASES = {
     "par_attn_large_logits": (case_par_attention, dict(batch=1, heads=1, L=512, qk_scale=3.0, seed=3)),
     "par_attn_l0_2d": (case_par_attention, dict(batch=4, heads=5, L=2880, seed=4)),
     "par_small_kernels": (case_par_small_kernels, dict()),
+    "par_multistep_step_3slots": (case_multistep_step, dict(f32=True, slots=3)),
+    "multistep_step_3slots": (case_multistep_step, dict(slots=3)),
+    "multistep_step_2slots": (case_multistep_step, dict(slots=2, seed=1)),
     # the result writer's antialiased down-scale (mosaic of a 48-view spatial task; of a 300-frame temporal task; an up-scale axis)
     "resize_aa_spatial_mosaic": (case_resize_aa, dict()),
     "resize_aa_temporal_mosaic": (case_resize_aa, dict(N=4, H=576, W=320, h=48, w=27)),
     "resize_aa_mixed": (case_resize_aa, dict(N=2, C=1, H=50, W=30, h=17, w=45)),
 }
 
-TOLS = {"resize_aa_spatial_mosaic": 5e-5, "resize_aa_temporal_mosaic": 5e-5, "resize_aa_mixed": 5e-5, "plucker_576x320": 2e-3, "plucker_odd_ratio": 2e-3, "plucker_identity_size": 2e-3, "layout": 0.0, "temb": 6e-3, "attn_kv_split": 0.0, "attn_kv_split3": 0.0, "attn_qs_kv_split": 0.0,
+TOLS = {"multistep_step_3slots": 1e-6, "multistep_step_2slots": 1e-6, "resize_aa_spatial_mosaic": 5e-5, "resize_aa_temporal_mosaic": 5e-5, "resize_aa_mixed": 5e-5, "plucker_576x320": 2e-3, "plucker_odd_ratio": 2e-3, "plucker_identity_size": 2e-3, "layout": 0.0, "temb": 6e-3, "attn_kv_split": 0.0, "attn_kv_split3": 0.0, "attn_qs_kv_split": 0.0,
         "conv_batch_invariance_l3": 0.0, "conv_batch_invariance_l2": 0.0}
 
 

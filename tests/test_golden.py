@@ -179,7 +179,7 @@ def test_planned_rows_reproduce_the_reference_pipeline_with_a_stateful_scheduler
     g, c, ou, ov, (pv, pl, sk, cm) = _dpm_task(name)
     log = []
     op = OraclePipeline(ov, ou, _PlannedRows(HS(HC(**c["sched"])), log), torch.float32)
-    res = op.sliding_iterative_denoise(pv, pl, sk, cm, g["latents_in"], c["domain"], g["timestep_indices_in"], g["noise"], **c["kw"])
+    res = op.sliding_iterative_denoise(pv, pl, sk, cm, g["latents_in"], c["domain"], g["timestep_indices_in"], g["noise"], decode=False, **c["kw"])
     assert rel(res["latents"], g["latents"]) <= 2e-5
     k = c["kw"]
     cond = [i in c["inputs"] for i in range(c["n"])]
@@ -188,3 +188,84 @@ def test_planned_rows_reproduce_the_reference_pipeline_with_a_stateful_scheduler
     flags = history_flags(plan.windows, plan.is_cond)
     planned = [bool(f) for fl, ic in zip(flags, plan.is_cond) for f, is_c in zip(fl, ic) if not is_c]
     assert planned == log and any(log) and not all(log)
+
+
+# ---- UniPC / DEIS: fixture = the REFERENCE's pipeline run with one stateful scheduler object per latent (make_golden.py multistep) ----
+MULTISTEP_CASES = ["unipc_spatial_bidir", "unipc_temporal_v_bh1_round2", "deis3_spatial_bidir", "deis2_temporal_v_round2"]
+
+
+def _multistep_task(name):
+    g = torch.load(G / "pipeline_multistep.pt")[name]
+    c, seeds = g["case"], g["seeds"]
+    _, ou = mc.make_unet(seeds["unet"])
+    _, ov = mc.make_vae(seeds["vae"])
+    return g, c, ou, ov, mc.synthetic_task(c["n"], 64, 64, c["inputs"], seeds["task"])
+
+
+def _oracle_multistep(c):
+    from oracle import multistep as ms
+    return ms.UniPCMultistepScheduler(ms.UniPCConfig(**c["sched"])) if c["kind"] == "unipc" else ms.DEISMultistepScheduler(ms.DEISConfig(**c["sched"]))
+
+
+def _host_multistep(c):
+    from diffuman4d_amd.host import scheduler as hs
+    return (hs.UniPCMultistepScheduler(hs.UniPCConfig.from_dict(c["sched"])) if c["kind"] == "unipc"
+            else hs.DEISMultistepScheduler(hs.DEISConfig.from_dict(c["sched"])))
+
+
+@pytest.mark.parametrize("name", MULTISTEP_CASES)
+def test_oracle_pipeline_with_stateful_unipc_deis_matches_reference_pipeline(name):
+    g, c, ou, ov, (pv, pl, sk, cm) = _multistep_task(name)
+    op = OraclePipeline(ov, ou, _oracle_multistep(c), torch.float32)
+    res = op.sliding_iterative_denoise(pv, pl, sk, cm, g["latents_in"], c["domain"], g["timestep_indices_in"], g["noise"], **c["kw"])
+    assert torch.equal(res["timestep_indices"], g["timestep_indices"])
+    assert rel(res["latents"], g["latents"]) <= 1e-5
+    assert rel(res["images"], g["images"]) <= 1e-3
+
+
+class _PlannedRows16:
+    """What the PRODUCT does with UniPC / DEIS, on the CPU: no scheduler object per latent, only the host's 16-float rows
+    (host/scheduler.py::step_rows) and up to three stored tensors per latent; records how many steps each latent had taken."""
+    init_noise_sigma = 1.0
+
+    def __init__(self, host_sched, log):
+        self.h, self.log, self.s, self.k, self.timesteps = host_sched, log, None, 0, None
+
+    def __deepcopy__(self, memo):
+        c = _PlannedRows16(self.h, self.log)
+        c.timesteps = self.timesteps
+        return c
+
+    def set_timesteps(self, n):
+        self.timesteps = torch.from_numpy(self.h.set_timesteps(n))
+        return self.timesteps
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def step(self, model_output, t, sample):
+        i = int((self.timesteps == int(t)).nonzero()[0])
+        self.log.append(self.k)
+        r = [float(v) for v in self.h.step_rows([i], [self.k])[0]]
+        s1, s2, s3 = self.s if self.s is not None else (torch.zeros_like(sample),) * 3
+        conv = r[0] * sample + r[1] * model_output
+        xc = r[2] * sample + r[3] * s3 + r[4] * s1 + r[5] * s2 + r[6] * conv
+        self.s, self.k = (conv, s1, xc), self.k + 1
+        return r[7] * xc + r[8] * conv + r[9] * s1 + r[10] * s2
+
+
+@pytest.mark.parametrize("name", MULTISTEP_CASES)
+def test_planned_16_float_rows_reproduce_the_reference_pipeline_with_stateful_unipc_deis(name):
+    from diffuman4d_amd.host.schedule import history_counts
+    g, c, ou, ov, (pv, pl, sk, cm) = _multistep_task(name)
+    log = []
+    op = OraclePipeline(ov, ou, _PlannedRows16(_host_multistep(c), log), torch.float32)
+    res = op.sliding_iterative_denoise(pv, pl, sk, cm, g["latents_in"], c["domain"], g["timestep_indices_in"], g["noise"], decode=False, **c["kw"])
+    assert rel(res["latents"], g["latents"]) <= 5e-5
+    k = c["kw"]
+    cond = [i in c["inputs"] for i in range(c["n"])]
+    plan = plan_sweep(cond, g["timestep_indices_in"].tolist(), c["domain"], k["window_size"], k["sliding_stride"],
+                      k["sliding_shift"], k["bidirectional"], k["num_denoising_steps"], k["alternation_rounds"])
+    counts = history_counts(plan.windows, plan.is_cond)
+    planned = [int(n) for cn, ic in zip(counts, plan.is_cond) for n, is_c in zip(cn, ic) if not is_c]
+    assert planned == log and max(log) >= 1

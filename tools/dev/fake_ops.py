@@ -222,6 +222,29 @@ def cfg_linear_step(latents, x0_prev, noise_pred, coef, is_cond, use_cfg, guidan
     return latents
 
 
+def cfg_multistep_step(latents, states, noise_pred, coef, is_cond, use_cfg, guidance_scale, frame_idx=None):
+    rows = frame_idx.long() if frame_idx is not None else torch.arange(latents.shape[0])
+    Fn = is_cond.shape[0]
+    npd = noise_pred.double()[..., :4]
+    m = npd[:Fn] + guidance_scale * (npd[Fn:] - npd[:Fn]) if use_cfg else npd
+    k = [coef[:, i].double()[:, None, None] for i in range(11)]
+    z = torch.zeros_like(latents[rows].double())
+    x = latents[rows].double()
+    s1, s2, s3 = (states[j][rows].double() if j < len(states) else z for j in range(3))
+    conv = k[0] * x + k[1] * m
+    xc = k[2] * x + k[3] * s3 + k[4] * s1 + k[5] * s2 + k[6] * conv
+    xn = k[7] * xc + k[8] * conv + k[9] * s1 + k[10] * s2
+    keep = ~is_cond.bool()
+    dt = latents.dtype
+    latents[rows[keep]] = xn.to(dt)[keep]
+    if len(states) >= 3:
+        states[2][rows[keep]] = xc.to(dt)[keep]
+    if len(states) >= 2:
+        states[1][rows[keep]] = s1.to(dt)[keep]
+    states[0][rows[keep]] = conv.to(dt)[keep]
+    return latents
+
+
 def nchw_to_nhwc(x, cpad=None):
     y = x.permute(0, 2, 3, 1)
     return F.pad(y, (0, (cpad or x.shape[1]) - x.shape[1])).contiguous()
@@ -276,7 +299,7 @@ def install():
     from diffuman4d_amd.host import ops
     me = sys.modules[__name__]
     for name in ("gemm", "conv_out_hw", "conv3x3", "dup_k", "split", "groupnorm", "layernorm", "attention", "attention_split", "softmax_rows",
-                 "softmax_rows_split", "timestep_embedding", "silu", "pack_model_input", "cfg_ddim_step", "cfg_linear_step", "nchw_to_nhwc",
+                 "softmax_rows_split", "timestep_embedding", "silu", "pack_model_input", "cfg_ddim_step", "cfg_linear_step", "cfg_multistep_step", "nchw_to_nhwc",
                  "nhwc_to_nchw", "vae_sample", "scale_pad", "resize_to_nhwc", "postprocess_images", "FeedForward", "Upsampler"):
         setattr(ops, name, getattr(me, name))
     from diffuman4d_amd.host import vae
@@ -292,6 +315,19 @@ def rel_l2(a, b):
 def main():
     install()
     import modelcheck as mc
+    from dataclasses import asdict
+    from diffuman4d_amd.host.unet import UNetConfig, UNetMultiviewConditionModel
+    from diffuman4d_amd.host.vae import AutoencoderKL, VAEConfig
+    if sys.argv[1:2] == ["golden"]:  # python tools/dev/fake_ops.py golden <modelcheck case> ...: a golden-pipeline case on the stand-in
+        mc.hip_unet = lambda cfg, om, precision="fast": UNetMultiviewConditionModel(UNetConfig.from_dict(asdict(cfg)), om.state_dict(), "cpu", precision)
+        mc.hip_vae = lambda cfg, om, precision="fast": AutoencoderKL(VAEConfig.from_dict(asdict(cfg)), om.state_dict(), "cpu", precision)
+        import diffuman4d_amd.host.pipeline as hp_
+        orig = hp_.Diffuman4DPipeline
+        hp_.Diffuman4DPipeline = lambda v, u, s, dev: orig(v, u, s, "cpu")
+        for name in sys.argv[2:]:
+            fn, kw = mc.CASES[name]
+            print(name, fn(**kw), flush=True)
+        return
     from dataclasses import asdict
     from diffuman4d_amd.host import ops
     from diffuman4d_amd.host.pipeline import Diffuman4DPipeline
