@@ -27,6 +27,7 @@ SIGNATURES = {
                                           _i64, _f, _u]),
     "dm4d_conv3x3_ws_bytes": (C.c_size_t, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "dm4d_conv2d_direct_nhwc_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
+    "dm4d_conv2d_direct_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
     "dm4d_groupnorm_ws_bytes": (C.c_size_t, [_i, _i, _i]),
     "dm4d_groupnorm_nhwc_bf16": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp]),
     "dm4d_layernorm_bf16": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _f]),

@@ -334,18 +334,22 @@ def conv_up2x(x: torch.Tensor, wp: torch.Tensor, *, bias=None) -> torch.Tensor:
 
 def conv2d_direct(x: torch.Tensor, wt: torch.Tensor, *, ksize: int, bias=None, stride: int = 1, pad: int = 1,
                   silu: bool = False) -> torch.Tensor:
-    """Thin-layer convolution (PoseEncoder): x [B,H,W,Cin] NHWC, wt [Cout, ksize*ksize*Cin] ((ky,kx,ci) order)."""
+    """Thin-layer convolution (PoseEncoder): x [B,H,W,Cin] NHWC, wt [Cout, ksize*ksize*Cin] ((ky,kx,ci) order).  bf16 tensors, or
+    (parity precision) x, wt, bias and the result all fp32."""
     lib = _l.load()
-    _req(x, "x"), _req(wt, "wt")
+    dt = F32 if x.dtype == F32 else BF16
+    _req(x, "x", dt), _req(wt, "wt", dt)
+    if bias is not None:
+        _req(bias, "bias", dt)
     assert x.is_contiguous() and wt.is_contiguous()
     B, H, W, Cin = x.shape
     Cout = wt.shape[0]
     assert wt.shape[1] == ksize * ksize * Cin, (wt.shape, ksize, Cin)
     Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
-    y = torch.empty((B, Ho, Wo, Cout), dtype=BF16, device=x.device)
-    rc = lib.dm4d_conv2d_direct_nhwc_bf16(_stream(), _p(x), B, H, W, Cin, _p(wt), _p(bias), _p(y), Ho, Wo, Cout, ksize,
-                                          stride, pad, 1 if silu else 0)
-    _l.check(rc, "dm4d_conv2d_direct_nhwc_bf16")
+    y = torch.empty((B, Ho, Wo, Cout), dtype=dt, device=x.device)
+    fn = lib.dm4d_conv2d_direct_nhwc_f32 if dt == F32 else lib.dm4d_conv2d_direct_nhwc_bf16
+    rc = fn(_stream(), _p(x), B, H, W, Cin, _p(wt), _p(bias), _p(y), Ho, Wo, Cout, ksize, stride, pad, 1 if silu else 0)
+    _l.check(rc, "dm4d_conv2d_direct_nhwc")
     return y
 
 

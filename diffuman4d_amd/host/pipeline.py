@@ -118,8 +118,10 @@ class Diffuman4DPipeline:
     def _to_dev_nhwc(self, x: torch.Tensor, cpad: Optional[int] = None) -> torch.Tensor:
         """CPU/GPU NCHW (any float dtype) -> device NHWC bf16 via the layout kernel (parity precision: fp32, permuted where it lies)."""
         if self.parity:
-            assert cpad is None
-            return x.float().permute(0, 2, 3, 1).contiguous().to(self._device)
+            y = x.float().permute(0, 2, 3, 1)
+            if cpad is not None and cpad > y.shape[-1]:
+                y = torch.nn.functional.pad(y, (0, cpad - y.shape[-1]))
+            return y.contiguous().to(self._device)
         x = x.to(device=self._device, dtype=BF16).contiguous()
         return ops.nchw_to_nhwc(x, cpad)
 

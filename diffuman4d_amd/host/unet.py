@@ -108,7 +108,9 @@ class _Weights:
 
 class _PoseEncoder:
     """pose_encoder.py:11-54: eight thin conv+SiLU layers (direct-conv kernel), a 1x1 projection and a learned scale.
-    Input: skeleton images NHWC bf16 [B, 8h, 8w, 4] (3 channels + one zero pad); output [B, h, w, C0]."""
+    Input: skeleton images NHWC bf16 [B, 8h, 8w, 4] (3 channels + one zero pad); output [B, h, w, C0].
+    Parity precision: fp32 images, filters and layer outputs (the direct kernel's fp32 FMA chain with nothing rounded), the projection
+    as a two-term GEMM, fp32 features."""
 
     LAYERS = ((3, 3, 3, 1), (3, 16, 4, 2), (16, 16, 3, 1), (16, 32, 4, 2), (32, 32, 3, 1), (32, 64, 4, 2),
               (64, 64, 3, 1), (64, 128, 3, 1))  # (Cin, Cout, kernel, stride), padding 1
@@ -124,7 +126,9 @@ class _PoseEncoder:
             wp, bp = torch.zeros(cop, k, k, cip), torch.zeros(cop)
             wp[:co, :, :, :ci] = w.permute(0, 2, 3, 1)
             bp[:co] = b
-            self.layers.append((wp.reshape(cop, k * k * cip).to(W.device, BF16).contiguous(), bp.to(W.device, BF16), k, s))
+            dt = torch.float32 if W.parity else BF16
+            self.layers.append((wp.reshape(cop, k * k * cip).to(W.device, dt).contiguous(), bp.to(W.device, dt), k, s))
+        self.parity = W.parity
         self.proj_w, self.proj_b = W.linear(pfx + "final_proj.weight"), W.vec(pfx + "final_proj.bias")
         self.scale = float(W.get(pfx + "scale").to(BF16).float().reshape(-1)[0])
 
@@ -133,11 +137,14 @@ class _PoseEncoder:
             raise ValueError("pose encoder input must be NHWC with 4 (3 + pad) channels")
         outs = []
         for xb in x.split(batch):
-            y = xb.contiguous()
+            y = xb.float().contiguous() if self.parity else xb.contiguous()
             for (w, b, k, s) in self.layers:
                 y = ops.conv2d_direct(y, w, ksize=k, bias=b, stride=s, pad=1, silu=True)
             B, h, wd, C = y.shape
-            outs.append(ops.gemm(y.view(B * h * wd, C), self.proj_w, bias=self.proj_b, out_scale=self.scale).view(B, h, wd, -1))
+            y = y.view(B * h * wd, C)
+            if self.parity:
+                y = ops.split(y)
+            outs.append(ops.gemm(y, self.proj_w, bias=self.proj_b, out_scale=self.scale, out_f32=self.parity).view(B, h, wd, -1))
         return outs[0] if len(outs) == 1 else torch.cat(outs)
 
 
@@ -276,8 +283,6 @@ class UNetMultiviewConditionModel:
             raise NotImplementedError("cross_attention_dim must be None (SURVEY.md section 0)")
         if cfg.in_channels > self.IN_PAD:
             raise NotImplementedError("in_channels > 32")
-        if self.parity and cfg.enable_pose_encoder:
-            raise NotImplementedError("precision='parity' does not cover enable_pose_encoder checkpoints")
         W = _Weights(state_dict, self.device, self.parity)
         boc = cfg.block_out_channels
         g, eps = cfg.norm_num_groups, cfg.norm_eps

@@ -102,6 +102,11 @@ int dm4d_conv_up2x_nhwc_bf16(void* stream, const void* X, int B, int H, int W, i
 int dm4d_conv2d_direct_nhwc_bf16(void* stream, const void* X, int B, int H, int W, int Cin, const void* Wt,
                                  const void* bias, void* Y, int Ho, int Wo, int Cout, int ksize, int stride, int pad,
                                  int apply_silu);
+/* The same chain on fp32 tensors (image, filters, bias, result all fp32; nothing rounded to bf16): the PoseEncoder of the parity
+ * precision (see "Parity precision" below).                                                                              */
+int dm4d_conv2d_direct_nhwc_f32(void* stream, const void* X, int B, int H, int W, int Cin, const void* Wt,
+                                const void* bias, void* Y, int Ho, int Wo, int Cout, int ksize, int stride, int pad,
+                                int apply_silu);
 
 /* GroupNorm (+SiLU) over [X1 | X2] (channel concat, X2 may be NULL), NHWC.
  *   replaces nn.GroupNorm + SiLU in ResnetBlock2D.norm1/norm2, TransformerMultiviewModel.norm

@@ -938,6 +938,7 @@ CASES.update({
     "par_golden_spatial": (case_golden_pipeline, dict(name="spatial", **PAR)),
     "par_golden_temporal_v": (case_golden_pipeline, dict(name="temporal_v", **PAR)),
     "par_golden_round2_shift": (case_golden_pipeline, dict(name="round2_shift", **PAR)),
+    "par_golden_pose_encoder": (case_golden_pipeline, dict(name="pose_encoder", **PAR)),
     "par_golden_dpm_temporal_v_heun_round2": (case_golden_pipeline, dict(name="dpm_temporal_v_heun_round2", **PAR)),
     "par_golden_unipc_temporal_v_bh1_round2": (case_golden_pipeline, dict(name="unipc_temporal_v_bh1_round2", **PAR)),
     "par_golden_unipc_spatial_bidir": (case_golden_pipeline, dict(name="unipc_spatial_bidir", **PAR)),

@@ -221,14 +221,16 @@ def case_conv_batch_invariance(B, H, W, Cin, Cout, seed=0):
     return worst, worst
 
 
-def case_conv_direct(B, H, W, Cin, Cout, k, stride, silu=True, seed=0):
-    """PoseEncoder layers (pose_encoder.py:14-31): thin direct convolution, channels zero-padded to multiples of 4."""
+def case_conv_direct(B, H, W, Cin, Cout, k, stride, silu=True, seed=0, f32=False):
+    """PoseEncoder layers (pose_encoder.py:14-31): thin direct convolution, channels zero-padded to multiples of 4.
+    f32: the parity precision's variant (fp32 image, filters, bias, result; inputs NOT bf16-representable)."""
     from diffuman4d_amd.host import ops
     g = torch.Generator().manual_seed(seed)
-    x = _rnd((B, Cin, H, W), g)
-    w = _rnd((Cout, Cin, k, k), g, 1.0 / math.sqrt(k * k * Cin))
-    b = _rnd((Cout,), g, 0.5)
-    ref = F.conv2d(x.float(), w.float(), b.float(), stride=stride, padding=1)
+    BF = torch.float32 if f32 else torch.bfloat16
+    x = torch.randn((B, Cin, H, W), generator=g) if f32 else _rnd((B, Cin, H, W), g)
+    w = torch.randn((Cout, Cin, k, k), generator=g) / math.sqrt(k * k * Cin) if f32 else _rnd((Cout, Cin, k, k), g, 1.0 / math.sqrt(k * k * Cin))
+    b = _rnd((Cout,), g, 0.5).float() * (1.0 + 2.0 ** -12) if f32 else _rnd((Cout,), g, 0.5)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=1).float()
     if silu:
         ref = F.silu(ref)
     cip, cop = (Cin + 3) // 4 * 4, (Cout + 3) // 4 * 4
@@ -872,6 +874,9 @@ CASES = {
     "convd_16to32_k4s2": (case_conv_direct, dict(B=3, H=20, W=12, Cin=16, Cout=32, k=4, stride=2)),
     "convd_32to64_k4s2_odd": (case_conv_direct, dict(B=2, H=11, W=7, Cin=32, Cout=64, k=4, stride=2)),
     "convd_64to128_k3": (case_conv_direct, dict(B=2, H=9, W=5, Cin=64, Cout=128, k=3, stride=1, silu=False)),
+    "par_convd_3to16_k4s2": (case_conv_direct, dict(B=2, H=40, W=24, Cin=3, Cout=16, k=4, stride=2, f32=True)),
+    "par_convd_32to64_k4s2_odd": (case_conv_direct, dict(B=2, H=11, W=7, Cin=32, Cout=64, k=4, stride=2, f32=True)),
+    "par_convd_64to128_k3": (case_conv_direct, dict(B=2, H=9, W=5, Cin=64, Cout=128, k=3, stride=1, silu=False, f32=True)),
     # --- attention -------------------------------------------------------------------------------
     # fused level-0 feed-forward: one 128-row tile, a ragged last tile, several tiles, no biases, row-strided operands, and the
     # judged shape (CFG batch 32 at 72x40: M = 92 160)

@@ -86,6 +86,14 @@ def conv3x3(x, wt, *, bias=None, rowbias=None, residual=None, stride=1, pad=1, p
     return _out((v * out_scale).float(), out_f32).contiguous()
 
 
+def conv2d_direct(x, wt, *, ksize, bias=None, stride=1, pad=1, silu=False):
+    B, H, W, Cin = x.shape
+    w = wt.double().view(-1, ksize, ksize, Cin).permute(0, 3, 1, 2)
+    y = F.conv2d(x.double().permute(0, 3, 1, 2), w, None if bias is None else bias.double(), stride=stride, padding=pad)
+    y = F.silu(y) if silu else y
+    return y.permute(0, 2, 3, 1).contiguous().to(x.dtype)
+
+
 def dup_k(w, taps=1, times=2):
     n, k = w.shape
     c = k // taps
@@ -298,7 +306,7 @@ def install():
     """Replace the wrappers of diffuman4d_amd.host.ops with the functions of this module (this process only)."""
     from diffuman4d_amd.host import ops
     me = sys.modules[__name__]
-    for name in ("gemm", "conv_out_hw", "conv3x3", "dup_k", "split", "groupnorm", "layernorm", "attention", "attention_split", "softmax_rows",
+    for name in ("gemm", "conv_out_hw", "conv3x3", "conv2d_direct", "dup_k", "split", "groupnorm", "layernorm", "attention", "attention_split", "softmax_rows",
                  "softmax_rows_split", "timestep_embedding", "silu", "pack_model_input", "cfg_ddim_step", "cfg_linear_step", "cfg_multistep_step", "nchw_to_nhwc",
                  "nhwc_to_nchw", "vae_sample", "scale_pad", "resize_to_nhwc", "postprocess_images", "FeedForward", "Upsampler"):
         setattr(ops, name, getattr(me, name))
