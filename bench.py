@@ -78,7 +78,7 @@ def parse():
                     help="BENCH-ONLY EXPERIMENT (the runners have no task batching; the judged line uses 1): tasks of a round "
                          "stacked into ONE window call through host/pipeline.py upload_plan(copies=); K steps are then "
                          "K / task-batch stacked units")
-    ap.add_argument("--task-streams", type=int, default=2,
+    ap.add_argument("--task-streams", type=int, default=3,
                     help="independent tasks in flight per GPU, each on its own HIP stream and worker thread (the runner's "
                          "gpu_streams). 1 = one task at a time")
     ap.add_argument("--grid-frames", type=int, default=N_FRAMES, help="grid mode: frames of the (48 camera x T frame) grid")

@@ -139,7 +139,7 @@ def _make_writer_pool(sampler, writer_processes: int):
 
 
 class SamplingRunner:
-    def __init__(self, sampler: SlidingIterativeSampler, prefetch_depth: int = 2, writers: int = 2, gpu_streams: int = 2,
+    def __init__(self, sampler: SlidingIterativeSampler, prefetch_depth: int = 2, writers: int = 2, gpu_streams: int = 3,
                  writer_processes: int = 0):
         self.sampler = sampler
         self.prefetch_depth, self.writers, self.gpu_streams = prefetch_depth, writers, gpu_streams
@@ -227,7 +227,7 @@ class DistributedSamplingRunner:
     MODES = ("task", "frame-shard", "hybrid")
 
     def __init__(self, sampler: SlidingIterativeSampler, group=None, prefetch_depth: int = 2, writers: int = 2,
-                 gpu_streams: int = 2, balance: bool = True, writer_processes: int = 0, mode: str = "task"):
+                 gpu_streams: int = 3, balance: bool = True, writer_processes: int = 0, mode: str = "task"):
         import torch.distributed as dist
         if mode not in self.MODES:
             raise ValueError(f"Unsupported runner mode: {mode}. Supported modes are {', '.join(self.MODES)}.")

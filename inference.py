@@ -37,7 +37,7 @@ def inference(cfg: dict):
     pipelines = cfglib.instantiate(cfg["model"])
     log.info("Instantiating sampler <%s>", cfg["sampler"]["_target_"])
     sampler = cfglib.instantiate(cfg["sampler"], dataset=dataset, pipelines=pipelines)
-    # runner.gpu_streams=N (default 2): tasks of a round in flight per GPU, one HIP stream each; 1 = the reference's
+    # runner.gpu_streams=N (default 3): tasks of a round in flight per GPU, one HIP stream each; 1 = the reference's
     # one-task-at-a-time order
     # runner.writer_processes=N (default 0): with sampler.device_results=true the JPEG / WebP encoding of every task's uint8
     # package runs in N writer processes (host/imgwrite.py) instead of the writer threads

@@ -1040,8 +1040,8 @@ def run_case(name):
 def main():
     torch.manual_seed(0)
     bad = 0
-    prefix = sys.argv[1] if len(sys.argv) > 1 else ""  # e.g. `opcheck.py attn`
-    names = [n for n in CASES if n.startswith(prefix)]
+    prefixes = tuple(sys.argv[1:]) or ("",)  # e.g. `opcheck.py attn par_attn`
+    names = [n for n in CASES if n.startswith(prefixes)]
     for name in names:
         try:
             err, mx, tol = run_case(name)

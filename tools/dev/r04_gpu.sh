@@ -64,5 +64,49 @@ PY
     done
     rm -f $out/r04_e2e_demo4d_*_timeline.json
     ;;
+  verify4)  # UniPC / DEIS (kernel + reference-pipeline fixtures), parity precision against the reference pipeline's fixtures, pose encoder;
+            # then the fast CLI path again with result packing kept on the device
+    timeout 300 python tests/opcheck.py multistep_step par_multistep par_convd convd_ > $out/r04_v4_opcheck.log 2>&1; tail -8 $out/r04_v4_opcheck.log
+    timeout 900 python tests/modelcheck.py golden_unipc golden_deis par_golden > $out/r04_v4_modelcheck_golden.log 2>&1
+    grep -v "^/opt\|Denoising" $out/r04_v4_modelcheck_golden.log | cut -c1-400 | tail -32
+    timeout 900 python tools/e2e_demo.py --exp demo_4d --fast-vae --prune --writers 2 --device-results --writer-processes 12 --host-threads 8 --depth 3 \
+        sampler.plucker_on_device=true data.plucker=cameras > $out/r04_v4_e2e_demo4d_fast.json 2> $out/r04_v4_e2e_demo4d_fast.err
+    cat $out/r04_v4_e2e_demo4d_fast.json; tail -2 $out/r04_v4_e2e_demo4d_fast.err | cut -c1-300
+    ;;
+  e2e5)  # where the fast CLI path loses its last 12 %: host-stage detail with 2 and 3 tasks in flight
+    for gs in 2 3; do
+      timeout 700 python tools/e2e_demo.py --exp demo_4d --fast-vae --prune --writers 2 --device-results --writer-processes 12 --host-threads 8 --depth 3 \
+        --gpu-streams $gs --timeline $out/r04_v5_tl_$gs.json sampler.plucker_on_device=true data.plucker=cameras > $out/r04_v5_e2e_fast_gs$gs.json 2> $out/r04_v5_e2e_fast_gs$gs.err
+      cat $out/r04_v5_e2e_fast_gs$gs.json
+      python - $out/r04_v5_tl_$gs.json <<'PY'
+import json, sys
+ev = json.load(open(sys.argv[1]))
+den = sorted((s, e) for n, s, e, th in ev if n == "denoise")
+# union of the intervals in which NO worker is between the start of its window sweep and the end of its device wait = certain GPU idle
+gpu = sorted((s, e) for n, s, e, th in ev if n in ("d.denoise_latents", "d.decode", "d.device_wait", "d.encode_scaled"))
+end = max(e for _, _, e, _ in ev)
+cov, cur = 0.0, None
+for s, e in gpu:
+    if cur is None or s > cur[1]:
+        cov += (cur[1] - cur[0]) if cur else 0.0
+        cur = [s, e]
+    else:
+        cur[1] = max(cur[1], e)
+cov += (cur[1] - cur[0]) if cur else 0.0
+print(f"  wall {end:.1f}s; some worker inside sweep/decode/wait/encode: {cov:.1f}s; first denoise starts at {den[0][0]:.2f}s")
+rounds = {}
+for n, s, e, th in ev:
+    if n == "denoise":
+        rounds.setdefault(th, []).append((s, e))
+gaps = []
+for th, iv in rounds.items():
+    iv.sort()
+    gaps += [(b[0] - a[1], a[1]) for a, b in zip(iv, iv[1:])]
+gaps.sort(reverse=True)
+print("  largest gaps between consecutive tasks of a worker (s, at):", [(round(g, 2), round(t, 1)) for g, t in gaps[:6]], "sum", round(sum(g for g, _ in gaps), 1))
+PY
+      rm -f $out/r04_v5_tl_$gs.json
+    done
+    ;;
   *) echo "unknown stage $stage"; exit 2;;
 esac

@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--size", default="576x320", help="image HxW (latents are 1/8)")
     ap.add_argument("--depth", type=int, default=2)
     ap.add_argument("--writers", type=int, default=8)
-    ap.add_argument("--gpu-streams", type=int, default=2, help="tasks of a round in flight on the GPU (runner.gpu_streams)")
+    ap.add_argument("--gpu-streams", type=int, default=3, help="tasks of a round in flight on the GPU (runner.gpu_streams)")
     ap.add_argument("--fast-vae", action="store_true",
                     help="sampler.vae_cache=true sampler.decode_policy=denoised (encoder moments cached per grid cell, "
                          "decode only the rows that are saved)")
