@@ -92,6 +92,14 @@ def checksums(pv, pl, sk, cm, noise, usd, vsd):
                 unet_weights=float(sum(f(v) for v in usd.values())), vae_weights=float(sum(f(v) for v in vsd.values())))
 
 
+def same_checksums(a, b, rel=1e-5):
+    """The checksums are fp32 / fp64 sums of ~1e7 terms: their last digits depend on the reduction order (thread count), so two runs of the
+    same seeds are compared within `rel`, never with ==."""
+    if isinstance(a, dict):
+        return isinstance(b, dict) and a.keys() == b.keys() and all(same_checksums(a[k], b[k], rel) for k in a)
+    return abs(a - b) <= rel * max(abs(a), abs(b), 1e-30)
+
+
 def state_dicts():
     from diffuman4d_amd.host.unet import UNetConfig as HU
     from diffuman4d_amd.host.vae import VAEConfig as HV
@@ -150,7 +158,8 @@ def main():
     if "matched" in which:
         assert "latents" in blob, "run the fp32 pass first"
         out, images, chk, secs = run_matched()
-        assert chk == blob["checksums"] and torch.equal(out["timestep_indices"], blob["timestep_indices"])
+        torch.save(dict(out=out, images=images, chk=chk, secs=secs), "/tmp/demo3d_matched_raw.pt")  # 1.5 h of CPU: kept before any check
+        assert same_checksums(chk, blob["checksums"]) and torch.equal(out["timestep_indices"].long(), blob["timestep_indices"].long())
         ref_img = blob["images_u16"].to(torch.int32).float() / 65535.0
         blob.update(matched_latents=out["latents"].to(BF), matched_images_u16=(images.float() * 65535.0).round().to(torch.int32).to(torch.uint16),
                     matched_vs_fp32_latents=rel_l2(out["latents"], blob["latents"]), matched_vs_fp32_images=rel_l2(images, ref_img),
@@ -168,7 +177,7 @@ def main():
     if "bf16" in which:
         assert "latents" in blob, "run the fp32 pass first"
         out, images, chk, secs = run(BF)
-        assert chk == blob["checksums"]
+        assert same_checksums(chk, blob["checksums"])
         assert torch.equal(out["timestep_indices"], blob["timestep_indices"])
         ref_img = blob["images_u16"].to(torch.int32).float() / 65535.0
         blob.update(yard_latents=rel_l2(out["latents"], blob["latents"]), yard_images=rel_l2(images, ref_img),

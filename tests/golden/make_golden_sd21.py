@@ -114,7 +114,7 @@ def golden_unet_matched(blob: dict, name: str):
     from oracle import matched
     g = blob[name]
     cfg, m, wchk = build_unet()
-    assert wchk == g["weights_checksum"]
+    assert abs(wchk - g["weights_checksum"]) <= 1e-5 * abs(wchk)  # a sum of ~1e9 terms: last digits depend on the reduction order
     x, t = unet_inputs(g["num_frames"], g["n_cond"], g["seed"], g.get("size"))
     t0 = time.time()
     out = matched.unet_forward(m, x.float(), t, domains=[g["domain"]] * 2, num_frames=g["num_frames"])

@@ -988,7 +988,10 @@ if (GOLDEN / "demo3d_sd21_72x40.pt").exists():
 TOL = {"task_batching_spatial": 0.0, "task_batching_temporal_x3": 0.0, "task_batching_dpm": 0.0, "pipeline_shard_rccl_world1": 0.0, "unet_frame_shard_p4": 0.0, "unet_frame_shard_p8": 0.0,
        "pipeline_cache_lazy_decode": 0.0, "pipeline_prune_cond_rows": 5e-3, "pipeline_prune_cond_rows_temporal": 5e-3,
        "pipeline_plucker_on_device": 5e-3, "resize": 4e-3}
-PARITY_TOLS: dict = {}  # tighter fixed bounds of individual par_* cases (name -> bound), from the measurements in DESIGN.md section 3
+# Tighter fixed bounds of individual par_* cases, ~8x above what MI355X measured (every quantity below 1.6e-5 where
+# the fixture is fp32 / 16-bit fixed point).  Cases whose fixture stores the decoded RGB in fp16 (floor 1.7-1.8e-4) keep 5e-4.
+PARITY_TOLS: dict = {n: 1e-4 for n in CASES if n.startswith("par_") and not n.startswith(("par_golden", "par_vae_sd"))}
+PARITY_TOLS.update({n: 5e-4 for n in CASES if n.startswith(("par_golden", "par_vae_sd"))})
 TOL.update({n: PARITY_TOLS.get(n, PARITY_TOL) for n in CASES if n.startswith("par_")})
 TOL.update({n: 0.0 for n in CASES if n.endswith("_matched")})  # band_excess must be zero (MATCHED_BAND)
 TOL.update({n: REPLAY_TOL for n in CASES if n.startswith("opreplay_")})

@@ -44,19 +44,20 @@ def test_bench_prints_one_contract_line():
 
 
 @pytest.mark.gpu
-def test_bench_with_two_task_streams():
-    """Default scheduling: the K steps are dealt to two tasks in flight (one HIP stream each); the roofline figures
-    come from the one-task-at-a-time pass that follows the timed region."""
-    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-grid-secondary"],
+def test_bench_with_the_default_task_streams():
+    """Default scheduling: the K steps are dealt to three tasks in flight (one HIP stream each, the runner's default); the roofline
+    figures come from the one-task-at-a-time pass that follows the timed region."""
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-grid-secondary",
+                        "--no-parity-precision", "--no-latent128"],
                        cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
-    assert d["steps"] == 2 and d["config"]["task_streams"] == 2 and d["config"]["finite_outputs"] is True
+    assert d["steps"] == 3 and d["config"]["task_streams"] == 3 and d["config"]["finite_outputs"] is True
     assert abs(d["value"] - 2.0 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
     rf = d["roofline"]
-    assert rf["launches"] == 2 * 48 and 0.05 < rf["frac"] < 1.0 and "one task in flight" in rf["measured_in"]
+    assert rf["launches"] == 3 * 48 and 0.05 < rf["frac"] < 1.0 and "one task in flight" in rf["measured_in"]
 
 
 @pytest.mark.gpu
@@ -81,3 +82,25 @@ def test_bench_self_launches_grid_mode_for_two_ranks():
     assert d["config"]["finite_outputs"] is True
     sg = d["secondary"]["grid"]  # same field names as the N = 1 line's secondary.grid: a 1 -> N curve is grid / grid
     assert sg["n_gpus"] == 2 and sg["latents_per_s"] == d["value"] and sg["calls"] == sum(g["calls_per_rank"])
+
+
+@pytest.mark.gpu
+def test_bench_hybrid_mode_runs_a_frame_sharded_tail_wave():
+    """`bench.py --gpus 4 --mode hybrid` on a 48 x 10 grid: the spatial rounds have 10 tasks = two full waves of 4 (task-parallel) and a
+    tail wave of 2 <= world / 2, which the product runner (DistributedSamplingRunner(mode="hybrid")) runs frame-sharded on two sub-groups
+    of two ranks; the 44 temporal tasks are 11 full waves.  All ranks share GPU 0 over gloo (testing only): what is checked is that the
+    HIP pipeline, the sub-group collectives and the cell exchange of the tail tasks work together and every target cell of the grid
+    reaches the final timestep index (bench raises otherwise)."""
+    import os
+    env = dict(os.environ, DM4D_BENCH_SHARED_GPU="1")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--mode", "hybrid", "--steps", "1", "--warmup", "1", "--grid-frames", "10"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=2400, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["config"]["mode"] == "grid" and "hybrid" in d["config"]["parallelism"] and d["config"]["finite_outputs"] is True
+    g = d["config"]["grid"]
+    # 10 spatial tasks x 1 call per spatial round (8 whole + 2 sharded over 2 ranks each, counted 0.5 per rank), 44 temporal tasks x 3 calls;
+    # who runs which whole task of rounds 2-3 follows the measured rates, so only the total is fixed
+    assert abs(sum(g["calls_per_rank"]) - (10 + 44 * 3 + 10)) < 0.05, g
