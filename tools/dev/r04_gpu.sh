@@ -108,5 +108,14 @@ PY
       rm -f $out/r04_v5_tl_$gs.json
     done
     ;;
+  final)  # the record set of the final tree: the whole GPU suite, the driver's command, the strict CLI path with the default three streams
+    ( time timeout 1700 python -m pytest tests -m gpu -x -q > $out/r04_pytest_gpu.log 2>&1 ) 2> $out/r04_pytest_gpu.time; tail -4 $out/r04_pytest_gpu.log; tail -3 $out/r04_pytest_gpu.time
+    timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $out/r04_smoke.log 2>&1; tail -2 $out/r04_smoke.log | cut -c1-600
+    ( time timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/r04_bench.json 2> $out/r04_bench.err ) 2> $out/r04_bench.time; tail -3 $out/r04_bench.time
+    bench_line $out/r04_bench.json "driver command:"
+    timeout 900 python tools/e2e_demo.py --exp demo_4d --writers 2 --device-results --writer-processes 12 --host-threads 8 --depth 3 \
+        sampler.plucker_on_device=true data.plucker=cameras > $out/r04_e2e_demo4d_strict_gs3.json 2> $out/r04_e2e_demo4d_strict_gs3.err
+    cat $out/r04_e2e_demo4d_strict_gs3.json
+    ;;
   *) echo "unknown stage $stage"; exit 2;;
 esac

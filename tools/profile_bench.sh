@@ -37,3 +37,5 @@ python tools/mfma_busy_summary.py "$DBM" attn_kernel > gpurun_out/${TAG}_attn_mf
 for K in conv_strip2_kernel gemm_lin2_kernel ff_proj_fused_kernel; do python tools/mfma_busy_summary.py "$DBM" $K; done > gpurun_out/${TAG}_other_mfma_busy_pmc.txt
 head -12 gpurun_out/${TAG}_kernel_stats.txt
 cat gpurun_out/${TAG}_attn_traffic_pmc.json gpurun_out/${TAG}_attn_mfma_busy_pmc.json gpurun_out/${TAG}_other_mfma_busy_pmc.txt
+# the raw rocprofv3 databases are tens of MB per pass: gpurun merges at most 64 MiB back, so only the summaries above are kept
+rm -rf "$OUT"
