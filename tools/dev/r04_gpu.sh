@@ -117,5 +117,9 @@ PY
         sampler.plucker_on_device=true data.plucker=cameras > $out/r04_e2e_demo4d_strict_gs3.json 2> $out/r04_e2e_demo4d_strict_gs3.err
     cat $out/r04_e2e_demo4d_strict_gs3.json
     ;;
+  suite)  # the whole GPU suite (no -x: one trip reports everything), the new hybrid bench test first on its own
+    timeout 900 python -m pytest tests/test_bench_gpu.py -m gpu -q -k hybrid > $out/r04_pytest_hybrid.log 2>&1; grep -v "^E  \|Denoising" $out/r04_pytest_hybrid.log | tail -5; grep "rank.\]:.*Error\|Error:" $out/r04_pytest_hybrid.log | head -5
+    ( time timeout 1700 python -m pytest tests -m gpu -q > $out/r04_pytest_gpu.log 2>&1 ) 2> $out/r04_pytest_gpu.time; tail -6 $out/r04_pytest_gpu.log | cut -c1-300; tail -3 $out/r04_pytest_gpu.time
+    ;;
   *) echo "unknown stage $stage"; exit 2;;
 esac
