@@ -367,11 +367,30 @@ def parity_precision_secondary(cfg, state_dict, dev, units: int):
             run_unit(pp, tasks, 1 + u)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        # where that step goes: one more unit with an event pair around every launch (untimed), summed per kernel family.  Rates are on
+        # the work EXECUTED in this precision (K doubled in every GEMM / conv, three MFMA terms per attention product, fp32 + two planes of
+        # bytes in the normalisations), against the same peaks as the fast precision's rows
+        from diffuman4d_amd.host import ops
+        ops.PROFILE = prof = []
+        run_unit(pp, tasks, 1 + units)
+        torch.cuda.synchronize()
+        ops.PROFILE = None
+    fam = {}
+    for name, work, unit, e0, e1, _rows in prof:
+        f = fam.setdefault(name, {"launches": 0, "ms": 0.0, "work": 0.0, "unit": unit})
+        f["launches"] += 1
+        f["ms"] += e0.elapsed_time(e1)
+        f["work"] += work
+    families = {}
+    for k, v in fam.items():
+        rate = v["work"] / (v["ms"] * 1e-3) / (1e12 if v["unit"] == "flop" else 1e9)
+        families[k] = {"launches": v["launches"], "ms": round(v["ms"], 2), ("tflops" if v["unit"] == "flop" else "gb_per_s"): round(rate, 1),
+                       "roofline_frac": round(rate / (2500.0 if v["unit"] == "flop" else 8000.0), 3)}
     finite = bool(torch.isfinite(tasks["spatial"]["lat"]).all() and torch.isfinite(tasks["temporal"]["lat"]).all())
     del pp, tasks
     torch.cuda.empty_cache()
     return {"ms_per_step": round(dt / units * 1e3, 3), "latents_per_s": round(LATENTS_PER_UNIT * units / dt, 4), "steps": units,
-            "task_streams": 1, "finite_outputs": finite,
+            "task_streams": 1, "finite_outputs": finite, "kernel_breakdown_one_step": families,
             "note": "precision 'parity' (fp32 tensors between kernels, two-term bf16 MFMA operands on K-duplicated weights, three MFMA "
                     "terms per attention product): the arithmetic within north_star's 1e-3 of the fp32 reference path; not the judged value"}
 

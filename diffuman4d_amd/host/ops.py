@@ -184,8 +184,9 @@ def split(x: torch.Tensor, x2: Optional[torch.Tensor] = None, *, cpad: Optional[
         C2, rs2 = x2.shape[1], x2.stride(0)
     Cp = cpad or (C1 + C2)
     y = torch.empty(lead + (planes * Cp,), dtype=BF16, device=x.device)
-    rc = lib.dm4d_split_f32(_stream(), _p(x), rs1, cs1, C1, _p(x2), rs2, C2, _p(y), planes * Cp, M, Cp, 1 if silu else 0, scale,
-                            pattern)
+    with _Prof("split", 4.0 * M * (C1 + C2) + 2.0 * M * planes * Cp, "byte", M):  # fp32 in, bf16 planes out
+        rc = lib.dm4d_split_f32(_stream(), _p(x), rs1, cs1, C1, _p(x2), rs2, C2, _p(y), planes * Cp, M, Cp, 1 if silu else 0, scale,
+                                pattern)
     _l.check(rc, "dm4d_split_f32")
     return y
 

@@ -37,6 +37,12 @@ def test_bench_prints_one_contract_line():
     assert 0.0 < pr["rel_l2"] < 2.5e-2 and pr["north_star_tolerance"] == 1e-3 and pr["meets_north_star"] == (pr["rel_l2"] <= 1e-3)
     # three distances: HIP vs oracle fp32, HIP vs oracle bf16 (the reference's arithmetic), oracle bf16 vs oracle fp32
     assert pr["hip_vs_oracle_fp32"] == pr["rel_l2"] and 0.0 < pr["hip_vs_oracle_bf16"] < 3e-2 and 0.0 < pr["oracle_bf16_vs_oracle_fp32"] < 3e-2
+    # both precisions against the fp32 oracle on that call, and the parity precision's own step time with its per-family breakdown
+    pm = pr["modes"]
+    assert pm["fast"]["rel_l2"] == pr["rel_l2"] and 0.0 < pm["parity"]["rel_l2"] < 1e-4 and pm["parity"]["meets_north_star"] is True
+    pp = d["secondary"]["parity_precision"]
+    assert pp["finite_outputs"] is True and pp["ms_per_step"] > d["ms_per_step"]
+    assert {"linear", "conv3x3", "attention", "groupnorm", "layernorm", "split"} <= set(pp["kernel_breakdown_one_step"])
     # the same-mode baseline of the N > 1 (grid) lines: one pass over the real round structure on this GPU
     g = d["secondary"]["grid"]
     assert g["n_gpus"] == 1 and g["window_calls_per_task"] == {"spatial": 1, "temporal": 3} and g["calls"] == (12 + 12) * 1 + 44 * 3
