@@ -48,6 +48,38 @@ def test_cli_path_on_synthetic_checkpoint(tmp_path, fast):
     assert len(glob.glob(f"{sampler.output_dir}/grids/*.webp")) == 4 + 6 + 4  # one snapshot mosaic per task
 
 
+def test_cli_path_in_the_parity_precision(tmp_path):
+    """`model.precision=parity` through the same CLI path (config key -> load_pipelines -> from_pretrained -> sampler -> runner -> writer), with
+    the VAE cache, decode-on-demand, device-side Pluecker maps and device-side result packing switched on: the job completes, the pipeline
+    really is the fp32 / two-term one, and its grid differs from the fast precision's (same seed, one task at a time) by bf16 rounding
+    noise -- not by zero (the key was ignored) and not by more (a wiring defect of the mode)."""
+    from diffuman4d_amd.host import config as cfglib
+    from diffuman4d_amd.host.results import check_sampling_results
+    from diffuman4d_amd.host.runner import SamplingRunner
+    from diffuman4d_amd.host.weights import write_synthetic_checkpoint
+    ucfg, vcfg = _tiny_cfgs()
+    ckpt = write_synthetic_checkpoint(tmp_path / "ckpt", ucfg, vcfg, seed=3)
+    grids = {}
+    for prec in ("fast", "parity"):
+        ov = ["exp=demo_4d_tiny", "model=diffuman4d_mi355x", "data=synthetic", f"model.model_dir={ckpt}", "model.gpu_ids=[0]",
+              f"model.precision={prec}", "data.height=64", "data.width=64", "data.num_cameras=8", f"result_dir={tmp_path / prec}",
+              "sampler.spa_label_range=[0,8,1]", "sampler.tem_label_range=[0,4,1]", "sampler.input_spa_labels=[1,5]",
+              "sampler.window_size=4", "sampler.sliding_stride=2", "sampler.vae_cache=true", "sampler.decode_policy=denoised",
+              "sampler.plucker_on_device=true", "data.plucker=cameras", "sampler.device_results=true"]
+        cfg = cfglib.compose(ov)
+        pipelines = cfglib.instantiate(cfg["model"])
+        assert pipelines[0].precision == prec and pipelines[0].dtype == (torch.float32 if prec == "parity" else torch.bfloat16)
+        sampler = cfglib.instantiate(cfg["sampler"], dataset=cfglib.instantiate(cfg["data"]), pipelines=pipelines)
+        torch.manual_seed(1234)
+        SamplingRunner(sampler, prefetch_depth=0, writers=1, gpu_streams=1).inference()
+        assert all(sampler.timestep_indices[c][f] == 6 for c in sampler.target_spa_labels for f in sampler.tem_labels)
+        assert check_sampling_results(sampler.spa_labels, sampler.tem_labels, sampler.output_dir)
+        grids[prec] = torch.stack([sampler.latents[c][f].float().cpu() for c in sampler.target_spa_labels for f in sampler.tem_labels])
+    assert bool(torch.isfinite(grids["parity"]).all())
+    d = float((grids["fast"] - grids["parity"]).norm() / grids["parity"].norm())
+    assert 1e-4 < d < 6e-2, d
+
+
 @pytest.mark.parametrize("domain,n", [("spatial", 8), ("temporal", 12)])
 def test_device_results_match_the_host_writer(tmp_path, domain, n):
     """results.pack_results_on_device on the GPU + imgwrite.write_package vs save_sampling_results on the host copy of the
