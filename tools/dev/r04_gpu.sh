@@ -117,9 +117,12 @@ PY
         sampler.plucker_on_device=true data.plucker=cameras > $out/r04_e2e_demo4d_strict_gs3.json 2> $out/r04_e2e_demo4d_strict_gs3.err
     cat $out/r04_e2e_demo4d_strict_gs3.json
     ;;
-  suite)  # the whole GPU suite (no -x: one trip reports everything), the new hybrid bench test first on its own
-    timeout 900 python -m pytest tests/test_bench_gpu.py -m gpu -q -k hybrid > $out/r04_pytest_hybrid.log 2>&1; grep -v "^E  \|Denoising" $out/r04_pytest_hybrid.log | tail -5; grep "rank.\]:.*Error\|Error:" $out/r04_pytest_hybrid.log | head -5
+  suite)  # the whole GPU suite (no -x: one trip reports everything), the matched demo_3d case with its ratios, the driver's command for the record
     ( time timeout 1700 python -m pytest tests -m gpu -q > $out/r04_pytest_gpu.log 2>&1 ) 2> $out/r04_pytest_gpu.time; tail -6 $out/r04_pytest_gpu.log | cut -c1-300; tail -3 $out/r04_pytest_gpu.time
+    grep "demo_3d fast vs rounding-matched" $out/r04_pytest_gpu.log | cut -c1-300
+    timeout 300 python tests/modelcheck.py demo3d_sd21_72x40_matched 2>&1 | grep "demo_3d\|PASS\|FAIL" | cut -c1-300 | tee $out/r04_modelcheck_demo3d_matched.log
+    ( time timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/r04_bench.json 2> $out/r04_bench.err ) 2> $out/r04_bench.time; tail -3 $out/r04_bench.time
+    bench_line $out/r04_bench.json "driver command:"
     ;;
   *) echo "unknown stage $stage"; exit 2;;
 esac
