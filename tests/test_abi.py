@@ -77,3 +77,32 @@ def test_conv_split_decision_depends_on_the_image_not_on_the_batch():
         assert ws(B, 9, 5, 1280, 1280, stride=2, Ho=5, Wo=3) == 0    # stride 2 is not a strip convolution
         assert ws(B, 9, 5, 1280, 1280, up=1, Ho=18, Wo=10) == 0      # neither is the fused up-sampling
         assert ws(B, 9, 5, 1280, 1284) == 0                          # N not a multiple of 8: no vector epilogue
+
+
+def test_a_stale_library_is_not_blessed(monkeypatch, tmp_path):
+    """`needs_build()` compares the content hash recorded when libdm4d.so was linked with the hash of the sources in the tree (file times do
+    not survive the copy to a GPU box): one changed byte in a kernel source, a header or a compile flag makes the library stale, and
+    `__graft_entry__.build()` asserts on exactly this predicate after building."""
+    from diffuman4d_amd import build
+    build.build(force=False, verbose=False)
+    assert not build.needs_build()
+    h0 = build.source_hash()
+    # a different recorded hash (= the library was linked from other sources)
+    stamp = tmp_path / "stamp"
+    stamp.write_text("0" * 64)
+    monkeypatch.setattr(build, "STAMP", stamp)
+    assert build.needs_build()
+    stamp.write_text(h0)
+    assert not build.needs_build()
+    # one more byte in a source: the tree's hash moves, the recorded one does not
+    fake = tmp_path / "csrc"
+    fake.mkdir()
+    for f in list(build.CSRC.glob("*.hip")) + list(build.CSRC.glob("*.h")):
+        (fake / f.name).write_bytes(f.read_bytes())
+    (fake / build.SOURCES[0]).write_bytes((fake / build.SOURCES[0]).read_bytes() + b"\n")
+    monkeypatch.setattr(build, "CSRC", fake)
+    assert build.source_hash() != h0 and build.needs_build()
+    # a missing stamp is stale too
+    monkeypatch.setattr(build, "CSRC", build.ROOT / "csrc")
+    monkeypatch.setattr(build, "STAMP", tmp_path / "absent")
+    assert build.needs_build()
