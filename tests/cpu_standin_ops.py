@@ -1,11 +1,12 @@
 #!/usr/bin/env python
-"""DEV TOOL (build container only, never imported by the product or by tests): a torch-CPU stand-in for `diffuman4d_amd.host.ops`,
+"""TEST / DEV INFRASTRUCTURE (never imported by the product; tests/test_host_wiring.py installs it for its own process and removes it
+again): a torch-CPU stand-in for `diffuman4d_amd.host.ops`,
 so that the HOST side of a precision mode -- weight layouts, operand planes, which tensor feeds which launch -- can be exercised
 without a GPU before a `gpurun` call is spent on it.  It mimics the documented semantics of every wrapper (rounding points
 included: bf16 outputs are rounded once, fp32 accumulation is emulated in fp32 / fp64), not the kernels; the kernels are
 checked on the GPU by tests/opcheck.py.
 
-    python tools/dev/fake_ops.py            # tiny UNet / VAE / pipeline, fast and parity precision, vs the fp32 oracle
+    python tests/cpu_standin_ops.py            # tiny UNet / VAE / pipeline, fast and parity precision, vs the fp32 oracle
 """
 from __future__ import annotations
 
@@ -16,7 +17,7 @@ from pathlib import Path
 import torch
 import torch.nn.functional as F
 
-ROOT = Path(__file__).resolve().parent.parent.parent
+ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 BF, F32 = torch.bfloat16, torch.float32
@@ -302,17 +303,31 @@ class Upsampler:
         return conv3x3(x, self.wt, bias=self.bias, upsample=True)
 
 
+_NAMES = ("gemm", "conv_out_hw", "conv3x3", "conv2d_direct", "dup_k", "split", "groupnorm", "layernorm", "attention", "attention_split", "softmax_rows",
+          "softmax_rows_split", "timestep_embedding", "silu", "pack_model_input", "cfg_ddim_step", "cfg_linear_step", "cfg_multistep_step", "nchw_to_nhwc",
+          "nhwc_to_nchw", "vae_sample", "scale_pad", "resize_to_nhwc", "postprocess_images", "FeedForward", "Upsampler")
+_SAVED = {}
+
+
 def install():
-    """Replace the wrappers of diffuman4d_amd.host.ops with the functions of this module (this process only)."""
-    from diffuman4d_amd.host import ops
+    """Replace the wrappers of diffuman4d_amd.host.ops with the functions of this module (this process only; `uninstall` undoes it)."""
+    from diffuman4d_amd.host import ops, vae
     me = sys.modules[__name__]
-    for name in ("gemm", "conv_out_hw", "conv3x3", "conv2d_direct", "dup_k", "split", "groupnorm", "layernorm", "attention", "attention_split", "softmax_rows",
-                 "softmax_rows_split", "timestep_embedding", "silu", "pack_model_input", "cfg_ddim_step", "cfg_linear_step", "cfg_multistep_step", "nchw_to_nhwc",
-                 "nhwc_to_nchw", "vae_sample", "scale_pad", "resize_to_nhwc", "postprocess_images", "FeedForward", "Upsampler"):
+    if not _SAVED:
+        _SAVED.update({"ops": {n: getattr(ops, n) for n in _NAMES}, "transpose": vae._transpose, "set_device": torch.cuda.set_device})
+    for name in _NAMES:
         setattr(ops, name, getattr(me, name))
-    from diffuman4d_amd.host import vae
     vae._transpose = lambda v, C: v.t().contiguous()
     torch.cuda.set_device = lambda *a, **k: None
+
+
+def uninstall():
+    from diffuman4d_amd.host import ops, vae
+    if _SAVED:
+        for n, f in _SAVED["ops"].items():
+            setattr(ops, n, f)
+        vae._transpose, torch.cuda.set_device = _SAVED["transpose"], _SAVED["set_device"]
+        _SAVED.clear()
 
 
 def rel_l2(a, b):
@@ -326,7 +341,7 @@ def main():
     from dataclasses import asdict
     from diffuman4d_amd.host.unet import UNetConfig, UNetMultiviewConditionModel
     from diffuman4d_amd.host.vae import AutoencoderKL, VAEConfig
-    if sys.argv[1:2] == ["golden"]:  # python tools/dev/fake_ops.py golden <modelcheck case> ...: a golden-pipeline case on the stand-in
+    if sys.argv[1:2] == ["golden"]:  # python tests/cpu_standin_ops.py golden <modelcheck case> ...: a golden-pipeline case on the stand-in
         mc.hip_unet = lambda cfg, om, precision="fast": UNetMultiviewConditionModel(UNetConfig.from_dict(asdict(cfg)), om.state_dict(), "cpu", precision)
         mc.hip_vae = lambda cfg, om, precision="fast": AutoencoderKL(VAEConfig.from_dict(asdict(cfg)), om.state_dict(), "cpu", precision)
         import diffuman4d_amd.host.pipeline as hp_

@@ -1,0 +1,60 @@
+"""CPU: the HOST side of both precisions -- weight layouts (K-duplicated matrices, fused QKV, padded channels), operand planes, which
+tensor feeds which launch, the planned scheduler rows, the pose encoder -- driven through the REAL host classes (host/unet.py, vae.py,
+pipeline.py, scheduler.py) with `tests/cpu_standin_ops.py` standing in for the kernel wrappers (a torch restatement of every wrapper's
+documented semantics and rounding points; the kernels themselves are checked on the GPU by tests/opcheck.py).  Compared with the fixtures
+the REFERENCE's own pipeline code produced (tests/golden/pipeline_*.pt, pose_encoder.pt): a wiring defect of the parity precision is orders
+of magnitude above its 1e-4, and the fast precision has to stay inside its bf16-oracle yardstick.  Nothing here runs product arithmetic
+on the CPU: the stand-in is test infrastructure, installed for these tests only and removed afterwards."""
+import sys
+from dataclasses import asdict
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture()
+def cpu_standin(monkeypatch):
+    import cpu_standin_ops as fake_ops
+    import modelcheck as mc
+    import diffuman4d_amd.host.pipeline as hp
+    from diffuman4d_amd.host.unet import UNetConfig, UNetMultiviewConditionModel
+    from diffuman4d_amd.host.vae import AutoencoderKL, VAEConfig
+    fake_ops.install()
+    monkeypatch.setattr(mc, "hip_unet", lambda cfg, om, precision="fast": UNetMultiviewConditionModel(UNetConfig.from_dict(asdict(cfg)), om.state_dict(), "cpu", precision))
+    monkeypatch.setattr(mc, "hip_vae", lambda cfg, om, precision="fast": AutoencoderKL(VAEConfig.from_dict(asdict(cfg)), om.state_dict(), "cpu", precision))
+    real = hp.Diffuman4DPipeline
+    monkeypatch.setattr(hp, "Diffuman4DPipeline", lambda v, u, s, dev: real(v, u, s, "cpu"))
+    try:
+        yield mc
+    finally:
+        fake_ops.uninstall()
+
+
+FIXTURES = ["spatial", "temporal_v", "round2_shift", "pose_encoder", "dpm_temporal_v_heun_round2", "unipc_temporal_v_bh1_round2", "deis3_spatial_bidir"]
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_parity_precision_host_wiring_reproduces_the_reference_fixture(cpu_standin, name):
+    mc = cpu_standin
+    err, _ = mc.case_golden_pipeline(name, precision="parity")
+    assert "bookkeeping" not in err, "timestep bookkeeping differs from the reference pipeline's"
+    assert err["latents"] <= 1e-4 and err["images"] <= 5e-4, err  # images: the fixtures store RGB in fp16 (floor 1.7e-4)
+
+
+@pytest.mark.parametrize("name", ["spatial", "dpm_temporal_v_heun_round2", "unipc_temporal_v_bh1_round2"])
+def test_fast_precision_host_wiring_stays_inside_the_bf16_yardstick(cpu_standin, name):
+    mc = cpu_standin
+    err, yard = mc.case_golden_pipeline(name)
+    assert "bookkeeping" not in err
+    for q in err:
+        assert err[q] <= mc.YARD_FACTOR * yard[q], (q, err[q], yard[q])
+
+
+def test_the_standin_is_removed_again():
+    """After the fixture the real wrappers are back: they refuse CPU tensors (no CPU compute path in the product)."""
+    import torch
+    from diffuman4d_amd.host import lib, ops
+    with pytest.raises(lib.Dm4dError):
+        ops.silu(torch.zeros(4, 8, dtype=torch.bfloat16))
