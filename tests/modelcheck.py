@@ -83,6 +83,22 @@ def make_vae(seed=1):
     return cfg, bf16_weights(v)
 
 
+_SD_CACHE: dict = {}
+
+
+def sd_weights(kind: str, seed: int):
+    """The seeded SD-2.1 UNet / SD VAE state dict on the CPU (random_state_dict: 6 s for the UNet's 816 M parameters), built once per
+    process: a dozen cases at the judged geometry use the same two dictionaries and none of them modifies a tensor."""
+    key = (kind, int(seed))
+    if key not in _SD_CACHE:
+        from diffuman4d_amd.host.unet import UNetConfig
+        from diffuman4d_amd.host.vae import VAEConfig
+        from diffuman4d_amd.host.weights import random_state_dict, unet_param_shapes, vae_param_shapes
+        shapes = unet_param_shapes(UNetConfig()) if kind == "unet" else vae_param_shapes(VAEConfig())
+        _SD_CACHE[key] = random_state_dict(shapes, int(seed), "cpu")
+    return _SD_CACHE[key]
+
+
 def hip_unet(cfg, oracle_model, precision="fast"):
     from dataclasses import asdict
     from diffuman4d_amd.host.unet import UNetConfig, UNetMultiviewConditionModel
@@ -323,7 +339,7 @@ def case_unet_sd21(name, precision="fast", fixture="sd21_72x40.pt", matched=Fals
     import make_golden_sd21 as mk
     g = torch.load(GOLDEN / fixture)[name]
     cfg = UNetConfig()
-    sd = random_state_dict(unet_param_shapes(cfg), mk.UNET_SEED, "cpu")
+    sd = sd_weights("unet", mk.UNET_SEED)
     _check_fixture_inputs("UNet weights", float(sum(v.float().abs().sum() for v in sd.values())), g["weights_checksum"])
     x, t = mk.unet_inputs(g["num_frames"], g["n_cond"], g["seed"], g.get("size"))
     _check_fixture_inputs("UNet input", float(x.float().abs().sum()), g["x_checksum"])
@@ -366,7 +382,7 @@ def case_vae_sd(name="vae_576x320", precision="fast"):
     import make_golden_sd21 as mk
     g = torch.load(GOLDEN / "sd21_72x40.pt")[name]
     cfg = VAEConfig.from_dict(g["config"])
-    sd = random_state_dict(vae_param_shapes(cfg), mk.VAE_SEED, "cpu")
+    sd = sd_weights("vae", mk.VAE_SEED)
     _check_fixture_inputs("VAE weights", float(sum(v.float().abs().sum() for v in sd.values())), g["weights_checksum"])
     img, noise = mk.vae_inputs(g["n"], g["seed"])
     _check_fixture_inputs("VAE input", float(img.float().abs().sum()), g["img_checksum"])
@@ -391,7 +407,7 @@ def case_demo3d_sd21(precision="fast", matched=False):
     sys.path.insert(0, str(GOLDEN))
     import make_golden_demo3d as mk
     g = torch.load(GOLDEN / "demo3d_sd21_72x40.pt")
-    usd, vsd = mk.state_dicts()
+    usd, vsd = sd_weights("unet", mk.UNET_SEED), sd_weights("vae", mk.VAE_SEED)
     pv, pl, sk, cm = mk.task_inputs()
     noise = mk.task_noise()
     got, want = mk.checksums(pv, pl, sk, cm, noise, usd, vsd), g["checksums"]
@@ -451,7 +467,7 @@ def case_vae_1024(name="vae_1024"):
     import make_golden_sd21 as mk
     g = torch.load(GOLDEN / "sd21_72x40.pt")[name]
     cfg = VAEConfig.from_dict(g["config"])
-    sd = random_state_dict(vae_param_shapes(cfg), mk.VAE_SEED, "cpu")
+    sd = sd_weights("vae", mk.VAE_SEED)
     _check_fixture_inputs("VAE weights", float(sum(v.float().abs().sum() for v in sd.values())), g["weights_checksum"])
     img, noise = mk.vae1024_inputs(g["seed"])
     _check_fixture_inputs("VAE 1024 input", float(img.float().abs().sum()), g["img_checksum"])
@@ -747,7 +763,7 @@ def case_opreplay_unet(sd21=False, num_frames=4, tem=True, domain="temporal"):
         sys.path.insert(0, str(GOLDEN))
         import make_golden_sd21 as mk
         cfg = UNetConfig()
-        hm = UNetMultiviewConditionModel(cfg, random_state_dict(unet_param_shapes(cfg), mk.UNET_SEED, "cpu"), "cuda")
+        hm = UNetMultiviewConditionModel(cfg, sd_weights("unet", mk.UNET_SEED), "cuda")
         x, t = mk.unet_inputs(16, 4, 101)
         num_frames, domain = 16, "spatial"
     else:
@@ -807,7 +823,7 @@ def case_opreplay_vae_sd():
     sys.path.insert(0, str(GOLDEN))
     import make_golden_sd21 as mk
     cfg = VAEConfig()
-    hv = AutoencoderKL(cfg, random_state_dict(vae_param_shapes(cfg), mk.VAE_SEED, "cpu"), "cuda")
+    hv = AutoencoderKL(cfg, sd_weights("vae", mk.VAE_SEED), "cuda")
     img, noise = mk.vae_inputs(1, 5)
     ops.TRACE = trace = []
     try:
@@ -838,7 +854,7 @@ def case_multiround_sd21(precision="fast"):
     import make_golden_demo3d as mk3
     import make_golden_multiround as mk
     g = torch.load(GOLDEN / "multiround_sd21_72x40.pt")
-    usd, vsd = mk3.state_dicts()
+    usd, vsd = sd_weights("unet", mk3.UNET_SEED), sd_weights("vae", mk3.VAE_SEED)
     f = lambda t: float(t.float().abs().sum())  # noqa: E731
     _check_fixture_inputs("multiround UNet weights", float(sum(f(v) for v in usd.values())), g["checksums"]["unet_weights"])
     _check_fixture_inputs("multiround VAE weights", float(sum(f(v) for v in vsd.values())), g["checksums"]["vae_weights"])
