@@ -12,7 +12,11 @@ feeds both the same seeded input and requires the outputs to agree to fp32 round
 
 Blocks: ResnetBlock2D (with / without shortcut, output_scale_factor), Downsample2D, Upsample2D, Timesteps + TimestepEmbedding,
 Attention (AttnProcessor2_0), FeedForward(GEGLU), BasicTransformerBlock wiring (norm1 / attn1 / norm3 / ff as the reference's
-MultiviewTransformerBlock inherits it), AutoencoderKL (moments, decode), DDIMScheduler and DPMSolverMultistepScheduler steps.
+MultiviewTransformerBlock inherits it), AutoencoderKL (moments, decode), DDIMScheduler, DPMSolverMultistepScheduler,
+UniPCMultistepScheduler and DEISMultistepScheduler steps (oracle/ddim.py, dpmsolver.py, multistep.py).
+
+    python tools/pin_with_diffusers.py --self-test    # no diffusers needed: the scheduler comparison loop run oracle-against-oracle, so that
+                                                      # the code of the check itself is exercised where the package is absent
 Test infrastructure: imports `oracle/`, never imported by the product.
 """
 from __future__ import annotations
@@ -166,12 +170,60 @@ def check_schedulers():
     return worst
 
 
+def _walk(make_o, make_u, n=12):
+    """Both schedulers over the same n steps from the same start and the same model outputs: worst relative deviation of the sample."""
+    x0, eps = torch.randn(1, 4, 8, 8, generator=_gen(15)), [torch.randn(1, 4, 8, 8, generator=_gen(20 + i)) for i in range(n)]
+    o, u = make_o(), make_u()
+    ts = o.set_timesteps(n)
+    u.set_timesteps(n)
+    assert [int(t) for t in u.timesteps] == [int(t) for t in ts], "timestep tables differ"
+    xo = xu = x0
+    worst = 0.0
+    for i, t in enumerate(ts):
+        ro, ru = o.step(eps[i], int(t), xo), u.step(eps[i], int(t), xu)
+        xo, xu = ro, getattr(ru, "prev_sample", ru)
+        worst = max(worst, _maxdiff(xu, xo))
+    return worst
+
+
+MULTISTEP_GRID = (
+    ("unipc", dict()),
+    ("unipc", dict(solver_type="bh1", prediction_type="v_prediction", timestep_spacing="leading", steps_offset=1, final_sigmas_type="sigma_min",
+                   disable_corrector=[5, 6])),
+    ("unipc", dict(solver_order=1, timestep_spacing="trailing")),
+    ("deis", dict()),
+    ("deis", dict(solver_order=3, prediction_type="v_prediction", timestep_spacing="trailing")),
+    ("deis", dict(solver_order=1, timestep_spacing="leading", steps_offset=1)),
+)
+
+
+def check_multistep(upstream=True):
+    """oracle/multistep.py (UniPC with its corrector, DEIS) against diffusers' classes of the same names; upstream=False (--self-test) walks
+    two oracle objects against each other: it proves nothing about diffusers and everything about this loop."""
+    from dataclasses import asdict
+    from oracle import multistep as ms
+    if upstream:
+        from diffusers import DEISMultistepScheduler as UDe, UniPCMultistepScheduler as UUn
+    worst = 0.0
+    for kind, kw in MULTISTEP_GRID:
+        cfg = (ms.UniPCConfig if kind == "unipc" else ms.DEISConfig)(**kw)
+        make_o = (lambda c=cfg, k=kind: (ms.UniPCMultistepScheduler if k == "unipc" else ms.DEISMultistepScheduler)(c))
+        make_u = (lambda c=cfg, k=kind: (UUn if k == "unipc" else UDe)(**asdict(c))) if upstream else make_o
+        worst = max(worst, _walk(make_o, make_u))
+    return worst
+
+
 CHECKS = [("ResnetBlock2D", check_resnet), ("Downsample2D / Upsample2D", check_samplers),
           ("Timesteps + TimestepEmbedding", check_time_embedding), ("Attention / FeedForward / BasicTransformerBlock", check_attention_ff_block),
-          ("AutoencoderKL", check_vae), ("DDIMScheduler / DPMSolverMultistepScheduler", check_schedulers)]
+          ("AutoencoderKL", check_vae), ("DDIMScheduler / DPMSolverMultistepScheduler", check_schedulers),
+          ("UniPCMultistepScheduler / DEISMultistepScheduler", check_multistep)]
 
 
 def main() -> int:
+    if "--self-test" in sys.argv[1:]:
+        w = check_multistep(upstream=False)
+        print(f"SELF-TEST scheduler comparison loop, oracle against oracle over {len(MULTISTEP_GRID)} configurations: deviation {w:.1e} (must be 0)")
+        return 0 if w == 0.0 else 1
     try:
         import diffusers
     except Exception as e:  # noqa: BLE001
