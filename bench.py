@@ -11,7 +11,7 @@ Modes (--mode; default `auto` = `task` at --gpus 1, `grid` at --gpus N > 1):
   task   one "step" = one schedule unit of the run: 2 spatial window calls (F = 4 inputs + 12 targets = 16 frames,
          CFG batch 32) + 1 temporal window call (F = 12 + 12 = 24 frames, CFG batch 48) -- exactly the 6600 : 3300 call
          mix of the full run = 36 latent-steps = 2 fully denoised latents.  The K timed steps are dealt
-         to --task-streams (default 2) independent tasks in flight, one HIP stream and worker thread each, as the runner
+         to --task-streams (default 3) independent tasks in flight, one HIP stream and worker thread each, as the runner
          does with the tasks of a round.  With N ranks every rank runs its own K units (weak scaling).
   grid   the REAL round structure of the 48-camera x 150-frame job over N ranks (strong scaling): spatial round (150
          tasks, one per frame), temporal round (44 tasks, one per target camera), spatial round, executed by the
@@ -30,8 +30,10 @@ carry the same object, so 1 -> N is `secondary.grid.latents_per_s` over `seconda
 `python bench.py --gpus N` launches its own N ranks (torch.distributed.run on 127.0.0.1) when it is not already
 running under a launcher; rank 0 prints ONE JSON line: the contract fields, `roofline` (attention kernel: HIP-event
 timing in a one-task-at-a-time pass, PMC traffic from profiles/), `cpu_baseline` + `parity` (N = 1 only: the CPU
-oracle on one full spatial window with the SAME weights and input as the HIP UNet, timed and compared), `secondary`
-and `kernel_breakdown_one_step`.
+oracle on one full spatial window with the SAME weights and input as the HIP UNet, timed and compared -- in both precisions of the
+product: `parity.modes.fast` is the judged arithmetic, `parity.modes.parity` the one that meets north_star's 1e-3), `secondary`
+(`grid`, `prune_cond_rows`, `vae`, `parity_precision` = the same step in the parity precision with its per-family rows, `latent128` = the
+reference's native size) and `kernel_breakdown_one_step` (per kernel family and per UNet level).
 """
 from __future__ import annotations
 
