@@ -679,7 +679,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_pipe(GemmParams p) {
 // the MFMAs of step s by scheduling directives.  Same K order as every other kernel of this file (ascending 16-wide k
 // steps into each accumulator), so results are bit-identical to gemm_kernel_pipe / gemm_kernel_glds.
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int NST, int BK = 64>
+template <int BM, int BN, int WM, int WN, int NST, int BK = 64, bool PAR = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_lin2_kernel(GemmParams p) {
   static_assert(BK == 32 || BK == 64, "K-slab of 32 (64-byte rows, 16 per DMA instruction) or 64 (128-byte rows, 8 per instruction)");
   constexpr int ROWB = BK * 2, RPI = 1024 / ROWB, CPR = BK / 8, KS = BK / 16;  // row bytes, rows per DMA instruction, chunks per row, k steps
@@ -845,7 +845,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_lin2_kernel(GemmParams p) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // all fragment reads done: the epilogue stages through the same LDS
   asm volatile("" ::: "memory");
-  gemm_epilogue<MI, NI, TM, TN, EpiBudget<WM * WN, MI, NI, SMEM_BYTES>::STRAIGHT>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
+  gemm_epilogue<MI, NI, TM, TN, EpiBudget<WM * WN, MI, NI, SMEM_BYTES>::STRAIGHT, PAR>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1000,13 +1000,13 @@ __host__ inline bool lin2_ok(const GemmParams& p) {
          (uint64_t)(2 * (uint64_t)p.N) * (uint64_t)p.ldw * 2u < (1ull << 32);
 }
 
-template <int BM, int BN, int WM, int WN, int NST, int BK = 64>
+template <int BM, int BN, int WM, int WN, int NST, int BK = 64, bool PAR = false>
 int launch_lin2(hipStream_t st, GemmParams& p) {
   const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
   const int bn_out = geglu ? BN / 2 : BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + bn_out - 1) / bn_out;
-  hipLaunchKernelGGL((gemm_lin2_kernel<BM, BN, WM, WN, NST, BK>), dim3(tiles_m * p.tiles_n), dim3(WM * WN * 64), 0, st, p);
+  hipLaunchKernelGGL((gemm_lin2_kernel<BM, BN, WM, WN, NST, BK, PAR>), dim3(tiles_m * p.tiles_n), dim3(WM * WN * 64), 0, st, p);
   return dm4d_check_launch("gemm_lin2_kernel");
 }
 
@@ -1298,6 +1298,18 @@ int launch_par(hipStream_t st, GemmParams& p) {
     if (!k64) {  // K-slab 32, register staged (P V of the VAE mid block: K = 3 Lp with Lp a multiple of 32)
       if (n128) return launch_cfg<128, 128, 2, 2, false, false, true>(st, p);
       return launch_cfg<128, 64, 4, 1, false, false, true>(st, p);
+    }
+    // Linear layers: the tiles the fast precision picks for this shape (K here is the doubled K of the two-term operand), PAR epilogue
+    if (lin2_ok(p)) {
+      switch (choose_cfg<false>(p)) {
+        case 67: return launch_lin2<256, 256, 2, 4, 2, 64, true>(st, p);
+        case 65: return launch_lin2<256, 128, 4, 2, 3, 32, true>(st, p);
+        case 61: return launch_lin2<256, 128, 4, 2, 3, 64, true>(st, p);
+        case 69: if (!geglu) return launch_lin2<128, 160, 4, 1, 2, 64, true>(st, p); break;
+        case 63: return launch_lin2<128, 128, 2, 2, 2, 64, true>(st, p);
+        case 64: return launch_lin2<128, 128, 4, 2, 3, 64, true>(st, p);
+        default: break;
+      }
     }
   }
   if (n128) {
