@@ -248,3 +248,15 @@ def test_hybrid_split_of_the_judged_grid():
     assert r._split_round(1)[2] == 8 and len(r._split_round(1)[1]) == 44
     with pytest.raises(ValueError, match="Unsupported runner mode"):
         DistributedSamplingRunner(s, mode="bogus")
+
+
+def test_frame_sharding_modes_refuse_the_parity_precision():
+    """precision 'parity' has no frame-sharded attention: the runner says so when it is built, not inside the first tail task."""
+    kw = dict(spa_label_range=[0, 8, 1], tem_label_range=[0, 4, 1], input_spa_labels=[1, 5], window_size=4, sliding_stride=2,
+              alternation_rounds=3, bidirectional=False)
+    s = make_sampler(kw)
+    s.pipelines[0].parity = True
+    for mode in ("hybrid", "frame-shard"):
+        with pytest.raises(ValueError, match="precision 'parity' does not support"):
+            DistributedSamplingRunner(s, mode=mode)
+
