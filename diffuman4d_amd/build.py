@@ -11,11 +11,13 @@ ROOT = Path(__file__).resolve().parent
 CSRC = ROOT / "csrc"
 INCLUDE = ROOT.parent / "include"
 LIB = ROOT / "libdm4d.so"
-SOURCES = ["api.hip", "gemm.hip", "ff_fused.hip", "conv_direct.hip", "attention.hip", "norm.hip", "elementwise.hip", "parity.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_h16.hip", "ff_fused.hip", "conv_direct.hip", "attention.hip", "norm.hip", "elementwise.hip", "parity.hip"]
 # attention.hip: the 4-wave x 64-row kernel form needs more than 256 registers per lane; without this flag hipcc puts every MFMA
 # result of such a kernel into AGPRs and copies the score accumulators to VGPRs and back on every step (0.67x, measured);
 # kernels that fit in 256 registers are unaffected
 EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+# sources that #include another .hip source (gemm_h16.hip = the PAR = 2 instantiations of gemm.hip's kernels)
+EXTRA_DEPS = {"gemm_h16.hip": ["gemm.hip"]}
 
 
 def _hipcc() -> str:
@@ -32,7 +34,7 @@ def source_hash() -> str:
     """sha256 over every source, header and compile flag that goes into libdm4d.so."""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted([CSRC / s for s in SOURCES] + list(CSRC.glob("*.h")) + list(INCLUDE.glob("*.h"))):
+    for f in sorted([CSRC / s for s in SOURCES] + list(CSRC.glob("*.h")) + list(INCLUDE.glob("*.h"))):  # EXTRA_DEPS are SOURCES too
         h.update(f.name.encode() + b"\0" + f.read_bytes() + b"\0")
     h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
@@ -46,16 +48,25 @@ def needs_build() -> bool:
     return STAMP.read_text().strip() != source_hash()
 
 
-def _stale(obj: Path, src: Path, headers) -> bool:
-    if not obj.exists():
-        return True
-    t = obj.stat().st_mtime
-    return src.stat().st_mtime > t or any(h.stat().st_mtime > t for h in headers)
+def _object_key(src: Path, deps, headers, cmd_flags) -> str:
+    """What an object file was made from: its source, the sources it includes, every header, and the full flag list (so that a
+    tuning build's -D objects are never reused by a plain build, and the other way round).  File times are not consulted."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in [src] + sorted(deps) + sorted(headers):
+        h.update(f.name.encode() + b"\0" + f.read_bytes() + b"\0")
+    h.update(repr(list(cmd_flags)).encode())
+    return h.hexdigest()
+
+
+def _stale(obj: Path, key: str) -> bool:
+    stamp = obj.with_suffix(".o.key")
+    return not obj.exists() or not stamp.exists() or stamp.read_text().strip() != key
 
 
 def build(force: bool = False, verbose: bool = True, defines=()) -> Path:
-    """One object per .hip source (compiled in parallel, rebuilt only when the source or a header changed), then one
-    link.  `defines`: extra -D flags (tuning builds); they force a full rebuild."""
+    """One object per .hip source (compiled in parallel; an object is reused only if the content hash recorded beside it -- source,
+    included sources, headers, flags -- matches), then one link.  `defines`: extra -D flags (tuning builds)."""
     if not force and not defines and not needs_build():
         return LIB
     from concurrent.futures import ThreadPoolExecutor
@@ -67,15 +78,25 @@ def build(force: bool = False, verbose: bool = True, defines=()) -> Path:
     jobs = []
     for s in SOURCES:
         src, obj = CSRC / s, objdir / (Path(s).stem + ".o")
-        if force or defines or _stale(obj, src, headers):
-            jobs.append([hipcc, *flags, *EXTRA_FLAGS.get(s, []), "-c", str(src), "-o", str(obj)])
+        cmd_flags = [*flags, *EXTRA_FLAGS.get(s, [])]
+        key = _object_key(src, [CSRC / d for d in EXTRA_DEPS.get(s, [])], headers, cmd_flags)
+        if force or _stale(obj, key):
+            jobs.append(([hipcc, *cmd_flags, "-c", str(src), "-o", str(obj)], obj, key))
 
     def run(cmd):
         if verbose:
             print("[dm4d build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+
+    def compile_one(job):
+        cmd, obj, key = job
+        stamp = obj.with_suffix(".o.key")
+        if stamp.exists():
+            stamp.unlink()  # a failed or interrupted compile leaves no key behind
+        run(cmd)
+        stamp.write_text(key + "\n")
     with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1) or 1) as ex:
-        list(ex.map(run, jobs))
+        list(ex.map(compile_one, jobs))
     run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB)] + [str(objdir / (Path(s).stem + ".o")) for s in SOURCES])
     if not defines:
         STAMP.write_text(source_hash() + "\n")

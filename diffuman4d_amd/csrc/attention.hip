@@ -89,6 +89,26 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
   return *reinterpret_cast<uint32_t*>(&b);
 }
 
+// H16 (template parameter of the kernels; precision "fp16", dm4d_attention_qscaled_kv_f16): Q / K / V / O and the probabilities are
+// IEEE fp16 instead of bf16 -- v_mfma_f32_32x32x16_f16 and v_cvt_pk_f16_f32 in place of their bf16 twins, same rate and fragment
+// layouts, so the loop is the same instruction for instruction.  What changes is the range: fp16 stops at 65504, so the optimistic
+// pass subtracts H16_OFF more than the first tile's row maximum (its largest probability is 2^-H16_OFF; later tiles may outgrow the
+// first by 2^(16 + H16_OFF) before a probability overflows, values below 2^-14 go subnormal with an absolute error of 2^-25, i.e.
+// 2^-17 of the row's largest term) and the row-sum check that sends a workgroup to the exact loop is l < 2^16 instead of 2^60
+// (a sum below 2^16 has no term above it; the first tile alone puts l >= 2^-H16_OFF).  The exact loop keeps every probability below
+// 2^RESCALE_THR = 256 already.
+constexpr float H16_OFF = 8.0f;
+template <bool H16>
+__device__ __forceinline__ uint32_t cvt_pk(float lo, float hi) {
+  if constexpr (H16) return pack_h2(lo, hi);
+  else return cvt_pk_bf16(lo, hi);
+}
+template <bool H16>
+__device__ __forceinline__ f32x16_t mfma16(const bf16x8_t& a, const bf16x8_t& b, const f32x16_t& c) {
+  if constexpr (H16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8_t, a), __builtin_bit_cast(h16x8_t, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 // ------------------------------------------------------------------------------------------------
 // "Optimistic" softmax variant (default).  tools/probes/issue_probe.hip shows that on a gfx950 SIMD a wave that
 // streams MFMAs starves its co-resident waves' VALU instructions, so a tile costs (MFMA cycles + VALU cycles), and at
@@ -99,7 +119,7 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
 // check the row sums at the end; a workgroup in which some sum left [0, 2^60) (or is NaN) simply redoes its rows
 // with the exact running-max loop (SAFE).  Results do not depend on how rows are grouped into waves (no vote).
 // ------------------------------------------------------------------------------------------------
-template <bool SAFE, bool FOLD, int NW>
+template <bool SAFE, bool FOLD, int NW, bool H16 = false>
 __device__ __forceinline__ void kv_loop(const AttnParams& p, const u16* Kb, const u16* Vb, u16* Ks, u16* Vs, const u16* v_lane,
                                         const bf16x8_t (&qf)[4], f32x16_t (&o)[2], float& m_run, float& l_run, int tid,
                                         int l31, int lh) {
@@ -141,7 +161,7 @@ __device__ __forceinline__ void kv_loop(const AttnParams& p, const u16* Kb, cons
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + (buf * KV + kb * 32 + l31) * LDS_LD + j * 16 + lh * 8);
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[j], s[kb], 0, 0, 0);
+        s[kb] = mfma16<H16>(kf, qf[j], s[kb]);
       }
     if ((t == nt - 1) && (Lk % KV) != 0) {
 #pragma unroll
@@ -185,10 +205,10 @@ __device__ __forceinline__ void kv_loop(const AttnParams& p, const u16* Kb, cons
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
         U4 w;
-        w.x = cvt_pk_bf16(pv[jj * 8 + 0], pv[jj * 8 + 1]);
-        w.y = cvt_pk_bf16(pv[jj * 8 + 2], pv[jj * 8 + 3]);
-        w.z = cvt_pk_bf16(pv[jj * 8 + 4], pv[jj * 8 + 5]);
-        w.w = cvt_pk_bf16(pv[jj * 8 + 6], pv[jj * 8 + 7]);
+        w.x = cvt_pk<H16>(pv[jj * 8 + 0], pv[jj * 8 + 1]);
+        w.y = cvt_pk<H16>(pv[jj * 8 + 2], pv[jj * 8 + 3]);
+        w.z = cvt_pk<H16>(pv[jj * 8 + 4], pv[jj * 8 + 5]);
+        w.w = cvt_pk<H16>(pv[jj * 8 + 6], pv[jj * 8 + 7]);
         pf[jj] = *reinterpret_cast<bf16x8_t*>(&w);
       }
 #pragma unroll
@@ -200,7 +220,7 @@ __device__ __forceinline__ void kv_loop(const AttnParams& p, const u16* Kb, cons
           s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vp + 8 * LDS_LDV));
           s16x8_t v01 = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
           bf16x8_t vf = *reinterpret_cast<bf16x8_t*>(&v01);
-          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[jj], o[db], 0, 0, 0);
+          o[db] = mfma16<H16>(vf, pf[jj], o[db]);
         }
     }
     if (t + 1 < nt) store_tile(buf ^ 1);
@@ -215,7 +235,7 @@ __device__ __forceinline__ void kv_loop(const AttnParams& p, const u16* Kb, cons
 // results sits in front of the wait: without it the scheduler sinks half of the MFMAs below the barrier into the next
 // step, which puts the wait a few MFMAs after the issue and exposes the L2/HBM latency once per tile.
 // ------------------------------------------------------------------------------------------------
-template <bool FOLD, int NW>
+template <bool FOLD, int NW, bool H16 = false>
 __device__ __forceinline__ void kv_loop_pipelined(const AttnParams& p, const u16* Kb, const u16* Vb, u16* Ks, u16* Vs,
                                                   const bf16x8_t (&qf)[4], f32x16_t (&o)[2], float& m_run, float& l_run,
                                                   int lane, int wave, int l31, int lh) {
@@ -283,7 +303,7 @@ __device__ __forceinline__ void kv_loop_pipelined(const AttnParams& p, const u16
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(Ks + stage * TILE + kb * 32 * 64 + k_lane[j]);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[j], (FOLD && j == 0) ? negm : s, 0, 0, 0);
+      s = mfma16<H16>(kf, qf[j], (FOLD && j == 0) ? negm : s);
     }
   };
   auto mask_tail = [&](int t, f32x16_t (&s)[2]) {
@@ -307,10 +327,10 @@ __device__ __forceinline__ void kv_loop_pipelined(const AttnParams& p, const u16
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       U4 w;
-      w.x = cvt_pk_bf16(pv[jj * 8 + 0], pv[jj * 8 + 1]);
-      w.y = cvt_pk_bf16(pv[jj * 8 + 2], pv[jj * 8 + 3]);
-      w.z = cvt_pk_bf16(pv[jj * 8 + 4], pv[jj * 8 + 5]);
-      w.w = cvt_pk_bf16(pv[jj * 8 + 6], pv[jj * 8 + 7]);
+      w.x = cvt_pk<H16>(pv[jj * 8 + 0], pv[jj * 8 + 1]);
+      w.y = cvt_pk<H16>(pv[jj * 8 + 2], pv[jj * 8 + 3]);
+      w.z = cvt_pk<H16>(pv[jj * 8 + 4], pv[jj * 8 + 5]);
+      w.w = cvt_pk<H16>(pv[jj * 8 + 6], pv[jj * 8 + 7]);
       pf[jj] = *reinterpret_cast<bf16x8_t*>(&w);
     }
   };
@@ -324,7 +344,7 @@ __device__ __forceinline__ void kv_loop_pipelined(const AttnParams& p, const u16
         s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(vp + 8 * 64));
         s16x8_t v01 = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
         bf16x8_t vf = *reinterpret_cast<bf16x8_t*>(&v01);
-        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[jj], o[db], 0, 0, 0);
+        o[db] = mfma16<H16>(vf, pf[jj], o[db]);
       }
   };
 
@@ -343,6 +363,7 @@ __device__ __forceinline__ void kv_loop_pipelined(const AttnParams& p, const u16
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s_cur[0][r], s_cur[1][r]));
     m_run = fmaxf(mx, __shfl_xor(mx, 32));
+    if constexpr (H16) m_run += H16_OFF / cs;  // the largest probability of the first tile is 2^-H16_OFF (see H16 above)
     mc = m_run * cs;
     if (FOLD) {
 #pragma unroll
@@ -399,7 +420,7 @@ __device__ __forceinline__ void kv_loop_pipelined(const AttnParams& p, const u16
   }
 }
 
-template <bool FOLD, int NW>
+template <bool FOLD, int NW, bool H16 = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnParams p) {  // two waves per SIMD: 8-wave workgroup alone, or two 4-wave workgroups
   constexpr int SMEM_EXACT = 2 * KV * LDS_LD + 2 * KV * LDS_LDV, SMEM_RINGS = 2 * RING * TILE;  // u16 elements
   __shared__ __attribute__((aligned(16))) u16 smem[SMEM_EXACT > SMEM_RINGS ? SMEM_EXACT : SMEM_RINGS];  // >= NW * 32 * LDS_LDO
@@ -436,11 +457,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnParams p) {  // tw
     for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
   float l_tot = -1.f;
   if (!p.exact_only) {
-    kv_loop_pipelined<FOLD, NW>(p, Kb, Vb, smem, smem + RING * TILE, qf, o, m_run, l_run, lane, wave, l31, lh);
+    kv_loop_pipelined<FOLD, NW, H16>(p, Kb, Vb, smem, smem + RING * TILE, qf, o, m_run, l_run, lane, wave, l31, lh);
     l_tot = l_run + __shfl_xor(l_run, 32);
   }
   // out of range (a later tile outgrew the first tile's max by more than 2^60) or NaN: redo with the exact loop
-  if (__syncthreads_or(!(l_tot < 0x1p60f) || !(l_tot > 0x1p-100f))) {
+  if (__syncthreads_or(!(l_tot < (H16 ? 0x1p16f : 0x1p60f)) || !(l_tot > 0x1p-100f))) {
     m_run = -1e30f;
     l_run = 0.f;
 #pragma unroll
@@ -450,7 +471,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnParams p) {  // tw
     u16* Ks = smem;
     u16* Vs = smem + 2 * KV * LDS_LD;
     const u16* v_lane = Vs + (4 * (lane >> 5) + ((lane & 15) >> 2)) * LDS_LDV + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-    kv_loop<true, FOLD, NW>(p, Kb, Vb, Ks, Vs, v_lane, qf, o, m_run, l_run, tid, l31, lh);
+    kv_loop<true, FOLD, NW, H16>(p, Kb, Vb, Ks, Vs, v_lane, qf, o, m_run, l_run, tid, l31, lh);
     l_tot = l_run + __shfl_xor(l_run, 32);
   }
   // Both loops end with a workgroup barrier, so the K/V stages are free: O goes through a wave-private LDS tile
@@ -463,8 +484,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnParams p) {  // tw
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       uint2 w;
-      w.x = cvt_pk_bf16(o[db][4 * g + 0] * inv, o[db][4 * g + 1] * inv);
-      w.y = cvt_pk_bf16(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+      w.x = cvt_pk<H16>(o[db][4 * g + 0] * inv, o[db][4 * g + 1] * inv);
+      w.y = cvt_pk<H16>(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
       *reinterpret_cast<uint2*>(Os + l31 * LDS_LDO + db * 32 + 8 * g + 4 * lh) = w;
     }
   // the same wave reads back what it wrote (the LDS executes a wave's accesses in order): no barrier
@@ -482,7 +503,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnParams p) {  // tw
 }  // namespace
 
 static int attention_launch(void* stream, const void* Q, const void* K, const void* V, void* O, int64_t ldq, int64_t ldk,
-                            int64_t ldv, int64_t ldo, int batch, int heads, int Lq, int Lk, float scale, bool q_scaled) {
+                            int64_t ldv, int64_t ldo, int batch, int heads, int Lq, int Lk, float scale, bool q_scaled,
+                            bool h16 = false) {
   if (!Q || !K || !V || !O || batch <= 0 || heads <= 0 || Lq <= 0 || Lk <= 0)
     return dm4d_set_error(DM4D_ERR_ARG, "attention: null pointer or empty shape");
   if ((ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 7))
@@ -503,7 +525,8 @@ static int attention_launch(void* stream, const void* Q, const void* K, const vo
   if (nwg > 0x7fffffffL) return dm4d_set_error(DM4D_ERR_ARG, "attention: grid too large");
   const dim3 grid((unsigned)nwg), block(nw * 64);
   hipStream_t st = (hipStream_t)stream;
-  if (q_scaled) hipLaunchKernelGGL((attn_kernel<true, nw>), grid, block, 0, st, p);
+  if (h16) hipLaunchKernelGGL((attn_kernel<true, nw, true>), grid, block, 0, st, p);  // fp16 operands: pre-scaled Q only
+  else if (q_scaled) hipLaunchKernelGGL((attn_kernel<true, nw>), grid, block, 0, st, p);
   else hipLaunchKernelGGL((attn_kernel<false, nw>), grid, block, 0, st, p);
   return dm4d_check_launch("attn_kernel");
 }
@@ -523,4 +546,9 @@ extern "C" int dm4d_attention_qscaled_kv_bf16(void* stream, const void* Q, const
                                               int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int batch, int heads,
                                               int Lq, int Lk) {
   return attention_launch(stream, Q, K, V, O, ldq, ldk, ldv, ldo, batch, heads, Lq, Lk, 1.0f, true);
+}
+
+extern "C" int dm4d_attention_qscaled_kv_f16(void* stream, const void* Q, const void* K, const void* V, void* O, int64_t ldq,
+                                             int64_t ldk, int64_t ldv, int64_t ldo, int batch, int heads, int Lq, int Lk) {
+  return attention_launch(stream, Q, K, V, O, ldq, ldk, ldv, ldo, batch, heads, Lq, Lk, 1.0f, true, true);
 }

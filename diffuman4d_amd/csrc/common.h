@@ -46,6 +46,39 @@ __device__ __forceinline__ U4 pack8(const float* f) {
   return v;
 }
 
+// fp16 twins (precision "fp16": single-term fp16 MFMA operands over fp32 tensors): v_cvt_pk_f16_f32 rounds to nearest even
+typedef _Float16 h16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
+  f32x2_t v = {lo, hi};
+  h16x2_t b = __builtin_convertvector(v, h16x2_t);
+  return *reinterpret_cast<uint32_t*>(&b);
+}
+__device__ __forceinline__ u16 f2h(float f) { return (u16)(pack_h2(f, 0.f) & 0xffffu); }
+__device__ __forceinline__ float h2f(u16 v) {
+  _Float16 h;
+  __builtin_memcpy(&h, &v, 2);
+  return (float)h;
+}
+__device__ __forceinline__ void unpack8h(const U4& v, float* f) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h16x2_t h;
+    __builtin_memcpy(&h, &w[i], 4);
+    f[2 * i] = (float)h[0];
+    f[2 * i + 1] = (float)h[1];
+  }
+}
+__device__ __forceinline__ U4 pack8h(const float* f) {
+  U4 v;
+  v.x = pack_h2(f[0], f[1]);
+  v.y = pack_h2(f[2], f[3]);
+  v.z = pack_h2(f[4], f[5]);
+  v.w = pack_h2(f[6], f[7]);
+  return v;
+}
+
 __device__ __forceinline__ U4 ldg16(const void* p) { return *reinterpret_cast<const U4*>(p); }
 __device__ __forceinline__ void stg16(void* p, const U4& v) { *reinterpret_cast<U4*>(p) = v; }
 

@@ -51,16 +51,22 @@ __global__ void silu_kernel(const u16* X, u16* Y, int64_t n) {
 // one thread per (frame, pixel): reads the 4+6+4+1 conditioning channels, writes both CFG halves.
 // T = u16: `out` rows are cpad bf16 channels.  T = float (parity precision): the task tensors are fp32 and `out` rows are the
 // two-term operand of conv_in, [hi(cpad) | lo(cpad)].
-template <bool SPLIT>
+// OUT: 0 = bf16 row, 1 = two-term operand [hi(cpad) | lo(cpad)] (parity precision), 2 = fp16 row (precision "fp16")
+template <int OUT>
 __device__ __forceinline__ void put_in(u16* row, int c, int cpad, float v) {  // bf16 values survive the float round trip bit for bit
-  const u16 hi = f2bf(v);
-  row[c] = hi;
-  if constexpr (SPLIT) row[cpad + c] = f2bf(v - bf2f(hi));
+  if constexpr (OUT == 2) {
+    row[c] = f2h(v);
+  } else {
+    const u16 hi = f2bf(v);
+    row[c] = hi;
+    if constexpr (OUT == 1) row[cpad + c] = f2bf(v - bf2f(hi));
+  }
 }
-template <typename T>
+template <typename T, bool H16 = false>
 __global__ void pack_kernel(T* latents, const T* pv, const T* pl, const T* sk, const T* mask, const int32_t* is_cond,
                             const int32_t* frame_idx, u16* out, int F, int HW, int cpad, int use_cfg) {
-  constexpr bool SPLIT = sizeof(T) == 4;
+  constexpr bool SPLIT = sizeof(T) == 4 && !H16;
+  constexpr int OUT = H16 ? 2 : (SPLIT ? 1 : 0);
   const int ldo = SPLIT ? 2 * cpad : cpad;
   const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // window-local (frame, pixel)
   if (o >= (int64_t)F * HW) return;
@@ -68,7 +74,7 @@ __global__ void pack_kernel(T* latents, const T* pv, const T* pl, const T* sk, c
   const bool cond = is_cond[f] != 0;
   // i = (frame, pixel) inside the task-level tensors the window is gathered from
   const int64_t i = frame_idx ? (int64_t)frame_idx[f] * HW + (o - (int64_t)f * HW) : o;
-  auto put = [&](u16* row, int c, float v) { put_in<SPLIT>(row, c, cpad, v); };
+  auto put = [&](u16* row, int c, float v) { put_in<OUT>(row, c, cpad, v); };
   float lat[4];
   if (cond) {
 #pragma unroll
@@ -414,13 +420,13 @@ extern "C" int dm4d_silu_bf16(void* stream, const void* X, void* Y, int64_t n) {
   return dm4d_check_launch("silu_kernel");
 }
 
-template <typename T>
+template <typename T, bool H16 = false>
 static int pack_impl(void* stream, void* latents, const void* pv_lat, const void* plucker, const void* skel, const void* mask,
                      const int32_t* is_cond, const int32_t* frame_idx, void* out, int F, int HW, int cpad, int use_cfg) {
   if (!latents || !pv_lat || !plucker || !mask || !is_cond || !out || F <= 0 || HW <= 0)
     return dm4d_set_error(DM4D_ERR_ARG, "pack_model_input: null pointer or empty shape");
   if (cpad < 11 + (skel ? 4 : 0)) return dm4d_set_error(DM4D_ERR_ARG, "pack_model_input: cpad too small");
-  hipLaunchKernelGGL(pack_kernel<T>, grid1d((int64_t)F * HW, 256), dim3(256), 0, (hipStream_t)stream, (T*)latents,
+  hipLaunchKernelGGL((pack_kernel<T, H16>), grid1d((int64_t)F * HW, 256), dim3(256), 0, (hipStream_t)stream, (T*)latents,
                      (const T*)pv_lat, (const T*)plucker, (const T*)skel, (const T*)mask, is_cond, frame_idx,
                      (u16*)out, F, HW, cpad, use_cfg);
   return dm4d_check_launch("pack_kernel");
@@ -434,6 +440,11 @@ extern "C" int dm4d_pack_model_input_f32_split(void* stream, float* latents, con
                                                const float* skel, const float* mask, const int32_t* is_cond,
                                                const int32_t* frame_idx, void* out, int F, int HW, int cpad, int use_cfg) {
   return pack_impl<float>(stream, latents, pv_lat, plucker, skel, mask, is_cond, frame_idx, out, F, HW, cpad, use_cfg);
+}
+extern "C" int dm4d_pack_model_input_f32_f16(void* stream, float* latents, const float* pv_lat, const float* plucker,
+                                             const float* skel, const float* mask, const int32_t* is_cond,
+                                             const int32_t* frame_idx, void* out, int F, int HW, int cpad, int use_cfg) {
+  return pack_impl<float, true>(stream, latents, pv_lat, plucker, skel, mask, is_cond, frame_idx, out, F, HW, cpad, use_cfg);
 }
 
 template <typename T>

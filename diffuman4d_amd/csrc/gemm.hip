@@ -45,7 +45,7 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // main path: K-slab 64, direct-to-LDS DMA, source-swizzled lane-linear LDS image
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool CONV, bool PAR = false>
+template <int BM, int BN, int WM, int WN, bool CONV, int PAR = 0>
 __global__ __launch_bounds__(256) void gemm_kernel_glds(GemmParams p) {
   constexpr int BK = 64;
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void gemm_kernel_glds(GemmParams p) {
   }
 
   f32x16_t acc[MI][NI];
-  acc_init<MI, NI, TN>(p, acc, n0, wn, lane, geglu);
+  acc_init<MI, NI, TN, PAR>(p, acc, n0, wn, lane, geglu);
 
   const int nk = p.K / BK;
   const int Hin = p.upsample ? 2 * p.H : p.H, Win = p.upsample ? 2 * p.W : p.W;
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void gemm_kernel_glds(GemmParams p) {
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          acc[i][j] = mfma_t(af[ks & 1][i], bfr[ks & 1][j], acc[i][j]);
+          acc[i][j] = mfma_t<PAR>(af[ks & 1][i], bfr[ks & 1][j], acc[i][j]);
     }
     __syncthreads();  // all waves done with `buf`; the DMA into buf^1 has landed (vmcnt(0) before the barrier)
   }
@@ -249,7 +249,7 @@ __device__ __forceinline__ void sched_mfma_reload() {
 // input whose weights are sums of the 3x3 taps that land on the same pixel (dm4d_conv_up2x_prepare_bf16) -- 4 / 9 of the
 // multiply-adds of the fused gather the first round shipped.  Same strip machinery: tap (dy, dx) of phase (py, px) reads
 // pixel (y + dy - 1 + py, x + dx - 1 + px); the grid carries the phase in its slowest dimension.
-template <int BM, int BN, int WM, int WN, int KT = 3, bool PAR = false>
+template <int BM, int BN, int WM, int WN, int KT = 3, int PAR = 0>
 __global__ __launch_bounds__(WM* WN * 64, (BN % 64 != 0 ? 2 : 1)) void conv_strip2_kernel(GemmParams p_in) {
   static_assert(KT == 2 || KT == 3, "3x3 taps, or the 2x2 taps of one upsampling phase");
   constexpr int BK = 64, ROWB = BK * 2;  // bytes per LDS row
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(WM* WN * 64, (BN % 64 != 0 ? 2 : 1)) void conv_stri
   }
 
   f32x16_t acc[MI][NI];
-  acc_init<MI, NI, TN>(p, acc, n0, wn, lane, false);
+  acc_init<MI, NI, TN, PAR>(p, acc, n0, wn, lane, false);
 
   // ---- the K walk: ky (kernel row) > cs (64-channel slab) > kx (tap column); one DMA'd step ahead -------------------
   const int nci = p.Cin / BK;
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(WM* WN * 64, (BN % 64 != 0 ? 2 : 1)) void conv_stri
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NI; ++j)
-            acc[i][j] = mfma_t(af[ks & 1][i], bfr[ks & 1][j], acc[i][j]);
+            acc[i][j] = mfma_t<PAR>(af[ks & 1][i], bfr[ks & 1][j], acc[i][j]);
       }
       __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);  // fragments of k step 0
       sched_mfma_with_reads<MI * NI, MI + NI>();
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(WM* WN * 64, (BN % 64 != 0 ? 2 : 1)) void conv_stri
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NI; ++j) {
-            acc[i][j] = mfma_t(af[i], bfr[j], acc[i][j]);
+            acc[i][j] = mfma_t<PAR>(af[i], bfr[j], acc[i][j]);
             if (ks + 1 < 4) {
               if (j == NI - 1) af[i] = read_a(ks + 1, i);
               if (i == MI - 1) bfr[j] = read_b(ks + 1, j);
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(WM* WN * 64, (BN % 64 != 0 ? 2 : 1)) void conv_stri
 // prefetch cannot cover the L2->LDS latency, and a 128x128 tile needs the CU's whole L1 bandwidth at
 // MFMA peak); larger tiles halve the bytes per flop, more stages cover the latency.
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int NST, bool CONV, int BK = 32>
+template <int BM, int BN, int WM, int WN, int NST, bool CONV, int BK = 32, int PAR = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_pipe(GemmParams p) {
   constexpr int NW = WM * WN;
   static_assert(BK == 32 || BK == 64, "K-slab of 32 (64-byte row pieces) or 64 (whole 128-byte lines)");
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_pipe(GemmParams p) {
                src_chunk((wave + NW * i) * RPI + d_row) * 8;
 
   f32x16_t acc[MI][NI];
-  acc_init<MI, NI, TN>(p, acc, n0, wn, lane, geglu);
+  acc_init<MI, NI, TN, PAR>(p, acc, n0, wn, lane, geglu);
 
   const int nk = p.K / BK;
   const int Hin = p.upsample ? 2 * p.H : p.H, Win = p.upsample ? 2 * p.W : p.W;
@@ -664,12 +664,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_pipe(GemmParams p) {
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = mfma_t(af[i], bfr[j], acc[i][j]);
+        for (int j = 0; j < NI; ++j) acc[i][j] = mfma_t<PAR>(af[i], bfr[j], acc[i][j]);
     }
     st = (st + 1 == NST) ? 0 : st + 1;
     st_issue = (st_issue + 1 == NST) ? 0 : st_issue + 1;
   }
-  gemm_epilogue<MI, NI, TM, TN, EpiBudget<WM * WN, MI, NI, SMEM_BYTES>::STRAIGHT>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
+  gemm_epilogue<MI, NI, TM, TN, EpiBudget<WM * WN, MI, NI, SMEM_BYTES>::STRAIGHT, PAR>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel_pipe(GemmParams p) {
 // the MFMAs of step s by scheduling directives.  Same K order as every other kernel of this file (ascending 16-wide k
 // steps into each accumulator), so results are bit-identical to gemm_kernel_pipe / gemm_kernel_glds.
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int NST, int BK = 64, bool PAR = false>
+template <int BM, int BN, int WM, int WN, int NST, int BK = 64, int PAR = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_lin2_kernel(GemmParams p) {
   static_assert(BK == 32 || BK == 64, "K-slab of 32 (64-byte rows, 16 per DMA instruction) or 64 (128-byte rows, 8 per instruction)");
   constexpr int ROWB = BK * 2, RPI = 1024 / ROWB, CPR = BK / 8, KS = BK / 16;  // row bytes, rows per DMA instruction, chunks per row, k steps
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_lin2_kernel(GemmParams p) {
   }
 
   f32x16_t acc[MI][NI];
-  acc_init<MI, NI, TN>(p, acc, n0, wn, lane, geglu);
+  acc_init<MI, NI, TN, PAR>(p, acc, n0, wn, lane, geglu);
 
   constexpr bool TWO_SETS = MI * NI <= 8;
   auto compute = [&](int st) {
@@ -785,7 +785,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_lin2_kernel(GemmParams p) {
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NI; ++j)
-            acc[i][j] = mfma_t(af[ks & 1][i], bfr[ks & 1][j], acc[i][j]);
+            acc[i][j] = mfma_t<PAR>(af[ks & 1][i], bfr[ks & 1][j], acc[i][j]);
       }
       __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
       sched_mfma_with_reads<MI * NI, MI + NI>();
@@ -806,7 +806,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_lin2_kernel(GemmParams p) {
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NI; ++j) {
-            acc[i][j] = mfma_t(af[i], bfr[j], acc[i][j]);
+            acc[i][j] = mfma_t<PAR>(af[i], bfr[j], acc[i][j]);
             if (ks + 1 < KS) {
               if (j == NI - 1) af[i] = read_a(ks + 1, i);
               if (i == MI - 1) bfr[j] = read_b(ks + 1, j);
@@ -851,7 +851,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_lin2_kernel(GemmParams p) {
 // ------------------------------------------------------------------------------------------------
 // fallback: K-slab 32, register staged, padded LDS rows (80 B stride => conflict-free fragment reads)
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool CONV, bool PAR = false>
+template <int BM, int BN, int WM, int WN, bool CONV, int PAR = 0>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   constexpr int LDK = 40;
   constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
@@ -901,7 +901,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   for (int i = 0; i < BI; ++i) w_base[i] = p.Wt + (int64_t)weight_row<TN>(p, n0, a_r + 64 * i, geglu) * p.ldw;
 
   f32x16_t acc[MI][NI];
-  acc_init<MI, NI, TN>(p, acc, n0, wn, lane, geglu);
+  acc_init<MI, NI, TN, PAR>(p, acc, n0, wn, lane, geglu);
 
   const int nk = p.K / 32;
   const int Hin = p.upsample ? 2 * p.H : p.H, Win = p.upsample ? 2 * p.W : p.W;
@@ -961,7 +961,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = mfma_t(af[i], bfr[j], acc[i][j]);
+        for (int j = 0; j < NI; ++j) acc[i][j] = mfma_t<PAR>(af[i], bfr[j], acc[i][j]);
     }
     if (kt + 1 < nk) store_slab(buf ^ 1);
     __syncthreads();
@@ -969,7 +969,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   gemm_epilogue<MI, NI, TM, TN, EpiBudget<WM * WN, MI, NI, SMEM_BYTES>::STRAIGHT, PAR>(p, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, wave, lane);
 }
 
-template <int BM, int BN, int WM, int WN, bool CONV, bool GLDS, bool PAR = false>
+template <int BM, int BN, int WM, int WN, bool CONV, bool GLDS, int PAR = 0>
 int launch_cfg(hipStream_t st, GemmParams& p) {
   const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
   const int bn_out = geglu ? BN / 2 : BN;
@@ -983,13 +983,13 @@ int launch_cfg(hipStream_t st, GemmParams& p) {
   return dm4d_check_launch("gemm_kernel");
 }
 
-template <int BM, int BN, int WM, int WN, int NST, bool CONV, int BK = 32>
+template <int BM, int BN, int WM, int WN, int NST, bool CONV, int BK = 32, int PAR = 0>
 int launch_pipe(hipStream_t st, GemmParams& p) {
   const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
   const int bn_out = geglu ? BN / 2 : BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + bn_out - 1) / bn_out;
-  hipLaunchKernelGGL((gemm_kernel_pipe<BM, BN, WM, WN, NST, CONV, BK>), dim3(tiles_m * p.tiles_n), dim3(WM * WN * 64), 0, st, p);
+  hipLaunchKernelGGL((gemm_kernel_pipe<BM, BN, WM, WN, NST, CONV, BK, PAR>), dim3(tiles_m * p.tiles_n), dim3(WM * WN * 64), 0, st, p);
   return dm4d_check_launch("gemm_kernel_pipe");
 }
 
@@ -1000,7 +1000,7 @@ __host__ inline bool lin2_ok(const GemmParams& p) {
          (uint64_t)(2 * (uint64_t)p.N) * (uint64_t)p.ldw * 2u < (1ull << 32);
 }
 
-template <int BM, int BN, int WM, int WN, int NST, int BK = 64, bool PAR = false>
+template <int BM, int BN, int WM, int WN, int NST, int BK = 64, int PAR = 0>
 int launch_lin2(hipStream_t st, GemmParams& p) {
   const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
   const int bn_out = geglu ? BN / 2 : BN;
@@ -1010,7 +1010,9 @@ int launch_lin2(hipStream_t st, GemmParams& p) {
   return dm4d_check_launch("gemm_lin2_kernel");
 }
 
-// out = epilogue(ws[0] + ws[1] + ws[2]) for the split strip convolution: 8 columns per thread, 16-byte stores
+// out = epilogue(ws[0] + ws[1] + ws[2]) for the split strip convolution: 8 columns per thread, 16-byte stores.
+// PAR = 2 (precision "fp16"): fp16 bias, fp32 row bias / residual (DM4D_EPI_F32SIDE), fp32 (DM4D_EPI_F32OUT) or fp16 output.
+template <int PAR = 0>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
   const int nv = p.N / 8;
   const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1029,25 +1031,48 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
     v[0] += a0[0]; v[1] += a0[1]; v[2] += a0[2]; v[3] += a0[3];
     v[4] += a1[0]; v[5] += a1[1]; v[6] += a1[2]; v[7] += a1[3];
   }
+  const bool f32side = PAR == 2 && (p.flags & DM4D_EPI_F32SIDE) != 0;
+  auto side = [&](const u16* base, int64_t off, float* t) {
+    if (f32side) {
+      const float* f = reinterpret_cast<const float*>(base) + off;
+      const f32x4_t t0 = *reinterpret_cast<const f32x4_t*>(f), t1 = *reinterpret_cast<const f32x4_t*>(f + 4);
+      t[0] = t0[0]; t[1] = t0[1]; t[2] = t0[2]; t[3] = t0[3];
+      t[4] = t1[0]; t[5] = t1[1]; t[6] = t1[2]; t[7] = t1[3];
+    } else if constexpr (PAR == 2) {
+      unpack8h(ldg16(base + off), t);
+    } else {
+      unpack8(ldg16(base + off), t);
+    }
+  };
   float t[8];
   if (p.bias) {
-    unpack8(ldg16(p.bias + n), t);
+    if constexpr (PAR == 2) unpack8h(ldg16(p.bias + n), t);
+    else unpack8(ldg16(p.bias + n), t);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += t[e];
   }
   if (p.rowbias) {
-    unpack8(ldg16(p.rowbias + (int64_t)(m / p.rows_per_rb) * p.ld_rb + n), t);
+    side(p.rowbias, (int64_t)(m / p.rows_per_rb) * p.ld_rb + n, t);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += t[e];
   }
   if (p.res) {
-    unpack8(ldg16(p.res + (int64_t)m * p.ld_res + n), t);
+    side(p.res, (int64_t)m * p.ld_res + n, t);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += t[e];
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
-  stg16(p.C + (int64_t)m * p.ldc + n, pack8(v));
+  if (PAR == 2 && (p.flags & DM4D_EPI_F32OUT)) {
+    float* cf = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
+    const f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+    *reinterpret_cast<f32x4_t*>(cf) = o0;
+    *reinterpret_cast<f32x4_t*>(cf + 4) = o1;
+  } else if constexpr (PAR == 2) {
+    stg16(p.C + (int64_t)m * p.ldc + n, pack8h(v));
+  } else {
+    stg16(p.C + (int64_t)m * p.ldc + n, pack8(v));
+  }
 }
 
 // Split-K applies to stride-1 convolutions on small images (the 9x5 level of the UNet: M = B*45 rows against a
@@ -1055,7 +1080,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
 // run (fewer frames per rank) sums in the same order as the unsharded one.
 __host__ inline bool strip_split_ok(const GemmParams& p) {
   return p.H * p.W <= 64 && p.Cin >= 512 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!p.res || (p.ld_res & 7) == 0) &&
-         (!p.rowbias || (p.ld_rb & 7) == 0) && p.flags == 0;
+         (!p.rowbias || (p.ld_rb & 7) == 0) && (p.flags & ~(DM4D_EPI_F32OUT | DM4D_EPI_F32SIDE | DM4D_EPI_H16)) == 0 &&
+         ((p.flags & DM4D_EPI_H16) || p.flags == 0);  // the parity precision (F32OUT / F32SIDE without H16) never splits
 }
 
 // the strip kernel addresses A and W with 32-bit byte offsets from a uniform base
@@ -1063,7 +1089,7 @@ __host__ inline bool strip2_ok(const GemmParams& p) {
   return (uint64_t)p.M * (uint64_t)p.Cin * 2u < (1ull << 32) && (uint64_t)p.N * (uint64_t)p.ldw * 2u < (1ull << 32);
 }
 
-template <int BM, int BN, int WM, int WN, bool PAR = false>
+template <int BM, int BN, int WM, int WN, int PAR = 0>
 int launch_strip2(hipStream_t st, GemmParams& p) {
   if (!strip2_ok(p)) return DM4D_ERR_ARG;  // 4 GiB or more of input or weights: the gather kernels take such a launch
   if (BN % 64 != 0 && p.splits > 1) return DM4D_ERR_ARG;
@@ -1074,7 +1100,7 @@ int launch_strip2(hipStream_t st, GemmParams& p) {
   int rc = dm4d_check_launch("conv_strip2_kernel");
   if (rc || p.splits == 1) return rc;
   const int64_t nthreads = (int64_t)p.M * (p.N / 8);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, p);
+  hipLaunchKernelGGL((splitk_reduce_kernel<PAR>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, p);
   return dm4d_check_launch("splitk_reduce_kernel");
 }
 
@@ -1112,37 +1138,37 @@ __global__ __launch_bounds__(256) void up2x_prepare_kernel(const u16* W, u16* Wp
 int g_tune_cfg = 0;  // 0 = heuristic; otherwise a kernel-configuration id (tuning hook, dm4d_tune_set_gemm_config)
 
 // Kernel configurations.  glds: K-slab 64, 2 LDS stages, 4 waves.  pipe: K-slab 32, 3-4 stages, 4 or 8 waves.
-template <bool CONV>
+template <bool CONV, int PAR = 0>
 int launch_by_id(int id, hipStream_t st, GemmParams& p) {
   const bool geglu = (p.flags & DM4D_EPI_GEGLU) != 0;
   const bool k64 = CONV ? (p.Cin % 64 == 0) : (p.K % 64 == 0 && (!p.A2 || p.K1 % 64 == 0));
   if (id >= 1 && id <= 4 && !k64) return DM4D_ERR_ARG;
   switch (id) {
-    case 1: return launch_cfg<128, 128, 2, 2, CONV, true>(st, p);
-    case 2: return launch_cfg<256, 64, 4, 1, CONV, true>(st, p);
-    case 3: return launch_cfg<128, 64, 4, 1, CONV, true>(st, p);
-    case 4: return geglu ? DM4D_ERR_ARG : launch_cfg<64, 64, 2, 2, CONV, true>(st, p);
-    case 13: return launch_pipe<256, 256, 2, 4, 4, CONV>(st, p);
-    case 14: return launch_pipe<256, 128, 4, 2, 3, CONV>(st, p);
+    case 1: return launch_cfg<128, 128, 2, 2, CONV, true, PAR>(st, p);
+    case 2: return launch_cfg<256, 64, 4, 1, CONV, true, PAR>(st, p);
+    case 3: return launch_cfg<128, 64, 4, 1, CONV, true, PAR>(st, p);
+    case 4: return geglu ? DM4D_ERR_ARG : launch_cfg<64, 64, 2, 2, CONV, true, PAR>(st, p);
+    case 13: return launch_pipe<256, 256, 2, 4, 4, CONV, 32, PAR>(st, p);
+    case 14: return launch_pipe<256, 128, 4, 2, 3, CONV, 32, PAR>(st, p);
     // 16 waves (one 1024-thread workgroup per CU, four waves per SIMD like two 8-wave workgroups) on a 256x256 tile: the
     // per-wave work of id 14 (64x64) with 2/3 of its L2->LDS bytes per flop
-    case 20: return launch_pipe<256, 256, 4, 4, 4, CONV>(st, p);
+    case 20: return launch_pipe<256, 256, 4, 4, 4, CONV, 32, PAR>(st, p);
     // 320-wide tile (see id 35), K-slab 64, 2 stages = 144 KB; per-wave tile 64 x 160 = 5 column blocks: no GEGLU pairing
-    case 46: return (k64 && !geglu) ? launch_pipe<256, 320, 4, 2, 2, CONV, 64>(st, p) : DM4D_ERR_ARG;
+    case 46: return (k64 && !geglu) ? launch_pipe<256, 320, 4, 2, 2, CONV, 64, PAR>(st, p) : DM4D_ERR_ARG;
     // stride-1 3x3 convolutions on the strip kernel (same K order on every tile, so the choice never changes a result)
     case 31: case 32: case 33: case 34: case 35: case 36: case 37:
       if constexpr (CONV) {
         if (!(k64 && p.stride == 1 && p.pad == 1 && !p.upsample && p.Ho == p.H && p.Wo == p.W)) return DM4D_ERR_ARG;
-        if (id == 31) return launch_strip2<128, 128, 2, 2>(st, p);
-        if (id == 32) return launch_strip2<256, 128, 4, 2>(st, p);
-        if (id == 33) return launch_strip2<128, 64, 4, 1>(st, p);
+        if (id == 31) return launch_strip2<128, 128, 2, 2, PAR>(st, p);
+        if (id == 32) return launch_strip2<256, 128, 4, 2, PAR>(st, p);
+        if (id == 33) return launch_strip2<128, 64, 4, 1, PAR>(st, p);
         // every channel count of an SD-class UNet is a multiple of 320: a 320-wide tile reads the A strip once per
         // kernel row for N = 320 (level 0) and feeds 40 MFMAs per wave between two barriers
-        if (id == 35) return launch_strip2<256, 320, 4, 2>(st, p);
+        if (id == 35) return launch_strip2<256, 320, 4, 2, PAR>(st, p);
         // 160-wide tiles for N = 320 (two column tiles, no padding): 4 waves x (32 x 160) at 78 KB = two workgroups per CU, or 8 waves
-        if (id == 36) return launch_strip2<128, 160, 4, 1>(st, p);
-        if (id == 37) return launch_strip2<256, 160, 8, 1>(st, p);
-        return launch_strip2<256, 256, 2, 4>(st, p);
+        if (id == 36) return launch_strip2<128, 160, 4, 1, PAR>(st, p);
+        if (id == 37) return launch_strip2<256, 160, 8, 1, PAR>(st, p);
+        return launch_strip2<256, 256, 2, 4, PAR>(st, p);
       } else {
         return DM4D_ERR_ARG;
       }
@@ -1152,21 +1178,21 @@ int launch_by_id(int id, hipStream_t st, GemmParams& p) {
     case 61: case 63: case 64: case 65: case 67: case 69:
       if constexpr (!CONV) {
         if (!lin2_ok(p)) return DM4D_ERR_ARG;
-        if (id == 67) return launch_lin2<256, 256, 2, 4, 2>(st, p);
-        if (id == 65) return launch_lin2<256, 128, 4, 2, 3, 32>(st, p);
-        if (id == 61) return launch_lin2<256, 128, 4, 2, 3>(st, p);
+        if (id == 67) return launch_lin2<256, 256, 2, 4, 2, 64, PAR>(st, p);
+        if (id == 65) return launch_lin2<256, 128, 4, 2, 3, 32, PAR>(st, p);
+        if (id == 61) return launch_lin2<256, 128, 4, 2, 3, 64, PAR>(st, p);
         // N = 320 on a tall problem (level 0: proj_in, attention output, proj_out) without padded columns: 128x160 on 4 waves
         // (32 x 160 per wave) at 74 KB = two workgroups per CU
-        if (id == 69) return geglu ? DM4D_ERR_ARG : launch_lin2<128, 160, 4, 1, 2>(st, p);
-        if (id == 63) return launch_lin2<128, 128, 2, 2, 2>(st, p);
-        return launch_lin2<128, 128, 4, 2, 3>(st, p);
+        if (id == 69) return geglu ? DM4D_ERR_ARG : launch_lin2<128, 160, 4, 1, 2, 64, PAR>(st, p);
+        if (id == 63) return launch_lin2<128, 128, 2, 2, 2, 64, PAR>(st, p);
+        return launch_lin2<128, 128, 4, 2, 3, 64, PAR>(st, p);
       } else {
         return DM4D_ERR_ARG;
       }
-    case 21: return launch_cfg<256, 128, 2, 2, CONV, false>(st, p);
-    case 22: return launch_cfg<128, 128, 2, 2, CONV, false>(st, p);
-    case 23: return launch_cfg<256, 64, 4, 1, CONV, false>(st, p);
-    case 24: return launch_cfg<128, 64, 4, 1, CONV, false>(st, p);
+    case 21: return launch_cfg<256, 128, 2, 2, CONV, false, PAR>(st, p);
+    case 22: return launch_cfg<128, 128, 2, 2, CONV, false, PAR>(st, p);
+    case 23: return launch_cfg<256, 64, 4, 1, CONV, false, PAR>(st, p);
+    case 24: return launch_cfg<128, 64, 4, 1, CONV, false, PAR>(st, p);
     default: return DM4D_ERR_ARG;
   }
 }
@@ -1278,6 +1304,7 @@ int choose_cfg(const GemmParams& p) {
   return tm256 * ((p.N + 63) / 64) >= 384 ? 2 : 3;
 }
 
+#ifndef DM4D_GEMM_H16_TU
 // Parity-precision launches (DM4D_EPI_F32SIDE / DM4D_EPI_SPLITOUT: fp32 side inputs, two-term output) run on their own
 // instantiations of a few tile geometries (PAR = true), chosen by the tail of the heuristic above; every kernel of this file walks
 // K in the same order, so the choice never changes a result.  The fast kernels do not carry that epilogue code.
@@ -1338,7 +1365,79 @@ int launch(hipStream_t st, GemmParams& p) {
   return launch_by_id<CONV>(choose_cfg<CONV>(p), st, p);
 }
 
+#else  // DM4D_GEMM_H16_TU: this translation unit (gemm_h16.hip) instantiates the PAR = 2 kernels only
+// Precision "fp16": every tile geometry of the fast precision with fp16 operands (v_mfma_f32_32x32x16_f16), chosen by the same
+// heuristic -- the problem shapes are the fast precision's (K is not doubled) -- including the split over the kernel rows at the
+// 9x5 level.  fp32 side inputs and outputs go through the general epilogue loop (gemm_common.h, PAR = 2).
+template <bool CONV>
+int launch_h16(hipStream_t st, GemmParams& p) {
+  p.splits = 1;
+  p.flags |= DM4D_EPI_H16;
+  if constexpr (CONV) {
+    if (p.ws && p.stride == 1 && p.pad == 1 && !p.upsample && p.Ho == p.H && p.Wo == p.W && p.Cin % 64 == 0 &&
+        strip_split_ok(p) && strip2_ok(p)) {
+      p.splits = 3;
+      return launch_by_id<CONV, 2>(31, st, p);
+    }
+  }
+  return launch_by_id<CONV, 2>(choose_cfg<CONV>(p), st, p);
+}
+#endif
+
 }  // namespace
+
+#ifdef DM4D_GEMM_H16_TU
+extern "C" int dm4d_gemm_f16(void* stream, const void* A, int64_t lda, const void* A2, int64_t lda2, int K1, const void* W,
+                             int64_t ldw, void* C, int64_t ldc, int M, int N, int K, const void* bias, const void* rowbias,
+                             int64_t ld_rowbias, int rows_per_rowbias, const void* residual, int64_t ld_res, unsigned flags,
+                             float out_scale, int scale_cols, float col_scale) {
+  if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return dm4d_set_error(DM4D_ERR_ARG, "gemm_f16: null pointer or empty shape");
+  if (K % 32 != 0) return dm4d_set_error(DM4D_ERR_ARG, "gemm_f16: K must be a multiple of 32");
+  if ((lda & 7) || (ldw & 7)) return dm4d_set_error(DM4D_ERR_ARG, "gemm_f16: lda/ldw must be multiples of 8");
+  if (A2 && ((K1 % 32) != 0 || K1 <= 0 || K1 >= K || (lda2 & 7)))
+    return dm4d_set_error(DM4D_ERR_ARG, "gemm_f16: bad split-A arguments");
+  if (rowbias && rows_per_rowbias <= 0) return dm4d_set_error(DM4D_ERR_ARG, "gemm_f16: rows_per_rowbias <= 0");
+  if ((flags & DM4D_EPI_GEGLU) && (N % 32 != 0)) return dm4d_set_error(DM4D_ERR_ARG, "gemm_f16: GEGLU needs N % 32 == 0");
+  if (flags & ~(DM4D_EPI_GEGLU | DM4D_EPI_SILU | DM4D_EPI_F32OUT | DM4D_EPI_F32SIDE))
+    return dm4d_set_error(DM4D_ERR_ARG, "gemm_f16: only GEGLU, SILU, F32OUT and F32SIDE apply");
+  if (scale_cols < 0 || scale_cols > N || (scale_cols & 7)) return dm4d_set_error(DM4D_ERR_ARG, "gemm_f16: scale_cols must be a multiple of 8 in [0, N]");
+  GemmParams p{};
+  p.A = (const u16*)A; p.lda = lda; p.A2 = (const u16*)A2; p.lda2 = lda2; p.K1 = K1;
+  p.Wt = (const u16*)W; p.ldw = ldw; p.C = (u16*)C; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+  p.bias = (const u16*)bias; p.rowbias = (const u16*)rowbias; p.ld_rb = ld_rowbias; p.rows_per_rb = rows_per_rowbias;
+  p.res = (const u16*)residual; p.ld_res = ld_res; p.flags = flags; p.out_scale = out_scale;
+  p.scale_cols = scale_cols; p.col_scale = col_scale;
+  return launch_h16<false>((hipStream_t)stream, p);
+}
+
+extern "C" int dm4d_conv3x3_nhwc_f16(void* stream, const void* X, int B, int H, int W, int Cin, const void* Wt, void* Y, int Ho,
+                                     int Wo, int Cout, int stride, int pad, int upsample, const void* bias, const void* rowbias,
+                                     int64_t ld_rowbias, const void* residual, int64_t ld_res, float out_scale, unsigned flags,
+                                     void* ws, size_t ws_bytes) {
+  if (!X || !Wt || !Y || B <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0)
+    return dm4d_set_error(DM4D_ERR_ARG, "conv3x3_f16: null pointer or empty shape");
+  if (Cin % 32 != 0) return dm4d_set_error(DM4D_ERR_ARG, "conv3x3_f16: Cin must be a multiple of 32 (pad the input)");
+  if (stride != 1 && stride != 2) return dm4d_set_error(DM4D_ERR_ARG, "conv3x3_f16: stride must be 1 or 2");
+  if (upsample && stride != 1) return dm4d_set_error(DM4D_ERR_ARG, "conv3x3_f16: upsample needs stride 1");
+  if (flags & ~(DM4D_EPI_F32OUT | DM4D_EPI_F32SIDE))
+    return dm4d_set_error(DM4D_ERR_ARG, "conv3x3_f16: only DM4D_EPI_F32OUT and DM4D_EPI_F32SIDE apply to a convolution");
+  if ((int64_t)B * H * W * Cin >= (int64_t)1 << 31 || (int64_t)B * Ho * Wo * Cout >= (int64_t)1 << 31)
+    return dm4d_set_error(DM4D_ERR_ARG, "conv3x3_f16: tensors of 2^31 or more elements are not supported (split the batch)");
+  GemmParams p{};
+  p.A = (const u16*)X; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.stride = stride; p.pad = pad;
+  p.upsample = upsample;
+  p.Wt = (const u16*)Wt; p.ldw = (int64_t)9 * Cin; p.C = (u16*)Y; p.ldc = Cout;
+  p.M = B * Ho * Wo; p.N = Cout; p.K = 9 * Cin;
+  p.bias = (const u16*)bias; p.rowbias = (const u16*)rowbias; p.ld_rb = ld_rowbias; p.rows_per_rb = Ho * Wo;
+  p.res = (const u16*)residual; p.ld_res = ld_res; p.flags = flags; p.out_scale = out_scale;
+  const bool strip = stride == 1 && pad == 1 && !upsample && Ho == H && Wo == W && Cin % 64 == 0;
+  GemmParams q = p;
+  q.flags |= DM4D_EPI_H16;
+  const size_t need = strip && strip_split_ok(q) ? (size_t)3 * B * Ho * Wo * Cout * sizeof(float) : 0;  // = dm4d_conv3x3_ws_bytes
+  p.ws = (ws && need && ws_bytes >= need) ? (float*)ws : nullptr;
+  return launch_h16<true>((hipStream_t)stream, p);
+}
+#else
 
 extern "C" int dm4d_tune_set_gemm_config(int id) {
   g_tune_cfg = id;
@@ -1451,3 +1550,4 @@ extern "C" int dm4d_conv3x3_nhwc_bf16_ws(void* stream, const void* X, int B, int
   return conv3x3_impl(stream, X, B, H, W, Cin, Wt, Y, Ho, Wo, Cout, stride, pad, upsample, bias, rowbias, ld_rowbias,
                       residual, ld_res, out_scale, ws, ws_bytes);
 }
+#endif  // DM4D_GEMM_H16_TU

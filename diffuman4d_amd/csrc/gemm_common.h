@@ -39,6 +39,10 @@ struct GemmParams {
   // phase-decomposed x2 upsampling convolution (conv_strip2_kernel<.., KT = 2>): rows m of the GEMM are LOW-resolution
   // pixels (b, y, x) of width up_w, output row = 2 m + 2 up_w (m / up_w) from a C pointer moved to the phase's first pixel
   int up_w;
+  // precision "fp16" (PAR = 2 kernels): output columns [0, scale_cols) are multiplied by col_scale in fp32 before the one rounding
+  // (the to_q third of a fused QKV projection takes scale * log2 e for dm4d_attention_qscaled_kv_f16); 0 = none
+  int scale_cols;
+  float col_scale;
 };
 
 __device__ __attribute__((aligned(16))) const uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
@@ -69,8 +73,15 @@ __device__ __forceinline__ int weight_row(const GemmParams& p, int n0, int r, bo
 // packed bf16) instead of one element per ds_write_b32 -- a quarter of the LDS store instructions -- and layers without a
 // residual / row bias round to bf16 BEFORE staging (same rounding point: nothing else is applied to them afterwards), which
 // halves the staged bytes and leaves a read-back loop of LDS reads and global stores only.
+// PAR (template parameter of every kernel): 0 = fast precision, 1 = parity precision (two-term bf16 operands), 2 = precision "fp16":
+// the same registers hold fp16 values and go through v_mfma_f32_32x32x16_f16 (same rate, same fragment layout).
+template <int PAR = 0>
 __device__ __forceinline__ f32x16_t mfma_t(const bf16x8_t& a_rows, const bf16x8_t& w_rows, const f32x16_t& c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_rows, a_rows, c, 0, 0, 0);
+  if constexpr (PAR == 2) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8_t, w_rows), __builtin_bit_cast(h16x8_t, a_rows), c, 0, 0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_rows, a_rows, c, 0, 0, 0);
+  }
 }
 
 // Stage one 32-row block of a wave (JN 32-column blocks of the transposed accumulators `a`, first one J0; the bias is
@@ -123,10 +134,10 @@ __device__ __forceinline__ bf16x8_t k0_fragment(u16 bits, int lh) {
   return f.v;
 }
 
-template <int MI, int NI, int TN>
+template <int MI, int NI, int TN, int PAR = 0>
 __device__ __forceinline__ void acc_init(const GemmParams& p, f32x16_t (&acc)[MI][NI], int n0, int wn, int lane, bool geglu) {
   const int l31 = lane & 31, lh = lane >> 5;
-  const bf16x8_t one0 = k0_fragment(0x3f80, lh);
+  const bf16x8_t one0 = k0_fragment(PAR == 2 ? 0x3c00 : 0x3f80, lh);  // 1.0 in the operand type (the bias vector has that type too)
   f32x16_t zero;
 #pragma unroll
   for (int r = 0; r < 16; ++r) zero[r] = 0.f;
@@ -137,7 +148,7 @@ __device__ __forceinline__ void acc_init(const GemmParams& p, f32x16_t (&acc)[MI
     if (use) bits = p.bias[weight_row<TN>(p, n0, wn * TN + j * 32 + l31, geglu)];  // clamped columns are never stored
     const bf16x8_t bf = k0_fragment(bits, lh);
 #pragma unroll
-    for (int i = 0; i < MI; ++i) acc[i][j] = mfma_t(one0, bf, zero);
+    for (int i = 0; i < MI; ++i) acc[i][j] = mfma_t<PAR>(one0, bf, zero);
   }
 }
 
@@ -148,7 +159,7 @@ __device__ __forceinline__ void acc_init(const GemmParams& p, f32x16_t (&acc)[MI
 // (runtime row stride).  Ablation (profiles/r02_gemm_ablation.log): the epilogue was 39 % of the K = 320 Linear layers'
 // time, the stores only 8 %.  With MODE a template parameter the staging stride, the chunk geometry and the trip counts
 // are constants: the staging stores take immediate offsets and the read-back loop unrolls.
-template <int MI, int NI, int TM, int TN, int MODE, int EPW, int J0, int JN, bool SYNC, bool STRAIGHT, bool PAR = false>
+template <int MI, int NI, int TM, int TN, int MODE, int EPW, int J0, int JN, bool SYNC, bool STRAIGHT, int PAR = 0>
 __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t (&acc)[MI][NI], float* smem_f, int m0, int n0,
                                                    int wm, int wn, int wave, int lane) {
   // This instance handles output blocks [J0, J0 + JN) of the wave's NJ 32-column blocks (a "column group"): wide per-wave
@@ -175,9 +186,11 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t
   // PAR instantiations (parity-precision launches, host/ops.py precision "parity") also take fp32 row bias / residual
   // (DM4D_EPI_F32SIDE) and split the result into two bf16 terms (DM4D_EPI_SPLITOUT).  They are separate kernels: the code below
   // would otherwise raise the register count of every fast kernel (the 74 KB two-workgroups-per-CU tiles live on 128 registers).
-  const bool f32side = PAR && (p.flags & DM4D_EPI_F32SIDE) != 0, splitout = PAR && (p.flags & DM4D_EPI_SPLITOUT) != 0;
+  // PAR == 2 (precision "fp16"): bias / 16-bit side inputs / 16-bit output are fp16, no two-term output; always the general loop.
+  constexpr bool H16 = PAR == 2;
+  const bool f32side = PAR && (p.flags & DM4D_EPI_F32SIDE) != 0, splitout = PAR == 1 && (p.flags & DM4D_EPI_SPLITOUT) != 0;
   const bool fast_ok = CPR_POW2 && vec_ok && p.ldc < (1 << 24) && (!p.res || p.ld_res < (1 << 24)) &&
-                       (!p.rowbias || p.rows_per_rb > 0) && !f32out && !(PAR && (f32side || splitout)) && p.up_w == 0;
+                       (!p.rowbias || p.rows_per_rb > 0) && !f32out && !(PAR && (f32side || splitout)) && p.up_w == 0 && !H16;
   // nothing is applied after the staging: round to bf16 first, stage packed halfwords, copy rows out
   const bool plain = fast_ok && !p.res && !p.rowbias && p.out_scale == 1.0f;
   // The staging area is private to a wave and LDS operations of one wave complete in program order, so only one
@@ -365,6 +378,8 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t
               const f32x4_t t0 = *reinterpret_cast<const f32x4_t*>(rb), t1 = *reinterpret_cast<const f32x4_t*>(rb + 4);
               t[0] = t0[0]; t[1] = t0[1]; t[2] = t0[2]; t[3] = t0[3];
               t[4] = t1[0]; t[5] = t1[1]; t[6] = t1[2]; t[7] = t1[3];
+            } else if constexpr (H16) {
+              unpack8h(ldg16(p.rowbias + (int64_t)(m / p.rows_per_rb) * p.ld_rb + n), t);
             } else {
               unpack8(ldg16(p.rowbias + (int64_t)(m / p.rows_per_rb) * p.ld_rb + n), t);
             }
@@ -378,19 +393,24 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t
               const f32x4_t t0 = *reinterpret_cast<const f32x4_t*>(rs), t1 = *reinterpret_cast<const f32x4_t*>(rs + 4);
               t[0] = t0[0]; t[1] = t0[1]; t[2] = t0[2]; t[3] = t0[3];
               t[4] = t1[0]; t[5] = t1[1]; t[6] = t1[2]; t[7] = t1[3];
+            } else if constexpr (H16) {
+              unpack8h(ldg16(p.res + (int64_t)m * p.ld_res + n), t);
             } else {
               unpack8(ldg16(p.res + (int64_t)m * p.ld_res + n), t);
             }
   #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += t[e];
           }
+          const float osc = (H16 && n < p.scale_cols) ? p.out_scale * p.col_scale : p.out_scale;  // chunks never straddle scale_cols (a multiple of 8)
   #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+          for (int e = 0; e < 8; ++e) v[e] *= osc;
           if (f32out) {
             float* cf = reinterpret_cast<float*>(p.C) + mo * p.ldc + n;
             f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
             *reinterpret_cast<f32x4_t*>(cf) = o0;
             *reinterpret_cast<f32x4_t*>(cf + 4) = o1;
+          } else if constexpr (H16) {
+            stg16(p.C + mo * p.ldc + n, pack8h(v));
           } else if (splitout) {  // x = hi + lo + O(2^-17 x): two bf16 planes, columns [0, N) and [N, 2N) of C
             const U4 hi = pack8(v);
             float h[8];
@@ -407,15 +427,18 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t
             float x = v[e];
             if (p.rowbias) {
               const int64_t o = (int64_t)(m / p.rows_per_rb) * p.ld_rb + n + e;
-              x += f32side ? reinterpret_cast<const float*>(p.rowbias)[o] : bf2f(p.rowbias[o]);
+              x += f32side ? reinterpret_cast<const float*>(p.rowbias)[o] : (H16 ? h2f(p.rowbias[o]) : bf2f(p.rowbias[o]));
             }
             if (p.res) {
               const int64_t o = (int64_t)m * p.ld_res + n + e;
-              x += f32side ? reinterpret_cast<const float*>(p.res)[o] : bf2f(p.res[o]);
+              x += f32side ? reinterpret_cast<const float*>(p.res)[o] : (H16 ? h2f(p.res[o]) : bf2f(p.res[o]));
             }
             x *= p.out_scale;
+            if (H16 && n + e < p.scale_cols) x *= p.col_scale;
             if (f32out) {
               reinterpret_cast<float*>(p.C)[mo * p.ldc + n + e] = x;
+            } else if constexpr (H16) {
+              p.C[mo * p.ldc + n + e] = f2h(x);
             } else if (splitout) {
               const u16 hi = f2bf(x);
               p.C[mo * p.ldc + n + e] = hi;
@@ -471,7 +494,7 @@ struct EpiGeom {
   static constexpr int EPW = TN <= 128 ? TN : 128;
 };
 
-template <int MI, int NI, int TM, int TN, int MODE, bool STRAIGHT, bool PAR = false>
+template <int MI, int NI, int TM, int TN, int MODE, bool STRAIGHT, int PAR = 0>
 __device__ __forceinline__ void gemm_epilogue_mode(const GemmParams& p, f32x16_t (&acc)[MI][NI], float* smem_f, int m0, int n0,
                                                    int wm, int wn, int wave, int lane) {
   constexpr int NJ = MODE == 2 ? NI / 2 : NI;
@@ -494,7 +517,7 @@ struct EpiBudget {
   static constexpr bool STRAIGHT = NW <= 8 && MI * NI <= 8 && !(NW == 8 && SMEM <= 80 * 1024);
 };
 
-template <int MI, int NI, int TM, int TN, bool STRAIGHT = false, bool PAR = false>
+template <int MI, int NI, int TM, int TN, bool STRAIGHT = false, int PAR = 0>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[MI][NI], float* smem_f, int m0, int n0,
                                               int wm, int wn, int wave, int lane) {
   // wave-uniform dispatch; GEGLU pairs hidden block j with gate block j + NI/2 inside the wave, so it needs an even NI

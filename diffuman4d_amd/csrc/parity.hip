@@ -43,7 +43,7 @@ struct SplitParams {
   int64_t ldy;
   int act;      // 1 = SiLU
   float scale;  // applied after the activation
-  int pattern;  // 0: [hi | lo]   1: [hi | lo | hi]   2: [hi | hi | lo]
+  int pattern;  // 0: [hi | lo]   1: [hi | lo | hi]   2: [hi | hi | lo]   3: one fp16 plane (precision "fp16")
 };
 
 __global__ __launch_bounds__(256) void split_kernel(SplitParams p) {
@@ -56,9 +56,13 @@ __global__ __launch_bounds__(256) void split_kernel(SplitParams p) {
   else if (c < p.C1 + p.C2) x = p.X2[m * p.rs2 + (c - p.C1)];
   if (p.act == 1) x = silu_f(x);
   x *= p.scale;
+  u16* y = p.Y + m * p.ldy + c;
+  if (p.pattern == 3) {
+    y[0] = f2h(x);
+    return;
+  }
   u16 hi, lo;
   split2(x, hi, lo);
-  u16* y = p.Y + m * p.ldy + c;
   y[0] = hi;
   if (p.pattern == 0) {
     y[p.Cp] = lo;
@@ -140,6 +144,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn32_stats_kernel(GN32Params p) {
   }
 }
 
+// H16 (precision "fp16"): gamma / beta are fp16 and the result is ONE fp16 plane, Y [B*HW, C].
+template <bool H16>
 __global__ __launch_bounds__(GN_THREADS) void gn32_apply_kernel(GN32Params p) {
   extern __shared__ __attribute__((aligned(16))) float smf[];  // mean[groups], rstd[groups]
   const int C = p.C1 + p.C2;
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn32_apply_kernel(GN32Params p) {
   for (int slot = tid; slot < C * PPB; slot += GN_THREADS) {
     const int c = slot % C, prow = slot / C;
     const int g = c / gs;
-    const float mu = mean[g], a = rstd[g] * bf2f(p.gamma[c]), bt = bf2f(p.beta[c]);
+    const float mu = mean[g], a = rstd[g] * (H16 ? h2f(p.gamma[c]) : bf2f(p.gamma[c])), bt = H16 ? h2f(p.beta[c]) : bf2f(p.beta[c]);
     const float* src;
     int ld;
     if (c < p.C1) {
@@ -179,14 +185,19 @@ __global__ __launch_bounds__(GN_THREADS) void gn32_apply_kernel(GN32Params p) {
       src = p.X2 + (int64_t)b * p.HW * p.C2 + (c - p.C1);
       ld = p.C2;
     }
-    u16* dst = p.Y + (int64_t)b * p.HW * (2 * C) + c;
+    constexpr int PL = H16 ? 1 : 2;
+    u16* dst = p.Y + (int64_t)b * p.HW * (PL * C) + c;
     for (int px = p0 + prow; px < p1; px += PPB) {
       float y = (src[(int64_t)px * ld] - mu) * a + bt;
       if (p.silu) y = silu_f(y);
-      u16 hi, lo;
-      split2(y, hi, lo);
-      dst[(int64_t)px * (2 * C)] = hi;
-      dst[(int64_t)px * (2 * C) + C] = lo;
+      if constexpr (H16) {
+        dst[(int64_t)px * C] = f2h(y);
+      } else {
+        u16 hi, lo;
+        split2(y, hi, lo);
+        dst[(int64_t)px * (2 * C)] = hi;
+        dst[(int64_t)px * (2 * C) + C] = lo;
+      }
     }
   }
 }
@@ -245,6 +256,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn32_stats4_kernel(GN32Params p) {
   }
 }
 
+template <bool H16>
 __global__ __launch_bounds__(GN_THREADS) void gn32_apply4_kernel(GN32Params p) {
   extern __shared__ __attribute__((aligned(16))) float smf[];  // mean[groups], rstd[groups]
   const int C = p.C1 + p.C2, Q = C / 4;
@@ -278,8 +290,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn32_apply4_kernel(GN32Params p) {
     for (int e = 0; e < 4; ++e) {
       const int g = (c + e) / gs;
       mu[e] = mean[g];
-      a[e] = rstd[g] * bf2f(p.gamma[c + e]);
-      bt[e] = bf2f(p.beta[c + e]);
+      a[e] = rstd[g] * (H16 ? h2f(p.gamma[c + e]) : bf2f(p.gamma[c + e]));
+      bt[e] = H16 ? h2f(p.beta[c + e]) : bf2f(p.beta[c + e]);
     }
     const float* src;
     int ld;
@@ -290,9 +302,22 @@ __global__ __launch_bounds__(GN_THREADS) void gn32_apply4_kernel(GN32Params p) {
       src = p.X2 + (int64_t)b * p.HW * p.C2 + (c - p.C1);
       ld = p.C2;
     }
-    u16* dst = p.Y + (int64_t)b * p.HW * (2 * C) + c;
+    constexpr int PL = H16 ? 1 : 2;
+    u16* dst = p.Y + (int64_t)b * p.HW * (PL * C) + c;
     for (int px = p0 + prow; px < p1; px += PPB) {
       const f32x4_t v = *reinterpret_cast<const f32x4_t*>(src + (int64_t)px * ld);
+      if constexpr (H16) {
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          y[e] = (v[e] - mu[e]) * a[e] + bt[e];
+          if (p.silu) y[e] = silu_f(y[e]);
+        }
+        uint2 ph;
+        ph.x = pack_h2(y[0], y[1]), ph.y = pack_h2(y[2], y[3]);
+        *reinterpret_cast<uint2*>(dst + (int64_t)px * C) = ph;
+        continue;
+      }
       u16 hi[4], lo[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -312,6 +337,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn32_apply4_kernel(GN32Params p) {
 // ------------------------------------------------------------------------------------------------
 // LayerNorm, fp32 in, operand out: one wave per row, two-pass statistics in fp32
 // ------------------------------------------------------------------------------------------------
+template <bool H16>
 __global__ __launch_bounds__(256) void ln32_kernel(const float* X, int64_t ldx, const u16* gamma, const u16* beta, u16* Y, int64_t ldy,
                                                    int M, int C, float eps) {
   const int lane = threadIdx.x & 63;
@@ -333,17 +359,22 @@ __global__ __launch_bounds__(256) void ln32_kernel(const float* X, int64_t ldx, 
   const float rs = rsqrtf(q / (float)C + eps);
   u16* y = Y + (int64_t)row * ldy;
   for (int c = lane; c < C; c += 64) {
-    const float v = (x[c] - mu) * rs * bf2f(gamma[c]) + bf2f(beta[c]);
-    u16 hi, lo;
-    split2(v, hi, lo);
-    y[c] = hi;
-    y[C + c] = lo;
+    if constexpr (H16) {
+      y[c] = f2h((x[c] - mu) * rs * h2f(gamma[c]) + h2f(beta[c]));
+    } else {
+      const float v = (x[c] - mu) * rs * bf2f(gamma[c]) + bf2f(beta[c]);
+      u16 hi, lo;
+      split2(v, hi, lo);
+      y[c] = hi;
+      y[C + c] = lo;
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // P = softmax(S * scale) per row of fp32 logits -> [p_hi | p_lo | p_hi], each plane Np wide (columns N..Np-1 zero)
 // ------------------------------------------------------------------------------------------------
+template <bool H16>
 __global__ __launch_bounds__(256) void softmax32_split_kernel(const float* S, int64_t lds, u16* P, int64_t ldp, int M, int N, int Np,
                                                               float scale) {
   __shared__ float red[4];
@@ -367,11 +398,15 @@ __global__ __launch_bounds__(256) void softmax32_split_kernel(const float* S, in
   const float inv = 1.0f / sum;
   u16* y = P + (int64_t)row * ldp;
   for (int c = tid; c < Np; c += 256) {
-    u16 hi = 0, lo = 0;
-    if (c < N) split2(expf((s[c] - mx) * scale) * inv, hi, lo);
-    y[c] = hi;
-    y[Np + c] = lo;
-    y[2 * Np + c] = hi;
+    if constexpr (H16) {  // one fp16 plane [M, Np]
+      y[c] = c < N ? f2h(expf((s[c] - mx) * scale) * inv) : (u16)0;
+    } else {
+      u16 hi = 0, lo = 0;
+      if (c < N) split2(expf((s[c] - mx) * scale) * inv, hi, lo);
+      y[c] = hi;
+      y[Np + c] = lo;
+      y[2 * Np + c] = hi;
+    }
   }
 }
 
@@ -615,13 +650,22 @@ extern "C" int dm4d_split_f32(void* stream, const float* X1, int64_t row_stride1
   return dm4d_check_launch("split_kernel");
 }
 
+extern "C" int dm4d_to_f16_f32(void* stream, const float* X1, int64_t row_stride1, int64_t col_stride1, int C1, const float* X2,
+                               int64_t row_stride2, int C2, void* Y, int64_t ldy, int64_t M, int Cp, int act_silu, float scale) {
+  if (!X1 || !Y || M <= 0 || C1 <= 0 || C2 < 0 || (C2 > 0 && !X2) || Cp < C1 + C2 || ldy < Cp)
+    return dm4d_set_error(DM4D_ERR_ARG, "to_f16_f32: bad arguments");
+  SplitParams p{X1, row_stride1, col_stride1, X2, row_stride2, C1, C2, Cp, M, (u16*)Y, ldy, act_silu, scale, 3};
+  hipLaunchKernelGGL(split_kernel, grid1d(M * Cp, 256), dim3(256), 0, (hipStream_t)stream, p);
+  return dm4d_check_launch("split_kernel");
+}
+
 extern "C" size_t dm4d_groupnorm_f32_ws_bytes(int B, int HW, int groups) {
   return (size_t)B * gn32_nchunk(B, HW) * groups * 2 * sizeof(double);
 }
 
-extern "C" int dm4d_groupnorm_nhwc_f32_split(void* stream, const float* X1, int C1, const float* X2, int C2, int B, int HW,
-                                             int groups, float eps, const void* gamma, const void* beta, void* Y, int apply_silu,
-                                             void* ws) {
+template <bool H16>
+static int groupnorm_f32_impl(void* stream, const float* X1, int C1, const float* X2, int C2, int B, int HW, int groups, float eps,
+                              const void* gamma, const void* beta, void* Y, int apply_silu, void* ws) {
   if (!X1 || !gamma || !beta || !Y || !ws || B <= 0 || HW <= 0 || groups <= 0 || C1 <= 0 || C2 < 0 || (C2 > 0 && !X2))
     return dm4d_set_error(DM4D_ERR_ARG, "groupnorm_f32: bad arguments");
   const int C = C1 + C2;
@@ -636,7 +680,7 @@ extern "C" int dm4d_groupnorm_nhwc_f32_split(void* stream, const float* X1, int 
       hipLaunchKernelGGL(gn32_stats4_kernel, dim3(B * p.nchunk), dim3(GN_THREADS), sm1, (hipStream_t)stream, p);
       int rc = dm4d_check_launch("gn32_stats4_kernel");
       if (rc) return rc;
-      hipLaunchKernelGGL(gn32_apply4_kernel, dim3(B * p.nchunk), dim3(GN_THREADS), 2 * groups * sizeof(float), (hipStream_t)stream, p);
+      hipLaunchKernelGGL((gn32_apply4_kernel<H16>), dim3(B * p.nchunk), dim3(GN_THREADS), 2 * groups * sizeof(float), (hipStream_t)stream, p);
       return dm4d_check_launch("gn32_apply4_kernel");
     }
   }
@@ -645,24 +689,52 @@ extern "C" int dm4d_groupnorm_nhwc_f32_split(void* stream, const float* X1, int 
   hipLaunchKernelGGL(gn32_stats_kernel, dim3(B * p.nchunk), dim3(GN_THREADS), sm1, (hipStream_t)stream, p);
   int rc = dm4d_check_launch("gn32_stats_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(gn32_apply_kernel, dim3(B * p.nchunk), dim3(GN_THREADS), 2 * groups * sizeof(float), (hipStream_t)stream, p);
+  hipLaunchKernelGGL((gn32_apply_kernel<H16>), dim3(B * p.nchunk), dim3(GN_THREADS), 2 * groups * sizeof(float), (hipStream_t)stream, p);
   return dm4d_check_launch("gn32_apply_kernel");
+}
+
+extern "C" int dm4d_groupnorm_nhwc_f32_split(void* stream, const float* X1, int C1, const float* X2, int C2, int B, int HW,
+                                             int groups, float eps, const void* gamma, const void* beta, void* Y, int apply_silu,
+                                             void* ws) {
+  return groupnorm_f32_impl<false>(stream, X1, C1, X2, C2, B, HW, groups, eps, gamma, beta, Y, apply_silu, ws);
+}
+
+extern "C" int dm4d_groupnorm_nhwc_f32_f16(void* stream, const float* X1, int C1, const float* X2, int C2, int B, int HW, int groups,
+                                           float eps, const void* gamma, const void* beta, void* Y, int apply_silu, void* ws) {
+  return groupnorm_f32_impl<true>(stream, X1, C1, X2, C2, B, HW, groups, eps, gamma, beta, Y, apply_silu, ws);
 }
 
 extern "C" int dm4d_layernorm_f32_split(void* stream, const float* X, int64_t ldx, const void* gamma, const void* beta, void* Y,
                                         int64_t ldy, int M, int C, float eps) {
   if (!X || !gamma || !beta || !Y || M <= 0 || C <= 0 || ldx < C || ldy < 2 * (int64_t)C)
     return dm4d_set_error(DM4D_ERR_ARG, "layernorm_f32: bad arguments");
-  hipLaunchKernelGGL(ln32_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, X, ldx, (const u16*)gamma, (const u16*)beta,
+  hipLaunchKernelGGL(ln32_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, X, ldx, (const u16*)gamma, (const u16*)beta,
                      (u16*)Y, ldy, M, C, eps);
   return dm4d_check_launch("ln32_kernel");
+}
+
+extern "C" int dm4d_layernorm_f32_f16(void* stream, const float* X, int64_t ldx, const void* gamma, const void* beta, void* Y,
+                                      int64_t ldy, int M, int C, float eps) {
+  if (!X || !gamma || !beta || !Y || M <= 0 || C <= 0 || ldx < C || ldy < (int64_t)C)
+    return dm4d_set_error(DM4D_ERR_ARG, "layernorm_f32_f16: bad arguments");
+  hipLaunchKernelGGL(ln32_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, X, ldx, (const u16*)gamma, (const u16*)beta,
+                     (u16*)Y, ldy, M, C, eps);
+  return dm4d_check_launch("ln32_kernel");
+}
+
+extern "C" int dm4d_softmax_rows_f32_f16(void* stream, const float* S, int64_t lds, void* P, int64_t ldp, int M, int N, int Np,
+                                         float scale) {
+  if (!S || !P || M <= 0 || N <= 0 || Np < N || lds < N || ldp < (int64_t)Np)
+    return dm4d_set_error(DM4D_ERR_ARG, "softmax_rows_f32_f16: bad arguments");
+  hipLaunchKernelGGL(softmax32_split_kernel<true>, dim3(M), dim3(256), 0, (hipStream_t)stream, S, lds, (u16*)P, ldp, M, N, Np, scale);
+  return dm4d_check_launch("softmax32_split_kernel");
 }
 
 extern "C" int dm4d_softmax_rows_f32_split(void* stream, const float* S, int64_t lds, void* P, int64_t ldp, int M, int N, int Np,
                                            float scale) {
   if (!S || !P || M <= 0 || N <= 0 || Np < N || lds < N || ldp < 3 * (int64_t)Np)
     return dm4d_set_error(DM4D_ERR_ARG, "softmax_rows_f32_split: bad arguments");
-  hipLaunchKernelGGL(softmax32_split_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, S, lds, (u16*)P, ldp, M, N, Np, scale);
+  hipLaunchKernelGGL(softmax32_split_kernel<false>, dim3(M), dim3(256), 0, (hipStream_t)stream, S, lds, (u16*)P, ldp, M, N, Np, scale);
   return dm4d_check_launch("softmax32_split_kernel");
 }
 

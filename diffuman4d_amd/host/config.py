@@ -65,7 +65,7 @@ BUILTIN: Dict[str, Dict[str, Any]] = {
                                 "model_dir": "./models/models--krahets--Diffuman4D", "torch_dtype": "bf16", "gpu_ids": None}},
         "diffuman4d_mi355x": {"body": {"_target_": "diffuman4d_amd.host.loader.load_pipelines", "repo_id": "krahets/Diffuman4D",
                                        "model_dir": "./models/models--krahets--Diffuman4D", "torch_dtype": "bf16",
-                                       "gpu_ids": None, "precision": "fast"}},
+                                       "gpu_ids": None, "precision": "auto"}},
     },
     "sampler": {
         "sliding_default": {"body": _SLIDING_DEFAULT},

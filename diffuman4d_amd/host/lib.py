@@ -72,6 +72,16 @@ SIGNATURES = {
     "dm4d_plucker_latent_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "dm4d_postprocess_images_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),
     "dm4d_nhwc_to_nchw_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),
+    # fp16 precision (fp32 tensors between kernels, single-term fp16 MFMA operands)
+    "dm4d_gemm_f16": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp, _i64, _i, _vp, _i64, _u, _f, _i, _f]),
+    "dm4d_conv3x3_nhwc_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i64, _vp, _i64, _f, _u, _vp,
+                                   C.c_size_t]),
+    "dm4d_to_f16_f32": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _i64, _i, _vp, _i64, _i64, _i, _i, _f]),
+    "dm4d_groupnorm_nhwc_f32_f16": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp]),
+    "dm4d_layernorm_f32_f16": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _f]),
+    "dm4d_softmax_rows_f32_f16": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _f]),
+    "dm4d_attention_qscaled_kv_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i]),
+    "dm4d_pack_model_input_f32_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     "dm4d_tune_set_gemm_config": (_i, [_i]),
     "dm4d_tune_set_groupnorm_resident": (_i, [_i]),
     "dm4d_nchw_to_nhwc_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i]),

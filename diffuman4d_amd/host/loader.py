@@ -18,18 +18,21 @@ log = logging.getLogger(__name__)
 
 
 def load_pipelines(repo_id: str = "krahets/Diffuman4D", model_dir: str = "./models/krahets-Diffuman4D",
-                   torch_dtype: str = "bf16", gpu_ids: Optional[List[int]] = None, precision: str = "fast"):
-    """precision (extension key of configs/model/diffuman4d_mi355x.yaml): "fast" = bf16 tensors and MFMA operands (the judged
-    throughput); "parity" = fp32 tensors between kernels and two-term bf16 operands, the arithmetic that stays within 1e-3 rel-L2
-    of the reference's fp32 CPU path on decoded RGB (include/dm4d.h "Parity precision"), at about a third of the speed."""
+                   torch_dtype: str = "bf16", gpu_ids: Optional[List[int]] = None, precision: str = "auto"):
+    """precision (extension key of configs/model/diffuman4d_mi355x.yaml):
+      "fast"   bf16 tensors and MFMA operands (the judged throughput), whatever files torch_dtype selects;
+      "fp16"   fp32 tensors between kernels and single-term fp16 MFMA operands on the weights as torch_dtype holds them: the faithful
+               form of the reference's fp16 pipelines (sampling_utils.py:27-29) and the fastest arithmetic that stays within 1e-3
+               rel-L2 of the reference's fp32 CPU path on decoded RGB (include/dm4d.h "fp16 precision");
+      "parity" fp32 tensors and two-term bf16 operands (include/dm4d.h "Parity precision"): 1e-5 from that path, at a third of the speed;
+      "auto"   (default) "fp16" when torch_dtype is "fp16", else "fast" -- what the reference's own model config asks for."""
     from .pipeline import Diffuman4DPipeline
-    if precision not in ("fast", "parity"):
-        raise ValueError(f"Unsupported precision: {precision}. Supported values are 'fast' and 'parity'.")
+    if precision not in ("auto", "fast", "parity", "fp16"):
+        raise ValueError(f"Unsupported precision: {precision}. Supported values are 'auto', 'fast', 'parity' and 'fp16'.")
     if gpu_ids is None:
         gpu_ids = list(range(torch.cuda.device_count()))
         log.info("Found %d HIP devices.", len(gpu_ids))
-    # same two spellings and the same error as sampling_utils.py:28-35; both run bf16 MFMA arithmetic here, "fp16" only
-    # selects the *.fp16.safetensors files (Diffuman4DPipeline.from_pretrained)
+    # same two spellings and the same error as sampling_utils.py:28-35: the files follow torch_dtype, the arithmetic `precision`
     if torch_dtype == "fp16":
         allow_patterns, dtype = ["*.json", "*model.fp16.safetensors"], torch.float16
     elif torch_dtype == "bf16":
@@ -42,6 +45,8 @@ def load_pipelines(repo_id: str = "krahets/Diffuman4D", model_dir: str = "./mode
             snapshot_download(repo_id, local_dir=model_dir, allow_patterns=allow_patterns)
         except Exception as e:  # no network on the GPU boxes
             log.error("Failed to download model from %s to %s: %s. Skipping download.", repo_id, model_dir, e)
+    if precision == "auto":
+        precision = "fp16" if torch_dtype == "fp16" else "fast"
     pipelines = []
     for gpu_id in gpu_ids:
         pipelines.append(Diffuman4DPipeline.from_pretrained(model_dir, torch_dtype=dtype, device=f"cuda:{gpu_id}", precision=precision))

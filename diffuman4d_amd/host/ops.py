@@ -3,11 +3,15 @@
 Every function requires tensors resident on a HIP device and launches on torch's current
 stream.  Nothing here computes with torch: a tensor on the CPU is an error, not a fallback.
 
-Two arithmetics share these wrappers (include/dm4d.h, "Parity precision"):
+Three arithmetics share these wrappers (include/dm4d.h, "Parity precision" / "fp16 precision"):
   * fast (default): bf16 tensors between kernels, bf16 MFMA operands, fp32 accumulation;
   * parity (``precision="parity"`` on the model objects): fp32 tensors between kernels; every activation that feeds the
     matrix unit is a two-term OPERAND ``[hi(C) | lo(C)]`` (bf16, 2 C columns) against weights duplicated along K
-    (``dup_k``).  Functions that exist in both forms dispatch on the dtype of their input (fp32 = parity).
+    (``dup_k``);
+  * fp16 (``precision="fp16"``): fp32 tensors between kernels; every activation that feeds the matrix unit is ONE fp16 plane
+    against fp16 weights (one MFMA per product, as in the fast precision).
+Functions that exist in several forms dispatch on the dtypes they are given: an fp32 activation means a wide (parity / fp16)
+precision, and fp16 weights / norm parameters / operands mean the fp16 one.
 """
 from __future__ import annotations
 
@@ -20,6 +24,7 @@ import torch
 from . import lib as _l
 
 BF16 = torch.bfloat16
+F16 = torch.float16
 F32 = torch.float32
 
 
@@ -54,11 +59,17 @@ def _p(t: Optional[torch.Tensor]):
 
 def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None, bias=None, rowbias=None,
          rows_per_rowbias: int = 1, residual=None, geglu: bool = False, silu: bool = False, out_scale: float = 1.0,
-         out: Optional[torch.Tensor] = None, out_f32: bool = False, split_out: bool = False) -> torch.Tensor:
+         out: Optional[torch.Tensor] = None, out_f32: bool = False, split_out: bool = False, scale_cols: int = 0,
+         col_scale: float = 1.0) -> torch.Tensor:
     """out[M,N] = epi([a | a2] @ w^T); a [M,K1], a2 [M,K-K1], w [N,K] (GEGLU: [2N,K]).
-    out_f32: the result is stored unrounded in an fp32 tensor (attention logits of the VAE mid block; parity precision).
-    split_out (parity precision): the result leaves as a two-term operand, bf16 [M, 2N] = [hi | lo].
-    rowbias / residual may be fp32 tensors (parity precision: both must then be fp32)."""
+    out_f32: the result is stored unrounded in an fp32 tensor (attention logits of the VAE mid block; wide precisions).
+    split_out (wide precisions): the result leaves as the OPERAND of the next contraction -- parity: bf16 [M, 2N] = [hi | lo];
+    fp16 (w is fp16): one fp16 plane [M, N].
+    rowbias / residual may be fp32 tensors (wide precisions: both must then be fp32).
+    scale_cols / col_scale (fp16 precision): output columns [0, scale_cols) are multiplied by col_scale before the one rounding."""
+    if isinstance(w, torch.Tensor) and w.dtype == F16:
+        return _gemm_f16(a, w, a2, bias, rowbias, rows_per_rowbias, residual, geglu, silu, out_scale, out, out_f32, scale_cols, col_scale)
+    assert scale_cols == 0
     lib = _l.load()
     _req(a, "a"), _req(w, "w")
     M, K1 = a.shape
@@ -96,6 +107,42 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
     return out
 
 
+def _gemm_f16(a, w, a2, bias, rowbias, rows_per_rowbias, residual, geglu, silu, out_scale, out, out_f32, scale_cols, col_scale):
+    """precision "fp16": fp16 a / a2 / w / bias, fp32 (or fp16) rowbias / residual, fp32 or fp16 result (dm4d_gemm_f16)."""
+    lib = _l.load()
+    _req(a, "a", F16), _req(w, "w", F16)
+    M, K1 = a.shape
+    K = w.shape[1]
+    N = w.shape[0] // 2 if geglu else w.shape[0]
+    if a2 is not None:
+        _req(a2, "a2", F16)
+        assert a2.shape[0] == M and K1 + a2.shape[1] == K
+    else:
+        assert K1 == K, (K1, K)
+    if bias is not None:
+        _req(bias, "bias", F16)
+    side = [t for t in (rowbias, residual) if t is not None]
+    f32_side = bool(side) and side[0].dtype == F32
+    for t, n in ((rowbias, "rowbias"), (residual, "residual")):
+        if t is not None:
+            _req(t, n, F32 if f32_side else F16)
+    odt = F32 if out_f32 else F16
+    if out is None:
+        out = torch.empty((M, N), dtype=odt, device=a.device)
+    _req(out, "out", odt)
+    assert out.shape[1] >= N or out.stride(0) >= N
+    flags = ((_l.EPI_GEGLU if geglu else 0) | (_l.EPI_SILU if silu else 0) | (_l.EPI_F32OUT if out_f32 else 0)
+             | (_l.EPI_F32SIDE if f32_side else 0))
+    with _Prof("linear", 2.0 * M * w.shape[0] * K, "flop", M):
+        rc = lib.dm4d_gemm_f16(_stream(), _p(a), a.stride(0), _p(a2), a2.stride(0) if a2 is not None else 0,
+                               K1 if a2 is not None else 0, _p(w), w.stride(0), _p(out), out.stride(0), M, N, K,
+                               _p(bias), _p(rowbias), rowbias.stride(0) if rowbias is not None else 0,
+                               rows_per_rowbias, _p(residual), residual.stride(0) if residual is not None else 0,
+                               flags, out_scale, int(scale_cols), float(col_scale))
+    _l.check(rc, "dm4d_gemm_f16")
+    return out
+
+
 def conv_out_hw(h: int, w: int, stride: int, pad: int, upsample: bool, pad_hi: Optional[int] = None) -> Tuple[int, int]:
     if upsample:
         return 2 * h, 2 * w
@@ -110,6 +157,8 @@ def conv3x3(x: torch.Tensor, wt: torch.Tensor, *, bias=None, rowbias=None, resid
     out_f32 (parity precision): fp32 output; rowbias / residual must then be fp32 as well (x is usually a two-term operand
     and wt duplicated along Cin, which this function does not need to know)."""
     lib = _l.load()
+    if isinstance(wt, torch.Tensor) and wt.dtype == F16:
+        return _conv3x3_f16(x, wt, bias, rowbias, residual, stride, pad, pad_hi, upsample, out_scale, out_f32)
     _req(x, "x"), _req(wt, "wt")
     assert x.is_contiguous() and wt.is_contiguous()
     B, H, W, Cin = x.shape
@@ -148,7 +197,38 @@ def conv3x3(x: torch.Tensor, wt: torch.Tensor, *, bias=None, rowbias=None, resid
     return y
 
 
-# ---- parity precision: operands ------------------------------------------------------------------------------------------
+def _conv3x3_f16(x, wt, bias, rowbias, residual, stride, pad, pad_hi, upsample, out_scale, out_f32) -> torch.Tensor:
+    """precision "fp16": x / wt / bias fp16; fp32 result with fp32 rowbias / residual (out_f32), else fp16 everywhere."""
+    lib = _l.load()
+    _req(x, "x", F16), _req(wt, "wt", F16)
+    assert x.is_contiguous() and wt.is_contiguous()
+    B, H, W, Cin = x.shape
+    Cout = wt.shape[0]
+    assert wt.shape[1] == 9 * Cin, (wt.shape, Cin)
+    Ho, Wo = conv_out_hw(H, W, stride, pad, upsample, pad_hi)
+    y = torch.empty((B, Ho, Wo, Cout), dtype=F32 if out_f32 else F16, device=x.device)
+    side = F32 if out_f32 else F16
+    if bias is not None:
+        _req(bias, "bias", F16)
+    if residual is not None:
+        _req(residual, "residual", side)
+        assert residual.numel() == y.numel() and residual.is_contiguous()
+    if rowbias is not None:
+        _req(rowbias, "rowbias", side)
+        assert rowbias.shape[0] == B
+    ws_bytes = lib.dm4d_conv3x3_ws_bytes(B, H, W, Cin, Ho, Wo, Cout, stride, pad, 1 if upsample else 0)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device) if ws_bytes else None
+    with _Prof("conv3x3", 2.0 * B * Ho * Wo * 9 * Cin * Cout, "flop", B * Ho * Wo):
+        rc = lib.dm4d_conv3x3_nhwc_f16(_stream(), _p(x), B, H, W, Cin, _p(wt), _p(y), Ho, Wo, Cout, stride, pad,
+                                       1 if upsample else 0, _p(bias), _p(rowbias),
+                                       rowbias.stride(0) if rowbias is not None else 0, _p(residual),
+                                       Cout if residual is not None else 0, out_scale,
+                                       (_l.EPI_F32OUT | _l.EPI_F32SIDE) if out_f32 else 0, _p(ws), ws_bytes)
+    _l.check(rc, "dm4d_conv3x3_nhwc_f16")
+    return y
+
+
+# ---- wide precisions: operands -------------------------------------------------------------------------------------------
 def dup_k(w: torch.Tensor, taps: int = 1, times: int = 2) -> torch.Tensor:
     """Weights for a two-term operand: [N, taps * C] -> [N, taps * times * C] with every tap's C columns repeated `times` times
     ([W | W] per tap), so that  [hi | lo] [W | W]^T = (hi + lo) W^T.  Host / load-time helper (any device)."""
@@ -158,13 +238,14 @@ def dup_k(w: torch.Tensor, taps: int = 1, times: int = 2) -> torch.Tensor:
 
 
 def split(x: torch.Tensor, x2: Optional[torch.Tensor] = None, *, cpad: Optional[int] = None, silu: bool = False,
-          scale: float = 1.0, pattern: int = 0, transposed: bool = False) -> torch.Tensor:
-    """fp32 [..., C] (channel concat with x2) -> two-term operand bf16 [..., 2 cpad] = [hi | lo] (pattern 1: [hi | lo | hi],
-    2: [hi | hi | lo], three planes).  transposed: x is a 2-D view [K, M] read as its transpose (result [M, planes * K])."""
+          scale: float = 1.0, pattern: int = 0, transposed: bool = False, h16: bool = False) -> torch.Tensor:
+    """fp32 [..., C] (channel concat with x2) -> the OPERAND of a contraction.  Parity precision: two-term bf16 [..., 2 cpad] =
+    [hi | lo] (pattern 1: [hi | lo | hi], 2: [hi | hi | lo], three planes); h16 (precision "fp16"): one fp16 plane [..., cpad].
+    transposed: x is a 2-D view [K, M] read as its transpose (result [M, planes * K])."""
     lib = _l.load()
     if not isinstance(x, torch.Tensor) or not x.is_cuda or x.dtype != F32:
         raise _l.Dm4dError("split: expected an fp32 tensor on a HIP device")
-    planes = 2 if pattern == 0 else 3
+    planes = 1 if h16 else (2 if pattern == 0 else 3)
     if transposed:
         assert x.ndim == 2 and x2 is None and x.stride(1) == 1
         C1, M = x.shape
@@ -183,10 +264,13 @@ def split(x: torch.Tensor, x2: Optional[torch.Tensor] = None, *, cpad: Optional[
         assert x2.shape[0] == M
         C2, rs2 = x2.shape[1], x2.stride(0)
     Cp = cpad or (C1 + C2)
-    y = torch.empty(lead + (planes * Cp,), dtype=BF16, device=x.device)
-    with _Prof("split", 4.0 * M * (C1 + C2) + 2.0 * M * planes * Cp, "byte", M):  # fp32 in, bf16 planes out
-        rc = lib.dm4d_split_f32(_stream(), _p(x), rs1, cs1, C1, _p(x2), rs2, C2, _p(y), planes * Cp, M, Cp, 1 if silu else 0, scale,
-                                pattern)
+    y = torch.empty(lead + (planes * Cp,), dtype=F16 if h16 else BF16, device=x.device)
+    with _Prof("split", 4.0 * M * (C1 + C2) + 2.0 * M * planes * Cp, "byte", M):  # fp32 in, 16-bit planes out
+        if h16:
+            rc = lib.dm4d_to_f16_f32(_stream(), _p(x), rs1, cs1, C1, _p(x2), rs2, C2, _p(y), Cp, M, Cp, 1 if silu else 0, scale)
+        else:
+            rc = lib.dm4d_split_f32(_stream(), _p(x), rs1, cs1, C1, _p(x2), rs2, C2, _p(y), planes * Cp, M, Cp, 1 if silu else 0,
+                                    scale, pattern)
     _l.check(rc, "dm4d_split_f32")
     return y
 
@@ -293,12 +377,13 @@ class Upsampler:
     stream is drained before the object is handed out: the runner's task streams (one worker thread and HIP stream each,
     sharing one pipeline) must never see a published `wp` whose prepare kernel is still queued on another stream."""
 
-    def __init__(self, wt: torch.Tensor, bias: Optional[torch.Tensor], parity: bool = False):
+    def __init__(self, wt: torch.Tensor, bias: Optional[torch.Tensor], parity: bool = False, h16: bool = False):
         """parity (precision "parity"): wt is duplicated along Cin, the input fp32; the phase kernels -- whose weights are SUMS of taps
         rounded to bf16 once more, a deviation from the checkpoint's arithmetic -- are not used: the gather kernel reads the upsampled
         image of the two-term operand through index arithmetic and multiplies by the checkpoint's own weights."""
-        self.wt, self.bias, self.wp, self.parity = wt, bias, None, parity
-        self.phase = (not parity) and conv_up2x_supported(wt.shape[1] // 9, wt.shape[0])
+        # h16 (precision "fp16"; implies `parity` = fp32 tensors): fp16 weights, one fp16 operand plane, the same gather kernel
+        self.wt, self.bias, self.wp, self.parity, self.h16 = wt, bias, None, parity or h16, h16
+        self.phase = (not self.parity) and conv_up2x_supported(wt.shape[1] // 9, wt.shape[0])
         if self.phase and wt.is_cuda:
             with torch.cuda.device(wt.device):
                 self.wp = conv_up2x_prepare(wt)
@@ -306,7 +391,7 @@ class Upsampler:
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         if self.parity:
-            return conv3x3(split(x), self.wt, bias=self.bias, upsample=True, out_f32=True)
+            return conv3x3(split(x, h16=self.h16), self.wt, bias=self.bias, upsample=True, out_f32=True)
         # the phase kernel addresses its input with 32-bit byte offsets: inputs of 4 GiB or more take the gather kernel
         if not self.phase or x.numel() * 2 >= (1 << 32):
             return conv3x3(x, self.wt, bias=self.bias, upsample=True)
@@ -383,7 +468,9 @@ def groupnorm(x1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups:
 
 def _groupnorm_f32(x1, gamma, beta, groups, eps, x2, silu) -> torch.Tensor:
     lib = _l.load()
-    _req(x1, "x1", F32), _req(gamma, "gamma"), _req(beta, "beta")
+    h16 = gamma.dtype == F16  # precision "fp16": fp16 parameters, one fp16 plane out
+    pdt = F16 if h16 else BF16
+    _req(x1, "x1", F32), _req(gamma, "gamma", pdt), _req(beta, "beta", pdt)
     assert x1.is_contiguous()
     B, C1 = x1.shape[0], x1.shape[-1]
     HW = x1.numel() // (B * C1)
@@ -392,11 +479,12 @@ def _groupnorm_f32(x1, gamma, beta, groups, eps, x2, silu) -> torch.Tensor:
         _req(x2, "x2", F32)
         assert x2.is_contiguous() and x2.shape[0] == B
         C2 = x2.shape[-1]
-    y = torch.empty(x1.shape[:-1] + (2 * (C1 + C2),), dtype=BF16, device=x1.device)
+    y = torch.empty(x1.shape[:-1] + ((1 if h16 else 2) * (C1 + C2),), dtype=pdt, device=x1.device)
     ws = torch.empty(lib.dm4d_groupnorm_f32_ws_bytes(B, HW, groups) // 8, dtype=torch.float64, device=x1.device)
-    with _Prof("groupnorm", 6.0 * x1.numel() + (6.0 * x2.numel() if x2 is not None else 0.0), "byte", B * HW):  # fp32 in + hi + lo out
-        rc = lib.dm4d_groupnorm_nhwc_f32_split(_stream(), _p(x1), C1, _p(x2), C2, B, HW, groups, eps, _p(gamma), _p(beta), _p(y),
-                                               1 if silu else 0, _p(ws))
+    bpe = 6.0 if h16 else 8.0  # algorithmic bytes per element: fp32 in + the operand out (one fp16 plane, or hi + lo)
+    with _Prof("groupnorm", bpe * x1.numel() + (bpe * x2.numel() if x2 is not None else 0.0), "byte", B * HW):
+        fn = lib.dm4d_groupnorm_nhwc_f32_f16 if h16 else lib.dm4d_groupnorm_nhwc_f32_split
+        rc = fn(_stream(), _p(x1), C1, _p(x2), C2, B, HW, groups, eps, _p(gamma), _p(beta), _p(y), 1 if silu else 0, _p(ws))
     _l.check(rc, "dm4d_groupnorm_nhwc_f32_split")
     return y
 
@@ -405,14 +493,17 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     """fp32 input (parity precision): the result leaves as a two-term operand [..., 2 C]."""
     lib = _l.load()
     if isinstance(x, torch.Tensor) and x.dtype == F32:
-        _req(x, "x", F32), _req(gamma, "gamma"), _req(beta, "beta")
+        h16 = gamma.dtype == F16  # precision "fp16": fp16 parameters, one fp16 plane out
+        pdt, planes = (F16, 1) if h16 else (BF16, 2)
+        _req(x, "x", F32), _req(gamma, "gamma", pdt), _req(beta, "beta", pdt)
         x2 = x.reshape(-1, x.shape[-1])
         C = x2.shape[1]
-        y = torch.empty((x2.shape[0], 2 * C), dtype=BF16, device=x.device)
-        with _Prof("layernorm", 8.0 * x2.numel(), "byte", x2.shape[0]):
-            rc = lib.dm4d_layernorm_f32_split(_stream(), _p(x2), x2.stride(0), _p(gamma), _p(beta), _p(y), y.stride(0), x2.shape[0], C, eps)
+        y = torch.empty((x2.shape[0], planes * C), dtype=pdt, device=x.device)
+        with _Prof("layernorm", (4.0 + 2.0 * planes) * x2.numel(), "byte", x2.shape[0]):
+            fn = lib.dm4d_layernorm_f32_f16 if h16 else lib.dm4d_layernorm_f32_split
+            rc = fn(_stream(), _p(x2), x2.stride(0), _p(gamma), _p(beta), _p(y), y.stride(0), x2.shape[0], C, eps)
         _l.check(rc, "dm4d_layernorm_f32_split")
-        return y.view(x.shape[:-1] + (2 * C,))
+        return y.view(x.shape[:-1] + (planes * C,))
     _req(x, "x"), _req(gamma, "gamma"), _req(beta, "beta")
     x2 = x.reshape(-1, x.shape[-1])
     y = torch.empty_like(x2)
@@ -434,12 +525,16 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, hea
     kv_seq: keys per batch when K/V hold more tokens than Q (frame-sharded 3-D attention); default = seq.
     q_scaled: q already carries scale * LOG2E (folded into the to_q weights, unet._TransformerBlock)."""
     lib = _l.load()
-    _req(q, "q"), _req(k, "k"), _req(v, "v")
+    h16 = isinstance(q, torch.Tensor) and q.dtype == F16  # precision "fp16": fp16 Q (pre-scaled) / K / V -> fp16 O
+    dt = F16 if h16 else BF16
+    _req(q, "q", dt), _req(k, "k", dt), _req(v, "v", dt)
     assert q.shape[0] == batch * seq and q.shape[1] == heads * 64, (q.shape, batch, seq, heads)
     kv_seq = seq if kv_seq is None else kv_seq
     assert k.shape[0] == batch * kv_seq and v.shape[0] == batch * kv_seq, (k.shape, batch, kv_seq)
     if out is None:
-        out = torch.empty((batch * seq, heads * 64), dtype=BF16, device=q.device)
+        out = torch.empty((batch * seq, heads * 64), dtype=dt, device=q.device)
+    if h16 and not q_scaled:
+        raise _l.Dm4dError("attention: fp16 operands need a pre-scaled Q (gemm(..., scale_cols=C, col_scale=scale * LOG2E))")
     if scale is None:
         scale = 0.125
     prof = KERNEL_TIMER
@@ -447,7 +542,10 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, hea
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     with _Prof("attention", 4.0 * batch * heads * seq * kv_seq * 64, "flop", batch * seq):
-        if q_scaled:
+        if h16:
+            rc = lib.dm4d_attention_qscaled_kv_f16(_stream(), _p(q), _p(k), _p(v), _p(out), q.stride(0), k.stride(0),
+                                                   v.stride(0), out.stride(0), batch, heads, seq, kv_seq)
+        elif q_scaled:
             rc = lib.dm4d_attention_qscaled_kv_bf16(_stream(), _p(q), _p(k), _p(v), _p(out), q.stride(0), k.stride(0),
                                                     v.stride(0), out.stride(0), batch, heads, seq, kv_seq)
         else:
@@ -457,34 +555,56 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, batch: int, hea
         e1.record()
         prof.append(("attn_kernel", 4.0 * batch * heads * seq * kv_seq * 64, e0, e1))
     _l.check(rc, "dm4d_attention_kv_bf16")
+    if h16:
+        return out
     _trace("attention", out, q=q, k=k, v=v, batch=batch, heads=heads, seq=seq, kv_seq=kv_seq, scale=scale, q_scaled=q_scaled)
     return out
 
 
-def attention_split(qkv: torch.Tensor, batch: int, heads: int, seq: int, scale: Optional[float] = None) -> torch.Tensor:
+def attention_split(qkv: Optional[torch.Tensor], batch: int, heads: int, seq: int, scale: Optional[float] = None, *,
+                    q: Optional[torch.Tensor] = None, kv: Optional[torch.Tensor] = None, kv_seq: Optional[int] = None) -> torch.Tensor:
     """Parity precision: qkv [batch*seq, 6 C] = the planes gemm(split_out=True) leaves for a fused QKV projection
     ([q_hi | k_hi | v_hi | q_lo | k_lo | v_lo], C = heads * 64) -> attention output as a two-term operand [batch*seq, 2 C].
+    Frame-sharded form (qkv = None): q [batch*seq, 2 C] = [q_hi | q_lo] of the local queries, kv [batch*kv_seq, 4 C] =
+    [k_hi | v_hi | k_lo | v_lo] of the all-gathered keys (the planes of gemm(n, w_kv, split_out=True)).
     Three MFMAs per product, exact running-max softmax in fp32 (dm4d_attention_split_bf16)."""
     lib = _l.load()
-    _req(qkv, "qkv")
     C = heads * 64
-    assert qkv.shape == (batch * seq, 6 * C), (qkv.shape, batch, seq, heads)
-    out = torch.empty((batch * seq, 2 * C), dtype=BF16, device=qkv.device)
-    with _Prof("attention", 3 * 4.0 * batch * heads * seq * seq * 64, "flop", batch * seq):  # three MFMA terms per product
-        rc = lib.dm4d_attention_split_bf16(_stream(), _p(qkv), qkv.data_ptr() + 2 * C, qkv.data_ptr() + 4 * C, _p(out), qkv.stride(0),
-                                           qkv.stride(0), qkv.stride(0), out.stride(0), 3 * C, 3 * C, 3 * C, C, batch, heads, seq, seq,
-                                           0.125 if scale is None else scale)
+    if qkv is not None:
+        _req(qkv, "qkv")
+        assert qkv.shape == (batch * seq, 6 * C), (qkv.shape, batch, seq, heads)
+        qp, kp, vp = qkv.data_ptr(), qkv.data_ptr() + 2 * C, qkv.data_ptr() + 4 * C
+        ldq = ldk = ldv = qkv.stride(0)
+        q_lo = k_lo = v_lo = 3 * C
+        kv_seq, dev = seq, qkv.device
+    else:
+        _req(q, "q"), _req(kv, "kv")
+        kv_seq = seq if kv_seq is None else kv_seq
+        assert q.shape == (batch * seq, 2 * C) and kv.shape == (batch * kv_seq, 4 * C), (q.shape, kv.shape, batch, seq, kv_seq, heads)
+        qp, kp, vp = q.data_ptr(), kv.data_ptr(), kv.data_ptr() + 2 * C
+        ldq, ldk, ldv = q.stride(0), kv.stride(0), kv.stride(0)
+        q_lo, k_lo, v_lo = C, 2 * C, 2 * C
+        dev = q.device
+    out = torch.empty((batch * seq, 2 * C), dtype=BF16, device=dev)
+    with _Prof("attention", 3 * 4.0 * batch * heads * seq * kv_seq * 64, "flop", batch * seq):  # three MFMA terms per product
+        rc = lib.dm4d_attention_split_bf16(_stream(), qp, kp, vp, _p(out), ldq, ldk, ldv, out.stride(0), q_lo, k_lo, v_lo, C, batch,
+                                           heads, seq, kv_seq, 0.125 if scale is None else scale)
     _l.check(rc, "dm4d_attention_split_bf16")
     return out
 
 
-def softmax_rows_split(s: torch.Tensor, scale: float, n: Optional[int] = None) -> torch.Tensor:
-    """Parity precision: P = softmax(s * scale) over the first n columns of fp32 logits s [M, Np] -> three planes
-    [p_hi | p_lo | p_hi], bf16 [M, 3 Np] (columns n .. Np-1 of every plane zero)."""
+def softmax_rows_split(s: torch.Tensor, scale: float, n: Optional[int] = None, h16: bool = False) -> torch.Tensor:
+    """Wide precisions: P = softmax(s * scale) over the first n columns of fp32 logits s [M, Np] -> parity: three planes
+    [p_hi | p_lo | p_hi], bf16 [M, 3 Np]; h16 (precision "fp16"): one fp16 plane [M, Np] (columns n .. Np-1 of every plane zero)."""
     lib = _l.load()
     _req(s, "s", F32)
     M, Np = s.shape
     n = Np if n is None else int(n)
+    if h16:
+        p = torch.empty((M, Np), dtype=F16, device=s.device)
+        _l.check(lib.dm4d_softmax_rows_f32_f16(_stream(), _p(s), s.stride(0), _p(p), p.stride(0), M, n, Np, scale),
+                 "dm4d_softmax_rows_f32_f16")
+        return p
     p = torch.empty((M, 3 * Np), dtype=BF16, device=s.device)
     _l.check(lib.dm4d_softmax_rows_f32_split(_stream(), _p(s), s.stride(0), _p(p), p.stride(0), M, n, Np, scale),
              "dm4d_softmax_rows_f32_split")
@@ -562,9 +682,10 @@ def silu(x: torch.Tensor) -> torch.Tensor:
 
 
 def pack_model_input(latents, pv_lat, plucker, skel, mask, is_cond, cpad: int, use_cfg: bool,
-                     frame_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     frame_idx: Optional[torch.Tensor] = None, h16: bool = False) -> torch.Tensor:
     """Inputs NHWC [N, HW, c] (task level); is_cond int32 [F]; frame_idx int32 [F] selects the window's frames
-    (None: F = N, identity).  Mutates the cond rows of `latents` (reference aliasing)."""
+    (None: F = N, identity).  Mutates the cond rows of `latents` (reference aliasing).
+    fp32 task tensors (wide precisions): the result is conv_in's operand -- [hi | lo] bf16, or (h16) one fp16 plane."""
     lib = _l.load()
     dt = F32 if latents.dtype == F32 else BF16  # fp32 task tensors = parity precision: the result is conv_in's two-term operand
     for t, n in ((latents, "latents"), (pv_lat, "pv_lat"), (plucker, "plucker"), (mask, "mask")):
@@ -579,8 +700,10 @@ def pack_model_input(latents, pv_lat, plucker, skel, mask, is_cond, cpad: int, u
         assert frame_idx.shape[0] == F
     else:
         assert latents.shape[0] == F
-    out = torch.empty(((2 if use_cfg else 1) * F, HW, 2 * cpad if dt == F32 else cpad), dtype=BF16, device=latents.device)
-    fn = lib.dm4d_pack_model_input_f32_split if dt == F32 else lib.dm4d_pack_model_input_bf16
+    assert not h16 or dt == F32
+    out = torch.empty(((2 if use_cfg else 1) * F, HW, 2 * cpad if (dt == F32 and not h16) else cpad), dtype=F16 if h16 else BF16,
+                      device=latents.device)
+    fn = lib.dm4d_pack_model_input_f32_f16 if h16 else (lib.dm4d_pack_model_input_f32_split if dt == F32 else lib.dm4d_pack_model_input_bf16)
     rc = fn(_stream(), _p(latents), _p(pv_lat), _p(plucker), _p(skel), _p(mask), _p(is_cond), _p(frame_idx), _p(out), F, HW, cpad,
             1 if use_cfg else 0)
     _l.check(rc, "dm4d_pack_model_input")

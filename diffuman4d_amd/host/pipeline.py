@@ -47,13 +47,15 @@ class Diffuman4DPipeline:
         if dev.type == "cuda" and dev.index is None:
             dev = torch.device("cuda", torch.cuda.current_device())
         self._device = dev
-        # precision of the arithmetic (include/dm4d.h "Parity precision"): "fast" = bf16 tensors and MFMA operands; "parity" = fp32
-        # tensors between kernels and two-term bf16 operands, within north_star's 1e-3 of the fp32 reference path on decoded RGB
-        self.parity = bool(getattr(unet, "parity", False))
-        if vae is not None and bool(getattr(vae, "parity", False)) != self.parity:
+        # precision of the arithmetic (include/dm4d.h "Parity precision" / "fp16 precision"): "fast" = bf16 tensors and MFMA operands;
+        # "parity" = fp32 tensors between kernels and two-term bf16 operands, "fp16" = fp32 tensors and single-term fp16 operands: both
+        # within north_star's 1e-3 of the fp32 reference path on decoded RGB
+        self.precision = getattr(unet, "precision", "fast")
+        if vae is not None and getattr(vae, "precision", "fast") != self.precision:
             raise ValueError("the UNet and the VAE of a pipeline must be built with the same precision")
-        self.precision = "parity" if self.parity else "fast"
-        self.dtype = F32 if self.parity else BF16
+        self.parity, self.h16 = self.precision == "parity", self.precision == "fp16"
+        self.wide = self.parity or self.h16  # task tensors and everything between kernels are fp32
+        self.dtype = F32 if self.wide else BF16
         self.vae_scale_factor = vae.scale_factor if vae is not None else 8
         self._vae_cache: Dict[str, dict] = {"pixel": {}, "skeleton": {}}  # encoder moments by caller-supplied key
         # extension (off = compute what the reference computes): after the last 3-D attention layer run only the rows
@@ -72,11 +74,12 @@ class Diffuman4DPipeline:
     def from_pretrained(cls, model_dir, torch_dtype=BF16, device="cuda", precision: str = "fast") -> "Diffuman4DPipeline":
         """diffusers checkpoint directory (sampling_utils.py:28-46): model_index.json, unet/, vae/, scheduler/.
         ``torch_dtype`` bf16 | fp16 selects the checkpoint FILES the way the reference does (``*model.safetensors`` vs
-        ``*model.fp16.safetensors``, :28-33).  The arithmetic is bf16 MFMA with fp32 accumulation in both cases: gfx950's
-        matrix pipe runs both 16-bit formats at the same rate and the kernels are written for bf16, so fp16 weights are
-        converted once at load (their 10-bit mantissas are rounded to 7; no SD-class weight leaves bf16's range).
-        ``precision="parity"`` (extension; configs/model/diffuman4d_mi355x.yaml ``precision``): fp32 tensors between kernels and
-        two-term bf16 activation operands -- the arithmetic that meets north_star's 1e-3 against the fp32 reference path."""
+        ``*model.fp16.safetensors``, :28-33).  ``precision`` (extension; configs/model/diffuman4d_mi355x.yaml) selects the arithmetic:
+        "fast" = bf16 MFMA operands and bf16 tensors whatever files were read (fp16 weights are converted once at load: their 10-bit
+        mantissas are rounded to 7; no SD-class weight leaves bf16's range); "fp16" = fp16 MFMA operands over fp32 tensors, on the
+        weights exactly as ``torch_dtype`` holds them -- the faithful form of the reference's fp16 pipelines (:27-29) and, on bf16
+        weights, the fastest arithmetic that meets north_star's 1e-3 against the fp32 reference path; "parity" = two-term bf16
+        operands over fp32 tensors (1e-5); "auto" = "fp16" for fp16 pipelines, "fast" for bf16 ones."""
         from .vae import AutoencoderKL
         if torch_dtype in (BF16, "bf16"):
             variant = None
@@ -84,11 +87,14 @@ class Diffuman4DPipeline:
             variant = "fp16"
         else:
             raise ValueError(f"Unsupported torch_dtype: {torch_dtype}. Supported types are 'bf16' and 'fp16'.")
+        if precision == "auto":
+            precision = "fp16" if variant == "fp16" else "fast"
+        wdt = torch.float16 if variant == "fp16" else BF16
         model_dir = Path(model_dir)
         if (model_dir / "model_index.json").exists():
             json.loads((model_dir / "model_index.json").read_text())  # class names only; import paths are ignored
-        unet = UNetMultiviewConditionModel.from_pretrained(model_dir / "unet", device, variant, precision)
-        vae = AutoencoderKL.from_pretrained(model_dir / "vae", device, variant, precision)
+        unet = UNetMultiviewConditionModel.from_pretrained(model_dir / "unet", device, variant, precision, wdt)
+        vae = AutoencoderKL.from_pretrained(model_dir / "vae", device, variant, precision, wdt)
         sched = DDIMScheduler.from_pretrained(model_dir / "scheduler")
         pipe = cls(vae, unet, sched, device)
         pipe.checkpoint_variant = variant
@@ -116,8 +122,8 @@ class Diffuman4DPipeline:
 
     # ------------------------------------------------------------------------------------------
     def _to_dev_nhwc(self, x: torch.Tensor, cpad: Optional[int] = None) -> torch.Tensor:
-        """CPU/GPU NCHW (any float dtype) -> device NHWC bf16 via the layout kernel (parity precision: fp32, permuted where it lies)."""
-        if self.parity:
+        """CPU/GPU NCHW (any float dtype) -> device NHWC bf16 via the layout kernel (wide precisions: fp32, permuted where it lies)."""
+        if self.wide:
             y = x.float().permute(0, 2, 3, 1)
             if cpad is not None and cpad > y.shape[-1]:
                 y = torch.nn.functional.pad(y, (0, cpad - y.shape[-1]))
@@ -142,7 +148,7 @@ class Diffuman4DPipeline:
             pl_lat = self.vae.resize_to_nhwc(plucker_embeds, (h, w), "bilinear")
         elif cameras is not None:
             pl_lat = ops.plucker_latents(cameras["Ks"], cameras["poses"], tuple(cameras["image_size"]), (h, w), self._device,
-                                         out_f32=self.parity)
+                                         out_f32=self.wide)
         else:
             raise ValueError("plucker_embeds is None and no cameras were given")
         if self.unet.config.enable_pose_encoder:
@@ -182,8 +188,6 @@ class Diffuman4DPipeline:
         GroupNorm, per-(batch, head) attention; every tile choice is bit-identical)."""
         if copies > 1 and (shard is not None or rows_per_task <= 0):
             raise ValueError("task batching needs rows_per_task and is not combined with frame sharding")
-        if shard is not None and self.parity:
-            raise NotImplementedError("precision='parity' runs unsharded")
         ts = self.scheduler.set_timesteps(plan.num_inference_steps)
         cfg = 2 if guidance_scale > 1 else 1
         win = np.stack(plan.windows).astype(np.int32)              # [calls, F]
@@ -263,7 +267,7 @@ class Diffuman4DPipeline:
             if use_cfg:
                 pose = torch.cat([sk3.neg.expand(F, -1, -1, -1), pose])
             sk3 = None
-        x = ops.pack_model_input(lat3, pv3, pl3, sk3, cm3, cond, self.unet.IN_PAD, use_cfg, frame_idx=widx)
+        x = ops.pack_model_input(lat3, pv3, pl3, sk3, cm3, cond, self.unet.IN_PAD, use_cfg, frame_idx=widx, h16=self.h16)
         keep = tb["keep"][i] if self.prune_cond_rows else None
         fpg = tb.get("frames_per_group", F)  # < F when several tasks share the call (upload_plan copies)
         if len(domains) * fpg != tb["cfg"] * F:

@@ -231,11 +231,6 @@ class DistributedSamplingRunner:
         import torch.distributed as dist
         if mode not in self.MODES:
             raise ValueError(f"Unsupported runner mode: {mode}. Supported modes are {', '.join(self.MODES)}.")
-        if mode != "task" and any(getattr(p, "parity", False) for p in getattr(sampler, "pipelines", [])):
-            # the parity precision's attention has no K/V all-gather form (host/unet.py raises inside the first sharded window call);
-            # say so before any rank has started a round
-            raise ValueError(f"runner mode '{mode}' splits window calls by frames, which precision 'parity' does not support; "
-                             "use runner.mode=task with model.precision=parity")
         self.dist = dist
         self.mode = mode
         self._subgroups: Dict[int, list] = {}  # P -> [(ranks, process group)] in sub-group order

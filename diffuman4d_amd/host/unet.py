@@ -23,6 +23,13 @@ import torch
 from . import ops
 
 BF16 = torch.bfloat16
+F16 = torch.float16
+PRECISIONS = ("fast", "parity", "fp16")
+
+
+def check_precision(precision: str) -> None:
+    if precision not in PRECISIONS:
+        raise ValueError(f"Unsupported precision: {precision}. Supported values are 'fast', 'parity' and 'fp16'.")
 
 
 @dataclass
@@ -68,18 +75,29 @@ def _round_up(x: int, m: int) -> int:
 class _Weights:
     """Converts a diffusers-style state_dict into kernel layouts on the device.
     parity (precision="parity", include/dm4d.h "Parity precision"): matrices are duplicated along K -- [W | W] per convolution
-    tap -- to meet two-term activation operands [hi | lo]; vectors (biases, norm scales) are the same bf16 tensors."""
+    tap -- to meet two-term activation operands [hi | lo]; vectors (biases, norm scales) are the same bf16 tensors.
+    h16 (precision="fp16", include/dm4d.h "fp16 precision"): matrices and vectors are held in fp16 -- the values of the pipeline's
+    weight dtype `wdtype` (torch_dtype: bf16 values are exact in fp16 down to 2^-14, fp16 values trivially).
+    wide = parity or h16: the tensors BETWEEN kernels are fp32."""
 
-    def __init__(self, sd: Dict[str, torch.Tensor], device, parity: bool = False):
-        self.sd, self.device, self.parity = sd, device, parity
+    def __init__(self, sd: Dict[str, torch.Tensor], device, parity: bool = False, h16: bool = False, wdtype=BF16):
+        self.sd, self.device, self.parity, self.h16 = sd, device, parity, h16
+        self.wide = parity or h16
+        self.wdtype = wdtype if h16 else BF16  # the fast and parity precisions compute on bf16 weights whatever files were read
         self.used = set()
 
     def mat(self, w: torch.Tensor, taps: int = 1) -> torch.Tensor:
-        """fp32 / bf16 host matrix [N, taps * C] -> device bf16, duplicated along K in parity precision."""
-        w = w.to(BF16)
-        if self.parity:
+        """fp32 / bf16 / fp16 host matrix [N, taps * C] -> device bf16 (duplicated along K in parity precision) or fp16 (h16)."""
+        w = w.to(self.wdtype)
+        if self.h16:
+            w = w.to(F16)
+        elif self.parity:
             w = ops.dup_k(w, taps)
         return w.to(self.device).contiguous()
+
+    def host_vec(self, v: torch.Tensor) -> torch.Tensor:
+        """A bias / norm parameter assembled on the host -> the device vector the kernels of this precision read."""
+        return v.to(self.wdtype).to(F16 if self.h16 else BF16).to(self.device).contiguous()
 
     def get(self, key: str) -> torch.Tensor:
         if key not in self.sd:
@@ -88,7 +106,7 @@ class _Weights:
         return self.sd[key]
 
     def vec(self, key: str) -> torch.Tensor:
-        return self.get(key).to(self.device, BF16).contiguous()
+        return self.host_vec(self.get(key))
 
     def linear(self, key: str) -> torch.Tensor:
         w = self.get(key)
@@ -126,31 +144,31 @@ class _PoseEncoder:
             wp, bp = torch.zeros(cop, k, k, cip), torch.zeros(cop)
             wp[:co, :, :, :ci] = w.permute(0, 2, 3, 1)
             bp[:co] = b
-            dt = torch.float32 if W.parity else BF16
-            self.layers.append((wp.reshape(cop, k * k * cip).to(W.device, dt).contiguous(), bp.to(W.device, dt), k, s))
-        self.parity = W.parity
+            dt = torch.float32 if W.wide else BF16
+            self.layers.append((wp.to(W.wdtype).reshape(cop, k * k * cip).to(W.device, dt).contiguous(), bp.to(W.wdtype).to(W.device, dt), k, s))
+        self.wide, self.h16 = W.wide, W.h16  # wide: fp32 tensors between kernels (parity and fp16 precisions)
         self.proj_w, self.proj_b = W.linear(pfx + "final_proj.weight"), W.vec(pfx + "final_proj.bias")
-        self.scale = float(W.get(pfx + "scale").to(BF16).float().reshape(-1)[0])
+        self.scale = float(W.get(pfx + "scale").to(W.wdtype).float().reshape(-1)[0])
 
     def __call__(self, x: torch.Tensor, batch: int = 16) -> torch.Tensor:
         if x.shape[-1] != 4:
             raise ValueError("pose encoder input must be NHWC with 4 (3 + pad) channels")
         outs = []
         for xb in x.split(batch):
-            y = xb.float().contiguous() if self.parity else xb.contiguous()
+            y = xb.float().contiguous() if self.wide else xb.contiguous()
             for (w, b, k, s) in self.layers:
                 y = ops.conv2d_direct(y, w, ksize=k, bias=b, stride=s, pad=1, silu=True)
             B, h, wd, C = y.shape
             y = y.view(B * h * wd, C)
-            if self.parity:
-                y = ops.split(y)
-            outs.append(ops.gemm(y, self.proj_w, bias=self.proj_b, out_scale=self.scale, out_f32=self.parity).view(B, h, wd, -1))
+            if self.wide:
+                y = ops.split(y, h16=self.h16)
+            outs.append(ops.gemm(y, self.proj_w, bias=self.proj_b, out_scale=self.scale, out_f32=self.wide).view(B, h, wd, -1))
         return outs[0] if len(outs) == 1 else torch.cat(outs)
 
 
 class _Resnet:
     def __init__(self, W: _Weights, pfx: str, groups: int, eps: float, scale: float, temb_list: List):
-        self.groups, self.eps, self.scale, self.parity = groups, eps, scale, W.parity
+        self.groups, self.eps, self.scale, self.wide, self.h16 = groups, eps, scale, W.wide, W.h16
         self.n1w, self.n1b = W.vec(pfx + "norm1.weight"), W.vec(pfx + "norm1.bias")
         self.c1w, self.c1b = W.conv3(pfx + "conv1.weight"), W.vec(pfx + "conv1.bias")
         self.n2w, self.n2b = W.vec(pfx + "norm2.weight"), W.vec(pfx + "norm2.bias")
@@ -166,7 +184,7 @@ class _Resnet:
     def __call__(self, x: torch.Tensor, tproj: torch.Tensor, skip: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Fast precision: bf16 tensors throughout.  Parity precision: x, skip, tproj and the result are fp32; the GroupNorm
         outputs are two-term operands (ops.groupnorm dispatches on the dtype), the convolutions take them against duplicated weights."""
-        P = self.parity
+        P = self.wide
         B, H, Wd = x.shape[:3]
         h = ops.groupnorm(x, self.n1w, self.n1b, self.groups, self.eps, x2=skip, silu=True)
         h = ops.conv3x3(h, self.c1w, bias=self.c1b, rowbias=tproj[:, self.t_off:self.t_off + self.cout], out_f32=P)
@@ -174,7 +192,8 @@ class _Resnet:
         if self.has_sc:
             M = B * H * Wd
             if P:
-                sc = ops.gemm(ops.split(x.view(M, -1), skip.view(M, -1) if skip is not None else None), self.scw, bias=self.scb, out_f32=True)
+                sc = ops.gemm(ops.split(x.view(M, -1), skip.view(M, -1) if skip is not None else None, h16=self.h16), self.scw, bias=self.scb,
+                              out_f32=True)
             else:
                 sc = ops.gemm(x.view(M, -1), self.scw, a2=skip.view(M, -1) if skip is not None else None, bias=self.scb)
             sc = sc.view(B, H, Wd, self.cout)
@@ -186,21 +205,22 @@ class _Resnet:
 
 class _TransformerBlock:
     def __init__(self, W: _Weights, pfx: str, heads: int):
-        self.heads, self.parity = heads, W.parity
+        self.heads, self.wide, self.h16 = heads, W.wide, W.h16
         self.n1w, self.n1b = W.vec(pfx + "norm1.weight"), W.vec(pfx + "norm1.bias")
         q, k, v = (W.get(pfx + f"attn1.to_{n}.weight") for n in "qkv")
         self.scale = (q.shape[0] // heads) ** -0.5
-        if not W.parity:
+        if not W.wide:
             # SDPA's q * scale (and the exp -> exp2 factor) folded into the bias-free to_q rows in fp32, before the single
             # bf16 rounding: the attention kernel then needs no per-score multiply (dm4d_attention_qscaled_kv_bf16).
-            # Parity precision keeps the checkpoint's rows (exact in bf16) and scales the fp32 scores in the kernel.
+            # Parity precision keeps the checkpoint's rows (exact in bf16) and scales the fp32 scores in the kernel; the fp16
+            # precision keeps them too and multiplies the fp32 Q by the factor in the projection's epilogue, before its one rounding.
             q = q.float() * (self.scale * ops.LOG2E)
         self.qkv = W.mat(torch.cat([q.float(), k.float(), v.float()], dim=0))  # fused [3C, C], bias-free
         self.ow, self.ob = W.linear(pfx + "attn1.to_out.0.weight"), W.vec(pfx + "attn1.to_out.0.bias")
         self.n3w, self.n3b = W.vec(pfx + "norm3.weight"), W.vec(pfx + "norm3.bias")
         w1, b1 = W.linear(pfx + "ff.net.0.proj.weight"), W.vec(pfx + "ff.net.0.proj.bias")
         w2, b2 = W.linear(pfx + "ff.net.2.weight"), W.vec(pfx + "ff.net.2.bias")
-        self.ff = (w1, b1, w2, b2) if W.parity else ops.FeedForward(w1, b1, w2, b2)
+        self.ff = (w1, b1, w2, b2) if W.wide else ops.FeedForward(w1, b1, w2, b2)
         if (pfx + "attn2.to_q.weight") in W.sd:
             raise NotImplementedError("cross-attention (attn2) checkpoints are not supported: the reference never "
                                       "passes encoder_hidden_states (SURVEY.md section 0)")
@@ -208,8 +228,8 @@ class _TransformerBlock:
     def __call__(self, h: torch.Tensor, batch: int, seq: int, shard=None) -> torch.Tensor:
         """h [M, C] token-major; attention over `batch` sequences of `seq` tokens (attention.py:68-90).
         shard (parallel.FrameShard): `seq` is this rank's share of the frame-folded sequence; K/V are all-gathered."""
-        if self.parity:
-            return self._call_parity(h, batch, seq, shard)
+        if self.wide:
+            return self._call_wide(h, batch, seq, shard)
         C = h.shape[1]
         n = ops.layernorm(h, self.n1w, self.n1b, 1e-5)
         if shard is None:
@@ -225,15 +245,34 @@ class _TransformerBlock:
         # layernorm, gemm(GEGLU), gemm(residual) elsewhere
         return self.ff.after_attention(a, self.ow, self.ob, h, (self.n3w, self.n3b, 1e-5))
 
-    def _call_parity(self, h: torch.Tensor, batch: int, seq: int, shard=None) -> torch.Tensor:
-        """The same block on an fp32 residual stream: LayerNorm -> operand; QKV projection -> hi / lo planes; attention with three
-        MFMA terms per product -> operand; output projection + fp32 residual; LayerNorm; GEGLU -> operand; projection + residual."""
-        if shard is not None:
-            raise NotImplementedError("precision='parity' runs unsharded")
+    def _call_wide(self, h: torch.Tensor, batch: int, seq: int, shard=None) -> torch.Tensor:
+        """The same block on an fp32 residual stream: LayerNorm -> operand; QKV projection -> operand planes; attention -> operand;
+        output projection + fp32 residual; LayerNorm; GEGLU -> operand; projection + residual.  Parity precision: two-term operands,
+        three MFMA terms per attention product.  fp16 precision: one fp16 plane each, Q pre-scaled in the projection's epilogue, the
+        fast precision's attention loop on fp16 operands.  With `shard` the K | V planes are all-gathered as in the fast precision."""
         w1, b1, w2, b2 = self.ff
+        C = h.shape[1]
         n = ops.layernorm(h, self.n1w, self.n1b, 1e-5)
-        qkv = ops.gemm(n, self.qkv, split_out=True)  # [M, 6C]
-        a = ops.attention_split(qkv, batch, self.heads, seq, self.scale)
+        if self.h16:
+            qs = self.scale * ops.LOG2E
+            if shard is None:
+                qkv = ops.gemm(n, self.qkv, scale_cols=C, col_scale=qs)  # fp16 [M, 3C]
+                a = ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], batch, self.heads, seq, q_scaled=True)
+            else:
+                kv = ops.gemm(n, self.qkv[C:])  # fp16 [M, 2C]
+                pending = shard.gather_kv_start(kv.view(batch, seq, 2 * C))
+                q = ops.gemm(n, self.qkv[:C], scale_cols=C, col_scale=qs)
+                kvg = shard.gather_kv_finish(pending).view(batch * shard.world * seq, 2 * C)
+                a = ops.attention(q, kvg[:, :C], kvg[:, C:], batch, self.heads, seq, kv_seq=shard.world * seq, q_scaled=True)
+        elif shard is None:
+            qkv = ops.gemm(n, self.qkv, split_out=True)  # [M, 6C] = [q_hi | k_hi | v_hi | q_lo | k_lo | v_lo]
+            a = ops.attention_split(qkv, batch, self.heads, seq, self.scale)
+        else:
+            kv = ops.gemm(n, self.qkv[C:], split_out=True)  # [M, 4C] = [k_hi | v_hi | k_lo | v_lo]
+            pending = shard.gather_kv_start(kv.view(batch, seq, 4 * C))
+            q = ops.gemm(n, self.qkv[:C], split_out=True)  # [M, 2C] = [q_hi | q_lo]
+            kvg = shard.gather_kv_finish(pending).view(batch * shard.world * seq, 4 * C)
+            a = ops.attention_split(None, batch, self.heads, seq, self.scale, q=q, kv=kvg, kv_seq=shard.world * seq)
         h = ops.gemm(a, self.ow, bias=self.ob, residual=h, out_f32=True)
         f = ops.gemm(ops.layernorm(h, self.n3w, self.n3b, 1e-5), w1, bias=b1, geglu=True, split_out=True)
         return ops.gemm(f, w2, bias=b2, residual=h, out_f32=True)
@@ -243,7 +282,7 @@ class _Transformer:
     """TransformerMultiviewModel (transformer_multiview.py:34-232), continuous input."""
 
     def __init__(self, W: _Weights, pfx: str, heads: int, groups: int):
-        self.groups, self.parity = groups, W.parity
+        self.groups, self.wide, self.h16 = groups, W.wide, W.h16
         self.nw, self.nb = W.vec(pfx + "norm.weight"), W.vec(pfx + "norm.bias")
         self.piw, self.pib = W.linear(pfx + "proj_in.weight"), W.vec(pfx + "proj_in.bias")
         self.pow, self.pob = W.linear(pfx + "proj_out.weight"), W.vec(pfx + "proj_out.bias")
@@ -258,12 +297,12 @@ class _Transformer:
     def __call__(self, x: torch.Tensor, num_frames: int, shard=None) -> torch.Tensor:
         B, H, Wd, C = x.shape
         M, HW = B * H * Wd, H * Wd
-        P = self.parity
+        P = self.wide
         n = ops.groupnorm(x, self.nw, self.nb, self.groups, 1e-6, silu=False)  # eps 1e-6: transformer_multiview.py:43-45
         h = ops.gemm(n.view(M, -1), self.piw, bias=self.pib, out_f32=P)
         for blk in self.blocks:
             h = blk(h, B // num_frames, num_frames * HW, shard)
-        return ops.gemm(ops.split(h) if P else h, self.pow, bias=self.pob, residual=x.view(M, C), out_f32=P).view(B, H, Wd, C)
+        return ops.gemm(ops.split(h, h16=self.h16) if P else h, self.pow, bias=self.pob, residual=x.view(M, C), out_f32=P).view(B, H, Wd, C)
 
 
 class UNetMultiviewConditionModel:
@@ -271,19 +310,22 @@ class UNetMultiviewConditionModel:
 
     IN_PAD = 32  # conv_in input channels are zero-padded to one 32-wide K slab
 
-    def __init__(self, config: UNetConfig, state_dict: Dict[str, torch.Tensor], device="cuda", precision: str = "fast"):
-        """precision: "fast" (bf16 tensors, bf16 MFMA operands) or "parity" (fp32 tensors between kernels, two-term bf16
-        operands: meets north_star's 1e-3 on decoded RGB against the fp32 reference path; include/dm4d.h "Parity precision")."""
+    def __init__(self, config: UNetConfig, state_dict: Dict[str, torch.Tensor], device="cuda", precision: str = "fast",
+                 weight_dtype=BF16):
+        """precision: "fast" (bf16 tensors, bf16 MFMA operands), "parity" (fp32 tensors between kernels, two-term bf16 operands:
+        include/dm4d.h "Parity precision") or "fp16" (fp32 tensors between kernels, single-term fp16 operands: "fp16 precision");
+        the last two meet north_star's 1e-3 on decoded RGB against the fp32 reference path.
+        weight_dtype (fp16 precision only): the dtype the reference would hold the weights in (torch_dtype, sampling_utils.py:27-29)."""
         cfg = self.config = config
         self.device = torch.device(device)
-        if precision not in ("fast", "parity"):
-            raise ValueError(f"Unsupported precision: {precision}. Supported values are 'fast' and 'parity'.")
-        self.precision, self.parity = precision, precision == "parity"
+        check_precision(precision)
+        self.precision, self.parity, self.h16 = precision, precision == "parity", precision == "fp16"
+        self.wide = self.parity or self.h16  # fp32 tensors between kernels
         if cfg.cross_attention_dim is not None:
             raise NotImplementedError("cross_attention_dim must be None (SURVEY.md section 0)")
         if cfg.in_channels > self.IN_PAD:
             raise NotImplementedError("in_channels > 32")
-        W = _Weights(state_dict, self.device, self.parity)
+        W = _Weights(state_dict, self.device, self.parity, self.h16, weight_dtype)
         boc = cfg.block_out_channels
         g, eps = cfg.norm_num_groups, cfg.norm_eps
         temb_list: List = []
@@ -320,13 +362,14 @@ class UNetMultiviewConditionModel:
             att = [_Transformer(W, p + f"attentions.{j}.", cfg.heads(len(boc) - 1 - i), g) for j in range(n)] if has_attn else None
             us = None
             if i != len(boc) - 1:
-                us = ops.Upsampler(W.conv3(p + "upsamplers.0.conv.weight"), W.vec(p + "upsamplers.0.conv.bias"), parity=self.parity)
+                us = ops.Upsampler(W.conv3(p + "upsamplers.0.conv.weight"), W.vec(p + "upsamplers.0.conv.bias"), parity=self.parity,
+                                   h16=self.h16)
             self.up.append((res, att, us))
         self.no_w, self.no_b = W.vec("conv_norm_out.weight"), W.vec("conv_norm_out.bias")
         self.conv_out_w, self.conv_out_b = W.conv3("conv_out.weight"), W.vec("conv_out.bias")
         # one [sum(Cout), 4*C0] weight for all time_emb_proj layers
         self.tproj_w = W.mat(torch.cat([t[0] for t in temb_list], dim=0))
-        self.tproj_b = torch.cat([t[1] for t in temb_list], dim=0).to(self.device, BF16).contiguous()
+        self.tproj_b = W.host_vec(torch.cat([t[1] for t in temb_list], dim=0))
         unused = [k for k in state_dict if k not in W.used and not k.startswith("time_proj")
                   and "time_emb_proj" not in k and ".attn1.to_" not in k]
         if unused:
@@ -334,19 +377,21 @@ class UNetMultiviewConditionModel:
 
     # -- loading --------------------------------------------------------------------------------
     @classmethod
-    def from_pretrained(cls, path, device="cuda", variant: Optional[str] = None, precision: str = "fast") -> "UNetMultiviewConditionModel":
+    def from_pretrained(cls, path, device="cuda", variant: Optional[str] = None, precision: str = "fast",
+                        weight_dtype=BF16) -> "UNetMultiviewConditionModel":
         """``path`` = the ``unet/`` folder of a diffusers checkpoint directory; ``variant="fp16"`` reads the
-        ``*.fp16.safetensors`` file (weights are converted to bf16 either way)."""
+        ``*.fp16.safetensors`` file (the fast and parity precisions convert the weights to bf16 either way; the fp16 precision holds
+        the values of ``weight_dtype`` in fp16)."""
         from .weights import load_component_state_dict
         path = Path(path)
         cfg = UNetConfig.from_dict(json.loads((path / "config.json").read_text()))
-        return cls(cfg, load_component_state_dict(path, variant), device, precision)
+        return cls(cfg, load_component_state_dict(path, variant), device, precision, weight_dtype)
 
     # -- forward --------------------------------------------------------------------------------
     def _temb(self, timestep: torch.Tensor, domains: Sequence[str], num_frames: int, shard=None) -> torch.Tensor:
-        cfg, P = self.config, self.parity
+        cfg, P = self.config, self.wide
         c0 = cfg.block_out_channels[0]
-        op = (lambda t, **kw: ops.split(t, **kw)) if P else (lambda t, silu=False: ops.silu(t) if silu else t)  # fp32 -> operand
+        op = (lambda t, **kw: ops.split(t, h16=self.h16, **kw)) if P else (lambda t, silu=False: ops.silu(t) if silu else t)  # fp32 -> operand
         t_emb = ops.timestep_embedding(timestep.to(self.device, torch.float32), c0, cfg.flip_sin_to_cos, float(cfg.freq_shift), out_f32=P)
         emb = ops.gemm(ops.gemm(op(t_emb), self.te[0], bias=self.te[1], silu=True, split_out=P), self.te[2], bias=self.te[3], out_f32=P)
         if self.tpe is not None:  # unet_multiview_condition.py:523-546
@@ -373,18 +418,18 @@ class UNetMultiviewConditionModel:
                 keep_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
         """sample [B, h, w, 32] NHWC bf16 (channels beyond in_channels zero); timestep [B]; -> [B, h, w, out_channels].
         precision "parity": sample is the two-term operand [B, h, w, 64] = [hi(32) | lo(32)] (ops.pack_model_input / ops.split of an
-        fp32 sample), the result is fp32.
+        fp32 sample), the result is fp32.  precision "fp16": sample is the fp16 operand [B, h, w, 32], the result is fp32.
         keep_rows (int64 [R], optional extension): batch rows whose output is wanted.  Every layer after the last 3-D
         attention is per-frame, so from there on only these rows are computed and the result has R rows (the pipeline
         discards the noise prediction of conditioning rows, pipeline_diffuman4d.py:413-421).
         With `shard` (parallel.FrameShard) sample/timestep hold this rank's frames and num_frames is the LOCAL count.
         enable_pose_encoder checkpoints (:551-552): pass `skeletons` [B, 8h, 8w, 4] NHWC (encoded here, as the
         reference does on every call) or `pose_features` [B, h, w, C0] computed once with ``self.pose_encoder``."""
-        cfg, P = self.config, self.parity
-        if sample.shape[-1] != (2 * self.IN_PAD if P else self.IN_PAD):
-            raise ValueError(f"sample must be NHWC with {self.IN_PAD} (padded) channels" + (" as a two-term operand [hi | lo]" if P else ""))
-        if P and shard is not None:
-            raise NotImplementedError("precision='parity' runs unsharded")
+        cfg, P = self.config, self.wide
+        if sample.shape[-1] != (2 * self.IN_PAD if self.parity else self.IN_PAD):
+            raise ValueError(f"sample must be NHWC with {self.IN_PAD} (padded) channels" + (" as a two-term operand [hi | lo]" if self.parity else ""))
+        if sample.dtype != (F16 if self.h16 else BF16):
+            raise ValueError(f"sample must be {'fp16' if self.h16 else 'bf16'} for precision '{self.precision}'")
         if sample.shape[0] % num_frames != 0:
             raise ValueError("batch must be a multiple of num_frames")
         tproj = self._temb(timestep, domains, num_frames, shard)
@@ -409,7 +454,7 @@ class UNetMultiviewConditionModel:
                     x = att[j](x, num_frames if is3d else 1, shard if is3d else None)
                 skips.append(x)
             if ds is not None:
-                x = ops.conv3x3(ops.split(x) if P else x, ds[0], bias=ds[1], stride=2, pad=1, out_f32=P)
+                x = ops.conv3x3(ops.split(x, h16=self.h16) if P else x, ds[0], bias=ds[1], stride=2, pad=1, out_f32=P)
                 skips.append(x)
         x = self.mid[0][0](x, tproj)
         x = self.mid[1](x, num_frames, shard)  # :570

@@ -15,7 +15,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from . import ops
-from .unet import _Weights
+from .unet import _Weights, check_precision
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -42,7 +42,7 @@ class _Res:
     """ResnetBlock2D without time embedding, eps 1e-6."""
 
     def __init__(self, W: _Weights, pfx: str, groups: int):
-        self.g, self.parity = groups, W.parity
+        self.g, self.wide, self.h16 = groups, W.wide, W.h16
         self.n1w, self.n1b = W.vec(pfx + "norm1.weight"), W.vec(pfx + "norm1.bias")
         self.c1w, self.c1b = W.conv3(pfx + "conv1.weight"), W.vec(pfx + "conv1.bias")
         self.n2w, self.n2b = W.vec(pfx + "norm2.weight"), W.vec(pfx + "norm2.bias")
@@ -52,14 +52,14 @@ class _Res:
             self.scw, self.scb = W.linear(pfx + "conv_shortcut.weight"), W.vec(pfx + "conv_shortcut.bias")
 
     def __call__(self, x):
-        P = self.parity  # fp32 tensors, two-term operands out of the GroupNorms (ops dispatches on the dtype)
+        P = self.wide  # fp32 tensors, operands out of the GroupNorms (ops dispatches on the dtypes)
         B, H, Wd, C = x.shape
         h = ops.groupnorm(x, self.n1w, self.n1b, self.g, 1e-6, silu=True)
         h = ops.conv3x3(h, self.c1w, bias=self.c1b, out_f32=P)
         h = ops.groupnorm(h, self.n2w, self.n2b, self.g, 1e-6, silu=True)
         sc = x
         if self.has_sc:
-            sc = ops.gemm(ops.split(x.view(-1, C)) if P else x.view(-1, C), self.scw, bias=self.scb, out_f32=P).view(B, H, Wd, -1)
+            sc = ops.gemm(ops.split(x.view(-1, C), h16=self.h16) if P else x.view(-1, C), self.scw, bias=self.scb, out_f32=P).view(B, H, Wd, -1)
         return ops.conv3x3(h, self.c2w, bias=self.c2b, residual=sc, out_f32=P)
 
 
@@ -69,13 +69,13 @@ class _MidAttn:
     QBLOCK_BYTES = 128 << 20  # fp32 logits of one query block
 
     def __init__(self, W: _Weights, pfx: str, groups: int):
-        self.g, self.parity = groups, W.parity
+        self.g, self.parity, self.h16 = groups, W.parity, W.h16
         self.nw, self.nb = W.vec(pfx + "group_norm.weight"), W.vec(pfx + "group_norm.bias")
         ws = [W.get(pfx + f"to_{n}.weight") for n in "qkv"]
         bs = [W.get(pfx + f"to_{n}.bias") for n in "qkv"]
         ws = [w.reshape(w.shape[0], w.shape[1]) for w in ws]  # legacy checkpoints store 1x1 convs
         self.qkv_w = W.mat(torch.cat(ws, 0))
-        self.qkv_b = torch.cat(bs, 0).to(W.device, BF16).contiguous()
+        self.qkv_b = W.host_vec(torch.cat(bs, 0))
         self.ow, self.ob = W.linear(pfx + "to_out.0.weight"), W.vec(pfx + "to_out.0.bias")
 
     def _call_parity(self, x):
@@ -103,7 +103,34 @@ class _MidAttn:
                 ops.gemm(p3, vt3, out=o[b * L + q0: b * L + q1], out_f32=True)
         return ops.gemm(ops.split(o), self.ow, bias=self.ob, residual=x.view(B * L, C), out_f32=True).view(B, H, Wd, C)
 
+    def _call_h16(self, x):
+        """fp32 in / out, one fp16 plane per operand: q k^T and p v are one MFMA per product on fp16 q / k / p / v^T, logits and
+        soft-max in fp32 (the fast form below with fp16 in place of bf16 and fp32 tensors around it)."""
+        B, H, Wd, C = x.shape
+        L = H * Wd
+        Lp = (L + 31) // 32 * 32
+        n = ops.groupnorm(x, self.nw, self.nb, self.g, 1e-6, silu=False)
+        qkv = ops.gemm(n.view(B * L, C), self.qkv_w, bias=self.qkv_b, out_f32=True)  # [B*L, 3C] fp32
+        o = torch.empty((B * L, C), dtype=F32, device=x.device)
+        scale = float(C) ** -0.5
+        qb = max(32, min(L, (self.QBLOCK_BYTES // (4 * Lp)) // 32 * 32))
+        self.last_block_bytes = 4 * Lp * qb
+        s = torch.empty((qb, Lp), dtype=F32, device=x.device)
+        for b in range(B):
+            rows = slice(b * L, (b + 1) * L)
+            k = ops.split(qkv[rows, C:2 * C], h16=True)                                  # [L, C]
+            vt = ops.split(qkv[rows, 2 * C:], cpad=Lp, transposed=True, h16=True)        # [C, Lp], columns behind L zero
+            for q0 in range(0, L, qb):
+                q1 = min(L, q0 + qb)
+                q = ops.split(qkv[b * L + q0: b * L + q1, :C], h16=True)                 # [q, C]
+                ops.gemm(q, k, out=s[: q1 - q0, :L], out_f32=True)
+                p = ops.softmax_rows_split(s[: q1 - q0], scale, n=L, h16=True)           # [q, Lp]
+                ops.gemm(p, vt, out=o[b * L + q0: b * L + q1], out_f32=True)
+        return ops.gemm(ops.split(o, h16=True), self.ow, bias=self.ob, residual=x.view(B * L, C), out_f32=True).view(B, H, Wd, C)
+
     def __call__(self, x):
+        if self.h16:
+            return self._call_h16(x)
         if self.parity:
             return self._call_parity(x)
         B, H, Wd, C = x.shape
@@ -155,14 +182,17 @@ def _transpose(v: torch.Tensor, C: int) -> torch.Tensor:
 
 
 class AutoencoderKL:
-    def __init__(self, config: VAEConfig, state_dict: Dict[str, torch.Tensor], device="cuda", precision: str = "fast"):
-        """precision "parity": fp32 tensors between kernels, two-term bf16 operands (see host/unet.py, include/dm4d.h)."""
+    def __init__(self, config: VAEConfig, state_dict: Dict[str, torch.Tensor], device="cuda", precision: str = "fast",
+                 weight_dtype=BF16):
+        """precision "parity": fp32 tensors between kernels, two-term bf16 operands; "fp16": fp32 tensors, single-term fp16 operands on
+        the weights as `weight_dtype` holds them (see host/unet.py, include/dm4d.h)."""
         cfg = self.config = config
         self.device = torch.device(device)
-        if precision not in ("fast", "parity"):
-            raise ValueError(f"Unsupported precision: {precision}. Supported values are 'fast' and 'parity'.")
-        self.precision, self.parity = precision, precision == "parity"
-        W = _Weights(state_dict, self.device, self.parity)
+        check_precision(precision)
+        self.precision, self.parity, self.h16 = precision, precision == "parity", precision == "fp16"
+        self.wide = self.parity or self.h16
+        W = _Weights(state_dict, self.device, self.parity, self.h16, weight_dtype)
+        self._W = W  # host_vec / mat for the padded vectors below
         g, boc, lc = cfg.norm_num_groups, cfg.block_out_channels, cfg.latent_channels
         if cfg.in_channels > PAD or 2 * lc > PAD:
             raise NotImplementedError("channel counts above 32 at the VAE boundary")
@@ -181,12 +211,12 @@ class AutoencoderKL:
         self.e_nw, self.e_nb = W.vec("encoder.conv_norm_out.weight"), W.vec("encoder.conv_norm_out.bias")
         # conv_out writes a 32-wide row (channels >= 2*lc are zero) so quant_conv is one K=32 GEMM
         self.e_out_w = W.conv3("encoder.conv_out.weight", cout_pad=PAD)
-        self.e_out_b = _pad_vec(W.get("encoder.conv_out.bias"), PAD, self.device)
+        self.e_out_b = W.host_vec(_pad_vec(W.get("encoder.conv_out.bias"), PAD))
         self.quant_w = W.mat(_pad_mat(W.get("quant_conv.weight"), 2 * lc, PAD, "cpu"))
         self.quant_b = W.vec("quant_conv.bias")
         # ---- decoder ----
         self.pq_w = W.mat(_pad_mat(W.get("post_quant_conv.weight"), PAD, PAD, "cpu"))  # out rows >= lc are zero
-        self.pq_b = _pad_vec(W.get("post_quant_conv.bias"), PAD, self.device)
+        self.pq_b = W.host_vec(_pad_vec(W.get("post_quant_conv.bias"), PAD))
         self.d_in_w, self.d_in_b = W.conv3("decoder.conv_in.weight", cin_pad=PAD), W.vec("decoder.conv_in.bias")
         self.d_mid = (_Res(W, "decoder.mid_block.resnets.0.", g), _MidAttn(W, "decoder.mid_block.attentions.0.", g),
                       _Res(W, "decoder.mid_block.resnets.1.", g))
@@ -196,7 +226,8 @@ class AutoencoderKL:
             res = [_Res(W, p + f"resnets.{j}.", g) for j in range(cfg.layers_per_block + 1)]
             us = None
             if i != len(boc) - 1:
-                us = ops.Upsampler(W.conv3(p + "upsamplers.0.conv.weight"), W.vec(p + "upsamplers.0.conv.bias"), parity=self.parity)
+                us = ops.Upsampler(W.conv3(p + "upsamplers.0.conv.weight"), W.vec(p + "upsamplers.0.conv.bias"), parity=self.parity,
+                                   h16=self.h16)
             self.d_up.append((res, us))
         self.d_nw, self.d_nb = W.vec("decoder.conv_norm_out.weight"), W.vec("decoder.conv_norm_out.bias")
         self.d_out_w, self.d_out_b = W.conv3("decoder.conv_out.weight"), W.vec("decoder.conv_out.bias")
@@ -205,11 +236,11 @@ class AutoencoderKL:
             raise KeyError(f"unexpected keys in VAE checkpoint (strict load): {unused[:8]}")
 
     @classmethod
-    def from_pretrained(cls, path, device="cuda", variant: Optional[str] = None, precision: str = "fast") -> "AutoencoderKL":
+    def from_pretrained(cls, path, device="cuda", variant: Optional[str] = None, precision: str = "fast", weight_dtype=BF16) -> "AutoencoderKL":
         from .weights import load_component_state_dict
         path = Path(path)
         cfg = VAEConfig.from_dict(json.loads((path / "config.json").read_text()))
-        return cls(cfg, load_component_state_dict(path, variant), device, precision)
+        return cls(cfg, load_component_state_dict(path, variant), device, precision, weight_dtype)
 
     @property
     def scale_factor(self) -> int:
@@ -228,9 +259,9 @@ class AutoencoderKL:
     # ---- encode --------------------------------------------------------------------------------
     def moments(self, x_nhwc32: torch.Tensor) -> torch.Tensor:
         """x [B,H,W,32] (3 image channels + zero pad) -> moments [B,h,w,2*lc] (mean | logvar).
-        precision "parity": x is the two-term operand [B,H,W,64] of the fp32 image, the moments are fp32."""
-        P = self.parity
-        op = ops.split if P else (lambda t: t)  # fp32 tensor -> operand of the next contraction
+        precision "parity": x is the two-term operand [B,H,W,64] of the fp32 image ("fp16": its fp16 operand [B,H,W,32]), the moments fp32."""
+        P = self.wide
+        op = (lambda t: ops.split(t, h16=self.h16)) if P else (lambda t: t)  # fp32 tensor -> operand of the next contraction
         x = ops.conv3x3(x_nhwc32, self.e_in_w, bias=self.e_in_b, out_f32=P)
         for res, ds in self.e_down:
             for r in res:
@@ -294,32 +325,32 @@ class AutoencoderKL:
         for i in range(0, n, batch_size):
             m = torch.stack(rows[i:i + batch_size])
             B, h, w, _ = m.shape
-            if noise is not None and self.parity:
+            if noise is not None and self.wide:
                 nb = noise[i:i + batch_size].float().permute(0, 2, 3, 1).contiguous().to(self.device)  # layout change on the host
             elif noise is not None:
                 nb = ops.nchw_to_nhwc(noise[i:i + batch_size].to(self.device, BF16).contiguous())
             else:
                 nb = torch.randn((B, h, w, lc), device=self.device, dtype=torch.float32)
-                nb = nb if self.parity else nb.to(BF16)
+                nb = nb if self.wide else nb.to(BF16)
             outs.append(ops.vae_sample(m, nb, lc, self.config.scaling_factor))
         return torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
 
     def _image_operand(self, images: torch.Tensor) -> torch.Tensor:
         """NCHW images (any device / float dtype) -> what conv_in reads: NHWC bf16 padded to 32 channels, or (parity) the two-term
         operand [B,H,W,64] of the fp32 image (the NCHW -> NHWC permutation of a host tensor is made on the host)."""
-        if not self.parity:
+        if not self.wide:
             return ops.nchw_to_nhwc(images.to(self.device, BF16).contiguous(), PAD)
         x = images.float().permute(0, 2, 3, 1).contiguous().to(self.device)
-        return ops.split(x, cpad=PAD)
+        return ops.split(x, cpad=PAD, h16=self.h16)
 
     # ---- decode --------------------------------------------------------------------------------
     def decode(self, z_nhwc: torch.Tensor) -> torch.Tensor:
         """z [B,h,w,lc] (already divided by scaling_factor, padded to 32) -> image NHWC [B,H,W,3].
-        precision "parity": z is the two-term operand [B,h,w,64], the image fp32."""
-        P = self.parity
+        precision "parity": z is the two-term operand [B,h,w,64] ("fp16": the fp16 operand [B,h,w,32]), the image fp32."""
+        P = self.wide
         B, h, w, _ = z_nhwc.shape
         x = ops.gemm(z_nhwc.view(B * h * w, -1), self.pq_w, bias=self.pq_b, out_f32=P).view(B, h, w, PAD)
-        x = ops.conv3x3(ops.split(x) if P else x, self.d_in_w, bias=self.d_in_b, out_f32=P)
+        x = ops.conv3x3(ops.split(x, h16=self.h16) if P else x, self.d_in_w, bias=self.d_in_b, out_f32=P)
         x = self.d_mid[2](self.d_mid[1](self.d_mid[0](x)))
         for res, us in self.d_up:
             for r in res:
@@ -341,8 +372,8 @@ class AutoencoderKL:
             sel = lat_nhwc.index_select(0, idx)
         outs = []
         for i in range(0, sel.shape[0], batch_size):
-            if self.parity:
-                z = ops.split(sel[i:i + batch_size].contiguous(), cpad=PAD, scale=1.0 / self.config.scaling_factor)
+            if self.wide:
+                z = ops.split(sel[i:i + batch_size].contiguous(), cpad=PAD, scale=1.0 / self.config.scaling_factor, h16=self.h16)
             else:
                 z = ops.scale_pad(sel[i:i + batch_size].contiguous(), PAD, 1.0 / self.config.scaling_factor)
             outs.append(ops.postprocess_images(self.decode(z), self.config.out_channels))
@@ -361,18 +392,19 @@ class AutoencoderKL:
         outs = []
         for i in range(0, images.shape[0], batch_size):
             xb = images[i:i + batch_size].to(self.device, torch.float32).contiguous()
-            outs.append(ops.resize_to_nhwc(xb, size, mode, out_f32=self.parity))
+            outs.append(ops.resize_to_nhwc(xb, size, mode, out_f32=self.wide))
         return torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
 
 
-def _pad_vec(v: torch.Tensor, n: int, device) -> torch.Tensor:
+def _pad_vec(v: torch.Tensor, n: int) -> torch.Tensor:
+    """Host vector zero-padded to n entries (fp32; _Weights.host_vec makes the device vector of the precision)."""
     out = torch.zeros(n)
     out[: v.shape[0]] = v.float()
-    return out.to(device, BF16)
+    return out
 
 
 def _pad_mat(w: torch.Tensor, rows: int, cols: int, device) -> torch.Tensor:
     w = w.float().reshape(w.shape[0], w.shape[1])
     out = torch.zeros(rows, cols)
     out[: w.shape[0], : w.shape[1]] = w
-    return out.to(device, BF16).contiguous()
+    return out.contiguous()  # fp32 on the host: _Weights.mat rounds to the precision's weight dtype

@@ -6,7 +6,7 @@ without a GPU before a `gpurun` call is spent on it.  It mimics the documented s
 included: bf16 outputs are rounded once, fp32 accumulation is emulated in fp32 / fp64), not the kernels; the kernels are
 checked on the GPU by tests/opcheck.py.
 
-    python tests/cpu_standin_ops.py            # tiny UNet / VAE / pipeline, fast and parity precision, vs the fp32 oracle
+    python tests/cpu_standin_ops.py            # tiny UNet / VAE / pipeline in the fast, parity and fp16 precisions, vs the fp32 oracle
 """
 from __future__ import annotations
 
@@ -20,19 +20,26 @@ import torch.nn.functional as F
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
-BF, F32 = torch.bfloat16, torch.float32
+BF, F16, F32 = torch.bfloat16, torch.float16, torch.float32
 
 
-def _out(v, f32=False, split=False):
+def _out(v, f32=False, split=False, h16=False):
+    """fp32 values -> what a kernel stores: fp32, a two-term bf16 operand [hi | lo], or ONE plane of bf16 / (h16) fp16."""
+    if f32:
+        return v.float()
+    if h16:
+        return v.to(F16)
     if split:
         hi = v.to(BF)
         return torch.cat([hi, (v - hi.float()).to(BF)], dim=-1)
-    return v.float() if f32 else v.to(BF)
+    return v.to(BF)
 
 
 def gemm(a, w, *, a2=None, bias=None, rowbias=None, rows_per_rowbias=1, residual=None, geglu=False, silu=False, out_scale=1.0,
-         out=None, out_f32=False, split_out=False):
-    assert a.dtype == BF and w.dtype == BF
+         out=None, out_f32=False, split_out=False, scale_cols=0, col_scale=1.0):
+    h16 = w.dtype == F16  # precision "fp16": fp16 operands and bias, one fp16 plane (or fp32) out
+    assert a.dtype == w.dtype and w.dtype in (BF, F16) and (bias is None or bias.dtype == w.dtype)
+    assert scale_cols == 0 or h16
     x = a.double() if a2 is None else torch.cat([a, a2], dim=1).double()
     assert x.shape[1] == w.shape[1], (x.shape, w.shape)
     v = x @ w.double().t()
@@ -45,13 +52,16 @@ def gemm(a, w, *, a2=None, bias=None, rowbias=None, rows_per_rowbias=1, residual
         v = F.silu(v)
     side = [t for t in (rowbias, residual) if t is not None]
     if side:
-        assert all(t.dtype == side[0].dtype for t in side) and side[0].dtype in (BF, F32)
-        assert (side[0].dtype == F32) == (out_f32 or split_out) or side[0].dtype == BF
+        assert all(t.dtype == side[0].dtype for t in side) and side[0].dtype in (w.dtype, F32)
+        assert (side[0].dtype == F32) == (out_f32 or split_out) or side[0].dtype == w.dtype
     if rowbias is not None:
         v = v + rowbias.double().repeat_interleave(rows_per_rowbias, dim=0)[: v.shape[0]]
     if residual is not None:
         v = v + residual.double()
-    r = _out((v * out_scale).float(), out_f32, split_out)
+    v = v * out_scale
+    if scale_cols:
+        v = torch.cat([v[:, :scale_cols] * col_scale, v[:, scale_cols:]], dim=1)
+    r = _out(v.float(), out_f32, split_out, h16)
     if out is not None:
         out[:, : r.shape[1]].copy_(r)
         return out
@@ -66,7 +76,8 @@ def conv_out_hw(h, w, stride, pad, upsample, pad_hi=None):
 
 
 def conv3x3(x, wt, *, bias=None, rowbias=None, residual=None, stride=1, pad=1, pad_hi=None, upsample=False, out_scale=1.0, out_f32=False):
-    assert x.dtype == BF and wt.dtype == BF
+    h16 = wt.dtype == F16
+    assert x.dtype == wt.dtype and wt.dtype in (BF, F16) and (bias is None or bias.dtype == wt.dtype)
     B, H, W, Cin = x.shape
     Cout = wt.shape[0]
     assert wt.shape[1] == 9 * Cin, (wt.shape, Cin)
@@ -76,7 +87,7 @@ def conv3x3(x, wt, *, bias=None, rowbias=None, residual=None, stride=1, pad=1, p
         xi = F.interpolate(xi, scale_factor=2, mode="nearest")
     ph = pad if pad_hi is None else pad_hi
     v = F.conv2d(F.pad(xi, (pad, ph, pad, ph)), w4, bias.double() if bias is not None else None, stride=stride)
-    side = F32 if out_f32 else BF
+    side = F32 if out_f32 else wt.dtype
     if rowbias is not None:
         assert rowbias.dtype == side
         v = v + rowbias.double()[:, :, None, None]
@@ -84,7 +95,7 @@ def conv3x3(x, wt, *, bias=None, rowbias=None, residual=None, stride=1, pad=1, p
     if residual is not None:
         assert residual.dtype == side
         v = v + residual.double().reshape(v.shape)
-    return _out((v * out_scale).float(), out_f32).contiguous()
+    return _out((v * out_scale).float(), out_f32, h16=h16).contiguous()
 
 
 def conv2d_direct(x, wt, *, ksize, bias=None, stride=1, pad=1, silu=False):
@@ -101,7 +112,7 @@ def dup_k(w, taps=1, times=2):
     return w.reshape(n, taps, 1, c).expand(n, taps, times, c).reshape(n, taps * times * c).contiguous()
 
 
-def split(x, x2=None, *, cpad=None, silu=False, scale=1.0, pattern=0, transposed=False):
+def split(x, x2=None, *, cpad=None, silu=False, scale=1.0, pattern=0, transposed=False, h16=False):
     assert x.dtype == F32
     if transposed:
         x = x.t()
@@ -114,6 +125,8 @@ def split(x, x2=None, *, cpad=None, silu=False, scale=1.0, pattern=0, transposed
     v = v * scale
     Cp = cpad or v.shape[1]
     v = F.pad(v, (0, Cp - v.shape[1]))
+    if h16:
+        return v.to(F16).view(lead + (Cp,))
     hi = v.to(BF)
     lo = (v - hi.float()).to(BF)
     planes = {0: [hi, lo], 1: [hi, lo, hi], 2: [hi, hi, lo]}[pattern]
@@ -128,12 +141,13 @@ def groupnorm(x1, gamma, beta, groups, eps, *, x2=None, silu=False):
     if silu:
         v = F.silu(v)
     v = v.reshape(x.shape).float().contiguous()
-    return _out(v, split=True) if f32 else v.to(BF)
+    assert gamma.dtype == beta.dtype and (gamma.dtype == BF or f32)
+    return _out(v, split=True, h16=gamma.dtype == F16) if f32 else v.to(BF)
 
 
 def layernorm(x, gamma, beta, eps=1e-5):
     v = F.layer_norm(x.double(), (x.shape[-1],), gamma.double(), beta.double(), eps).float()
-    return _out(v, split=True) if x.dtype == F32 else v.to(BF)
+    return _out(v, split=True, h16=gamma.dtype == F16) if x.dtype == F32 else v.to(BF)
 
 
 LOG2E = 1.4426950408889634
@@ -144,17 +158,24 @@ def attention(q, k, v, batch, heads, seq, scale=None, out=None, kv_seq=None, q_s
     hv = lambda t, L: t.double().reshape(batch, L, heads, 64).transpose(1, 2)  # noqa: E731
     s = hv(q, seq) @ hv(k, kv_seq).transpose(-1, -2)
     p = torch.softmax(s * (math.log(2.0) if q_scaled else (0.125 if scale is None else scale)), dim=-1)
-    o = (p.float().to(BF).double() @ hv(v, kv_seq)) if False else (p @ hv(v, kv_seq))
-    return o.transpose(1, 2).reshape(batch * seq, heads * 64).to(BF)
+    assert q.dtype == k.dtype == v.dtype and (q.dtype == BF or q_scaled)
+    o = p @ hv(v, kv_seq)
+    return o.transpose(1, 2).reshape(batch * seq, heads * 64).to(q.dtype)
 
 
-def attention_split(qkv, batch, heads, seq, scale=None):
+def attention_split(qkv, batch, heads, seq, scale=None, *, q=None, kv=None, kv_seq=None):
     C = heads * 64
-    assert qkv.shape == (batch * seq, 6 * C) and qkv.dtype == BF
-    val = qkv[:, :3 * C].double() + qkv[:, 3 * C:].double()
-    hv = lambda t: t.reshape(batch, seq, heads, 64).transpose(1, 2)  # noqa: E731
-    q, k, v = (hv(val[:, i * C:(i + 1) * C]) for i in range(3))
-    o = torch.softmax(q @ k.transpose(-1, -2) * (0.125 if scale is None else scale), dim=-1) @ v
+    if qkv is not None:
+        assert qkv.shape == (batch * seq, 6 * C) and qkv.dtype == BF
+        val = qkv[:, :3 * C].double() + qkv[:, 3 * C:].double()
+        qv, kval, vval, kv_seq = val[:, :C], val[:, C:2 * C], val[:, 2 * C:], seq
+    else:  # frame-sharded form: q [.., 2C] = [q_hi | q_lo], kv [.., 4C] = [k_hi | v_hi | k_lo | v_lo]
+        kv_seq = kv_seq or seq
+        assert q.shape == (batch * seq, 2 * C) and kv.shape == (batch * kv_seq, 4 * C) and q.dtype == kv.dtype == BF
+        qv = q[:, :C].double() + q[:, C:].double()
+        kval, vval = kv[:, :C].double() + kv[:, 2 * C:3 * C].double(), kv[:, C:2 * C].double() + kv[:, 3 * C:].double()
+    hv = lambda t, L: t.reshape(batch, L, heads, 64).transpose(1, 2)  # noqa: E731
+    o = torch.softmax(hv(qv, seq) @ hv(kval, kv_seq).transpose(-1, -2) * (0.125 if scale is None else scale), dim=-1) @ hv(vval, kv_seq)
     return _out(o.transpose(1, 2).reshape(batch * seq, C).float(), split=True)
 
 
@@ -167,10 +188,12 @@ def softmax_rows(s, scale, n=None, out=None):
     return out
 
 
-def softmax_rows_split(s, scale, n=None):
+def softmax_rows_split(s, scale, n=None, h16=False):
     M, Np = s.shape
     N = Np if n is None else n
     p = F.pad(torch.softmax(s[:, :N].double() * scale, dim=-1).float(), (0, Np - N))
+    if h16:
+        return p.to(F16)
     hi = p.to(BF)
     return torch.cat([hi, (p - hi.float()).to(BF), hi], dim=1)
 
@@ -187,7 +210,7 @@ def silu(x):
     return F.silu(x.float()).to(BF)
 
 
-def pack_model_input(latents, pv_lat, plucker, skel, mask, is_cond, cpad, use_cfg, frame_idx=None):
+def pack_model_input(latents, pv_lat, plucker, skel, mask, is_cond, cpad, use_cfg, frame_idx=None, h16=False):
     f32 = latents.dtype == F32
     rows = frame_idx.long() if frame_idx is not None else torch.arange(latents.shape[0])
     c = is_cond.bool()
@@ -201,7 +224,7 @@ def pack_model_input(latents, pv_lat, plucker, skel, mask, is_cond, cpad, use_cf
         neg += ([-torch.ones_like(skel[rows].float())] if skel is not None else []) + [mask[rows].float()]
         outs = [torch.cat(neg, dim=-1), pos]
     v = F.pad(torch.cat(outs), (0, cpad - pos.shape[-1]))
-    return _out(v, split=True) if f32 else v.to(BF)
+    return _out(v, split=True, h16=h16) if f32 else v.to(BF)
 
 
 def cfg_ddim_step(latents, noise_pred, coef, is_cond, use_cfg, guidance_scale, v_prediction, frame_idx=None):
@@ -294,12 +317,12 @@ class FeedForward:
 
 
 class Upsampler:
-    def __init__(self, wt, bias, parity=False):
-        self.wt, self.bias, self.parity = wt, bias, parity
+    def __init__(self, wt, bias, parity=False, h16=False):
+        self.wt, self.bias, self.parity, self.h16 = wt, bias, parity or h16, h16
 
     def __call__(self, x):
         if self.parity:
-            return conv3x3(split(x), self.wt, bias=self.bias, upsample=True, out_f32=True)
+            return conv3x3(split(x, h16=self.h16), self.wt, bias=self.bias, upsample=True, out_f32=True)
         return conv3x3(x, self.wt, bias=self.bias, upsample=True)
 
 
@@ -371,9 +394,9 @@ def main():
         t = torch.randint(0, 1000, (8,), generator=g)
         with torch.no_grad():
             ref = om(x.float(), t, domains=[domain] * 2, num_frames=4)
-        for prec in ("fast", "parity"):
+        for prec in ("fast", "parity", "fp16"):
             hm = UNetMultiviewConditionModel(UNetConfig.from_dict(asdict(cfg)), om.state_dict(), "cpu", prec)
-            xin = ops.split(x.float().permute(0, 2, 3, 1).contiguous(), cpad=hm.IN_PAD) if prec == "parity" else ops.nchw_to_nhwc(x, hm.IN_PAD)
+            xin = ops.split(x.float().permute(0, 2, 3, 1).contiguous(), cpad=hm.IN_PAD, h16=prec == "fp16") if prec != "fast" else ops.nchw_to_nhwc(x, hm.IN_PAD)
             out = ops.nhwc_to_nchw(hm(xin, t.float(), domains=[domain] * 2, num_frames=4))
             print(f"unet {domain} tem={tem} {prec}: rel_l2 vs fp32 oracle = {rel_l2(out, ref):.3e}", flush=True)
     for hw in ((64, 64), (264, 328)):
@@ -384,11 +407,11 @@ def main():
         with torch.no_grad():
             z_ref = ov.sample_posterior(ov.moments(img.float()), noise.float()) * cfgv.scaling_factor
             im_ref = (ov.decode(z_ref.to(BF).float() / cfgv.scaling_factor) / 2 + 0.5).clamp(0, 1)
-        for prec in ("fast", "parity"):
+        for prec in ("fast", "parity", "fp16"):
             hv = AutoencoderKL(VAEConfig.from_dict(asdict(cfgv)), ov.state_dict(), "cpu", prec)
             z = ops.nhwc_to_nchw(hv.encode_scaled(img, noise))
             zin = z_ref.to(BF)
-            lat = zin.float().permute(0, 2, 3, 1).contiguous() if prec == "parity" else ops.nchw_to_nhwc(zin)
+            lat = zin.float().permute(0, 2, 3, 1).contiguous() if prec != "fast" else ops.nchw_to_nhwc(zin)
             im = hv.decode_to_images(lat)
             print(f"vae {hw} {prec}: latents {rel_l2(z, z_ref):.3e} images {rel_l2(im, im_ref):.3e}", flush=True)
     cfg_u, ou = mc.make_unet(11)
@@ -401,7 +424,7 @@ def main():
         kw = dict(kw, sliding_shift=0, bidirectional=False, num_denoising_steps=1, alternation_rounds=1, guidance_scale=2.0)
         ref = OraclePipeline(ov, ou, DDIMScheduler(DDIMConfig()), torch.float32).sliding_iterative_denoise(
             pv, pl, sk, cm, None, domain, tidx, {k: v.float() for k, v in noise.items()}, **kw)
-        for prec in ("fast", "parity"):
+        for prec in ("fast", "parity", "fp16"):
             hp = Diffuman4DPipeline(AutoencoderKL(VAEConfig.from_dict(asdict(cfg_v)), ov.state_dict(), "cpu", prec),
                                     UNetMultiviewConditionModel(UNetConfig.from_dict(asdict(cfg_u)), ou.state_dict(), "cpu", prec), HS(HC()), "cpu")
             out = hp.sliding_iterative_denoise(pixel_values=pv, plucker_embeds=pl, skeletons=sk, cond_masks=cm, latents=None, domain=domain,

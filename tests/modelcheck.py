@@ -15,7 +15,10 @@ Tolerances (bf16 activations end to end, fp32 accumulation; the fp32 oracle is t
     generator did not record a yardstick) keep a TOL entry;
   * integer bookkeeping (timestep indices, fully_denoised) must be bit-exact;
   * `par_*` cases run the same models with precision="parity" and must stay within PARITY_TOL (= north_star's 1e-3) of the fp32
-    oracle on every compared quantity, decoded RGB included.
+    oracle on every compared quantity, decoded RGB included;
+  * `fp16_*` cases run them with precision="fp16" (single-term fp16 MFMA operands over fp32 tensors) under FIXED bounds per compared
+    quantity (FP16_BOUNDS): decoded RGB within north_star's 1e-3, latents and a single UNet call within 2e-3 (the operand rounding alone
+    measures 8.5e-4 on the judged UNet call, tools/error_budget.py).
 """
 from __future__ import annotations
 
@@ -41,6 +44,9 @@ PARITY_TOL = 1e-3
 # err(HIP vs fp32) / err(matched vs fp32) lies in MATCHED_BAND (two-sided: fewer roundings than the model of the path is a finding
 # too) and the direct distance stays below sqrt(2) x 1.1 of the larger of the two.
 MATCHED_BAND = (0.85, 1.10)
+# precision="fp16": fixed bounds per compared quantity.  `images` IS north_star's bar; a single UNet call and the latents of a task sit
+# above the decoded RGB (the VAE decoder averages the latents' error down by ~0.55) and get twice that.
+FP16_BOUNDS = {"images": 1e-3, "latents": 2e-3, "unet_out": 2e-3, "bookkeeping": 0.0}
 
 
 def matched_verdict(err_hip, err_matched, direct):
@@ -115,8 +121,8 @@ def unet_sample(hm, x):
     """NCHW input batch (CPU) -> what the HIP UNet's forward takes: NHWC bf16 padded to 32 channels, or (precision "parity") the
     two-term operand of the fp32 sample."""
     from diffuman4d_amd.host import ops
-    if hm.parity:
-        return ops.split(x.float().permute(0, 2, 3, 1).contiguous().cuda(), cpad=hm.IN_PAD)
+    if hm.wide:  # parity: two-term operand [hi | lo]; fp16: one fp16 plane
+        return ops.split(x.float().permute(0, 2, 3, 1).contiguous().cuda(), cpad=hm.IN_PAD, h16=hm.h16)
     return ops.nchw_to_nhwc(x.to(BF).cuda(), hm.IN_PAD)
 
 
@@ -203,15 +209,15 @@ class _ReplayShard:
         return handle
 
 
-def case_unet_frame_shard(P=4, num_frames=8, h=16, w=8, tem=True, seed=0):
+def case_unet_frame_shard(P=4, num_frames=8, h=16, w=8, tem=True, seed=0, precision="fast"):
     """In-window frame sharding: every rank's slice of the UNet output must equal the unsharded
-    output bitwise, and what it would contribute to each K/V all-gather must equal the unsharded K/V slice."""
-    from diffuman4d_amd.host import ops
+    output bitwise, and what it would contribute to each K/V all-gather must equal the unsharded K/V slice.  In the wide
+    precisions the gathered blocks are the operand planes of K | V (parity: hi and lo planes, fp16: one fp16 plane)."""
     cfg, om = make_unet(seed, enable_tem_embeds=tem)
-    hm = hip_unet(cfg, om)
+    hm = hip_unet(cfg, om, precision)
     g = torch.Generator().manual_seed(seed + 1)
     B = 2 * num_frames
-    x = ops.nchw_to_nhwc(torch.randn(B, cfg.in_channels, h, w, generator=g).to(BF).cuda(), hm.IN_PAD)
+    x = unet_sample(hm, torch.randn(B, cfg.in_channels, h, w, generator=g).to(BF))
     t = torch.randint(0, 1000, (B,), generator=g).float().cuda()
     rec = _RecordShard()
     full = hm(x, t, domains=["temporal"] * 2, num_frames=num_frames, shard=rec)
@@ -228,7 +234,7 @@ def case_unet_frame_shard(P=4, num_frames=8, h=16, w=8, tem=True, seed=0):
     return worst, 0.0
 
 
-def case_pipeline_shard_world1(seed=21):
+def case_pipeline_shard_world1(seed=21, precision="fast"):
     """denoise_latents with a REAL process group (RCCL, world size 1): the sharded code path (table slicing, K/V and
     latent-row all-gathers, index_copy) must reproduce the plain path bitwise."""
     import os
@@ -245,12 +251,12 @@ def case_pipeline_shard_world1(seed=21):
         created = True
     try:
         cfg, om = make_unet(seed)
-        pipe = Diffuman4DPipeline(None, hip_unet(cfg, om), DDIMScheduler(), "cuda")
+        pipe = Diffuman4DPipeline(None, hip_unet(cfg, om, precision), DDIMScheduler(), "cuda")
         g = torch.Generator(device="cuda").manual_seed(seed)
         n, h, w = 8, 16, 8
-        rnd = lambda c, s=1.0: (torch.randn(n, h, w, c, generator=g, device="cuda") * s).to(BF)  # noqa: E731
+        rnd = lambda c, s=1.0: (torch.randn(n, h, w, c, generator=g, device="cuda") * s).to(pipe.dtype)  # noqa: E731
         cond = [i in (1, 5) for i in range(n)]
-        mask = torch.tensor([0.0 if c else 1.0 for c in cond], device="cuda").to(BF)[:, None, None, None].expand(n, h, w, 1).contiguous()
+        mask = torch.tensor([0.0 if c else 1.0 for c in cond], device="cuda").to(pipe.dtype)[:, None, None, None].expand(n, h, w, 1).contiguous()
         pv, pl, sk, lat0 = rnd(4), rnd(6, 0.5), rnd(4), rnd(4)
         plan = plan_sweep(cond, [0] * n, "spatial", 4, 2, 0, False, 1, 1)
         a = pipe.denoise_latents(pv, pl, sk, mask, lat0.clone(), plan, "spatial", 2.0)
@@ -293,9 +299,9 @@ def case_task_batching(domain="spatial", copies=2, sched="ddim", seed=23):
 
 
 def latents_nhwc(hv, z):
-    """NCHW latents (CPU) -> the NHWC device tensor decode_to_images takes (bf16, or fp32 under precision "parity")."""
+    """NCHW latents (CPU) -> the NHWC device tensor decode_to_images takes (bf16, or fp32 under the wide precisions)."""
     from diffuman4d_amd.host import ops
-    if hv.parity:
+    if hv.wide:
         return z.float().permute(0, 2, 3, 1).contiguous().cuda()
     return ops.nchw_to_nhwc(z.to(BF).contiguous().cuda())
 
@@ -632,7 +638,7 @@ def case_pipeline_cache_lazy(seed=31):
     return bad, 0.0
 
 
-def case_pipeline_prune(domain="spatial", seed=41):
+def case_pipeline_prune(domain="spatial", seed=41, precision="fast"):
     """prune_cond_rows extension: the UNet tail after the last 3-D attention runs only for non-conditioning rows.  The
     latents must agree with the strict path to within kernel-configuration noise (other tile shapes for the smaller
     batch) and the bookkeeping exactly."""
@@ -647,7 +653,7 @@ def case_pipeline_prune(domain="spatial", seed=41):
     kw = dict(pixel_values=pv, plucker_embeds=pl, skeletons=sk, cond_masks=cm, latents=None, domain=domain,
               timestep_indices=torch.zeros(n, dtype=torch.int64), window_size=4, sliding_stride=2 if domain == "spatial" else 1,
               sliding_shift=0, bidirectional=False, num_denoising_steps=1, alternation_rounds=1, guidance_scale=2.0, noise=noise)
-    hp = Diffuman4DPipeline(hip_vae(cfg_v, ov), hip_unet(cfg_u, ou), HS(HC()), "cuda")
+    hp = Diffuman4DPipeline(hip_vae(cfg_v, ov, precision), hip_unet(cfg_u, ou, precision), HS(HC()), "cuda")
     ref = hp.sliding_iterative_denoise(**kw)
     hp.prune_cond_rows = True
     out = hp.sliding_iterative_denoise(**kw)
@@ -721,8 +727,8 @@ def case_golden_pipeline(name, precision="fast"):
     exact = torch.equal(out["timestep_indices"].cpu(), g["timestep_indices"]) and \
         torch.equal(out["fully_denoised"].cpu(), g["fully_denoised"])
     e_lat, e_img = rel_l2(out["latents"], g["latents"]), rel_l2(out["images"], g["images"])
-    if precision == "parity":  # fixed bound against the reference pipeline's own fp32 output
-        print(f"    [golden {name} parity] latents rel_l2={e_lat:.3e} images rel_l2={e_img:.3e} (fixture images are fp16) bookkeeping_exact={exact}", flush=True)
+    if precision in ("parity", "fp16"):  # fixed bound against the reference pipeline's own fp32 output
+        print(f"    [golden {name} {precision}] latents rel_l2={e_lat:.3e} images rel_l2={e_img:.3e} (fixture images are fp16) bookkeeping_exact={exact}", flush=True)
         return ({"bookkeeping": 1.0}, {"bookkeeping": 0.0}) if not exact else ({"latents": e_lat, "images": e_img}, {"latents": 0.0, "images": 0.0})
     # yardstick: the oracle run in bf16 on the same task, measured against the same fixture (= the reference's fp32 output)
     from oracle.pipeline import OraclePipeline
@@ -963,6 +969,41 @@ CASES.update({
     "par_unet_sd21_72x40_f16": (case_unet_sd21, dict(name="unet_f16_spatial", **PAR)),
     "par_vae_sd_576x320": (case_vae_sd, dict(**PAR)),
 })
+# the parity precision's holes of round 4: the F = 24 temporal call at SD width, frame sharding (K | V operand planes all-gathered),
+# the cond-row pruning extension
+CASES.update({
+    "par_unet_sd21_72x40_f24": (case_unet_sd21, dict(name="unet_f24_temporal", **PAR)),
+    "par_unet_frame_shard_p4": (case_unet_frame_shard, dict(P=4, num_frames=8, **PAR)),
+    "par_pipeline_shard_rccl_world1": (case_pipeline_shard_world1, dict(**PAR)),
+    "par_pipeline_prune_cond_rows": (case_pipeline_prune, dict(domain="spatial", **PAR)),
+})
+# precision="fp16" (round 5): single-term fp16 MFMA operands over fp32 tensors -- fixed bounds per quantity (FP16_BOUNDS)
+FP16 = dict(precision="fp16")
+CASES.update({
+    "fp16_unet_spatial": (case_unet, dict(num_frames=4, cfg_batch=2, **FP16)),
+    "fp16_unet_temporal_temb": (case_unet, dict(num_frames=4, cfg_batch=2, tem=True, domain="temporal", **FP16)),
+    "fp16_unet_2d_only": (case_unet, dict(num_frames=1, cfg_batch=3, h=8, w=8, **FP16)),
+    "fp16_unet_pose_encoder": (case_unet, dict(num_frames=4, cfg_batch=2, pose=True, **FP16)),
+    "fp16_vae": (case_vae, dict(**FP16)),
+    "fp16_vae_odd_latent_area": (case_vae, dict(h=264, w=328, **FP16)),
+    "fp16_pipeline_spatial": (case_pipeline, dict(domain="spatial", **FP16)),
+    "fp16_pipeline_temporal_v": (case_pipeline, dict(domain="temporal", T=4, window=4, stride=1, pred="v_prediction", **FP16)),
+    "fp16_pipeline_bidir_nocfg": (case_pipeline, dict(domain="spatial", window=3, stride=3, bidir=True, gs=1.0, steps=2, **FP16)),
+    "fp16_pipeline_dpm_spatial": (case_pipeline, dict(domain="spatial", sched="dpm", steps=2, window=4, stride=2, bidir=True, **FP16)),
+    "fp16_golden_spatial": (case_golden_pipeline, dict(name="spatial", **FP16)),
+    "fp16_golden_temporal_v": (case_golden_pipeline, dict(name="temporal_v", **FP16)),
+    "fp16_golden_round2_shift": (case_golden_pipeline, dict(name="round2_shift", **FP16)),
+    "fp16_golden_pose_encoder": (case_golden_pipeline, dict(name="pose_encoder", **FP16)),
+    "fp16_golden_dpm_temporal_v_heun_round2": (case_golden_pipeline, dict(name="dpm_temporal_v_heun_round2", **FP16)),
+    "fp16_golden_unipc_temporal_v_bh1_round2": (case_golden_pipeline, dict(name="unipc_temporal_v_bh1_round2", **FP16)),
+    "fp16_golden_deis3_spatial_bidir": (case_golden_pipeline, dict(name="deis3_spatial_bidir", **FP16)),
+    "fp16_unet_sd21_72x40_f16": (case_unet_sd21, dict(name="unet_f16_spatial", **FP16)),
+    "fp16_unet_sd21_72x40_f24": (case_unet_sd21, dict(name="unet_f24_temporal", **FP16)),
+    "fp16_vae_sd_576x320": (case_vae_sd, dict(**FP16)),
+    "fp16_unet_frame_shard_p4": (case_unet_frame_shard, dict(P=4, num_frames=8, **FP16)),
+    "fp16_pipeline_shard_rccl_world1": (case_pipeline_shard_world1, dict(**FP16)),
+    "fp16_pipeline_prune_cond_rows": (case_pipeline_prune, dict(domain="spatial", **FP16)),
+})
 # fast precision, launch by launch against fp64 on the device's own tensors (oracle/replay.py): fixed bound REPLAY_TOL
 CASES.update({
     "opreplay_unet_small": (case_opreplay_unet, dict()),
@@ -987,9 +1028,11 @@ del _sd21
 if (GOLDEN / "sd21_128x128.pt").exists():
     CASES["unet_sd21_128x128_f16"] = (case_unet_sd21, dict(name="unet_f16_spatial_128", fixture="sd21_128x128.pt"))
     CASES["par_unet_sd21_128x128_f16"] = (case_unet_sd21, dict(name="unet_f16_spatial_128", fixture="sd21_128x128.pt", **PAR))
+    CASES["fp16_unet_sd21_128x128_f16"] = (case_unet_sd21, dict(name="unet_f16_spatial_128", fixture="sd21_128x128.pt", **FP16))
 if (GOLDEN / "multiround_sd21_72x40.pt").exists():  # spatial -> temporal -> spatial through the sampler (make_golden_multiround.py)
     CASES["multiround_sd21_72x40"] = (case_multiround_sd21, dict())
     CASES["par_multiround_sd21_72x40"] = (case_multiround_sd21, dict(**PAR))
+    CASES["fp16_multiround_sd21_72x40"] = (case_multiround_sd21, dict(**FP16))
 # BASELINE.json configs[0] end to end at the judged geometry, vs tests/golden/demo3d_sd21_72x40.pt (made by
 # tests/golden/make_golden_demo3d.py: two CPU-hours; the case exists once the fixture does)
 if "vae_1024" in torch.load(GOLDEN / "sd21_72x40.pt"):  # the VAE at the reference's native 1024 x 1024 (make_golden_sd21.py vae1024)
@@ -997,18 +1040,22 @@ if "vae_1024" in torch.load(GOLDEN / "sd21_72x40.pt"):  # the VAE at the referen
 if (GOLDEN / "demo3d_sd21_72x40.pt").exists():
     CASES["demo3d_sd21_72x40"] = (case_demo3d_sd21, dict())
     CASES["par_demo3d_sd21_72x40"] = (case_demo3d_sd21, dict(**PAR))  # north_star: decoded RGB within 1e-3 of the fp32 reference path
+    CASES["fp16_demo3d_sd21_72x40"] = (case_demo3d_sd21, dict(**FP16))  # the same bar at one MFMA per product
     if "matched_latents" in torch.load(GOLDEN / "demo3d_sd21_72x40.pt"):  # make_golden_demo3d.py matched
         CASES["demo3d_sd21_72x40_matched"] = (case_demo3d_sd21, dict(matched=True))
 # Cases with a fixed bound of their own: bitwise equalities (0.0), extension-vs-strict comparisons, exact resampling.
 # Every other case is judged against its bf16-oracle yardstick (YARD_FACTOR, see the module docstring).
 TOL = {"task_batching_spatial": 0.0, "task_batching_temporal_x3": 0.0, "task_batching_dpm": 0.0, "pipeline_shard_rccl_world1": 0.0, "unet_frame_shard_p4": 0.0, "unet_frame_shard_p8": 0.0,
+       "par_unet_frame_shard_p4": 0.0, "par_pipeline_shard_rccl_world1": 0.0, "fp16_unet_frame_shard_p4": 0.0, "fp16_pipeline_shard_rccl_world1": 0.0,
+       "par_pipeline_prune_cond_rows": 1e-4, "fp16_pipeline_prune_cond_rows": 1e-3,
        "pipeline_cache_lazy_decode": 0.0, "pipeline_prune_cond_rows": 5e-3, "pipeline_prune_cond_rows_temporal": 5e-3,
        "pipeline_plucker_on_device": 5e-3, "resize": 4e-3}
 # Tighter fixed bounds of individual par_* cases, ~8x above what MI355X measured (every quantity below 1.6e-5 where
 # the fixture is fp32 / 16-bit fixed point).  Cases whose fixture stores the decoded RGB in fp16 (floor 1.7-1.8e-4) keep 5e-4.
 PARITY_TOLS: dict = {n: 1e-4 for n in CASES if n.startswith("par_") and not n.startswith(("par_golden", "par_vae_sd"))}
 PARITY_TOLS.update({n: 5e-4 for n in CASES if n.startswith(("par_golden", "par_vae_sd"))})
-TOL.update({n: PARITY_TOLS.get(n, PARITY_TOL) for n in CASES if n.startswith("par_")})
+TOL.update({n: PARITY_TOLS.get(n, PARITY_TOL) for n in CASES if n.startswith("par_") and n not in TOL})
+TOL.update({n: FP16_BOUNDS for n in CASES if n.startswith("fp16_") and n not in TOL})  # a dict: one fixed bound per compared quantity
 TOL.update({n: 0.0 for n in CASES if n.endswith("_matched")})  # band_excess must be zero (MATCHED_BAND)
 TOL.update({n: REPLAY_TOL for n in CASES if n.startswith("opreplay_")})
 
@@ -1019,7 +1066,7 @@ def judge(name, err, yard):
     yards = yard if isinstance(yard, dict) else {k: yard for k in errs}
     rows = []
     for q, e in errs.items():
-        bound = TOL[name] if name in TOL else YARD_FACTOR * yards[q]
+        bound = (TOL[name][q] if isinstance(TOL[name], dict) else TOL[name]) if name in TOL else YARD_FACTOR * yards[q]
         rows.append((e / bound if bound > 0 else (0.0 if e == 0 else math.inf), e, yards.get(q, 0.0), bound, q))
     rows.sort(reverse=True)
     _, e, y, bound, q = rows[0]

@@ -695,6 +695,202 @@ def case_par_attention(batch, heads, L, seed=0, spike=False, qk_scale=1.0):
     return rel_l2(got, ref), float((got - ref).abs().max())
 
 
+# ---- fp16 precision (include/dm4d.h "fp16 precision"): fp32 tensors, single-term fp16 operands ---------------------------------------
+# Operands are drawn fp16-representable, references are fp64 on the SAME numbers: what is left is fp32 accumulation (outputs stored in
+# fp32: TOL_H16_F32) or the one fp16 rounding of an operand output (2^-12 relative, 1.4e-4 rms: TOL_H16).  Attention rounds P as well.
+F16 = torch.float16
+TOL_H16_F32 = 2e-5
+TOL_H16 = 4e-4
+TOL_H16_ATTN = 6e-4
+
+
+def _rndh(shape, gen, scale=1.0):
+    return (torch.randn(shape, generator=gen) * scale).to(F16)
+
+
+def case_h16_split(M=300, C1=96, C2=0, cpad=None, silu=False, scale=1.0, transposed=False, seed=0):
+    """ops.split(h16=True): the plane must hold exactly fp16(act(x) * scale), columns behind C1 + C2 zero."""
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, C1, generator=g) * 3
+    x2 = torch.randn(M, C2, generator=g) if C2 else None
+    src = x.t().contiguous() if transposed else x
+    op = ops.split(src.cuda(), x2.cuda() if C2 else None, cpad=cpad, silu=silu, scale=scale, transposed=transposed, h16=True).cpu()
+    Cp = cpad or (C1 + C2)
+    v = torch.cat([x, x2], dim=1) if C2 else x
+    if silu:
+        v = F.silu(v)
+    v = F.pad(v * scale, (0, Cp - v.shape[1]))
+    assert op.shape == v.shape and op.dtype == F16, (op.shape, op.dtype)
+    if not silu:
+        assert torch.equal(op, v.to(F16)), f"plane differs: max abs {float((op.float() - v).abs().max()):.3e}"
+        return 0.0, 0.0
+    return rel_l2(op, v.double()), float((op.double() - v.double()).abs().max())
+
+
+def case_h16_gemm(M, N, K, bias=True, rowbias=False, residual=False, geglu=False, silu=False, out_f32=True, a2=0, scale_cols=0, seed=0):
+    """dm4d_gemm_f16: fp16 A (optionally two sources) / W / bias, fp32 row bias / residual, fp32 or fp16 result, column-range scale."""
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    a = _rndh((M, K), g)
+    w = _rndh(((2 * N) if geglu else N, K), g, 1.0 / math.sqrt(K))
+    b = _rndh(((2 * N) if geglu else N,), g, 0.5) if bias else None
+    rpr = 7
+    rb = torch.randn((M + rpr - 1) // rpr, N, generator=g) if rowbias else None
+    res = torch.randn(M, N, generator=g) if residual else None
+    ref = a.double() @ w.double().t()
+    if b is not None:
+        ref = ref + b.double()
+    if geglu:
+        h, gate = ref.chunk(2, dim=-1)
+        ref = h * F.gelu(gate)
+    if silu:
+        ref = F.silu(ref)
+    if rb is not None:
+        ref = ref + rb.double().repeat_interleave(rpr, dim=0)[:M]
+    if res is not None:
+        ref = ref + res.double()
+    cs = 0.125 * 1.4426950408889634
+    if scale_cols:
+        ref = torch.cat([ref[:, :scale_cols] * cs, ref[:, scale_cols:]], dim=1)
+    d = "cuda"
+    k1 = K - a2
+    out = ops.gemm(a[:, :k1].contiguous().to(d) if a2 else a.to(d), w.to(d), a2=a[:, k1:].contiguous().to(d) if a2 else None,
+                   bias=b.to(d) if b is not None else None, rowbias=rb.to(d) if rb is not None else None, rows_per_rowbias=rpr,
+                   residual=res.to(d) if res is not None else None, geglu=geglu, silu=silu, out_f32=out_f32, scale_cols=scale_cols,
+                   col_scale=cs)
+    assert out.dtype == (torch.float32 if out_f32 else F16)
+    got = out.double().cpu()
+    return rel_l2(got, ref), float((got - ref).abs().max())
+
+
+def case_h16_conv(B, H, W, Cin, Cout, stride=1, pad=1, pad_hi=None, upsample=False, bias=True, rowbias=False, residual=False,
+                  scale=1.0, out_f32=True, seed=0):
+    """dm4d_conv3x3_nhwc_f16 (incl. the split over the kernel rows on small images with a deep K)."""
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    x = _rndh((B, Cin, H, W), g)
+    w = _rndh((Cout, Cin, 3, 3), g, 1.0 / math.sqrt(9 * Cin))
+    b = _rndh((Cout,), g, 0.5) if bias else None
+    xi = F.interpolate(x.double(), scale_factor=2, mode="nearest") if upsample else x.double()
+    ph = pad if pad_hi is None else pad_hi
+    ref = F.conv2d(F.pad(xi, (pad, ph, pad, ph)), w.double(), b.double() if bias else None, stride=stride)
+    Ho, Wo = ref.shape[-2:]
+    sdt = torch.float32 if out_f32 else F16
+    rb = torch.randn(B, Cout, generator=g).to(sdt) if rowbias else None
+    res = torch.randn(B, Ho, Wo, Cout, generator=g).to(sdt) if residual else None
+    if rb is not None:
+        ref = ref + rb.double()[:, :, None, None]
+    if res is not None:
+        ref = ref + res.double().permute(0, 3, 1, 2)
+    ref = ref * scale
+    d = "cuda"
+    wt = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().to(d)
+    out = ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().to(d), wt, bias=b.to(d) if bias else None,
+                      rowbias=rb.to(d) if rb is not None else None, residual=res.to(d) if res is not None else None, stride=stride,
+                      pad=pad, pad_hi=pad_hi, upsample=upsample, out_scale=scale, out_f32=out_f32)
+    got = out.double().cpu().permute(0, 3, 1, 2)
+    return rel_l2(got, ref), float((got - ref).abs().max())
+
+
+def case_h16_groupnorm(B, HW, C1, C2=0, groups=32, silu=True, eps=1e-5, mean_shift=0.0, seed=0):
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    x1 = torch.randn(B, HW, C1, generator=g) * 2 + mean_shift
+    x2 = torch.randn(B, HW, C2, generator=g) if C2 else None
+    C = C1 + C2
+    gam, bet = (1.0 + 0.1 * torch.randn(C, generator=g)).to(F16), (0.1 * torch.randn(C, generator=g)).to(F16)
+    x = torch.cat([x1, x2], dim=-1) if C2 else x1
+    ref = F.group_norm(x.double().permute(0, 2, 1), groups, gam.double(), bet.double(), eps).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    out = ops.groupnorm(x1.cuda(), gam.cuda(), bet.cuda(), groups, eps, x2=x2.cuda() if C2 else None, silu=silu)
+    assert out.dtype == F16 and out.shape[-1] == C
+    got = out.double().cpu()
+    return rel_l2(got, ref), float((got - ref).abs().max())
+
+
+def case_h16_layernorm(M, C, seed=0):
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, C, generator=g) * 3 + 0.5
+    gam, bet = (1.0 + 0.1 * torch.randn(C, generator=g)).to(F16), (0.1 * torch.randn(C, generator=g)).to(F16)
+    ref = F.layer_norm(x.double(), (C,), gam.double(), bet.double(), 1e-5)
+    out = ops.layernorm(x.cuda(), gam.cuda(), bet.cuda(), 1e-5)
+    assert out.dtype == F16 and out.shape == (M, C)
+    got = out.double().cpu()
+    return rel_l2(got, ref), float((got - ref).abs().max())
+
+
+def case_h16_softmax(M, N, Np, scale=0.05, seed=0):
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    s = torch.randn(M, Np, generator=g) * 40
+    ref = torch.softmax(s[:, :N].double() * scale, dim=-1)
+    p = ops.softmax_rows_split(s.cuda(), scale, n=N, h16=True).cpu()
+    assert p.shape == (M, Np) and p.dtype == F16 and bool((p[:, N:] == 0).all()), "one fp16 plane, padded columns zero"
+    got = p[:, :N].double()
+    return rel_l2(got, ref), float((got - ref).abs().max())
+
+
+def case_h16_attention(batch, heads, L, seed=0, spike=False, ramp=False, flat=False, threads=None, parts=0):
+    """dm4d_attention_qscaled_kv_f16 against fp64/fp32 SDPA on the same fp16 numbers (Q carries scale * log2 e).  spike / ramp: late keys
+    outgrow the first tile's maximum (ramp: by more than 2^24, so the workgroup must redo its rows with the exact loop); flat: every
+    score equal -- the row sum is L times the largest probability.  parts > 0: queries of each part against all keys (frame sharding)
+    must reproduce the unsharded result bitwise."""
+    from diffuman4d_amd.host import ops
+    if threads:
+        torch.set_num_threads(min(threads, torch.get_num_threads()))
+    g = torch.Generator().manual_seed(seed)
+    C = heads * 64
+    qkv = _rndh((batch * L, 3 * C), g)
+    fac = 0.125 * ops.LOG2E
+    if flat:
+        qkv[:, :C] = 0
+    if spike:
+        qkv[L - 3, C:2 * C] *= 8.0
+    if ramp:
+        qkv[100, C:2 * C] *= 64.0
+        qkv[L - 70, C:2 * C] *= 48.0
+    qkv[:, :C] = (qkv[:, :C].float() * fac).to(F16)
+
+    def hv(t):
+        return t.float().view(batch, L, heads, 64).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(hv(qkv[:, :C]) / fac, hv(qkv[:, C:2 * C]), hv(qkv[:, 2 * C:]))
+    ref = ref.transpose(1, 2).reshape(batch * L, C)
+    dq = qkv.to("cuda")
+    out = ops.attention(dq[:, :C], dq[:, C:2 * C], dq[:, 2 * C:], batch, heads, L, q_scaled=True)
+    assert out.dtype == F16
+    if parts:
+        ls = L // parts
+        kv = dq[:, C:].contiguous()
+        full = out.view(batch, L, C)
+        for r in range(parts):
+            q_loc = dq[:, :C].view(batch, L, C)[:, r * ls:(r + 1) * ls].reshape(batch * ls, C).contiguous()
+            o = ops.attention(q_loc, kv[:, :C], kv[:, C:], batch, heads, ls, kv_seq=L, q_scaled=True).view(batch, ls, C)
+            assert torch.equal(o, full[:, r * ls:(r + 1) * ls]), f"part {r} of {parts} differs from the unsharded result"
+    return rel_l2(out, ref), float((out.float().cpu() - ref).abs().max())
+
+
+def case_h16_pack(F_=8, HW=30, use_cfg=True, skel=True, seed=0):
+    """dm4d_pack_model_input_f32_f16: the fp16 operand of conv_in = fp16 of the parity precision's recombined operand."""
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    N = F_ + 3
+    t = lambda c: torch.randn(N, HW, c, generator=g)  # noqa: E731
+    lat, pv, pl, sk, mask = t(4), t(4), t(6), (t(4) if skel else None), (torch.rand(N, HW, 1, generator=g) > 0.5).float()
+    cond = (torch.arange(F_) % 3 == 0).to(torch.int32)
+    widx = torch.randperm(N, generator=g)[:F_].to(torch.int32)
+    d = "cuda"
+    args = lambda: (lat.clone().to(d), pv.to(d), pl.to(d), sk.to(d) if skel else None, mask.to(d), cond.to(d))  # noqa: E731
+    a = ops.pack_model_input(*args(), 32, use_cfg, frame_idx=widx.to(d), h16=True)
+    b = ops.pack_model_input(*args(), 32, use_cfg, frame_idx=widx.to(d))  # [hi | lo]
+    want = (b[..., :32].float() + b[..., 32:].float()).to(F16)
+    assert a.dtype == F16 and a.shape == want.shape
+    assert torch.equal(a, want), f"max abs {float((a.float() - want.float()).abs().max()):.3e}"
+    return 0.0, 0.0
+
+
 def case_multistep_step(f32=False, slots=3, seed=0):
     """dm4d_cfg_multistep_step_*: the general linear multistep update (UniPC with its corrector, DEIS) against its formula in fp64, two
     consecutive steps so that the stored tensors written by the first are read by the second."""
@@ -1017,6 +1213,62 @@ CASES = {
     "par_attn_large_logits": (case_par_attention, dict(batch=1, heads=1, L=512, qk_scale=3.0, seed=3)),
     "par_attn_l0_2d": (case_par_attention, dict(batch=4, heads=5, L=2880, seed=4)),
     "par_small_kernels": (case_par_small_kernels, dict()),
+    # the parity attention at the judged 3-D level-1 shapes (the fast kernel's attn_qs_judged_3d_l1_f16 / _f24)
+    "par_attn_judged_3d_l1_f16": (case_par_attention, dict(batch=2, heads=10, L=16 * 720, seed=5)),
+    "par_attn_judged_3d_l1_f24": (case_par_attention, dict(batch=2, heads=10, L=24 * 720, seed=6)),
+    # --- fp16 precision: fp32 tensors, single-term fp16 operands (TOL_H16*) -------------------------------------------------------
+    "h16_split": (case_h16_split, dict()),
+    "h16_split_concat_pad_scale": (case_h16_split, dict(M=77, C1=4, C2=0, cpad=32, scale=1.0 / 0.18215)),
+    "h16_split_two_sources": (case_h16_split, dict(M=333, C1=64, C2=32)),
+    "h16_split_silu": (case_h16_split, dict(M=64, C1=320, silu=True)),
+    "h16_split_transposed_pad": (case_h16_split, dict(M=64, C1=45, cpad=64, transposed=True)),
+    "h16_gemm_resid": (case_h16_gemm, dict(M=1000, N=320, K=320, residual=True)),
+    "h16_gemm_rowbias_tails": (case_h16_gemm, dict(M=333, N=200, K=96, residual=True, rowbias=True)),
+    "h16_gemm_n4": (case_h16_gemm, dict(M=500, N=4, K=288)),
+    "h16_gemm_geglu_h16out": (case_h16_gemm, dict(M=700, N=1280, K=320, geglu=True, out_f32=False)),
+    "h16_gemm_silu_h16out": (case_h16_gemm, dict(M=32, N=1280, K=320, silu=True, out_f32=False)),
+    "h16_gemm_qkv_qscale": (case_h16_gemm, dict(M=2880, N=960, K=320, bias=False, out_f32=False, scale_cols=320)),
+    "h16_gemm_qkv_qscale_l1": (case_h16_gemm, dict(M=1440, N=1920, K=640, bias=False, out_f32=False, scale_cols=640)),
+    "h16_gemm_tall_n320": (case_h16_gemm, dict(M=256 * 257 + 40, N=320, K=320, residual=True)),
+    "h16_gemm_deep": (case_h16_gemm, dict(M=1440, N=1280, K=5120, residual=True)),
+    "h16_gemm_wide_k640": (case_h16_gemm, dict(M=23040, N=1280, K=640, residual=False, out_f32=False)),
+    "h16_gemm_two_sources": (case_h16_gemm, dict(M=2880, N=640, K=1920, a2=640)),
+    "h16_conv_l0": (case_h16_conv, dict(B=2, H=72, W=40, Cin=320, Cout=320, rowbias=True)),
+    "h16_conv_l0_tall": (case_h16_conv, dict(B=24, H=72, W=40, Cin=320, Cout=320, rowbias=True, residual=True)),
+    "h16_conv_resid_scale": (case_h16_conv, dict(B=2, H=36, W=20, Cin=640, Cout=640, residual=True, scale=0.5)),
+    "h16_conv_l1_wide": (case_h16_conv, dict(B=32, H=36, W=20, Cin=640, Cout=640, rowbias=True)),
+    "h16_conv_l2": (case_h16_conv, dict(B=32, H=18, W=10, Cin=1280, Cout=1280, residual=True)),
+    "h16_conv_in": (case_h16_conv, dict(B=3, H=24, W=16, Cin=32, Cout=320)),
+    "h16_conv_out4": (case_h16_conv, dict(B=2, H=24, W=16, Cin=320, Cout=4)),
+    "h16_conv_9x5_deep_splitk": (case_h16_conv, dict(B=4, H=9, W=5, Cin=1280, Cout=1280, rowbias=True, residual=True)),
+    "h16_conv_stride2": (case_h16_conv, dict(B=2, H=36, W=20, Cin=320, Cout=320, stride=2)),
+    "h16_conv_stride2_vae_pad": (case_h16_conv, dict(B=2, H=32, W=24, Cin=128, Cout=128, stride=2, pad=0, pad_hi=1)),
+    "h16_conv_upsample": (case_h16_conv, dict(B=2, H=18, W=10, Cin=640, Cout=640, upsample=True)),
+    "h16_conv_upsample_1280": (case_h16_conv, dict(B=8, H=18, W=10, Cin=1280, Cout=1280, upsample=True)),
+    "h16_gn_silu": (case_h16_groupnorm, dict(B=3, HW=720, C1=320)),
+    "h16_gn_two_sources": (case_h16_groupnorm, dict(B=2, HW=180, C1=1280, C2=640)),
+    "h16_gn_vae_128ch_eps6": (case_h16_groupnorm, dict(B=2, HW=4096, C1=128, eps=1e-6)),
+    "h16_gn_mean_200sigma": (case_h16_groupnorm, dict(B=2, HW=512, C1=64, groups=8, silu=False, mean_shift=400.0)),
+    "h16_gn_odd_channels": (case_h16_groupnorm, dict(B=2, HW=77, C1=66, groups=6, silu=True)),
+    "h16_ln": (case_h16_layernorm, dict(M=1000, C=320)),
+    "h16_ln_1280": (case_h16_layernorm, dict(M=333, C=1280)),
+    "h16_softmax": (case_h16_softmax, dict(M=96, N=2880, Np=2880)),
+    "h16_softmax_padded": (case_h16_softmax, dict(M=33, N=1353, Np=1376)),
+    "h16_attn_small": (case_h16_attention, dict(batch=2, heads=2, L=128)),
+    "h16_attn_tail45": (case_h16_attention, dict(batch=3, heads=1, L=45)),
+    "h16_attn_L65": (case_h16_attention, dict(batch=2, heads=1, L=65)),
+    "h16_attn_L321": (case_h16_attention, dict(batch=1, heads=1, L=321)),
+    "h16_attn_tail720": (case_h16_attention, dict(batch=2, heads=3, L=720)),
+    "h16_attn_2d": (case_h16_attention, dict(batch=8, heads=5, L=2880)),
+    "h16_attn_spike": (case_h16_attention, dict(batch=1, heads=2, L=1000, spike=True)),
+    "h16_attn_ramp_fallback": (case_h16_attention, dict(batch=2, heads=2, L=1500, ramp=True)),
+    "h16_attn_flat_rows": (case_h16_attention, dict(batch=1, heads=1, L=24 * 720, flat=True, threads=32)),
+    "h16_attn_kv_split": (case_h16_attention, dict(batch=2, heads=2, L=16 * 180, parts=8)),
+    "h16_attn_judged_3d_l1_f16": (case_h16_attention, dict(batch=2, heads=10, L=16 * 720, threads=32)),
+    "h16_attn_judged_3d_l1_f24": (case_h16_attention, dict(batch=2, heads=10, L=24 * 720, threads=32)),
+    "h16_attn_judged_2d_l0": (case_h16_attention, dict(batch=32, heads=5, L=2880, threads=32)),
+    "h16_pack_cfg": (case_h16_pack, dict()),
+    "h16_pack_nocfg_noskel": (case_h16_pack, dict(F_=5, HW=17, use_cfg=False, skel=False, seed=1)),
     "par_multistep_step_3slots": (case_multistep_step, dict(f32=True, slots=3)),
     "multistep_step_3slots": (case_multistep_step, dict(slots=3)),
     "multistep_step_2slots": (case_multistep_step, dict(slots=2, seed=1)),
@@ -1034,6 +1286,10 @@ def run_case(name):
     fn, kw = CASES[name]
     err, mx = fn(**kw)
     default = (TOL_PAR_ATTN if name.startswith("par_attn") else TOL_PAR) if name.startswith("par_") else TOL
+    if name.startswith("h16_"):  # fp16 precision: an fp16 result carries its one rounding, an fp32 result only the accumulation
+        kw = CASES[name][1]
+        f32_out = name.startswith(("h16_gemm", "h16_conv")) and kw.get("out_f32", True)
+        default = TOL_H16_ATTN if name.startswith("h16_attn") else (TOL_H16_F32 if f32_out else TOL_H16)
     return err, mx, TOLS.get(name, default)
 
 

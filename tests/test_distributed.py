@@ -250,13 +250,52 @@ def test_hybrid_split_of_the_judged_grid():
         DistributedSamplingRunner(s, mode="bogus")
 
 
-def test_frame_sharding_modes_refuse_the_parity_precision():
-    """precision 'parity' has no frame-sharded attention: the runner says so when it is built, not inside the first tail task."""
-    kw = dict(spa_label_range=[0, 8, 1], tem_label_range=[0, 4, 1], input_spa_labels=[1, 5], window_size=4, sliding_stride=2,
-              alternation_rounds=3, bidirectional=False)
-    s = make_sampler(kw)
-    s.pipelines[0].parity = True
-    for mode in ("hybrid", "frame-shard"):
-        with pytest.raises(ValueError, match="precision 'parity' does not support"):
-            DistributedSamplingRunner(s, mode=mode)
+def _wide_shard_worker(rank, world, port, outdir, precision):
+    """One rank of a frame-sharded window sweep in a WIDE precision, on the CPU stand-in of the kernel wrappers (tests/cpu_standin_ops.py)
+    over gloo: the real host classes -- UNet with its split Q / K|V projections, parallel.FrameShard, pipeline.denoise_latents with its
+    sliced plan tables and latent-row all-gathers -- against the same sweep run unsharded in the same process."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        import cpu_standin_ops as fake_ops
+        import modelcheck as mc
+        from dataclasses import asdict
+        from diffuman4d_amd.host.parallel import FrameShard
+        from diffuman4d_amd.host.pipeline import Diffuman4DPipeline
+        from diffuman4d_amd.host.schedule import plan_sweep
+        from diffuman4d_amd.host.scheduler import DDIMScheduler
+        from diffuman4d_amd.host.unet import UNetConfig, UNetMultiviewConditionModel
+        fake_ops.install()
+        cfg, om = mc.make_unet(21)
+        unet = UNetMultiviewConditionModel(UNetConfig.from_dict(asdict(cfg)), om.state_dict(), "cpu", precision)
+        pipe = Diffuman4DPipeline(None, unet, DDIMScheduler(), "cpu")
+        g = torch.Generator().manual_seed(21)
+        n, h, w = 8, 16, 8
+        rnd = lambda c, s=1.0: (torch.randn(n, h, w, c, generator=g) * s).to(pipe.dtype)  # noqa: E731
+        cond = [i in (1, 5) for i in range(n)]
+        mask = torch.tensor([0.0 if c else 1.0 for c in cond]).to(pipe.dtype)[:, None, None, None].expand(n, h, w, 1).contiguous()
+        pv, pl, sk, lat0 = rnd(4), rnd(6, 0.5), rnd(4), rnd(4)
+        plan = plan_sweep(cond, [0] * n, "spatial", 4, 2, 0, False, 1, 1)  # windows of 2 inputs + 4 targets = 6 frames -> 3 per rank
+        a = pipe.denoise_latents(pv, pl, sk, mask, lat0.clone(), plan, "spatial", 2.0)
+        b = pipe.denoise_latents(pv, pl, sk, mask, lat0.clone(), plan, "spatial", 2.0, shard=FrameShard())
+        err = float((a.double() - b.double()).norm() / a.double().norm())
+        torch.save({"err": err, "moved": float((a.double() - lat0.double()).norm()), "lat": b}, f"{outdir}/r{rank}.pt")
+    finally:
+        dist.destroy_process_group()
 
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("precision", ["parity", "fp16"])
+def test_frame_sharding_in_the_wide_precisions_equals_the_unsharded_sweep(tmp_path, precision):
+    """Round 4 refused runner.mode=frame-shard|hybrid with precision 'parity' (its attention had no K/V all-gather form).  Both wide
+    precisions now gather the OPERAND PLANES of K | V (parity: hi and lo planes [k_hi | v_hi | k_lo | v_lo], fp16: one plane): world 2
+    over gloo ends with the latents of the unsharded sweep (not bitwise on the stand-in: its fp64 matmuls are blocked differently for
+    half the query rows; the GPU kernels are bitwise, tests/modelcheck.py *_unet_frame_shard_p4), identical on both ranks."""
+    port = 29800 + (os.getpid() % 1000) + (7 if precision == "fp16" else 0)
+    mp.spawn(_wide_shard_worker, args=(2, port, str(tmp_path), precision), nprocs=2, join=True)
+    blobs = [torch.load(tmp_path / f"r{r}.pt") for r in range(2)]
+    for b in blobs:
+        assert b["moved"] > 0.1, "the sweep did not update the latents"
+        assert b["err"] < (1e-6 if precision == "parity" else 2e-4), b["err"]
+    assert torch.equal(blobs[0]["lat"], blobs[1]["lat"]), "the ranks of a shard group must end with identical task latents"

@@ -1,4 +1,4 @@
-"""CPU: the HOST side of both precisions -- weight layouts (K-duplicated matrices, fused QKV, padded channels), operand planes, which
+"""CPU: the HOST side of the three precisions -- weight layouts (K-duplicated matrices, fused QKV, padded channels), operand planes, which
 tensor feeds which launch, the planned scheduler rows, the pose encoder -- driven through the REAL host classes (host/unet.py, vae.py,
 pipeline.py, scheduler.py) with `tests/cpu_standin_ops.py` standing in for the kernel wrappers (a torch restatement of every wrapper's
 documented semantics and rounding points; the kernels themselves are checked on the GPU by tests/opcheck.py).  Compared with the fixtures
@@ -41,6 +41,17 @@ def test_parity_precision_host_wiring_reproduces_the_reference_fixture(cpu_stand
     err, _ = mc.case_golden_pipeline(name, precision="parity")
     assert "bookkeeping" not in err, "timestep bookkeeping differs from the reference pipeline's"
     assert err["latents"] <= 1e-4 and err["images"] <= 5e-4, err  # images: the fixtures store RGB in fp16 (floor 1.7e-4)
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_fp16_precision_host_wiring_meets_its_fixed_bounds(cpu_standin, name):
+    """precision "fp16" (fp32 tensors, one fp16 plane per MFMA operand, fp16 weights) through the same host classes: decoded RGB within
+    north_star's 1e-3 of the reference pipeline's fp32 output, latents within 2e-3 (modelcheck.FP16_BOUNDS)."""
+    mc = cpu_standin
+    err, _ = mc.case_golden_pipeline(name, precision="fp16")
+    assert "bookkeeping" not in err, "timestep bookkeeping differs from the reference pipeline's"
+    for q in err:
+        assert err[q] <= mc.FP16_BOUNDS[q], (q, err[q])
 
 
 @pytest.mark.parametrize("name", ["spatial", "dpm_temporal_v_heun_round2", "unipc_temporal_v_bh1_round2"])

@@ -5,9 +5,10 @@ set -e
 tag=$1; stem=$2; shift 2
 python -m diffuman4d_amd.build > /dev/null
 mkdir -p /tmp/vb
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -Iinclude -Idiffuman4d_amd/csrc -c diffuman4d_amd/csrc/$stem.hip -o /tmp/vb/${stem}_$tag.o
+extra=""; [ $stem = attention ] && extra="-mllvm -amdgpu-mfma-vgpr-form=1"  # build.EXTRA_FLAGS
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $extra "$@" -Iinclude -Idiffuman4d_amd/csrc -c diffuman4d_amd/csrc/$stem.hip -o /tmp/vb/${stem}_$tag.o
 objs=""
-for f in api gemm ff_fused conv_direct attention norm elementwise; do
+for f in $(python -c "from diffuman4d_amd import build; print(' '.join(s[:-4] for s in build.SOURCES))"); do  # every object host/lib.py resolves symbols from
   if [ $f = $stem ]; then objs="$objs /tmp/vb/${stem}_$tag.o"; else objs="$objs diffuman4d_amd/build/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o tools/dev/libdm4d_$tag.so $objs

@@ -20,6 +20,8 @@ def kernels(path):
 def norm(name):
     """A trailing `false` template argument added since (round 4: PAR = false on the GEMM / convolution kernels) does not make a
     different kernel: gemm_kernel_glds<128,128,2,2,false> of the old listing is <128,128,2,2,false,false> of the new one."""
+    name = re.sub(r'Li0E(EEvNS_10GemmParamsE)$', r'\1', name)   # round 5: PAR became an int (0 = fast) ...
+    name = re.sub(r'Lb0E(EEvNS_10AttnParamsE)$', r'\1', name)   # ... and attn_kernel got H16 = false
     return re.sub(r'Lb0E(EEvNS_10GemmParamsE)$', r'\1', name)
 
 

@@ -15,7 +15,11 @@ output stored in tests/golden/sd21_72x40.pt (`unet_f16_spatial`):
              outputs.  = an emulation of the shipped HIP path (compare with the measured HIP error).
   -attn      `operands` without the attention-internal roundings (Q / K / V, P): what the 3-D / 2-D attention adds.
 
-    python tools/error_budget.py [operands] [stream] [noattn]       # default: all three; ~1-4 min each on 8 cores
+  fp16       `operands` with the operands rounded to fp16 (3 more mantissa bits, one MFMA per product): the budget of
+             precision "fp16" (round 5) -- fp32 tensors between kernels, single-term fp16 MFMA operands.
+  fp16noattn the same without the attention-internal roundings.
+
+    python tools/error_budget.py [operands] [stream] [noattn] [fp16] [fp16noattn]   # default: first three; ~1-4 min each on 8 cores
 
 Result of the run recorded in DESIGN.md section 3 / profiles/r03_error_budget.log.
 """
@@ -33,10 +37,11 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests" / "golden"))
 BF = torch.bfloat16
+OPERAND_DTYPE = BF  # the type MFMA operands are rounded to: bf16 (fast precision) or fp16 (precision "fp16", the `fp16` / `fp16noattn` rows)
 
 
 def r(x):
-    return x.to(BF).float()
+    return x.to(OPERAND_DTYPE).float()
 
 
 class Policy:
@@ -141,9 +146,11 @@ def main():
     x, t = mk.unet_inputs(g["num_frames"], g["n_cond"], g["seed"])
     ref = g["out"].float()
     modes = {"operands": (True, True, False), "stream": (True, True, True), "noattn": (True, False, False),
-             "none": (False, False, False)}
+             "none": (False, False, False), "fp16": (True, True, False), "fp16noattn": (True, False, False)}
     print(f"reference: fp32 oracle output of tests/golden/sd21_72x40.pt (stored fp16); bf16-oracle yardstick {g['yard_bf16']:.3e}", flush=True)
     for name in which:
+        global OPERAND_DTYPE
+        OPERAND_DTYPE = torch.float16 if name.startswith("fp16") else BF
         P.operands, P.attn, P.stream = modes[name]
         t0 = time.time()
         with torch.no_grad():
