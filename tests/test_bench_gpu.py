@@ -43,6 +43,12 @@ def test_bench_prints_one_contract_line():
     pp = d["secondary"]["parity_precision"]
     assert pp["finite_outputs"] is True and pp["ms_per_step"] > d["ms_per_step"]
     assert {"linear", "conv3x3", "attention", "groupnorm", "layernorm", "split"} <= set(pp["kernel_breakdown_one_step"])
+    # the tolerance mode: precision "fp16" meets 1e-3 on this call at one MFMA per product -- faster than the parity precision
+    assert 0.0 < pm["fp16"]["rel_l2"] < 1e-3 and pm["fp16"]["meets_north_star"] is True
+    tm = d["secondary"]["tolerance_mode"]
+    assert tm["precision"] == "fp16" and tm["finite_outputs"] is True and d["ms_per_step"] < tm["ms_per_step_one_task"] < pp["ms_per_step_one_task"]
+    assert {"linear", "conv3x3", "attention", "groupnorm", "layernorm"} <= set(tm["kernel_breakdown_one_step"])
+    assert "seconds_f16_all" in cb and len(cb["seconds_f16_all"]) >= 1
     # the same-mode baseline of the N > 1 (grid) lines: one pass over the real round structure on this GPU
     g = d["secondary"]["grid"]
     assert g["n_gpus"] == 1 and g["window_calls_per_task"] == {"spatial": 1, "temporal": 3} and g["calls"] == (12 + 12) * 1 + 44 * 3
@@ -54,7 +60,7 @@ def test_bench_with_the_default_task_streams():
     """Default scheduling: the K steps are dealt to three tasks in flight (one HIP stream each, the runner's default); the roofline
     figures come from the one-task-at-a-time pass that follows the timed region."""
     r = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-grid-secondary",
-                        "--no-parity-precision", "--no-latent128"],
+                        "--no-parity-precision", "--no-tolerance-mode", "--no-latent128"],
                        cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -64,6 +70,17 @@ def test_bench_with_the_default_task_streams():
     assert abs(d["value"] - 2.0 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
     rf = d["roofline"]
     assert rf["launches"] == 3 * 48 and 0.05 < rf["frac"] < 1.0 and "one task in flight" in rf["measured_in"]
+
+
+@pytest.mark.gpu
+def test_bench_main_line_in_the_fp16_precision():
+    """`--precision fp16` (a profiling aid: the judged line stays bf16): the same units on the fp16 precision's kernels, `dtype` says so."""
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--precision", "fp16", "--no-grid-secondary", "--no-latent128",
+                        "--no-vae"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+    assert d["dtype"] == "fp16" and d["config"]["precision"] == "fp16" and d["config"]["finite_outputs"] is True and "cpu_baseline" not in d
+    assert "tolerance_mode" not in d["secondary"] and "parity_precision" not in d["secondary"]
 
 
 @pytest.mark.gpu
