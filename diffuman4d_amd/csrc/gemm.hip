@@ -1105,17 +1105,19 @@ int launch_strip2(hipStream_t st, GemmParams& p) {
 }
 
 // Phase-decomposed x2 upsampling convolution: grid = 4 phases x tiles, weights [4][N][4 Cin] from up2x_prepare_kernel
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int PAR = 0>
 int launch_up2x(hipStream_t st, GemmParams& p) {
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   p.splits = 1;
-  hipLaunchKernelGGL((conv_strip2_kernel<BM, BN, WM, WN, 2>), dim3(4 * tiles_m * p.tiles_n), dim3(WM * WN * 64), 0, st, p);
+  hipLaunchKernelGGL((conv_strip2_kernel<BM, BN, WM, WN, 2, PAR>), dim3(4 * tiles_m * p.tiles_n), dim3(WM * WN * 64), 0, st, p);
   return dm4d_check_launch("conv_strip2_kernel<up2x>");
 }
 
 // Wp[phase = 2 py + px][n][(dy, dx, ci)] = sum of W[n][(ky, kx, ci)] over the 3x3 taps that read low-resolution pixel
-// (dy, dx) of the phase: rows py = 0: {0} | {1, 2}, py = 1: {0, 1} | {2}; same along x.  fp32 sums, one rounding to bf16.
+// (dy, dx) of the phase: rows py = 0: {0} | {1, 2}, py = 1: {0, 1} | {2}; same along x.  fp32 sums, one rounding to bf16 (H16: fp16
+// weights in, one rounding to fp16).
+template <bool H16 = false>
 __global__ __launch_bounds__(256) void up2x_prepare_kernel(const u16* W, u16* Wp, int N, int Cin) {
   const int64_t total = (int64_t)4 * N * 4 * Cin;
   const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1131,8 +1133,11 @@ __global__ __launch_bounds__(256) void up2x_prepare_kernel(const u16* W, u16* Wp
   const int kx_lo = px == 0 ? (dx == 0 ? 0 : 1) : (dx == 0 ? 0 : 2), kx_hi = px == 0 ? (dx == 0 ? 0 : 2) : (dx == 0 ? 1 : 2);
   float acc = 0.f;
   for (int ky = ky_lo; ky <= ky_hi; ++ky)
-    for (int kx = kx_lo; kx <= kx_hi; ++kx) acc += bf2f(W[(int64_t)n * 9 * Cin + (ky * 3 + kx) * Cin + ci]);
-  Wp[id] = f2bf(acc);
+    for (int kx = kx_lo; kx <= kx_hi; ++kx) {
+      const u16 w = W[(int64_t)n * 9 * Cin + (ky * 3 + kx) * Cin + ci];
+      acc += H16 ? h2f(w) : bf2f(w);
+    }
+  Wp[id] = H16 ? f2h(acc) : f2bf(acc);
 }
 
 int g_tune_cfg = 0;  // 0 = heuristic; otherwise a kernel-configuration id (tuning hook, dm4d_tune_set_gemm_config)
@@ -1437,6 +1442,36 @@ extern "C" int dm4d_conv3x3_nhwc_f16(void* stream, const void* X, int B, int H, 
   p.ws = (ws && need && ws_bytes >= need) ? (float*)ws : nullptr;
   return launch_h16<true>((hipStream_t)stream, p);
 }
+
+extern "C" int dm4d_conv_up2x_prepare_f16(void* stream, const void* W, void* Wp, int Cout, int Cin) {
+  if (!W || !Wp || Cout <= 0 || Cin <= 0) return dm4d_set_error(DM4D_ERR_ARG, "conv_up2x_prepare_f16: null pointer or empty shape");
+  const int64_t total = (int64_t)16 * Cout * Cin;
+  hipLaunchKernelGGL(up2x_prepare_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const u16*)W, (u16*)Wp, Cout, Cin);
+  return dm4d_check_launch("up2x_prepare_kernel");
+}
+
+extern "C" int dm4d_conv_up2x_nhwc_f16(void* stream, const void* X, int B, int H, int W, int Cin, const void* Wp, void* Y, int Cout,
+                                       const void* bias, unsigned flags) {
+  if (!X || !Wp || !Y || B <= 0 || H <= 0 || W <= 0 || Cout <= 0)
+    return dm4d_set_error(DM4D_ERR_ARG, "conv_up2x_f16: null pointer or empty shape");
+  if (Cin % 64 != 0 || (Cout & 7) != 0)
+    return dm4d_set_error(DM4D_ERR_ARG, "conv_up2x_f16: Cin must be a multiple of 64 and Cout of 8 (use conv3x3_f16 with upsample = 1)");
+  if (flags & ~DM4D_EPI_F32OUT) return dm4d_set_error(DM4D_ERR_ARG, "conv_up2x_f16: only DM4D_EPI_F32OUT applies");
+  if ((int64_t)B * H * W * Cin >= (int64_t)1 << 31 || (int64_t)B * 4 * H * W * Cout >= (int64_t)1 << 31)
+    return dm4d_set_error(DM4D_ERR_ARG, "conv_up2x_f16: tensors of 2^31 or more elements are not supported (split the batch)");
+  GemmParams p{};
+  p.A = (const u16*)X; p.H = H; p.W = W; p.Cin = Cin; p.Ho = H; p.Wo = W; p.stride = 1; p.pad = 1; p.upsample = 0;
+  p.Wt = (const u16*)Wp; p.ldw = (int64_t)4 * Cin; p.C = (u16*)Y; p.ldc = Cout;
+  p.M = B * H * W; p.N = Cout; p.K = 4 * Cin;
+  p.bias = (const u16*)bias; p.rows_per_rb = H * W; p.flags = flags | DM4D_EPI_H16; p.out_scale = 1.0f; p.up_w = W;
+  if (!strip2_ok(p)) return dm4d_set_error(DM4D_ERR_ARG, "conv_up2x_f16: input or weights of 4 GiB or more");
+  hipStream_t st = (hipStream_t)stream;
+  const long tm256 = (p.M + 255) / 256;  // tile choice as dm4d_conv_up2x_nhwc_bf16
+  if (Cout % 128 == 0 && tm256 * (Cout / 128) >= 200) return launch_up2x<256, 128, 4, 2, 2>(st, p);
+  if (Cout % 128 == 0) return launch_up2x<128, 128, 2, 2, 2>(st, p);
+  return launch_up2x<128, 64, 4, 1, 2>(st, p);
+}
 #else
 
 extern "C" int dm4d_tune_set_gemm_config(int id) {
@@ -1515,7 +1550,7 @@ extern "C" int dm4d_conv3x3_nhwc_bf16_flags(void* stream, const void* X, int B, 
 extern "C" int dm4d_conv_up2x_prepare_bf16(void* stream, const void* W, void* Wp, int Cout, int Cin) {
   if (!W || !Wp || Cout <= 0 || Cin <= 0) return dm4d_set_error(DM4D_ERR_ARG, "conv_up2x_prepare: null pointer or empty shape");
   const int64_t total = (int64_t)16 * Cout * Cin;
-  hipLaunchKernelGGL(up2x_prepare_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(up2x_prepare_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const u16*)W, (u16*)Wp, Cout, Cin);
   return dm4d_check_launch("up2x_prepare_kernel");
 }

@@ -357,6 +357,68 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmParams& p, f32x16_t
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       continue;  // next 32-row block of this wave
     }
+    if constexpr (H16) {
+      // precision "fp16": the read-back loop of the fast precision (row / chunk from shifts, 32-bit offsets from wave-uniform
+      // row-block bases, the row-bias row from one division per 32-row block) with fp32 or fp16 side inputs and outputs
+      if (CPR_POW2 && vec_ok && p.up_w == 0 && p.ldc < (1 << 23) && (!p.res || p.ld_res < (1 << 23)) && (!p.rowbias || p.rows_per_rb > 0)) {
+        const int sb = f32side ? 4 : 2, ob = f32out ? 4 : 2;  // bytes per side-input / output element
+        const char* res_base = p.res ? reinterpret_cast<const char*>(p.res) + ((int64_t)m_base * p.ld_res + ncol0) * sb : nullptr;
+        char* c_base = reinterpret_cast<char*>(p.C) + ((int64_t)m_base * p.ldc + ncol0) * ob;
+        int q0 = 0, r0 = 0;
+        if (p.rowbias) {
+          q0 = m_base / p.rows_per_rb;
+          r0 = m_base - q0 * p.rows_per_rb;
+        }
+        auto side8 = [&](const char* ptr, float* t) {
+          if (f32side) {
+            const f32x4_t t0 = *reinterpret_cast<const f32x4_t*>(ptr), t1 = *reinterpret_cast<const f32x4_t*>(ptr + 16);
+            t[0] = t0[0]; t[1] = t0[1]; t[2] = t0[2]; t[3] = t0[3];
+            t[4] = t1[0]; t[5] = t1[1]; t[6] = t1[2]; t[7] = t1[3];
+          } else {
+            unpack8h(ldg16(ptr), t);
+          }
+        };
+#pragma unroll
+        for (int it = 0; it < (TASKS + 63) / 64; ++it) {
+          const int id = lane + it * 64;
+          if (TASKS % 64 != 0 && id >= TASKS) continue;
+          const int row = id >> cshift, cc = id & cmask;
+          if (m_base + row >= p.M || ncol0 + cc * 8 >= p.N) continue;
+          float v[8];
+          const float* s = stage + row * SLD + cc * 8;
+          const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(s), s1 = *reinterpret_cast<const f32x4_t*>(s + 4);
+          v[0] = s0[0]; v[1] = s0[1]; v[2] = s0[2]; v[3] = s0[3];
+          v[4] = s1[0]; v[5] = s1[1]; v[6] = s1[2]; v[7] = s1[3];
+          if (p.rowbias) {
+            const int q = p.rows_per_rb >= 32 ? q0 + ((r0 + row >= p.rows_per_rb) ? 1 : 0) : (m_base + row) / p.rows_per_rb;
+            float t[8];
+            side8(reinterpret_cast<const char*>(p.rowbias) + ((int64_t)q * p.ld_rb + ncol0 + cc * 8) * sb, t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += t[e];
+          }
+          if (p.res) {
+            float t[8];
+            side8(res_base + (uint32_t)((row * (int)p.ld_res + cc * 8) * sb), t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += t[e];
+          }
+          const float osc = (ncol0 + cc * 8 < p.scale_cols) ? p.out_scale * p.col_scale : p.out_scale;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= osc;
+          char* cp = c_base + (uint32_t)((row * (int)p.ldc + cc * 8) * ob);
+          if (f32out) {
+            const f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+            *reinterpret_cast<f32x4_t*>(cp) = o0;
+            *reinterpret_cast<f32x4_t*>(cp + 16) = o1;
+          } else {
+            stg16(cp, pack8h(v));
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // ... and the row reads ahead of the next block's stores
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        continue;  // next 32-row block of this wave
+      }
+    }
     for (int id = lane; id < TASKS; id += 64) {
       int row = id / CPR, cc = id % CPR;
       int m = m_base + row;

@@ -18,9 +18,46 @@ __host__ __device__ inline int gn_nchunk(int B, int HW) {
   return n;
 }
 
+// IO (template parameter of the GroupNorm / LayerNorm kernels): what a tensor element is on the way in and out.
+//   0  bf16 in, bf16 out, bf16 gamma / beta                    (fast precision)
+//   2  fp32 in, ONE fp16 plane out, fp16 gamma / beta          (precision "fp16": dm4d_groupnorm_nhwc_f32_f16 / dm4d_layernorm_f32_f16)
+// A "vector" is eight channels either way: 16 bytes of bf16, or 32 bytes of fp32 in and 16 bytes of fp16 out.
+template <int IO>
+struct NormIO;
+template <>
+struct NormIO<0> {
+  typedef u16 in_t;
+  typedef U4 raw_t;
+  static __device__ __forceinline__ raw_t ldraw(const u16* p) { return ldg16(p); }
+  static __device__ __forceinline__ void unpack(const raw_t& r, float* v) { unpack8(r, v); }
+  static __device__ __forceinline__ float ld1(const u16* p) { return bf2f(*p); }
+  static __device__ __forceinline__ void st8(u16* p, const float* v) { stg16(p, pack8(v)); }
+  static __device__ __forceinline__ void par8(const u16* p, float* v) { unpack8(ldg16(p), v); }
+};
+template <>
+struct NormIO<2> {
+  typedef float in_t;
+  struct raw_t {
+    f32x4_t a, b;
+  };
+  static __device__ __forceinline__ raw_t ldraw(const float* p) {
+    raw_t r;
+    r.a = *reinterpret_cast<const f32x4_t*>(p);
+    r.b = *reinterpret_cast<const f32x4_t*>(p + 4);
+    return r;
+  }
+  static __device__ __forceinline__ void unpack(const raw_t& r, float* v) {
+    v[0] = r.a[0]; v[1] = r.a[1]; v[2] = r.a[2]; v[3] = r.a[3];
+    v[4] = r.b[0]; v[5] = r.b[1]; v[6] = r.b[2]; v[7] = r.b[3];
+  }
+  static __device__ __forceinline__ float ld1(const float* p) { return *p; }
+  static __device__ __forceinline__ void st8(u16* p, const float* v) { stg16(p, pack8h(v)); }
+  static __device__ __forceinline__ void par8(const u16* p, float* v) { unpack8h(ldg16(p), v); }
+};
+
 struct GNParams {
-  const u16* X1;
-  const u16* X2;
+  const void* X1;  // NormIO<IO>::in_t
+  const void* X2;
   int C1, C2, B, HW, groups, nchunk;
   float eps;
   const u16* gamma;
@@ -35,25 +72,33 @@ struct GNParams {
 // var = Q / n - (S / n)^2 then cancel at the scale of the group's SPREAD, not of its mean -- with raw sums a group whose mean
 // is 200 standard deviations loses 15 of fp32's 24 bits (1e-2 relative error on the output; 3e-4 at 50).  All channels of a
 // group share the shift, so partial sums of different threads, chunks and kernels add up exactly as before.
+template <int IO = 0>
 __device__ __forceinline__ float gn_shift(const GNParams& p, int b, int g, int gs) {
+  typedef typename NormIO<IO>::in_t in_t;
   const int c = g * gs;  // first channel of the group, in the concatenated channel axis
-  return c < p.C1 ? bf2f(p.X1[(int64_t)b * p.HW * p.C1 + c]) : bf2f(p.X2[(int64_t)b * p.HW * p.C2 + (c - p.C1)]);
+  return c < p.C1 ? NormIO<IO>::ld1(static_cast<const in_t*>(p.X1) + (int64_t)b * p.HW * p.C1 + c)
+                  : NormIO<IO>::ld1(static_cast<const in_t*>(p.X2) + (int64_t)b * p.HW * p.C2 + (c - p.C1));
 }
 // the shifts of the eight channels of vector cv: groups of eight or more channels put at most two groups in a vector
+template <int IO = 0>
 __device__ __forceinline__ void gn_shift8(const GNParams& p, int b, int cv, int gs, float (&sh)[8]) {
   const int g0 = (cv * 8) / gs, g1 = (cv * 8 + 7) / gs;
   if (g1 - g0 <= 1) {
-    const float s0 = gn_shift(p, b, g0, gs), s1 = g1 != g0 ? gn_shift(p, b, g1, gs) : s0;
+    const float s0 = gn_shift<IO>(p, b, g0, gs), s1 = g1 != g0 ? gn_shift<IO>(p, b, g1, gs) : s0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) sh[e] = (cv * 8 + e) / gs == g0 ? s0 : s1;
   } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) sh[e] = gn_shift(p, b, (cv * 8 + e) / gs, gs);
+    for (int e = 0; e < 8; ++e) sh[e] = gn_shift<IO>(p, b, (cv * 8 + e) / gs, gs);
   }
 }
 
 // pass 1: per (batch, pixel chunk) partial sum / sum of squares of every group, fixed summation order
+template <int IO = 0>
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(GNParams p) {
+  typedef NormIO<IO> io;
+  typedef typename io::in_t in_t;
+  typedef typename io::raw_t raw_t;
   extern __shared__ __attribute__((aligned(16))) float sm[];  // [PPB][C][2]
   const int C = p.C1 + p.C2, CV = C / 8, CV1 = p.C1 / 8;
   const int b = blockIdx.x / p.nchunk, chunk = blockIdx.x % p.nchunk;
@@ -65,26 +110,26 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(GNParams p) {
   for (int slot = tid; slot < CV * PPB; slot += GN_THREADS) {
     const int cv = slot % CV, prow = slot / CV;
     float s[8], q[8], sh[8];
-    gn_shift8(p, b, cv, C / p.groups, sh);
+    gn_shift8<IO>(p, b, cv, C / p.groups, sh);
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
-    const u16* src;
+    const in_t* src;
     int ld, c;
     if (cv < CV1) {
-      src = p.X1 + (int64_t)b * p.HW * p.C1;
+      src = static_cast<const in_t*>(p.X1) + (int64_t)b * p.HW * p.C1;
       ld = p.C1;
       c = cv * 8;
     } else {
-      src = p.X2 + (int64_t)b * p.HW * p.C2;
+      src = static_cast<const in_t*>(p.X2) + (int64_t)b * p.HW * p.C2;
       ld = p.C2;
       c = (cv - CV1) * 8;
     }
     // two loads in flight per thread (a chunk is only a few passes long: one load per pass leaves the kernel waiting on a
     // memory round trip per pass; four cost 92 registers and three of the eight resident workgroups); the sums still run
     // pixel by pixel in ascending order
-    auto add = [&](const U4& r) {
+    auto add = [&](const raw_t& r) {
       float v[8];
-      unpack8(r, v);
+      io::unpack(r, v);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float d = v[e] - sh[e];
@@ -95,12 +140,12 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(GNParams p) {
     int px = p0 + prow;
 #pragma nounroll
     for (; px + PPB < p1; px += 2 * PPB) {
-      const u16* a = src + (int64_t)px * ld + c;
-      const U4 r0 = ldg16(a), r1 = ldg16(a + (int64_t)PPB * ld);
+      const in_t* a = src + (int64_t)px * ld + c;
+      const raw_t r0 = io::ldraw(a), r1 = io::ldraw(a + (int64_t)PPB * ld);
       add(r0);
       add(r1);
     }
-    for (; px < p1; px += PPB) add(ldg16(src + (int64_t)px * ld + c));
+    for (; px < p1; px += PPB) add(io::ldraw(src + (int64_t)px * ld + c));
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       sm[(prow * C + cv * 8 + e) * 2 + 0] = s[e];
@@ -123,7 +168,11 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(GNParams p) {
 }
 
 // pass 2: y = (x - mean) * rstd * gamma + beta, optional SiLU; writes the concatenated tensor
+template <int IO = 0>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GNParams p) {
+  typedef NormIO<IO> io;
+  typedef typename io::in_t in_t;
+  typedef typename io::raw_t raw_t;
   extern __shared__ __attribute__((aligned(16))) float sm[];  // reduction scratch, then mean[g], rstd[g]
   const int C = p.C1 + p.C2, CV = C / 8, CV1 = p.C1 / 8;
   float* sc = sm;  // reduction scratch
@@ -163,7 +212,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GNParams p) {
     const float dm = s / n;  // mean of (x - shift)
     float var = q / n - dm * dm;
     var = var < 0.f ? 0.f : var;
-    mean[g] = gn_shift(p, b, g, gs) + dm;
+    mean[g] = gn_shift<IO>(p, b, g, gs) + dm;
     rstd[g] = rsqrtf(var + p.eps);
   }
   __syncthreads();
@@ -175,8 +224,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GNParams p) {
     float a[8], sft[8];
     {
       float gm[8], bt[8];
-      unpack8(ldg16(p.gamma + cv * 8), gm);
-      unpack8(ldg16(p.beta + cv * 8), bt);
+      io::par8(p.gamma + cv * 8, gm);
+      io::par8(p.beta + cv * 8, bt);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int g = (cv * 8 + e) / gs;
@@ -184,37 +233,37 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GNParams p) {
         sft[e] = bt[e] - mean[g] * a[e];
       }
     }
-    const u16* src;
+    const in_t* src;
     int ld;
     if (cv < CV1) {
-      src = p.X1 + (int64_t)b * p.HW * p.C1 + cv * 8;
+      src = static_cast<const in_t*>(p.X1) + (int64_t)b * p.HW * p.C1 + cv * 8;
       ld = p.C1;
     } else {
-      src = p.X2 + (int64_t)b * p.HW * p.C2 + (cv - CV1) * 8;
+      src = static_cast<const in_t*>(p.X2) + (int64_t)b * p.HW * p.C2 + (cv - CV1) * 8;
       ld = p.C2;
     }
     u16* dst = p.Y + (int64_t)b * p.HW * C + cv * 8;
-    auto put = [&](const U4& r, int px) {
+    auto put = [&](const raw_t& r, int px) {
       float v[8];
-      unpack8(r, v);
+      io::unpack(r, v);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float y = v[e] * a[e] + sft[e];
         v[e] = p.silu ? silu_f(y) : y;
       }
-      stg16(dst + (int64_t)px * C, pack8(v));
+      io::st8(dst + (int64_t)px * C, v);
     };
     int px = p0 + prow;
 #pragma nounroll
     for (; px + 3 * PPB < p1; px += 4 * PPB) {  // four loads in flight per thread, as in the statistics pass
-      const u16* s0 = src + (int64_t)px * ld;
-      const U4 r0 = ldg16(s0), r1 = ldg16(s0 + (int64_t)PPB * ld), r2 = ldg16(s0 + (int64_t)2 * PPB * ld), r3 = ldg16(s0 + (int64_t)3 * PPB * ld);
+      const in_t* s0 = src + (int64_t)px * ld;
+      const raw_t r0 = io::ldraw(s0), r1 = io::ldraw(s0 + (int64_t)PPB * ld), r2 = io::ldraw(s0 + (int64_t)2 * PPB * ld), r3 = io::ldraw(s0 + (int64_t)3 * PPB * ld);
       put(r0, px);
       put(r1, px + PPB);
       put(r2, px + 2 * PPB);
       put(r3, px + 3 * PPB);
     }
-    for (; px < p1; px += PPB) put(ldg16(src + (int64_t)px * ld), px);
+    for (; px < p1; px += PPB) put(io::ldraw(src + (int64_t)px * ld), px);
   }
 }
 
@@ -225,8 +274,11 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GNParams p) {
 // the summation order is fixed by (HW, C, groups) only, never by the batch.
 constexpr int GN_RES_MAXGPS = 8;
 
-template <int NV>
+template <int NV, int IO = 0>
 __global__ __launch_bounds__(GN_THREADS) void gn_resident_kernel(GNParams p, int gps, int SV, int PPB, int NS, int xcd_map) {
+  typedef NormIO<IO> io;
+  typedef typename io::in_t in_t;
+  typedef typename io::raw_t raw_t;
   __shared__ float sm[2 * 8 * GN_THREADS];  // [PPB][SC][2]
   __shared__ float sm2[2 * GN_THREADS];     // [PARTS][SC][2]
   __shared__ float stat[2 * GN_RES_MAXGPS];
@@ -243,24 +295,24 @@ __global__ __launch_bounds__(GN_THREADS) void gn_resident_kernel(GNParams p, int
   const int tid = threadIdx.x, sv = tid % SV, prow = tid / SV;
   const bool active = prow < PPB;
   const int cv = slab * gps * gs / 8 + sv;  // vector index in the concatenated channel axis
-  const u16* src;
+  const in_t* src;
   int ld;
   if (cv < CV1) {
-    src = p.X1 + (int64_t)b * p.HW * p.C1 + cv * 8;
+    src = static_cast<const in_t*>(p.X1) + (int64_t)b * p.HW * p.C1 + cv * 8;
     ld = p.C1;
   } else {
-    src = p.X2 + (int64_t)b * p.HW * p.C2 + (cv - CV1) * 8;
+    src = static_cast<const in_t*>(p.X2) + (int64_t)b * p.HW * p.C2 + (cv - CV1) * 8;
     ld = p.C2;
   }
-  U4 r[NV];
+  raw_t r[NV];
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int px = prow + k * PPB;
-    if (active && px < p.HW) r[k] = ldg16(src + (int64_t)px * ld);
+    if (active && px < p.HW) r[k] = io::ldraw(src + (int64_t)px * ld);
   }
   {
     float s[8], q[8], sh[8];
-    gn_shift8(p, b, cv, gs, sh);
+    gn_shift8<IO>(p, b, cv, gs, sh);
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
 #pragma unroll
@@ -268,7 +320,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_resident_kernel(GNParams p, int
       const int px = prow + k * PPB;
       if (active && px < p.HW) {
         float v[8];
-        unpack8(r[k], v);
+        io::unpack(r[k], v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float d = v[e] - sh[e];
@@ -319,7 +371,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_resident_kernel(GNParams p, int
         const float dm = s / n;  // mean of (x - shift)
         float var = q / n - dm * dm;
         var = var < 0.f ? 0.f : var;
-        stat[g * 2 + 0] = gn_shift(p, b, slab * gps + g, gs) + dm;
+        stat[g * 2 + 0] = gn_shift<IO>(p, b, slab * gps + g, gs) + dm;
         stat[g * 2 + 1] = rsqrtf(var + p.eps);
       }
     }
@@ -329,8 +381,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_resident_kernel(GNParams p, int
   float a[8], sft[8];
   {
     float gm[8], bt[8];
-    unpack8(ldg16(p.gamma + cv * 8), gm);
-    unpack8(ldg16(p.beta + cv * 8), bt);
+    io::par8(p.gamma + cv * 8, gm);
+    io::par8(p.beta + cv * 8, bt);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int g = (sv * 8 + e) / gs;
@@ -344,13 +396,13 @@ __global__ __launch_bounds__(GN_THREADS) void gn_resident_kernel(GNParams p, int
     const int px = prow + k * PPB;
     if (px < p.HW) {
       float v[8];
-      unpack8(r[k], v);
+      io::unpack(r[k], v);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float y = v[e] * a[e] + sft[e];
         v[e] = p.silu ? silu_f(y) : y;
       }
-      stg16(dst + (int64_t)px * C, pack8(v));
+      io::st8(dst + (int64_t)px * C, v);
     }
   }
 }
@@ -373,9 +425,10 @@ bool gn_resident_plan(int C, int HW, int groups, int* gps, int* SV, int* PPB, in
 }
 
 // LayerNorm: one wave per row, row kept in registers (two-pass mean / variance)
-template <int NV>  // 16-byte vectors per lane
-__global__ __launch_bounds__(256) void ln_kernel(const u16* X, int64_t ldx, const u16* gamma, const u16* beta, u16* Y,
+template <int NV, int IO = 0>  // eight-channel vectors per lane
+__global__ __launch_bounds__(256) void ln_kernel(const typename NormIO<IO>::in_t* X, int64_t ldx, const u16* gamma, const u16* beta, u16* Y,
                                                  int64_t ldy, int M, int C, float eps) {
+  typedef NormIO<IO> io;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
   if (row >= M) return;
@@ -387,7 +440,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const u16* X, int64_t ldx, cons
     const int cv = lane + 64 * i;
     on[i] = cv < CV;
     if (on[i]) {
-      unpack8(ldg16(X + (int64_t)row * ldx + cv * 8), v[i]);
+      io::unpack(io::ldraw(X + (int64_t)row * ldx + cv * 8), v[i]);
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
@@ -400,10 +453,10 @@ __global__ __launch_bounds__(256) void ln_kernel(const u16* X, int64_t ldx, cons
     const int cv = lane + 64 * i;
     if (on[i]) {
       float g[8], bt[8], y[8];
-      unpack8(ldg16(gamma + cv * 8), g);
-      unpack8(ldg16(beta + cv * 8), bt);
+      io::par8(gamma + cv * 8, g);
+      io::par8(beta + cv * 8, bt);
       ln_row_apply(v[i], mu, rs, g, bt, y);
-      stg16(Y + (int64_t)row * ldy + cv * 8, pack8(y));
+      io::st8(Y + (int64_t)row * ldy + cv * 8, y);
     }
   }
 }
@@ -491,16 +544,16 @@ extern "C" size_t dm4d_groupnorm_ws_bytes(int B, int HW, int groups) {
   return (size_t)B * gn_nchunk(B, HW) * groups * 2 * sizeof(float);
 }
 
-extern "C" int dm4d_groupnorm_nhwc_bf16(void* stream, const void* X1, int C1, const void* X2, int C2, int B, int HW,
-                                        int groups, float eps, const void* gamma, const void* beta, void* Y,
-                                        int apply_silu, void* ws) {
+template <int IO>
+static int groupnorm_impl(void* stream, const void* X1, int C1, const void* X2, int C2, int B, int HW, int groups, float eps,
+                          const void* gamma, const void* beta, void* Y, int apply_silu, void* ws) {
   if (!X1 || !gamma || !beta || !Y || !ws || B <= 0 || HW <= 0 || groups <= 0)
     return dm4d_set_error(DM4D_ERR_ARG, "groupnorm: null pointer or empty shape");
   if (!X2) C2 = 0;
   const int C = C1 + C2;
   if ((C1 & 7) || (C2 & 7) || C % groups != 0 || C > GN_MAXC)
     return dm4d_set_error(DM4D_ERR_ARG, "groupnorm: channels must be multiples of 8, divisible by groups, <= 4096");
-  GNParams p{(const u16*)X1, (const u16*)X2, C1, C2, B, HW, groups, gn_nchunk(B, HW), eps,
+  GNParams p{X1, X2, C1, C2, B, HW, groups, gn_nchunk(B, HW), eps,
              (const u16*)gamma, (const u16*)beta, (u16*)Y, apply_silu, (float*)ws};
   hipStream_t st = (hipStream_t)stream;
   {
@@ -508,10 +561,10 @@ extern "C" int dm4d_groupnorm_nhwc_bf16(void* stream, const void* X1, int C1, co
     if (g_gn_resident && gn_resident_plan(C, HW, groups, &gps, &SV, &RPB, &NV)) {
       const int NS = groups / gps, xcd = (B % 8 == 0);
       const dim3 grid(B * NS), blk(GN_THREADS);
-      if (NV <= 2) hipLaunchKernelGGL(gn_resident_kernel<2>, grid, blk, 0, st, p, gps, SV, RPB, NS, xcd);
-      else if (NV <= 4) hipLaunchKernelGGL(gn_resident_kernel<4>, grid, blk, 0, st, p, gps, SV, RPB, NS, xcd);
-      else if (NV <= 8) hipLaunchKernelGGL(gn_resident_kernel<8>, grid, blk, 0, st, p, gps, SV, RPB, NS, xcd);
-      else hipLaunchKernelGGL(gn_resident_kernel<16>, grid, blk, 0, st, p, gps, SV, RPB, NS, xcd);
+      if (NV <= 2) hipLaunchKernelGGL((gn_resident_kernel<2, IO>), grid, blk, 0, st, p, gps, SV, RPB, NS, xcd);
+      else if (NV <= 4) hipLaunchKernelGGL((gn_resident_kernel<4, IO>), grid, blk, 0, st, p, gps, SV, RPB, NS, xcd);
+      else if (NV <= 8) hipLaunchKernelGGL((gn_resident_kernel<8, IO>), grid, blk, 0, st, p, gps, SV, RPB, NS, xcd);
+      else hipLaunchKernelGGL((gn_resident_kernel<16, IO>), grid, blk, 0, st, p, gps, SV, RPB, NS, xcd);
       return dm4d_check_launch("gn_resident_kernel");
     }
   }
@@ -519,11 +572,47 @@ extern "C" int dm4d_groupnorm_nhwc_bf16(void* stream, const void* X1, int C1, co
   const int PPB = CV >= GN_THREADS ? 1 : GN_THREADS / CV;
   const size_t sm1 = (size_t)PPB * C * 2 * sizeof(float);
   const size_t sm2 = ((size_t)(2 * C > 2 * GN_THREADS ? 2 * C : 2 * GN_THREADS) + 2 * groups) * sizeof(float);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(B * p.nchunk), dim3(GN_THREADS), sm1, st, p);
+  hipLaunchKernelGGL(gn_stats_kernel<IO>, dim3(B * p.nchunk), dim3(GN_THREADS), sm1, st, p);
   int rc = dm4d_check_launch("gn_stats_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(B * p.nchunk), dim3(GN_THREADS), sm2, st, p);
+  hipLaunchKernelGGL(gn_apply_kernel<IO>, dim3(B * p.nchunk), dim3(GN_THREADS), sm2, st, p);
   return dm4d_check_launch("gn_apply_kernel");
+}
+
+extern "C" int dm4d_groupnorm_nhwc_bf16(void* stream, const void* X1, int C1, const void* X2, int C2, int B, int HW,
+                                        int groups, float eps, const void* gamma, const void* beta, void* Y,
+                                        int apply_silu, void* ws) {
+  return groupnorm_impl<0>(stream, X1, C1, X2, C2, B, HW, groups, eps, gamma, beta, Y, apply_silu, ws);
+}
+
+// precision "fp16": fp32 NHWC in (shifted fp32 statistics as above), one fp16 plane out.  Channel counts that are not multiples
+// of 8 take the general kernels of parity.hip (dm4d_groupnorm_f32_f16_general: fp64 statistics, one / four channels per thread).
+extern "C" int dm4d_groupnorm_f32_f16_general(void* stream, const float* X1, int C1, const float* X2, int C2, int B, int HW, int groups,
+                                              float eps, const void* gamma, const void* beta, void* Y, int apply_silu, void* ws);
+extern "C" int dm4d_groupnorm_nhwc_f32_f16(void* stream, const float* X1, int C1, const float* X2, int C2, int B, int HW, int groups,
+                                           float eps, const void* gamma, const void* beta, void* Y, int apply_silu, void* ws) {
+  if (!X2) C2 = 0;
+  if ((C1 & 7) || (C2 & 7) || (((uintptr_t)X1) & 15) || (X2 && (((uintptr_t)X2) & 15)) || (((uintptr_t)Y) & 15))
+    return dm4d_groupnorm_f32_f16_general(stream, X1, C1, X2, C2, B, HW, groups, eps, gamma, beta, Y, apply_silu, ws);
+  return groupnorm_impl<2>(stream, X1, C1, X2, C2, B, HW, groups, eps, gamma, beta, Y, apply_silu, ws);
+}
+
+template <int IO>
+static int layernorm_impl(void* stream, const void* X, int64_t ldx, const void* gamma, const void* beta, void* Y, int64_t ldy, int M,
+                          int C, float eps) {
+  typedef typename NormIO<IO>::in_t in_t;
+  hipStream_t st = (hipStream_t)stream;
+  const int nv = (C / 8 + 63) / 64;
+  dim3 grid((M + 3) / 4), block(256);
+#define LN_LAUNCH(NV) \
+  hipLaunchKernelGGL((ln_kernel<NV, IO>), grid, block, 0, st, (const in_t*)X, ldx, (const u16*)gamma, (const u16*)beta, (u16*)Y, ldy, M, C, eps)
+  if (nv <= 1) LN_LAUNCH(1);
+  else if (nv <= 2) LN_LAUNCH(2);
+  else if (nv <= 3) LN_LAUNCH(3);
+  else if (nv <= 4) LN_LAUNCH(4);
+  else LN_LAUNCH(8);
+#undef LN_LAUNCH
+  return dm4d_check_launch("ln_kernel");
 }
 
 extern "C" int dm4d_layernorm_bf16(void* stream, const void* X, int64_t ldx, const void* gamma, const void* beta,
@@ -532,18 +621,21 @@ extern "C" int dm4d_layernorm_bf16(void* stream, const void* X, int64_t ldx, con
     return dm4d_set_error(DM4D_ERR_ARG, "layernorm: null pointer or empty shape");
   if ((C & 7) || (ldx & 7) || (ldy & 7) || C > 64 * 8 * 8)
     return dm4d_set_error(DM4D_ERR_ARG, "layernorm: C must be a multiple of 8 and <= 4096");
-  hipStream_t st = (hipStream_t)stream;
-  const int nv = (C / 8 + 63) / 64;
-  dim3 grid((M + 3) / 4), block(256);
-#define LN_LAUNCH(NV) \
-  hipLaunchKernelGGL((ln_kernel<NV>), grid, block, 0, st, (const u16*)X, ldx, (const u16*)gamma, (const u16*)beta, (u16*)Y, ldy, M, C, eps)
-  if (nv <= 1) LN_LAUNCH(1);
-  else if (nv <= 2) LN_LAUNCH(2);
-  else if (nv <= 3) LN_LAUNCH(3);
-  else if (nv <= 4) LN_LAUNCH(4);
-  else LN_LAUNCH(8);
-#undef LN_LAUNCH
-  return dm4d_check_launch("ln_kernel");
+  return layernorm_impl<0>(stream, X, ldx, gamma, beta, Y, ldy, M, C, eps);
+}
+
+// precision "fp16": fp32 rows in (kept in registers: read once), one fp16 plane out.  Rows that are not 16-byte vectors of eight
+// channels take the general kernel of parity.hip.
+extern "C" int dm4d_layernorm_f32_f16_general(void* stream, const float* X, int64_t ldx, const void* gamma, const void* beta, void* Y,
+                                              int64_t ldy, int M, int C, float eps);
+extern "C" int dm4d_layernorm_f32_f16(void* stream, const float* X, int64_t ldx, const void* gamma, const void* beta, void* Y,
+                                      int64_t ldy, int M, int C, float eps) {
+  if (!X || !gamma || !beta || !Y || M <= 0 || C <= 0 || ldx < C || ldy < (int64_t)C)
+    return dm4d_set_error(DM4D_ERR_ARG, "layernorm_f32_f16: bad arguments");
+  if ((C & 7) || (ldx & 3) || (ldy & 7) || C > 64 * 8 * 8 || (((uintptr_t)X) & 15) || (((uintptr_t)Y) & 15) || (((uintptr_t)gamma) & 15) ||
+      (((uintptr_t)beta) & 15))
+    return dm4d_layernorm_f32_f16_general(stream, X, ldx, gamma, beta, Y, ldy, M, C, eps);
+  return layernorm_impl<2>(stream, X, ldx, gamma, beta, Y, ldy, M, C, eps);
 }
 
 extern "C" int dm4d_softmax_rows_bf16(void* stream, const void* S, int64_t lds, void* P, int64_t ldp, int M, int N,

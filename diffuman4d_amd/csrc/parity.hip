@@ -699,7 +699,7 @@ extern "C" int dm4d_groupnorm_nhwc_f32_split(void* stream, const float* X1, int 
   return groupnorm_f32_impl<false>(stream, X1, C1, X2, C2, B, HW, groups, eps, gamma, beta, Y, apply_silu, ws);
 }
 
-extern "C" int dm4d_groupnorm_nhwc_f32_f16(void* stream, const float* X1, int C1, const float* X2, int C2, int B, int HW, int groups,
+extern "C" int dm4d_groupnorm_f32_f16_general(void* stream, const float* X1, int C1, const float* X2, int C2, int B, int HW, int groups,
                                            float eps, const void* gamma, const void* beta, void* Y, int apply_silu, void* ws) {
   return groupnorm_f32_impl<true>(stream, X1, C1, X2, C2, B, HW, groups, eps, gamma, beta, Y, apply_silu, ws);
 }
@@ -713,7 +713,7 @@ extern "C" int dm4d_layernorm_f32_split(void* stream, const float* X, int64_t ld
   return dm4d_check_launch("ln32_kernel");
 }
 
-extern "C" int dm4d_layernorm_f32_f16(void* stream, const float* X, int64_t ldx, const void* gamma, const void* beta, void* Y,
+extern "C" int dm4d_layernorm_f32_f16_general(void* stream, const float* X, int64_t ldx, const void* gamma, const void* beta, void* Y,
                                       int64_t ldy, int M, int C, float eps) {
   if (!X || !gamma || !beta || !Y || M <= 0 || C <= 0 || ldx < C || ldy < (int64_t)C)
     return dm4d_set_error(DM4D_ERR_ARG, "layernorm_f32_f16: bad arguments");

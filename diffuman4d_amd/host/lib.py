@@ -76,6 +76,8 @@ SIGNATURES = {
     "dm4d_gemm_f16": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _vp, _i64, _vp, _i64, _i, _i, _i, _vp, _vp, _i64, _i, _vp, _i64, _u, _f, _i, _f]),
     "dm4d_conv3x3_nhwc_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i64, _vp, _i64, _f, _u, _vp,
                                    C.c_size_t]),
+    "dm4d_conv_up2x_prepare_f16": (_i, [_vp, _vp, _vp, _i, _i]),
+    "dm4d_conv_up2x_nhwc_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _u]),
     "dm4d_to_f16_f32": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _i64, _i, _vp, _i64, _i64, _i, _i, _f]),
     "dm4d_groupnorm_nhwc_f32_f16": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp]),
     "dm4d_layernorm_f32_f16": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _f]),

@@ -275,6 +275,7 @@ def split(x: torch.Tensor, x2: Optional[torch.Tensor] = None, *, cpad: Optional[
     return y
 
 
+UP2X_PHASE = os.environ.get("DM4D_UP2X_PHASE", "1") != "0"  # Upsample2D as four 2x2 phase convolutions; off = the gather kernel (A/B, tests)
 FF_FUSED = os.environ.get("DM4D_FF_FUSED", "1") != "0"  # level-0 feed-forward (C = 320) as one launch; off = the two-GEMM form (A/B, tests)
 # the attention output projection + residual as a prologue of that launch (FeedForward.after_attention); off = its own GEMM (A/B, tests)
 FF_PROJ_FUSED = os.environ.get("DM4D_FF_PROJ_FUSED", "1") != "0"
@@ -358,11 +359,13 @@ def conv_up2x_prepare(wt: torch.Tensor) -> torch.Tensor:
     """3x3 weights [Cout, 9*Cin] ((ky,kx,ci) order) -> the four 2x2 phase kernels [4, Cout, 4*Cin] of conv_up2x (once per
     layer: sums of the taps that read the same low-resolution pixel, fp32, rounded to bf16 once)."""
     lib = _l.load()
-    _req(wt, "wt")
+    h16 = wt.dtype == F16  # precision "fp16": fp16 taps in, fp16 phase kernels out
+    _req(wt, "wt", F16 if h16 else BF16)
     assert wt.is_contiguous() and wt.shape[1] % 9 == 0
     Cout, Cin = wt.shape[0], wt.shape[1] // 9
-    wp = torch.empty((4, Cout, 4 * Cin), dtype=BF16, device=wt.device)
-    _l.check(lib.dm4d_conv_up2x_prepare_bf16(_stream(), _p(wt), _p(wp), Cout, Cin), "dm4d_conv_up2x_prepare_bf16")
+    wp = torch.empty((4, Cout, 4 * Cin), dtype=wt.dtype, device=wt.device)
+    fn = lib.dm4d_conv_up2x_prepare_f16 if h16 else lib.dm4d_conv_up2x_prepare_bf16
+    _l.check(fn(_stream(), _p(wt), _p(wp), Cout, Cin), "dm4d_conv_up2x_prepare")
     return wp
 
 
@@ -381,15 +384,20 @@ class Upsampler:
         """parity (precision "parity"): wt is duplicated along Cin, the input fp32; the phase kernels -- whose weights are SUMS of taps
         rounded to bf16 once more, a deviation from the checkpoint's arithmetic -- are not used: the gather kernel reads the upsampled
         image of the two-term operand through index arithmetic and multiplies by the checkpoint's own weights."""
-        # h16 (precision "fp16"; implies `parity` = fp32 tensors): fp16 weights, one fp16 operand plane, the same gather kernel
+        # h16 (precision "fp16"; implies `parity` = fp32 tensors): fp16 weights, one fp16 operand plane; the phase kernels ARE used (their
+        # extra weight rounding is 2^-12 relative in fp16, inside the precision's budget -- in bf16 it would be 2^-9)
         self.wt, self.bias, self.wp, self.parity, self.h16 = wt, bias, None, parity or h16, h16
-        self.phase = (not self.parity) and conv_up2x_supported(wt.shape[1] // 9, wt.shape[0])
+        self.phase = (h16 or not self.parity) and conv_up2x_supported(wt.shape[1] // 9, wt.shape[0]) and UP2X_PHASE
         if self.phase and wt.is_cuda:
             with torch.cuda.device(wt.device):
                 self.wp = conv_up2x_prepare(wt)
                 torch.cuda.current_stream(wt.device).synchronize()
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if self.h16 and self.phase and x.numel() * 2 < (1 << 32):
+            if self.wp is None or self.wp.device != x.device:
+                raise _l.Dm4dError("Upsampler: phase kernels were not prepared on the input's device")
+            return conv_up2x(split(x, h16=True), self.wp, bias=self.bias, out_f32=True)
         if self.parity:
             return conv3x3(split(x, h16=self.h16), self.wt, bias=self.bias, upsample=True, out_f32=True)
         # the phase kernel addresses its input with 32-bit byte offsets: inputs of 4 GiB or more take the gather kernel
@@ -401,20 +409,27 @@ class Upsampler:
         return conv_up2x(x, self.wp, bias=self.bias)
 
 
-def conv_up2x(x: torch.Tensor, wp: torch.Tensor, *, bias=None) -> torch.Tensor:
-    """conv3x3(nearest_upsample_x2(x)) from the phase kernels of conv_up2x_prepare: x [B,H,W,Cin] -> [B,2H,2W,Cout]."""
+def conv_up2x(x: torch.Tensor, wp: torch.Tensor, *, bias=None, out_f32: bool = False) -> torch.Tensor:
+    """conv3x3(nearest_upsample_x2(x)) from the phase kernels of conv_up2x_prepare: x [B,H,W,Cin] -> [B,2H,2W,Cout].
+    fp16 x / wp / bias (precision "fp16"): fp32 (out_f32) or fp16 result."""
     lib = _l.load()
-    _req(x, "x"), _req(wp, "wp")
-    assert x.is_contiguous() and wp.is_contiguous()
+    h16 = wp.dtype == F16
+    dt = F16 if h16 else BF16
+    _req(x, "x", dt), _req(wp, "wp", dt)
+    assert x.is_contiguous() and wp.is_contiguous() and (h16 or not out_f32)
     B, H, W, Cin = x.shape
     Cout = wp.shape[1]
     assert wp.shape == (4, Cout, 4 * Cin), (wp.shape, Cin)
-    y = torch.empty((B, 2 * H, 2 * W, Cout), dtype=BF16, device=x.device)
+    y = torch.empty((B, 2 * H, 2 * W, Cout), dtype=F32 if out_f32 else dt, device=x.device)
     # credited with the multiply-adds it executes (4 taps per output pixel), not the 9 of the op it replaces
     with _Prof("conv3x3", 2.0 * B * 4 * H * W * 4 * Cin * Cout, "flop", B * 4 * H * W):
-        rc = lib.dm4d_conv_up2x_nhwc_bf16(_stream(), _p(x), B, H, W, Cin, _p(wp), _p(y), Cout, _p(bias))
-    _l.check(rc, "dm4d_conv_up2x_nhwc_bf16")
-    _trace("conv_up2x", y, x=x, wp=wp, bias=bias)
+        if h16:
+            rc = lib.dm4d_conv_up2x_nhwc_f16(_stream(), _p(x), B, H, W, Cin, _p(wp), _p(y), Cout, _p(bias), _l.EPI_F32OUT if out_f32 else 0)
+        else:
+            rc = lib.dm4d_conv_up2x_nhwc_bf16(_stream(), _p(x), B, H, W, Cin, _p(wp), _p(y), Cout, _p(bias))
+    _l.check(rc, "dm4d_conv_up2x_nhwc")
+    if not h16:
+        _trace("conv_up2x", y, x=x, wp=wp, bias=bias)
     return y
 
 

@@ -225,11 +225,13 @@ class _TransformerBlock:
             raise NotImplementedError("cross-attention (attn2) checkpoints are not supported: the reference never "
                                       "passes encoder_hidden_states (SURVEY.md section 0)")
 
-    def __call__(self, h: torch.Tensor, batch: int, seq: int, shard=None) -> torch.Tensor:
+    def __call__(self, h: torch.Tensor, batch: int, seq: int, shard=None, operand_out: bool = False) -> torch.Tensor:
         """h [M, C] token-major; attention over `batch` sequences of `seq` tokens (attention.py:68-90).
-        shard (parallel.FrameShard): `seq` is this rank's share of the frame-folded sequence; K/V are all-gathered."""
+        shard (parallel.FrameShard): `seq` is this rank's share of the frame-folded sequence; K/V are all-gathered.
+        operand_out (wide precisions): the result leaves as the OPERAND of the next contraction (the transformer's proj_out, when this is
+        its last block) instead of an fp32 tensor: the same one rounding ops.split would apply to the stored fp32 sum, without storing it."""
         if self.wide:
-            return self._call_wide(h, batch, seq, shard)
+            return self._call_wide(h, batch, seq, shard, operand_out)
         C = h.shape[1]
         n = ops.layernorm(h, self.n1w, self.n1b, 1e-5)
         if shard is None:
@@ -245,7 +247,7 @@ class _TransformerBlock:
         # layernorm, gemm(GEGLU), gemm(residual) elsewhere
         return self.ff.after_attention(a, self.ow, self.ob, h, (self.n3w, self.n3b, 1e-5))
 
-    def _call_wide(self, h: torch.Tensor, batch: int, seq: int, shard=None) -> torch.Tensor:
+    def _call_wide(self, h: torch.Tensor, batch: int, seq: int, shard=None, operand_out: bool = False) -> torch.Tensor:
         """The same block on an fp32 residual stream: LayerNorm -> operand; QKV projection -> operand planes; attention -> operand;
         output projection + fp32 residual; LayerNorm; GEGLU -> operand; projection + residual.  Parity precision: two-term operands,
         three MFMA terms per attention product.  fp16 precision: one fp16 plane each, Q pre-scaled in the projection's epilogue, the
@@ -275,7 +277,7 @@ class _TransformerBlock:
             a = ops.attention_split(None, batch, self.heads, seq, self.scale, q=q, kv=kvg, kv_seq=shard.world * seq)
         h = ops.gemm(a, self.ow, bias=self.ob, residual=h, out_f32=True)
         f = ops.gemm(ops.layernorm(h, self.n3w, self.n3b, 1e-5), w1, bias=b1, geglu=True, split_out=True)
-        return ops.gemm(f, w2, bias=b2, residual=h, out_f32=True)
+        return ops.gemm(f, w2, bias=b2, residual=h, out_f32=not operand_out, split_out=operand_out)
 
 
 class _Transformer:
@@ -300,9 +302,11 @@ class _Transformer:
         P = self.wide
         n = ops.groupnorm(x, self.nw, self.nb, self.groups, 1e-6, silu=False)  # eps 1e-6: transformer_multiview.py:43-45
         h = ops.gemm(n.view(M, -1), self.piw, bias=self.pib, out_f32=P)
-        for blk in self.blocks:
-            h = blk(h, B // num_frames, num_frames * HW, shard)
-        return ops.gemm(ops.split(h, h16=self.h16) if P else h, self.pow, bias=self.pob, residual=x.view(M, C), out_f32=P).view(B, H, Wd, C)
+        for i, blk in enumerate(self.blocks):  # wide precisions: the last block hands proj_out its operand directly
+            h = blk(h, B // num_frames, num_frames * HW, shard, operand_out=P and i == len(self.blocks) - 1)
+        if P and not self.blocks:
+            h = ops.split(h, h16=self.h16)
+        return ops.gemm(h, self.pow, bias=self.pob, residual=x.view(M, C), out_f32=P).view(B, H, Wd, C)
 
 
 class UNetMultiviewConditionModel:

@@ -336,6 +336,13 @@ int dm4d_conv3x3_nhwc_f16(void* stream, const void* X, int B, int H, int W, int 
                           int Cout, int stride, int pad, int upsample, const void* bias, const void* rowbias, int64_t ld_rowbias,
                           const void* residual, int64_t ld_res, float out_scale, unsigned flags, void* ws, size_t ws_bytes);
 
+/* dm4d_conv_up2x_prepare_bf16 / dm4d_conv_up2x_nhwc_bf16 (Upsample2D as four 2x2 phase convolutions) with fp16 weights and input: the
+ *   phase kernels are sums of up to four taps taken in fp32 and rounded ONCE to fp16 (relative 2^-12 per weight; the model-level effect is
+ *   inside the precision's budget, tests/modelcheck.py fp16_unet_sd21_*).  flags: DM4D_EPI_F32OUT (Y is float*), else Y is fp16.          */
+int dm4d_conv_up2x_prepare_f16(void* stream, const void* W, void* Wp, int Cout, int Cin);
+int dm4d_conv_up2x_nhwc_f16(void* stream, const void* X, int B, int H, int W, int Cin, const void* Wp, void* Y, int Cout,
+                            const void* bias, unsigned flags);
+
 /* fp32 -> fp16 operand: Y[m, :Cp] = fp16(act(X[m, :]) * scale), columns behind C1 + C2 zero (dm4d_split_f32's addressing: second
  *   source = the up-block channel concat, col_stride1 != 1 = a transposed read).                                                  */
 int dm4d_to_f16_f32(void* stream, const float* X1, int64_t row_stride1, int64_t col_stride1, int C1, const float* X2,
