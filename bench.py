@@ -544,6 +544,26 @@ def vae_secondary(dev):
                 ms = e0.elapsed_time(e1) / 3 / n
                 flops = tf * 1e12 * (H * W) / (576 * 320)
                 res[name] = {"ms_per_image": round(ms, 3), "tflops": round(flops / (ms * 1e-3) / 1e12, 1)}
+            # where an encode / a decode goes: one more pass with an event pair around every launch, summed per kernel family (per image)
+            from diffuman4d_amd.host import ops
+            for name, fn in (("encode", lambda: vae.encode_scaled(img, noise)), ("decode", lambda: vae.decode_to_images(z))):
+                ops.PROFILE = prof = []
+                fn()
+                torch.cuda.synchronize()
+                ops.PROFILE = None
+                fam = {}
+                for fname, work, unit, e0, e1, _rows in prof:
+                    f = fam.setdefault(fname, {"launches": 0, "ms": 0.0, "work": 0.0, "unit": unit})
+                    f["launches"] += 1
+                    f["ms"] += e0.elapsed_time(e1)
+                    f["work"] += work
+                rows = {}
+                for k, v in fam.items():
+                    rate = v["work"] / (v["ms"] * 1e-3) / (1e12 if v["unit"] == "flop" else 1e9)
+                    rows[k] = {"launches": v["launches"], "ms_per_image": round(v["ms"] / n, 4),
+                               ("tflops" if v["unit"] == "flop" else "gb_per_s"): round(rate, 1),
+                               "roofline_frac": round(rate / (2500.0 if v["unit"] == "flop" else 8000.0), 3)}
+                res[name]["kernel_breakdown"] = rows
         res["images"] = f"{n} x {H}x{W}, SD geometry (128,256,512,512), random init"
         res["peak_device_memory_gib"] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
         return res

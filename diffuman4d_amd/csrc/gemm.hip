@@ -473,7 +473,11 @@ __global__ __launch_bounds__(WM* WN * 64, (BN % 64 != 0 ? 2 : 1)) void conv_stri
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // also publishes the zero rows
   for (int g = 0; g < nstrips; ++g) {
+#ifdef STRIP2_CS_OUTER
+    set_a_addrs(c_ky);
+#else
     if (c_cs == 0) set_a_addrs(c_ky);
+#endif
     const int abuf = g & 1;
     const int b0 = KT == 3 ? abuf : 0;  // weight buffer of the strip's first step
     issue_b(wp + cin, b0 ^ 1);  // (g, kx = 1)
@@ -484,12 +488,24 @@ __global__ __launch_bounds__(WM* WN * 64, (BN % 64 != 0 ? 2 : 1)) void conv_stri
       compute(abuf, std::integral_constant<int, 1>{});
       dma_wait_barrier();
     }
+#ifdef STRIP2_CS_OUTER
+    // experiment (round 5): channel slab outermost, kernel row inside -- the three strips of a slab overlap by (BM - W) / BM of their
+    // rows and are staged back to back, so the second and third read of a row should meet the first in the XCD's L2 instead of the
+    // Infinity Cache (the shipped order stages them nci strips apart).  Changes the K order (results differ in the last bits).
+    if (++c_ky == ky1) {
+      c_ky = ky0;
+      ++c_cs;
+    }
+    if (g + 1 < nstrips) {
+      set_a_voff(c_ky);
+#else
     if (++c_cs == nci) {
       c_cs = 0;
       ++c_ky;
     }
     if (g + 1 < nstrips) {  // the next strip's A rows and its first weight slab
       if (c_cs == 0) set_a_voff(c_ky);
+#endif
       wp = p.Wt + (c_ky * KT * cin + c_cs * BK);
       issue_a(p.A + c_cs * BK, abuf ^ 1);
       issue_b(wp, KT == 3 ? (abuf ^ 1) : 0);

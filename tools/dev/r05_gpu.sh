@@ -39,5 +39,35 @@ case $stage in
     bench_line $out/r05_bench_a.json "driver command:"
     tail -5 $out/r05_bench_a.err | cut -c1-300
     ;;
+  fp16b)  # second contact: vectorised fp32-in norms, phase-decomposed upsampling, direct operand out, the new epilogue loop; the F = 24 parity
+          # case against its fp32 fixture; the driver command; then A/B of two experiments of the FAST path (variant libraries built on the
+          # build host: tools/dev/build_variant.sh csouter gemm -DSTRIP2_CS_OUTER / ffabl ff_fused -DFF_ABLATE_H_ROUNDTRIP)
+    timeout 900 python tests/opcheck.py h16_ > $out/r05_b_opcheck_h16.log 2>&1; quiet $out/r05_b_opcheck_h16.log | grep -v "^PASS" | tail -30
+    timeout 1200 python tests/modelcheck.py fp16_unet_spatial fp16_vae fp16_pipeline_spatial fp16_unet_sd21 fp16_vae_sd fp16_demo3d fp16_multiround \
+        fp16_unet_frame fp16_pipeline_shard par_unet_sd21_72x40_f24 par_unet_spatial par_pipeline_spatial > $out/r05_b_modelcheck.log 2>&1
+    quiet $out/r05_b_modelcheck.log 600 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl\|socket.cpp" | tail -30
+    ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/r05_bench_b.json 2> $out/r05_bench_b.err ) 2> $out/r05_bench_b.time; tail -3 $out/r05_bench_b.time
+    bench_line $out/r05_bench_b.json "driver command:"
+    python - <<'PY'
+import json
+try:
+    d = json.load(open("gpurun_out/r05_bench_b.json"))
+    for k in ("encode", "decode"):
+        print("vae", k, d["secondary"]["vae"][k]["ms_per_image"], {f: (v["ms_per_image"], v["roofline_frac"]) for f, v in d["secondary"]["vae"][k].get("kernel_breakdown", {}).items()})
+    t = d["secondary"]["tolerance_mode"]["kernel_breakdown_one_step"]
+    print("tolerance levels:", {k: (v["ms"], v["roofline_frac"]) for k, v in t.items() if "." in k and k.split(".")[0] in ("linear", "conv3x3", "groupnorm", "layernorm", "split")})
+except Exception as e:
+    print("bench b unreadable:", e)
+PY
+    ab="--steps 9 --warmup 3 --no-cpu-baseline --no-grid-secondary --no-vae --no-parity-precision --no-tolerance-mode --no-latent128"
+    cp diffuman4d_amd/libdm4d.so /tmp/cur.so
+    for rep in 1 2; do for v in cur csouter ffabl; do
+      if [ $v = cur ]; then cp /tmp/cur.so diffuman4d_amd/libdm4d.so; else cp tools/dev/libdm4d_$v.so diffuman4d_amd/libdm4d.so; fi
+      timeout 300 python bench.py $ab > $out/r05_ab_${v}_$rep.json 2>/dev/null; bench_line $out/r05_ab_${v}_$rep.json "A/B $v rep $rep:"
+    done; done
+    cp tools/dev/libdm4d_csouter.so diffuman4d_amd/libdm4d.so
+    timeout 600 python tests/opcheck.py conv > $out/r05_ab_csouter_opcheck_conv.log 2>&1; tail -3 $out/r05_ab_csouter_opcheck_conv.log
+    cp /tmp/cur.so diffuman4d_amd/libdm4d.so
+    ;;
   *) echo "unknown stage $stage"; exit 2;;
 esac
