@@ -68,9 +68,7 @@ __device__ __forceinline__ void rows_layernorm(char* tile, const LnArgs& ln, int
     if (on[0]) {
       const U4 rawv = *reinterpret_cast<const U4*>(a);
       if constexpr (RAW) {
-#ifndef FF_ABLATE_H_ROUNDTRIP  // timing-only ablation (wrong results): what the store of h and its read-back as the residual cost
         if (r < rows_valid) stg16(raw + (int64_t)r * ldraw + lane * 8, rawv);
-#endif
       }
       unpack8(rawv, v[0]);
     } else {
@@ -509,9 +507,6 @@ extern "C" int dm4d_attn_out_ff_geglu_fused_bf16(void* stream, const void* A0, i
   GemmParams p{};
   p.A = (const u16*)A0; p.lda = lda0; p.C = (u16*)Out; p.ldc = ldo; p.M = M; p.N = C; p.K = hidden;
   p.bias = (const u16*)b2; p.res = (const u16*)Out; p.ld_res = ldo; p.flags = 0; p.out_scale = 1.0f; p.splits = 1;
-#ifdef FF_ABLATE_H_ROUNDTRIP
-  p.res = (const u16*)X; p.ld_res = ldx;  // the residual read comes from rows this workgroup fetched a moment ago instead of rows it wrote
-#endif
   p.rows_per_rb = 1; p.tiles_n = 1;
   const LnArgs ln{(const u16*)ln_gamma, (const u16*)ln_beta, ln_eps};
   const ProjArgs proj{(const u16*)A0, lda0, (const u16*)Wo, (const u16*)bo, (const u16*)X, ldx};

@@ -283,7 +283,8 @@ __global__ __launch_bounds__(WM* WN * 64, (BN % 64 != 0 ? 2 : 1)) void conv_stri
     xs = px - 1;
     ys = py - 1;
     p.Wt = p_in.Wt + (int64_t)phase * p_in.N * p_in.ldw;
-    p.C = p_in.C + ((int64_t)py * 2 * p_in.W + px) * p_in.ldc;
+    // first output pixel of the phase; C counts 2-byte elements unless the launch stores fp32 (DM4D_EPI_F32OUT: precision "fp16")
+    p.C = p_in.C + ((int64_t)py * 2 * p_in.W + px) * p_in.ldc * ((PAR && (p_in.flags & DM4D_EPI_F32OUT)) ? 2 : 1);
   }
   int split = 0, tm, tn;
   if (KT == 3 && p.splits > 1) {
@@ -473,11 +474,7 @@ __global__ __launch_bounds__(WM* WN * 64, (BN % 64 != 0 ? 2 : 1)) void conv_stri
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // also publishes the zero rows
   for (int g = 0; g < nstrips; ++g) {
-#ifdef STRIP2_CS_OUTER
-    set_a_addrs(c_ky);
-#else
     if (c_cs == 0) set_a_addrs(c_ky);
-#endif
     const int abuf = g & 1;
     const int b0 = KT == 3 ? abuf : 0;  // weight buffer of the strip's first step
     issue_b(wp + cin, b0 ^ 1);  // (g, kx = 1)
@@ -488,24 +485,12 @@ __global__ __launch_bounds__(WM* WN * 64, (BN % 64 != 0 ? 2 : 1)) void conv_stri
       compute(abuf, std::integral_constant<int, 1>{});
       dma_wait_barrier();
     }
-#ifdef STRIP2_CS_OUTER
-    // experiment (round 5): channel slab outermost, kernel row inside -- the three strips of a slab overlap by (BM - W) / BM of their
-    // rows and are staged back to back, so the second and third read of a row should meet the first in the XCD's L2 instead of the
-    // Infinity Cache (the shipped order stages them nci strips apart).  Changes the K order (results differ in the last bits).
-    if (++c_ky == ky1) {
-      c_ky = ky0;
-      ++c_cs;
-    }
-    if (g + 1 < nstrips) {
-      set_a_voff(c_ky);
-#else
     if (++c_cs == nci) {
       c_cs = 0;
       ++c_ky;
     }
     if (g + 1 < nstrips) {  // the next strip's A rows and its first weight slab
       if (c_cs == 0) set_a_voff(c_ky);
-#endif
       wp = p.Wt + (c_ky * KT * cin + c_cs * BK);
       issue_a(p.A + c_cs * BK, abuf ^ 1);
       issue_b(wp, KT == 3 ? (abuf ^ 1) : 0);

@@ -56,6 +56,12 @@ class Diffuman4DPipeline:
         self.parity, self.h16 = self.precision == "parity", self.precision == "fp16"
         self.wide = self.parity or self.h16  # task tensors and everything between kernels are fp32
         self.dtype = F32 if self.wide else BF16
+        ucfg = getattr(unet, "config", None)
+        if ucfg is not None and hasattr(ucfg, "in_channels"):
+            want = 11 if getattr(ucfg, "enable_pose_encoder", False) else 15  # [latent 4 | Pluecker 6 | skeleton latent 4 | mask 1] (:389-395)
+            if ucfg.in_channels != want:
+                raise ValueError(f"unet/config.json: in_channels = {ucfg.in_channels}, but this pipeline assembles {want} channels per frame "
+                                 f"(enable_pose_encoder = {bool(getattr(ucfg, 'enable_pose_encoder', False))}; pipeline_diffuman4d.py:389-395)")
         self.vae_scale_factor = vae.scale_factor if vae is not None else 8
         self._vae_cache: Dict[str, dict] = {"pixel": {}, "skeleton": {}}  # encoder moments by caller-supplied key
         # extension (off = compute what the reference computes): after the last 3-D attention layer run only the rows
@@ -305,13 +311,13 @@ class Diffuman4DPipeline:
         Extensions, off by default (= the reference's behaviour): `noise` injects the random draws; `cache_keys`
         (one hashable per frame) reuses VAE encoder moments across calls; `decode="denoised"` runs the VAE decoder
         only for fully denoised rows -- the only ones the sampler saves (sampling_utils.py:103-104) -- and returns
-        zero images for the rest; `cameras` (with plucker_embeds=None) evaluates the Pluecker maps on the device at latent
+        zero images for the rest (`decode="none"`: for no row at all -- the non-leading ranks of a frame-shard group); `cameras` (with plucker_embeds=None) evaluates the Pluecker maps on the device at latent
         resolution (see prepare_all_latents); `shard` (parallel.FrameShard): the ranks of its group run THIS task together, every
         window call split over them by frames with K/V all-gathers in the 3-D attention layers -- every rank
         passes the same arguments and gets the same result; `noise_seed`: the random draws come from a device generator seeded
         with it instead of the global one, so that the ranks of a shard group draw the same numbers."""
-        if decode not in ("all", "denoised"):
-            raise ValueError("decode must be 'all' or 'denoised'")
+        if decode not in ("all", "denoised", "none"):
+            raise ValueError("decode must be 'all', 'denoised' or 'none'")
         if self.vae is None:
             raise RuntimeError("this pipeline was built without a VAE; use denoise_latents()")
         torch.cuda.set_device(self._device)  # worker threads inherit device 0 (sampling_runner.py:36)
@@ -325,7 +331,7 @@ class Diffuman4DPipeline:
                                                                        cond_masks, latents, noise, cache_keys, cameras)
         self.denoise_latents(pv_lat, pl_lat, sk_lat, cm_lat, lat, plan, domain, guidance_scale, tqdm, shard=shard)
         tidx = torch.from_numpy(plan.final_timestep_indices)
-        rows = (tidx == plan.num_inference_steps) if decode == "denoised" else None
+        rows = (tidx == plan.num_inference_steps) if decode == "denoised" else (torch.zeros_like(tidx, dtype=torch.bool) if decode == "none" else None)
         images = self.vae.decode_to_images(lat, rows=rows)  # [N,3,H,W] in [0,1]
         return {
             "images": images,

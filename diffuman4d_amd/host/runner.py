@@ -233,6 +233,11 @@ class DistributedSamplingRunner:
             raise ValueError(f"Unsupported runner mode: {mode}. Supported modes are {', '.join(self.MODES)}.")
         self.dist = dist
         self.mode = mode
+        if mode != "task" and group is not None and dist.is_initialized() and dist.get_world_size(group) != dist.get_world_size():
+            # the sub-groups of the frame-sharding modes are made with dist.new_group, which is collective over the DEFAULT group: ranks
+            # outside `group` would never make the call and the first tail wave would hang
+            raise ValueError(f"runner mode '{mode}' needs the runner's group to be the whole world (new_group is collective over it); "
+                             "use mode='task' on a sub-group, or one runner over all ranks")
         self._subgroups: Dict[int, list] = {}  # P -> [(ranks, process group)] in sub-group order
         self.sampler = sampler
         self.prefetch_depth, self.writers, self.gpu_streams = prefetch_depth, writers, gpu_streams
@@ -456,12 +461,13 @@ class DistributedSamplingRunner:
         s = self.sampler
         keep = s.result_writer
         s.frame_shard = FrameShard(group)
-        if self.rank != ranks[0]:
+        if self.rank != ranks[0]:  # a follower: nobody writes or reads its images, so it neither decodes nor copies them to the host
             s.result_writer = None
+            s.shard_follower = True
         try:
             s.execute_one_task(task)
         finally:
-            s.frame_shard, s.result_writer = None, keep
+            s.frame_shard, s.result_writer, s.shard_follower = None, keep, False
 
     def inference(self):
         s = self.sampler

@@ -213,6 +213,8 @@ class SlidingIterativeSampler:
             from .results import pack_results_on_device
             sample["_package"] = pack_results_on_device(sample, result["images"], output_dir=self.output_dir, device=pipe.device)
             sample["images"] = None  # the float images never leave the device (the package holds what gets written)
+        elif getattr(self, "shard_follower", False):
+            sample["images"] = None  # nothing was decoded on this rank and nothing will be written
         else:
             sample["images"] = result["images"].float().cpu()
         # hand the cells over only when they are complete: with several task streams per GPU (runner gpu_streams) another
@@ -236,14 +238,20 @@ class SlidingIterativeSampler:
             kw["cache_keys"] = [(spa, tem) for _, spa, tem in sample["labels"]]
         if self.decode_policy != "all":
             kw["decode"] = self.decode_policy
+        if getattr(self, "shard_follower", False):
+            kw["decode"] = "none"  # a non-leading rank of a frame-shard group: nobody reads its images (the leader writes the results)
         if self.frame_shard is not None:
             kw["shard"] = self.frame_shard
             kw["noise_seed"] = self.task_noise_seed(sample["alt"], sample["domain"], sample["domain_label"])
         return kw
 
     def task_noise_seed(self, alt: int, domain: str, domain_label: str) -> int:
-        """A seed every rank derives alike for one task (a pure function of the task's identity and `noise_base_seed`)."""
-        return (int(self.noise_base_seed) * 1000003 + int(alt) * 100003 + (0 if domain == "spatial" else 50021) + int(domain_label)) % (2 ** 31 - 1)
+        """A seed every rank derives alike for one task (a pure function of the task's identity and `noise_base_seed`).  A hash of the
+        tuple, not a sum of scaled fields: frame labels run to 999999 (`%06d`), so weighted sums made (round 1, frame 100003 + x) collide
+        with (round 2, frame x) and spatial frame 50021 + c with temporal camera c -- tasks that would then draw identical noise."""
+        import hashlib
+        key = f"{int(self.noise_base_seed)}/{int(alt)}/{domain}/{domain_label}".encode()
+        return int.from_bytes(hashlib.sha256(key).digest()[:4], "little") & 0x7FFFFFFF
 
     def execute_one_task(self, task: dict, pipe_idx: int = 0) -> dict:
         sample = self.denoise(self.load_sample(**task), pipe_idx=pipe_idx)

@@ -222,8 +222,9 @@ class _TransformerBlock:
         w2, b2 = W.linear(pfx + "ff.net.2.weight"), W.vec(pfx + "ff.net.2.bias")
         self.ff = (w1, b1, w2, b2) if W.wide else ops.FeedForward(w1, b1, w2, b2)
         if (pfx + "attn2.to_q.weight") in W.sd:
-            raise NotImplementedError("cross-attention (attn2) checkpoints are not supported: the reference never "
-                                      "passes encoder_hidden_states (SURVEY.md section 0)")
+            raise NotImplementedError(f"unet checkpoint holds '{pfx}attn2.*' (a cross-attention block, i.e. unet/config.json: "
+                                      "cross_attention_dim is not null): not supported -- the reference never passes encoder_hidden_states "
+                                      "(pipeline_diffuman4d.py:398-405)")
 
     def __call__(self, h: torch.Tensor, batch: int, seq: int, shard=None, operand_out: bool = False) -> torch.Tensor:
         """h [M, C] token-major; attention over `batch` sequences of `seq` tokens (attention.py:68-90).
@@ -294,7 +295,10 @@ class _Transformer:
             self.blocks.append(_TransformerBlock(W, pfx + f"transformer_blocks.{i}.", heads))
             i += 1
         if (self.pob.shape[0] // heads) != 64:
-            raise NotImplementedError("the HIP attention kernel is specialised for head_dim 64")
+            raise NotImplementedError(
+                f"unet/config.json: block_out_channels / attention_head_dim give a head dimension of {self.pob.shape[0] // heads} at "
+                f"'{pfx[:-1]}' ({self.pob.shape[0]} channels over {heads} heads -- `attention_head_dim` is the NUMBER of heads, "
+                "unet_multiview_condition.py:222-228); the HIP attention kernels are built for head dimension 64 (SD-2.1 geometry)")
 
     def __call__(self, x: torch.Tensor, num_frames: int, shard=None) -> torch.Tensor:
         B, H, Wd, C = x.shape
@@ -312,7 +316,7 @@ class _Transformer:
 class UNetMultiviewConditionModel:
     """Inference-only, HIP-backed.  ``forward`` takes/returns NHWC bf16 (see ``Diffuman4DPipeline``)."""
 
-    IN_PAD = 32  # conv_in input channels are zero-padded to one 32-wide K slab
+    IN_PAD = 32  # conv_in input channels are zero-padded to whole 32-wide K slabs: 32, or 64 for in_channels in 33..64 (per instance)
 
     def __init__(self, config: UNetConfig, state_dict: Dict[str, torch.Tensor], device="cuda", precision: str = "fast",
                  weight_dtype=BF16):
@@ -326,9 +330,14 @@ class UNetMultiviewConditionModel:
         self.precision, self.parity, self.h16 = precision, precision == "parity", precision == "fp16"
         self.wide = self.parity or self.h16  # fp32 tensors between kernels
         if cfg.cross_attention_dim is not None:
-            raise NotImplementedError("cross_attention_dim must be None (SURVEY.md section 0)")
-        if cfg.in_channels > self.IN_PAD:
-            raise NotImplementedError("in_channels > 32")
+            raise NotImplementedError(
+                f"unet/config.json: cross_attention_dim = {cfg.cross_attention_dim}; this path builds self-attention blocks only -- the "
+                "reference's UNet forward takes no encoder_hidden_states and its pipeline never passes any "
+                "(unet_multiview_condition.py:290-291, :501-509; pipeline_diffuman4d.py:398-405), so cross_attention_dim must be null")
+        if cfg.in_channels > 64:
+            raise NotImplementedError(f"unet/config.json: in_channels = {cfg.in_channels}; conv_in is built for up to 64 input channels "
+                                      "(the reference's pipeline assembles 15, or 11 with enable_pose_encoder: pipeline_diffuman4d.py:389-395)")
+        self.IN_PAD = 32 if cfg.in_channels <= 32 else 64
         W = _Weights(state_dict, self.device, self.parity, self.h16, weight_dtype)
         boc = cfg.block_out_channels
         g, eps = cfg.norm_num_groups, cfg.norm_eps

@@ -39,7 +39,10 @@ class ShardStubPipeline(StubPipeline):
 
     def sliding_iterative_denoise(self, pixel_values, plucker_embeds, skeletons, cond_masks, latents, domain,
                                   timestep_indices, window_size, sliding_stride, sliding_shift, bidirectional,
-                                  num_denoising_steps, alternation_rounds, guidance_scale, tqdm=None, shard=None, noise_seed=None):
+                                  num_denoising_steps, alternation_rounds, guidance_scale, tqdm=None, shard=None, noise_seed=None,
+                                  decode="all"):
+        if shard is not None:  # the non-leading ranks of a shard group decode nothing (runner._run_sharded), the leader everything
+            assert decode == ("all" if shard.rank == 0 else "none"), (shard.rank, decode)
         if shard is None:
             return super().sliding_iterative_denoise(pixel_values, plucker_embeds, skeletons, cond_masks, latents, domain,
                                                      timestep_indices, window_size, sliding_stride, sliding_shift, bidirectional,

@@ -69,3 +69,35 @@ def test_the_standin_is_removed_again():
     from diffuman4d_amd.host import lib, ops
     with pytest.raises(lib.Dm4dError):
         ops.silu(torch.zeros(4, 8, dtype=torch.bfloat16))
+
+
+def test_wide_input_checkpoint_and_config_field_messages(cpu_standin):
+    """unet/config.json generality (unet_multiview_condition.py:149-212): a checkpoint with up to 64 input channels loads and runs (conv_in
+    padded to two 32-wide K slabs); what this path does not build is refused AT LOAD with a message naming the config.json field."""
+    import torch
+    from diffuman4d_amd.host import ops
+    from diffuman4d_amd.host.unet import UNetConfig, UNetMultiviewConditionModel
+    mc = cpu_standin
+    cfg, om = mc.make_unet(3, in_channels=40)
+    hm = UNetMultiviewConditionModel(UNetConfig.from_dict(asdict(cfg)), om.state_dict(), "cpu", "parity")
+    assert hm.IN_PAD == 64
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(4, 40, 16, 8, generator=g).to(torch.bfloat16)
+    t = torch.randint(0, 1000, (4,), generator=g)
+    with torch.no_grad():
+        ref = om(x.float(), t, domains=["spatial"] * 2, num_frames=2)
+    out = ops.nhwc_to_nchw(hm(ops.split(x.float().permute(0, 2, 3, 1).contiguous(), cpad=hm.IN_PAD), t.float(), domains=["spatial"] * 2, num_frames=2))
+    assert float((out - ref).norm() / ref.norm()) < 1e-4
+    base = asdict(mc.make_unet(0)[0])
+    sd = mc.make_unet(0)[1].state_dict()
+    with pytest.raises(NotImplementedError, match="in_channels = 80"):
+        UNetMultiviewConditionModel(UNetConfig.from_dict(dict(base, in_channels=80)), sd, "cpu")
+    with pytest.raises(NotImplementedError, match="cross_attention_dim = 1024"):
+        UNetMultiviewConditionModel(UNetConfig.from_dict(dict(base, cross_attention_dim=1024)), sd, "cpu")
+    heads = tuple(2 * h for h in base["attention_head_dim"])  # twice the heads over the same channels: head dimension 32
+    with pytest.raises(NotImplementedError, match="attention_head_dim give a head dimension of 32"):
+        UNetMultiviewConditionModel(UNetConfig.from_dict(dict(base, attention_head_dim=heads)), sd, "cpu")
+    with pytest.raises(ValueError, match="in_channels = 40, but this pipeline assembles 15"):
+        import diffuman4d_amd.host.pipeline as hp
+        from diffuman4d_amd.host.scheduler import DDIMScheduler
+        hp.Diffuman4DPipeline(None, hm, DDIMScheduler(), "cpu")

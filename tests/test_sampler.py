@@ -101,3 +101,21 @@ def test_load_pipelines_rejects_unknown_dtype():
     from diffuman4d_amd.host.loader import load_pipelines
     with pytest.raises(ValueError, match="Unsupported torch_dtype"):
         load_pipelines(torch_dtype="fp32", gpu_ids=[])
+
+
+def test_task_noise_seeds_do_not_collide():
+    """Every task of a large job gets its own seed (the frame-shard groups draw their noise from it): the weighted-sum form of round 4
+    mapped (round 1, frame 100003 + x) onto (round 2, frame x) and spatial frame 50021 + c onto temporal camera c."""
+    s = make()
+    assert s.task_noise_seed(1, "spatial", "100003") != s.task_noise_seed(2, "spatial", "000000")
+    assert s.task_noise_seed(1, "spatial", "050021") != s.task_noise_seed(1, "temporal", "00")
+    seeds = {s.task_noise_seed(alt, dom, lab) for alt in (1, 2, 3, 4, 5) for dom, labs in
+             (("spatial", [f"{f:06d}" for f in range(0, 3000, 7)]), ("temporal", [f"{c:02d}" for c in range(48)])) for lab in labs}
+    assert len(seeds) == 5 * (len(range(0, 3000, 7)) + 48)
+    assert all(0 <= v < 2 ** 31 for v in seeds) and s.task_noise_seed(1, "spatial", "000003") == s.task_noise_seed(1, "spatial", "000003")
+    load_pipelines_precisions = ("auto", "fast", "parity", "fp16")
+    from diffuman4d_amd.host.loader import load_pipelines
+    with pytest.raises(ValueError, match="Unsupported precision"):
+        load_pipelines(gpu_ids=[], precision="fp8")
+    for prec in load_pipelines_precisions:  # no GPU ids: nothing is loaded, the argument checks run
+        assert load_pipelines(model_dir="/nonexistent-but-unused", gpu_ids=[], precision=prec) == []

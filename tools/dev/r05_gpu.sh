@@ -69,5 +69,21 @@ PY
     timeout 600 python tests/opcheck.py conv > $out/r05_ab_csouter_opcheck_conv.log 2>&1; tail -3 $out/r05_ab_csouter_opcheck_conv.log
     cp /tmp/cur.so diffuman4d_amd/libdm4d.so
     ;;
+  fp16c)  # after the fix of the phase kernels' fp32 output offset: the fp16 precision again, then the driver command
+    timeout 900 python tests/opcheck.py h16_ conv_up2x > $out/r05_c_opcheck_h16.log 2>&1; quiet $out/r05_c_opcheck_h16.log | grep -v "^PASS" | tail -30
+    timeout 1200 python tests/modelcheck.py fp16_ > $out/r05_c_modelcheck_fp16.log 2>&1
+    quiet $out/r05_c_modelcheck_fp16.log 600 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl\|socket.cpp\|^    \[golden\|^    \[pipeline" | tail -40
+    ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/r05_bench_c.json 2> $out/r05_bench_c.err ) 2> $out/r05_bench_c.time; tail -3 $out/r05_bench_c.time
+    bench_line $out/r05_bench_c.json "driver command:"
+    python - <<'PY'
+import json
+try:
+    d = json.load(open("gpurun_out/r05_bench_c.json"))
+    t = d["secondary"]["tolerance_mode"]["kernel_breakdown_one_step"]
+    print("tolerance levels:", {k: (v["ms"], v["roofline_frac"]) for k, v in t.items() if "." in k and k.split(".")[0] in ("linear", "conv3x3", "attention", "groupnorm", "layernorm", "split")})
+except Exception as e:
+    print("bench c unreadable:", e)
+PY
+    ;;
   *) echo "unknown stage $stage"; exit 2;;
 esac
