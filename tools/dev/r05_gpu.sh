@@ -85,5 +85,24 @@ except Exception as e:
     print("bench c unreadable:", e)
 PY
     ;;
+  dot2)  # A/B: attention row sums from the packed probabilities (v_dot2c against (1, 1)) -- tools/dev/build_variant.sh dot2 attention -DATTN_DOT2_SUM
+    cp diffuman4d_amd/libdm4d.so /tmp/cur.so
+    cp tools/dev/libdm4d_dot2.so diffuman4d_amd/libdm4d.so
+    timeout 900 python tests/opcheck.py attn h16_attn > $out/r05_dot2_opcheck_attn.log 2>&1; quiet $out/r05_dot2_opcheck_attn.log | grep -v "^PASS" | tail; grep -c "^PASS" $out/r05_dot2_opcheck_attn.log
+    grep "judged\|65536\|attn_qs_2d \|attn_qs_3d " $out/r05_dot2_opcheck_attn.log | cut -c1-120
+    cp /tmp/cur.so diffuman4d_amd/libdm4d.so
+    timeout 600 python tests/opcheck.py attn_qs_judged attn_qs_128sq attn_qs_2d attn_qs_3d h16_attn_judged > $out/r05_dot2_opcheck_attn_base.log 2>&1; grep "judged\|65536\|attn_qs_2d \|attn_qs_3d " $out/r05_dot2_opcheck_attn_base.log | cut -c1-120
+    ab="--steps 9 --warmup 3 --no-cpu-baseline --no-grid-secondary --no-vae --no-parity-precision --no-latent128"
+    for rep in 1 2; do for v in cur dot2; do
+      if [ $v = cur ]; then cp /tmp/cur.so diffuman4d_amd/libdm4d.so; else cp tools/dev/libdm4d_$v.so diffuman4d_amd/libdm4d.so; fi
+      timeout 300 python bench.py $ab > $out/r05_dot2_${v}_$rep.json 2>/dev/null; bench_line $out/r05_dot2_${v}_$rep.json "A/B $v rep $rep:"
+    done; done
+    for v in cur dot2; do
+      if [ $v = cur ]; then cp /tmp/cur.so diffuman4d_amd/libdm4d.so; else cp tools/dev/libdm4d_$v.so diffuman4d_amd/libdm4d.so; fi
+      timeout 300 python bench.py --latent 128x128 --steps 2 --warmup 1 --task-streams 1 --no-cpu-baseline --no-grid-secondary --no-vae --no-parity-precision --no-tolerance-mode --no-latent128 > $out/r05_dot2_${v}_128.json 2>/dev/null
+      bench_line $out/r05_dot2_${v}_128.json "A/B $v 128x128:"
+    done
+    cp /tmp/cur.so diffuman4d_amd/libdm4d.so
+    ;;
   *) echo "unknown stage $stage"; exit 2;;
 esac
