@@ -103,17 +103,6 @@ __device__ __forceinline__ uint32_t cvt_pk(float lo, float hi) {
   if constexpr (H16) return pack_h2(lo, hi);
   else return cvt_pk_bf16(lo, hi);
 }
-// c + x.lo + x.hi for a packed pair of bf16 (H16: fp16) values: v_dot2c_f32_bf16 / v_dot2c_f32_f16 against (1, 1)
-template <bool H16>
-__device__ __forceinline__ float dot2_ones(uint32_t x, float c) {
-  if constexpr (H16) {
-    const uint32_t one = 0x3c003c00u;
-    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2_t, x), __builtin_bit_cast(h16x2_t, one), c, false);
-  } else {
-    const uint32_t one = 0x3f803f80u;
-    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, x), __builtin_bit_cast(bf16x2_t, one), c, false);
-  }
-}
 template <bool H16>
 __device__ __forceinline__ f32x16_t mfma16(const bf16x8_t& a, const bf16x8_t& b, const f32x16_t& c) {
   if constexpr (H16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8_t, a), __builtin_bit_cast(h16x8_t, b), c, 0, 0, 0);
@@ -326,18 +315,15 @@ __device__ __forceinline__ void kv_loop_pipelined(const AttnParams& p, const u16
         if (key0 + (r & 3) + 8 * (r >> 2) >= Lk) s[kb][r] = -1e30f;
     }
   };
-  float l_alt = 0.f;  // second row-sum accumulator (ATTN_DOT2_SUM): two short dependency chains instead of one
   float mc = 0.f;
   auto softmax_block = [&](const f32x16_t& s, bf16x8_t (&pf)[2]) {
     float pv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) pv[r] = FOLD ? __builtin_amdgcn_exp2f(s[r]) : __builtin_amdgcn_exp2f(s[r] * cs - mc);
-#ifndef ATTN_DOT2_SUM
     float sum = pv[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) sum += pv[r];
     l_run += sum;
-#endif
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       U4 w;
@@ -346,15 +332,6 @@ __device__ __forceinline__ void kv_loop_pipelined(const AttnParams& p, const u16
       w.z = cvt_pk<H16>(pv[jj * 8 + 4], pv[jj * 8 + 5]);
       w.w = cvt_pk<H16>(pv[jj * 8 + 6], pv[jj * 8 + 7]);
       pf[jj] = *reinterpret_cast<bf16x8_t*>(&w);
-#ifdef ATTN_DOT2_SUM
-      // row sum of the ROUNDED probabilities -- the numbers the P V product multiplies -- two per instruction (v_dot2c_f32_bf16 /
-      // _f16 against (1, 1), fp32 accumulation): 8 instructions per 32-key block instead of 15 adds, and numerator and denominator
-      // of the soft-max now carry the same rounding
-      l_run = dot2_ones<H16>(w.x, l_run);
-      l_alt = dot2_ones<H16>(w.y, l_alt);
-      l_run = dot2_ones<H16>(w.z, l_run);
-      l_alt = dot2_ones<H16>(w.w, l_alt);
-#endif
     }
   };
   auto pv_block = [&](int stage, int kb, const bf16x8_t (&pf)[2]) {
@@ -441,7 +418,6 @@ __device__ __forceinline__ void kv_loop_pipelined(const AttnParams& p, const u16
       __syncthreads();
     }
   }
-  l_run += l_alt;
 }
 
 template <bool FOLD, int NW, bool H16 = false>
