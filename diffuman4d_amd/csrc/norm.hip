@@ -65,6 +65,9 @@ struct GNParams {
   u16* Y;
   int silu;
   float* ws;  // [B][nchunk][groups][2]
+  // IO = 2 only: a second output, the UN-normalised input rounded to fp16 ([B*HW, C], the channel concat of X1 | X2) -- the operand of a
+  // resnet's 1x1 shortcut convolution, which reads the same tensor as its first GroupNorm (unet_multiview_blocks.py:667, resnet.py)
+  u16* Yraw;
 };
 
 // Shifted statistics.  Sum / sum of squares are taken of (x - s_g), s_g = the sample's value at pixel 0 in the first channel
@@ -243,9 +246,13 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(GNParams p) {
       ld = p.C2;
     }
     u16* dst = p.Y + (int64_t)b * p.HW * C + cv * 8;
+    u16* dst_raw = (IO == 2 && p.Yraw) ? p.Yraw + (int64_t)b * p.HW * C + cv * 8 : nullptr;
     auto put = [&](const raw_t& r, int px) {
       float v[8];
       io::unpack(r, v);
+      if constexpr (IO == 2) {
+        if (dst_raw) io::st8(dst_raw + (int64_t)px * C, v);
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float y = v[e] * a[e] + sft[e];
@@ -391,12 +398,16 @@ __global__ __launch_bounds__(GN_THREADS) void gn_resident_kernel(GNParams p, int
     }
   }
   u16* dst = p.Y + (int64_t)b * p.HW * C + cv * 8;
+  u16* dst_raw = (IO == 2 && p.Yraw) ? p.Yraw + (int64_t)b * p.HW * C + cv * 8 : nullptr;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int px = prow + k * PPB;
     if (px < p.HW) {
       float v[8];
       io::unpack(r[k], v);
+      if constexpr (IO == 2) {
+        if (dst_raw) io::st8(dst_raw + (int64_t)px * C, v);
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float y = v[e] * a[e] + sft[e];
@@ -546,7 +557,7 @@ extern "C" size_t dm4d_groupnorm_ws_bytes(int B, int HW, int groups) {
 
 template <int IO>
 static int groupnorm_impl(void* stream, const void* X1, int C1, const void* X2, int C2, int B, int HW, int groups, float eps,
-                          const void* gamma, const void* beta, void* Y, int apply_silu, void* ws) {
+                          const void* gamma, const void* beta, void* Y, int apply_silu, void* ws, void* Yraw = nullptr) {
   if (!X1 || !gamma || !beta || !Y || !ws || B <= 0 || HW <= 0 || groups <= 0)
     return dm4d_set_error(DM4D_ERR_ARG, "groupnorm: null pointer or empty shape");
   if (!X2) C2 = 0;
@@ -554,7 +565,7 @@ static int groupnorm_impl(void* stream, const void* X1, int C1, const void* X2, 
   if ((C1 & 7) || (C2 & 7) || C % groups != 0 || C > GN_MAXC)
     return dm4d_set_error(DM4D_ERR_ARG, "groupnorm: channels must be multiples of 8, divisible by groups, <= 4096");
   GNParams p{X1, X2, C1, C2, B, HW, groups, gn_nchunk(B, HW), eps,
-             (const u16*)gamma, (const u16*)beta, (u16*)Y, apply_silu, (float*)ws};
+             (const u16*)gamma, (const u16*)beta, (u16*)Y, apply_silu, (float*)ws, (u16*)Yraw};
   hipStream_t st = (hipStream_t)stream;
   {
     int gps, SV, RPB, NV;
@@ -595,6 +606,15 @@ extern "C" int dm4d_groupnorm_nhwc_f32_f16(void* stream, const float* X1, int C1
   if ((C1 & 7) || (C2 & 7) || (((uintptr_t)X1) & 15) || (X2 && (((uintptr_t)X2) & 15)) || (((uintptr_t)Y) & 15))
     return dm4d_groupnorm_f32_f16_general(stream, X1, C1, X2, C2, B, HW, groups, eps, gamma, beta, Y, apply_silu, ws);
   return groupnorm_impl<2>(stream, X1, C1, X2, C2, B, HW, groups, eps, gamma, beta, Y, apply_silu, ws);
+}
+
+extern "C" int dm4d_groupnorm_nhwc_f32_f16_raw(void* stream, const float* X1, int C1, const float* X2, int C2, int B, int HW, int groups,
+                                               float eps, const void* gamma, const void* beta, void* Y, void* Yraw, int apply_silu,
+                                               void* ws) {
+  if (!X2) C2 = 0;
+  if (!Yraw || (C1 & 7) || (C2 & 7) || (((uintptr_t)X1) & 15) || (X2 && (((uintptr_t)X2) & 15)) || ((((uintptr_t)Y) | ((uintptr_t)Yraw)) & 15))
+    return dm4d_set_error(DM4D_ERR_ARG, "groupnorm_f32_f16_raw: needs Yraw, channel counts that are multiples of 8 and 16-byte aligned tensors");
+  return groupnorm_impl<2>(stream, X1, C1, X2, C2, B, HW, groups, eps, gamma, beta, Y, apply_silu, ws, Yraw);
 }
 
 template <int IO>

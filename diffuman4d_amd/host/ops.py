@@ -455,12 +455,15 @@ def conv2d_direct(x: torch.Tensor, wt: torch.Tensor, *, ksize: int, bias=None, s
 
 
 def groupnorm(x1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, *,
-              x2: Optional[torch.Tensor] = None, silu: bool = False) -> torch.Tensor:
+              x2: Optional[torch.Tensor] = None, silu: bool = False, raw_out: bool = False):
     """GroupNorm(+SiLU) over the channel concat [x1 | x2]; x [B, HW, C] (any leading spatial shape).
-    fp32 input (parity precision): fp64 statistics, the result leaves as a two-term operand [..., 2 C]."""
+    fp32 input (wide precisions): the result leaves as an operand -- parity: fp64 statistics, two-term [..., 2 C]; fp16 (fp16 gamma / beta):
+    one fp16 plane.  raw_out (fp16 precision): also returns fp16 of the un-normalised concat [x1 | x2] (the shortcut convolution's operand)
+    -> (y, raw)."""
     lib = _l.load()
     if isinstance(x1, torch.Tensor) and x1.dtype == F32:
-        return _groupnorm_f32(x1, gamma, beta, groups, eps, x2, silu)
+        return _groupnorm_f32(x1, gamma, beta, groups, eps, x2, silu, raw_out)
+    assert not raw_out
     _req(x1, "x1"), _req(gamma, "gamma"), _req(beta, "beta")
     assert x1.is_contiguous()
     B, C1 = x1.shape[0], x1.shape[-1]
@@ -481,7 +484,7 @@ def groupnorm(x1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups:
     return y
 
 
-def _groupnorm_f32(x1, gamma, beta, groups, eps, x2, silu) -> torch.Tensor:
+def _groupnorm_f32(x1, gamma, beta, groups, eps, x2, silu, raw_out=False):
     lib = _l.load()
     h16 = gamma.dtype == F16  # precision "fp16": fp16 parameters, one fp16 plane out
     pdt = F16 if h16 else BF16
@@ -497,6 +500,20 @@ def _groupnorm_f32(x1, gamma, beta, groups, eps, x2, silu) -> torch.Tensor:
     y = torch.empty(x1.shape[:-1] + ((1 if h16 else 2) * (C1 + C2),), dtype=pdt, device=x1.device)
     ws = torch.empty(lib.dm4d_groupnorm_f32_ws_bytes(B, HW, groups) // 8, dtype=torch.float64, device=x1.device)
     bpe = 6.0 if h16 else 8.0  # algorithmic bytes per element: fp32 in + the operand out (one fp16 plane, or hi + lo)
+    if raw_out:
+        if not h16:
+            raise _l.Dm4dError("groupnorm: raw_out is a feature of the fp16 precision")
+        fused = C1 % 8 == 0 and C2 % 8 == 0 and all(t is None or t.data_ptr() % 16 == 0 for t in (x1, x2))
+        if not fused:  # shapes the vectorised kernels do not take: the operand from its own pass
+            M = B * HW
+            return (_groupnorm_f32(x1, gamma, beta, groups, eps, x2, silu),
+                    split(x1.reshape(M, C1), x2.reshape(M, C2) if x2 is not None else None, h16=True).view(y.shape))
+        raw = torch.empty_like(y)
+        with _Prof("groupnorm", (bpe + 2.0) * (x1.numel() + (x2.numel() if x2 is not None else 0)), "byte", B * HW):
+            rc = lib.dm4d_groupnorm_nhwc_f32_f16_raw(_stream(), _p(x1), C1, _p(x2), C2, B, HW, groups, eps, _p(gamma), _p(beta), _p(y), _p(raw),
+                                                     1 if silu else 0, _p(ws))
+        _l.check(rc, "dm4d_groupnorm_nhwc_f32_f16_raw")
+        return y, raw
     with _Prof("groupnorm", bpe * x1.numel() + (bpe * x2.numel() if x2 is not None else 0.0), "byte", B * HW):
         fn = lib.dm4d_groupnorm_nhwc_f32_f16 if h16 else lib.dm4d_groupnorm_nhwc_f32_split
         rc = fn(_stream(), _p(x1), C1, _p(x2), C2, B, HW, groups, eps, _p(gamma), _p(beta), _p(y), 1 if silu else 0, _p(ws))

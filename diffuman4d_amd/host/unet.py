@@ -186,12 +186,18 @@ class _Resnet:
         outputs are two-term operands (ops.groupnorm dispatches on the dtype), the convolutions take them against duplicated weights."""
         P = self.wide
         B, H, Wd = x.shape[:3]
-        h = ops.groupnorm(x, self.n1w, self.n1b, self.groups, self.eps, x2=skip, silu=True)
+        raw = None
+        if self.h16 and self.has_sc:  # the shortcut's operand (fp16 of x | skip) comes out of the GroupNorm pass that reads the same tensor
+            h, raw = ops.groupnorm(x, self.n1w, self.n1b, self.groups, self.eps, x2=skip, silu=True, raw_out=True)
+        else:
+            h = ops.groupnorm(x, self.n1w, self.n1b, self.groups, self.eps, x2=skip, silu=True)
         h = ops.conv3x3(h, self.c1w, bias=self.c1b, rowbias=tproj[:, self.t_off:self.t_off + self.cout], out_f32=P)
         h = ops.groupnorm(h, self.n2w, self.n2b, self.groups, self.eps, silu=True)
         if self.has_sc:
             M = B * H * Wd
-            if P:
+            if raw is not None:
+                sc = ops.gemm(raw.view(M, -1), self.scw, bias=self.scb, out_f32=True)
+            elif P:
                 sc = ops.gemm(ops.split(x.view(M, -1), skip.view(M, -1) if skip is not None else None, h16=self.h16), self.scw, bias=self.scb,
                               out_f32=True)
             else:

@@ -54,12 +54,17 @@ class _Res:
     def __call__(self, x):
         P = self.wide  # fp32 tensors, operands out of the GroupNorms (ops dispatches on the dtypes)
         B, H, Wd, C = x.shape
-        h = ops.groupnorm(x, self.n1w, self.n1b, self.g, 1e-6, silu=True)
+        raw = None
+        if self.h16 and self.has_sc:  # the shortcut's fp16 operand out of the GroupNorm pass that reads the same tensor
+            h, raw = ops.groupnorm(x, self.n1w, self.n1b, self.g, 1e-6, silu=True, raw_out=True)
+        else:
+            h = ops.groupnorm(x, self.n1w, self.n1b, self.g, 1e-6, silu=True)
         h = ops.conv3x3(h, self.c1w, bias=self.c1b, out_f32=P)
         h = ops.groupnorm(h, self.n2w, self.n2b, self.g, 1e-6, silu=True)
         sc = x
         if self.has_sc:
-            sc = ops.gemm(ops.split(x.view(-1, C), h16=self.h16) if P else x.view(-1, C), self.scw, bias=self.scb, out_f32=P).view(B, H, Wd, -1)
+            a = raw.view(-1, C) if raw is not None else (ops.split(x.view(-1, C), h16=self.h16) if P else x.view(-1, C))
+            sc = ops.gemm(a, self.scw, bias=self.scb, out_f32=P).view(B, H, Wd, -1)
         return ops.conv3x3(h, self.c2w, bias=self.c2b, residual=sc, out_f32=P)
 
 

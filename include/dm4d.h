@@ -352,6 +352,11 @@ int dm4d_to_f16_f32(void* stream, const float* X1, int64_t row_stride1, int64_t 
  *   Y [M, ldy >= C] / P [M, ldp >= Np] (columns N .. Np-1 zero).  GroupNorm statistics in fp64, ws as dm4d_groupnorm_f32_ws_bytes. */
 int dm4d_groupnorm_nhwc_f32_f16(void* stream, const float* X1, int C1, const float* X2, int C2, int B, int HW, int groups, float eps,
                                 const void* gamma, const void* beta, void* Y, int apply_silu, void* ws);
+/* ... and the same GroupNorm with a SECOND output Yraw [B*HW, C1 + C2] = fp16 of the un-normalised input (the channel concat of X1 | X2):
+ *   the operand of a resnet's 1x1 shortcut convolution, which reads the tensor its first GroupNorm reads (unet_multiview_blocks.py:667 +
+ *   ResnetBlock2D.conv_shortcut), without a pass of its own over the fp32 tensor.  C1, C2 multiples of 8, 16-byte aligned tensors.  */
+int dm4d_groupnorm_nhwc_f32_f16_raw(void* stream, const float* X1, int C1, const float* X2, int C2, int B, int HW, int groups, float eps,
+                                    const void* gamma, const void* beta, void* Y, void* Yraw, int apply_silu, void* ws);
 int dm4d_layernorm_f32_f16(void* stream, const float* X, int64_t ldx, const void* gamma, const void* beta, void* Y, int64_t ldy, int M,
                            int C, float eps);
 int dm4d_softmax_rows_f32_f16(void* stream, const float* S, int64_t lds, void* P, int64_t ldp, int M, int N, int Np, float scale);

@@ -133,9 +133,12 @@ def split(x, x2=None, *, cpad=None, silu=False, scale=1.0, pattern=0, transposed
     return torch.cat(planes, dim=1).view(lead + (len(planes) * Cp,))
 
 
-def groupnorm(x1, gamma, beta, groups, eps, *, x2=None, silu=False):
+def groupnorm(x1, gamma, beta, groups, eps, *, x2=None, silu=False, raw_out=False):
     f32 = x1.dtype == F32
     x = x1 if x2 is None else torch.cat([x1, x2], dim=-1)
+    if raw_out:
+        assert f32 and gamma.dtype == F16
+        return groupnorm(x1, gamma, beta, groups, eps, x2=x2, silu=silu), x.to(F16)
     B, C = x.shape[0], x.shape[-1]
     v = F.group_norm(x.double().reshape(B, -1, C).permute(0, 2, 1), groups, gamma.double(), beta.double(), eps).permute(0, 2, 1)
     if silu:

@@ -821,7 +821,8 @@ def case_h16_conv_up2x(B, H, W, Cin, Cout, bias=True, seed=0):
     return rel_l2(got, ref), float((got - ref).abs().max())
 
 
-def case_h16_groupnorm(B, HW, C1, C2=0, groups=32, silu=True, eps=1e-5, mean_shift=0.0, seed=0):
+def case_h16_groupnorm(B, HW, C1, C2=0, groups=32, silu=True, eps=1e-5, mean_shift=0.0, seed=0, raw=False):
+    """raw: the second output (fp16 of the un-normalised concat, the shortcut convolution's operand) must be bit for bit what ops.split makes."""
     from diffuman4d_amd.host import ops
     g = torch.Generator().manual_seed(seed)
     x1 = torch.randn(B, HW, C1, generator=g) * 2 + mean_shift
@@ -832,7 +833,12 @@ def case_h16_groupnorm(B, HW, C1, C2=0, groups=32, silu=True, eps=1e-5, mean_shi
     ref = F.group_norm(x.double().permute(0, 2, 1), groups, gam.double(), bet.double(), eps).permute(0, 2, 1)
     if silu:
         ref = F.silu(ref)
-    out = ops.groupnorm(x1.cuda(), gam.cuda(), bet.cuda(), groups, eps, x2=x2.cuda() if C2 else None, silu=silu)
+    out = ops.groupnorm(x1.cuda(), gam.cuda(), bet.cuda(), groups, eps, x2=x2.cuda() if C2 else None, silu=silu, raw_out=raw)
+    if raw:
+        out, rawv = out
+        plain = ops.groupnorm(x1.cuda(), gam.cuda(), bet.cuda(), groups, eps, x2=x2.cuda() if C2 else None, silu=silu)
+        assert torch.equal(out, plain), "the normalised plane must not depend on the second output"
+        assert rawv.dtype == F16 and torch.equal(rawv.cpu(), x.to(F16)), "raw plane is not fp16(x1 | x2)"
     assert out.dtype == F16 and out.shape[-1] == C
     got = out.double().cpu()
     return rel_l2(got, ref), float((got - ref).abs().max())
@@ -1285,6 +1291,9 @@ CASES = {
     "h16_gn_silu": (case_h16_groupnorm, dict(B=3, HW=720, C1=320)),
     "h16_gn_l0_two_launch": (case_h16_groupnorm, dict(B=4, HW=2880, C1=320)),
     "h16_gn_l0_concat": (case_h16_groupnorm, dict(B=2, HW=2880, C1=320, C2=320)),
+    "h16_gn_l0_concat_raw": (case_h16_groupnorm, dict(B=2, HW=2880, C1=640, C2=320, raw=True)),
+    "h16_gn_l2_concat_raw_resident": (case_h16_groupnorm, dict(B=3, HW=180, C1=1280, C2=640, raw=True)),
+    "h16_gn_odd_raw_fallback": (case_h16_groupnorm, dict(B=2, HW=77, C1=66, groups=6, raw=True)),
     "h16_gn_two_sources": (case_h16_groupnorm, dict(B=2, HW=180, C1=1280, C2=640)),
     "h16_gn_vae_128ch_eps6": (case_h16_groupnorm, dict(B=2, HW=4096, C1=128, eps=1e-6)),
     "h16_gn_mean_200sigma": (case_h16_groupnorm, dict(B=2, HW=512, C1=64, groups=8, silu=False, mean_shift=400.0)),
