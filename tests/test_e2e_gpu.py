@@ -48,11 +48,12 @@ def test_cli_path_on_synthetic_checkpoint(tmp_path, fast):
     assert len(glob.glob(f"{sampler.output_dir}/grids/*.webp")) == 4 + 6 + 4  # one snapshot mosaic per task
 
 
-def test_cli_path_in_the_parity_precision(tmp_path):
-    """`model.precision=parity` through the same CLI path (config key -> load_pipelines -> from_pretrained -> sampler -> runner -> writer), with
+def test_cli_path_in_the_wide_precisions(tmp_path):
+    """`model.precision=parity` and `model.precision=fp16` through the same CLI path (config key -> load_pipelines -> from_pretrained -> sampler -> runner -> writer), with
     the VAE cache, decode-on-demand, device-side Pluecker maps and device-side result packing switched on: the job completes, the pipeline
-    really is the fp32 / two-term one, and its grid differs from the fast precision's (same seed, one task at a time) by bf16 rounding
-    noise -- not by zero (the key was ignored) and not by more (a wiring defect of the mode)."""
+    really is the fp32-tensor one, and its grid differs from the fast precision's (same seed, one task at a time) by bf16 rounding
+    noise -- not by zero (the key was ignored) and not by more (a wiring defect of the mode); the two wide precisions sit an order of
+    magnitude closer to each other than either does to the fast one."""
     from diffuman4d_amd.host import config as cfglib
     from diffuman4d_amd.host.results import check_sampling_results
     from diffuman4d_amd.host.runner import SamplingRunner
@@ -60,7 +61,7 @@ def test_cli_path_in_the_parity_precision(tmp_path):
     ucfg, vcfg = _tiny_cfgs()
     ckpt = write_synthetic_checkpoint(tmp_path / "ckpt", ucfg, vcfg, seed=3)
     grids = {}
-    for prec in ("fast", "parity"):
+    for prec in ("fast", "parity", "fp16"):
         ov = ["exp=demo_4d_tiny", "model=diffuman4d_mi355x", "data=synthetic", f"model.model_dir={ckpt}", "model.gpu_ids=[0]",
               f"model.precision={prec}", "data.height=64", "data.width=64", "data.num_cameras=8", f"result_dir={tmp_path / prec}",
               "sampler.spa_label_range=[0,8,1]", "sampler.tem_label_range=[0,4,1]", "sampler.input_spa_labels=[1,5]",
@@ -68,7 +69,7 @@ def test_cli_path_in_the_parity_precision(tmp_path):
               "sampler.plucker_on_device=true", "data.plucker=cameras", "sampler.device_results=true"]
         cfg = cfglib.compose(ov)
         pipelines = cfglib.instantiate(cfg["model"])
-        assert pipelines[0].precision == prec and pipelines[0].dtype == (torch.float32 if prec == "parity" else torch.bfloat16)
+        assert pipelines[0].precision == prec and pipelines[0].dtype == (torch.bfloat16 if prec == "fast" else torch.float32)
         sampler = cfglib.instantiate(cfg["sampler"], dataset=cfglib.instantiate(cfg["data"]), pipelines=pipelines)
         torch.manual_seed(1234)
         SamplingRunner(sampler, prefetch_depth=0, writers=1, gpu_streams=1).inference()
@@ -78,6 +79,8 @@ def test_cli_path_in_the_parity_precision(tmp_path):
     assert bool(torch.isfinite(grids["parity"]).all())
     d = float((grids["fast"] - grids["parity"]).norm() / grids["parity"].norm())
     assert 1e-4 < d < 6e-2, d
+    dh = float((grids["fp16"] - grids["parity"]).norm() / grids["parity"].norm())
+    assert 1e-6 < dh < 0.2 * d, (dh, d)
 
 
 @pytest.mark.parametrize("domain,n", [("spatial", 8), ("temporal", 12)])
@@ -185,11 +188,13 @@ def test_tasks_on_concurrent_streams_equal_serial(tmp_path):
 
 
 def test_fp16_checkpoint_files_through_the_factory(tmp_path):
-    """`torch_dtype: fp16` (sampling_utils.py:28-30) selects the *.fp16.safetensors files; arithmetic stays bf16 MFMA.
-    Both file sets hold the same numbers here (weights below fp16's normal range are zeroed so that every bf16 value is
-    exactly an fp16 value), so the fp16 load must reproduce the bf16 load BIT FOR BIT -- anything else would mean the two
-    spellings run different arithmetic.  The plain files are removed before the fp16 load to prove which ones were read;
-    `.to()` of a loaded pipeline is the identity on its own device."""
+    """`torch_dtype: fp16` (sampling_utils.py:28-30) selects the *.fp16.safetensors files.  With `precision: "fast"` the arithmetic stays bf16
+    MFMA: both file sets hold the same numbers here (weights below fp16's normal range are zeroed so that every bf16 value is exactly an fp16
+    value), so that load must reproduce the bf16 load BIT FOR BIT.  With the default `precision: "auto"` an fp16 pipeline computes in the fp16
+    precision (fp16 MFMA operands over fp32 tensors, the faithful form of the reference's fp16 pipelines): same weights, so its result is the
+    bf16 pipeline's up to the bf16 path's own rounding noise, and the same files loaded as a bf16 pipeline in `precision: "fp16"` give it bit
+    for bit.  The plain files are removed before the fp16 loads to prove which ones were read; `.to()` of a loaded pipeline is the identity
+    on its own device."""
     import os
     from safetensors.torch import load_file, save_file
     from diffuman4d_amd.host.loader import load_pipelines
@@ -204,10 +209,13 @@ def test_fp16_checkpoint_files_through_the_factory(tmp_path):
         save_file(sd, f)
         save_file({k: v.to(torch.float16) for k, v in sd.items()}, f"{ckpt}/{sub}/diffusion_pytorch_model.fp16.safetensors")
     ref_pipe = load_pipelines(model_dir=ckpt, torch_dtype="bf16", gpu_ids=[0])[0]
+    h16_ref = load_pipelines(model_dir=ckpt, torch_dtype="bf16", gpu_ids=[0], precision="fp16")[0]
     for sub in ("unet", "vae"):
         os.remove(f"{ckpt}/{sub}/diffusion_pytorch_model.safetensors")
-    pipe = load_pipelines(model_dir=ckpt, torch_dtype="fp16", gpu_ids=[0])[0]
+    pipe = load_pipelines(model_dir=ckpt, torch_dtype="fp16", gpu_ids=[0], precision="fast")[0]
+    auto = load_pipelines(model_dir=ckpt, torch_dtype="fp16", gpu_ids=[0])[0]
     assert pipe.checkpoint_variant == "fp16" and ref_pipe.checkpoint_variant is None and pipe.to("cuda:0") is pipe
+    assert pipe.precision == "fast" and auto.precision == "fp16" and auto.dtype == torch.float32 and ref_pipe.precision == "fast"
     n = 8
     pv, pl, sk, cm = synthetic_task(n, 64, 64, [1, 5], 9)
     g = torch.Generator().manual_seed(10)
@@ -218,3 +226,7 @@ def test_fp16_checkpoint_files_through_the_factory(tmp_path):
     a, b = pipe.sliding_iterative_denoise(**kw), ref_pipe.sliding_iterative_denoise(**kw)
     assert torch.equal(a["timestep_indices"], b["timestep_indices"])
     assert torch.equal(a["latents"], b["latents"]) and torch.equal(a["images"], b["images"])
+    c, d = auto.sliding_iterative_denoise(**kw), h16_ref.sliding_iterative_denoise(**kw)
+    assert torch.equal(c["latents"], d["latents"]) and torch.equal(c["images"], d["images"]) and c["latents"].dtype == torch.float32
+    rel = float((c["images"].float() - b["images"].float()).norm() / b["images"].float().norm())
+    assert 1e-4 < rel < 2e-2, rel  # the fp16 precision against the bf16 one: the bf16 path's rounding noise, not a different model

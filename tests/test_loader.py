@@ -61,3 +61,40 @@ def test_load_pipelines_dtype_seam(tmp_path):
     assert load_pipelines(model_dir=str(d), torch_dtype="fp16", gpu_ids=[]) == []
     with pytest.raises(ValueError, match="Unsupported torch_dtype: fp32. Supported types are 'bf16' and 'fp16'."):
         load_pipelines(model_dir=str(d), torch_dtype="fp32", gpu_ids=[])
+
+
+def test_weight_dtypes_of_the_three_precisions():
+    """What the kernels of each precision are handed (host/unet.py::_Weights): the fast and parity precisions compute on the bf16 rounding of
+    whatever was loaded (parity: duplicated along K); the fp16 precision holds the values of the pipeline's weight dtype in fp16 -- fp16
+    checkpoint values exactly, bf16 values exactly (down to 2^-14), fp32 values rounded to the weight dtype first, as the reference's
+    `from_pretrained(torch_dtype=...)` would."""
+    from diffuman4d_amd.host.unet import _Weights
+    w = torch.tensor([[1.0009765625, -0.333251953125, 3.0517578125e-05, 1.2345678]])  # fp16-exact, fp16-exact, 2^-15, neither
+    bias = torch.tensor([0.1, -2.5])
+    fast = _Weights({"b": bias}, "cpu")
+    assert fast.mat(w).dtype == torch.bfloat16 and torch.equal(fast.mat(w), w.to(torch.bfloat16)) and fast.vec("b").dtype == torch.bfloat16
+    par = _Weights({}, "cpu", parity=True)
+    assert par.mat(w).shape == (1, 8) and torch.equal(par.mat(w)[:, :4], par.mat(w)[:, 4:])
+    h_bf = _Weights({"b": bias}, "cpu", h16=True, wdtype=torch.bfloat16)   # bf16 pipeline in the fp16 precision
+    assert h_bf.mat(w).dtype == torch.float16 and torch.equal(h_bf.mat(w).float(), w.to(torch.bfloat16).float())
+    assert h_bf.vec("b").dtype == torch.float16 and torch.equal(h_bf.vec("b").float(), bias.to(torch.bfloat16).float())
+    h_fp = _Weights({}, "cpu", h16=True, wdtype=torch.float16)             # fp16 pipeline: the checkpoint's own values
+    assert torch.equal(h_fp.mat(w.to(torch.float16)), w.to(torch.float16)) and float(h_fp.mat(w)[0, 0]) == 1.0009765625
+    assert h_bf.wide and h_fp.wide and par.wide and not fast.wide
+
+
+def test_auto_precision_follows_the_torch_dtype(monkeypatch):
+    """`precision: "auto"` (the default of load_pipelines and of configs/model/diffuman4d_mi355x.yaml): fp16 pipelines compute with fp16 MFMA
+    operands, as the reference's fp16 pipelines do (sampling_utils.py:27-29); bf16 pipelines stay on the bf16 kernels."""
+    import diffuman4d_amd.host.pipeline as hp
+    seen = []
+
+    def fake(model_dir, torch_dtype=None, device=None, precision=None):
+        seen.append((torch_dtype, precision))
+        return object()
+    monkeypatch.setattr(hp.Diffuman4DPipeline, "from_pretrained", staticmethod(fake))
+    load_pipelines(model_dir="/tmp", torch_dtype="fp16", gpu_ids=[0])
+    load_pipelines(model_dir="/tmp", torch_dtype="bf16", gpu_ids=[0])
+    load_pipelines(model_dir="/tmp", torch_dtype="fp16", gpu_ids=[0], precision="fast")
+    load_pipelines(model_dir="/tmp", torch_dtype="bf16", gpu_ids=[0], precision="fp16")
+    assert seen == [(torch.float16, "fp16"), (torch.bfloat16, "fast"), (torch.float16, "fast"), (torch.bfloat16, "fp16")]
