@@ -104,5 +104,30 @@ PY
     done
     cp /tmp/cur.so diffuman4d_amd/libdm4d.so
     ;;
+  gnraw)  # the GroupNorm that also emits the shortcut operand; then task streams 3 / 4 / 6 in both precisions
+    timeout 600 python tests/opcheck.py h16_gn h16_conv_up2x gn_ > $out/r05_gnraw_opcheck.log 2>&1; quiet $out/r05_gnraw_opcheck.log | grep -v "^PASS" | tail
+    timeout 900 python tests/modelcheck.py fp16_unet_spatial fp16_vae fp16_pipeline_spatial fp16_unet_sd21_72x40_f16 fp16_demo3d fp16_vae_sd unet_spatial pipeline_spatial \
+        > $out/r05_gnraw_modelcheck.log 2>&1; quiet $out/r05_gnraw_modelcheck.log 500 | grep "^PASS\|^FAIL\|^ERROR\|modelcheck:" | tail -12
+    ab="--steps 12 --warmup 3 --no-cpu-baseline --no-grid-secondary --no-vae --no-parity-precision --no-latent128"
+    for rep in 1 2; do for ts in 3 4 6; do
+      timeout 300 python bench.py $ab --task-streams $ts > $out/r05_ts${ts}_$rep.json 2>/dev/null; bench_line $out/r05_ts${ts}_$rep.json "task streams $ts rep $rep:"
+    done; done
+    ;;
+  final1)  # the whole GPU suite, smoke(), the driver command on the final tree
+    ( time timeout 2400 python -m pytest tests -m gpu -x -q > $out/r05_pytest_gpu.log 2>&1 ) 2> $out/r05_pytest_gpu.time; tail -5 $out/r05_pytest_gpu.log; tail -3 $out/r05_pytest_gpu.time
+    timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $out/r05_smoke.log 2>&1; tail -2 $out/r05_smoke.log | cut -c1-1500
+    ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/r05_bench.json 2> $out/r05_bench.err ) 2> $out/r05_bench.time; tail -3 $out/r05_bench.time
+    bench_line $out/r05_bench.json "driver command:"
+    ;;
+  final2)  # records: rocprofv3 kernel tables of the three precisions, PMC passes of the fast one, BASELINE configs[4], the CLI path in the fp16 precision
+    bash tools/profile_bench.sh r05 fast > $out/r05_profile.log 2>&1; tail -14 $out/r05_profile.log | cut -c1-220
+    bash tools/profile_bench.sh r05_fp16 fp16 stats > $out/r05_profile_fp16.log 2>&1; tail -12 $out/r05_profile_fp16.log | cut -c1-200
+    bash tools/profile_bench.sh r05_parity parity stats > $out/r05_profile_parity.log 2>&1; tail -8 $out/r05_profile_parity.log | cut -c1-200
+    timeout 600 python bench.py --config5 --steps 12 --warmup 3 --no-vae > $out/r05_bench_config5.json 2> $out/r05_bench_config5.err; bench_line $out/r05_bench_config5.json "config5 (48 x 225, sliding_default):"
+    timeout 600 python bench.py --config5 --precision fp16 --steps 12 --warmup 3 --no-vae > $out/r05_bench_config5_fp16.json 2>/dev/null; bench_line $out/r05_bench_config5_fp16.json "config5, fp16 precision:"
+    timeout 900 python tools/e2e_demo.py --exp demo_4d --fast-vae --prune --writers 2 --device-results --writer-processes 12 --host-threads 8 --depth 3 \
+        sampler.plucker_on_device=true data.plucker=cameras model.precision=fp16 > $out/r05_e2e_demo4d_fp16.json 2> $out/r05_e2e_demo4d_fp16.err
+    cat $out/r05_e2e_demo4d_fp16.json | cut -c1-600; tail -2 $out/r05_e2e_demo4d_fp16.err | cut -c1-300
+    ;;
   *) echo "unknown stage $stage"; exit 2;;
 esac

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Profiles of the bench command on a GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 900 -- 'bash tools/profile_bench.sh <tag>'
+#   gpurun --timeout 900 -- 'bash tools/profile_bench.sh <tag> [precision] [stats-only]'
+#   precision: fast (default) | fp16 | parity = bench.py --precision ...; a third argument limits the run to step 1 (the kernel table)
 # 1. rocprofv3 --kernel-trace --stats      -> gpurun_out/<tag>_kernel_stats.txt   (per-kernel time table)
 # 2. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel trace only, as MI355X_MICROARCH.md's HBM section
 #    prescribes)                            -> gpurun_out/<tag>_attn_traffic_pmc.json (per-launch averages for attn_kernel)
@@ -10,10 +11,12 @@
 set -u
 # every rocprofv3 run is under `timeout`: after a fault in the profiled process the tool waits for ever (23 GPU-minutes lost once)
 TAG=${1:-r01}
+PREC=${2:-fast}
+STATS_ONLY=${3:-}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 # one task in flight: the bench's roofline figures come from its one-task-at-a-time pass, and with two task streams the
 # kernel intervals of different tasks overlap in the trace
-BENCH="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --task-streams 1 --no-grid-secondary --no-vae --no-parity-precision --no-latent128"
+BENCH="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --task-streams 1 --no-grid-secondary --no-vae --no-parity-precision --no-tolerance-mode --no-latent128 --precision $PREC"
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"
@@ -22,6 +25,7 @@ DB=$(find "$OUT" -name "stats*results.db" | head -1)
 python tools/profile_summary.py "$DB" "rocprofv3 --kernel-trace --stats -- $BENCH ($TAG; 1 warm-up + 2 timed + 2 roofline-pass + 1 breakdown units, plus weight-init kernels)" \
   > gpurun_out/${TAG}_kernel_stats.txt
 tail -1 "$OUT.bench.log" > gpurun_out/${TAG}_bench_under_rocprof.json
+if [ -n "$STATS_ONLY" ]; then head -16 gpurun_out/${TAG}_kernel_stats.txt; rm -rf "$OUT"; exit 0; fi
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $C -d "$OUT" -o pmc_$C -- $BENCH > /dev/null 2> "$OUT.pmc_$C.err"
 done
