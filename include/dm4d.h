@@ -360,6 +360,12 @@ int dm4d_groupnorm_nhwc_f32_f16_raw(void* stream, const float* X1, int C1, const
 int dm4d_layernorm_f32_f16(void* stream, const float* X, int64_t ldx, const void* gamma, const void* beta, void* Y, int64_t ldy, int M,
                            int C, float eps);
 int dm4d_softmax_rows_f32_f16(void* stream, const float* S, int64_t lds, void* P, int64_t ldp, int M, int N, int Np, float scale);
+/* The two entries above take any channel count / alignment: shapes that are not 16-byte vectors of eight channels are forwarded to these
+ *   general kernels (fp64 GroupNorm statistics, one or four channels per thread; one wave per LayerNorm row), same arguments.           */
+int dm4d_groupnorm_f32_f16_general(void* stream, const float* X1, int C1, const float* X2, int C2, int B, int HW, int groups, float eps,
+                                   const void* gamma, const void* beta, void* Y, int apply_silu, void* ws);
+int dm4d_layernorm_f32_f16_general(void* stream, const float* X, int64_t ldx, const void* gamma, const void* beta, void* Y, int64_t ldy,
+                                   int M, int C, float eps);
 
 /* dm4d_attention_qscaled_kv_bf16 on fp16 Q (carrying scale * log2 e) / K / V -> fp16 O: the same optimistic-softmax loop with
  *   v_mfma_f32_32x32x16_f16; probabilities are kept below 65504 by an offset of 2^-8 on the first tile's maximum and a row-sum check

@@ -114,7 +114,7 @@ PY
     done; done
     ;;
   final1)  # the whole GPU suite, smoke(), the driver command on the final tree
-    ( time timeout 2400 python -m pytest tests -m gpu -x -q > $out/r05_pytest_gpu.log 2>&1 ) 2> $out/r05_pytest_gpu.time; tail -5 $out/r05_pytest_gpu.log; tail -3 $out/r05_pytest_gpu.time
+    ( time timeout 2400 python -m pytest tests -m gpu -q > $out/r05_pytest_gpu.log 2>&1 ) 2> $out/r05_pytest_gpu.time; tail -5 $out/r05_pytest_gpu.log; tail -3 $out/r05_pytest_gpu.time
     timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $out/r05_smoke.log 2>&1; tail -2 $out/r05_smoke.log | cut -c1-1500
     ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/r05_bench.json 2> $out/r05_bench.err ) 2> $out/r05_bench.time; tail -3 $out/r05_bench.time
     bench_line $out/r05_bench.json "driver command:"
