@@ -119,7 +119,9 @@ PY
     ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/r05_bench.json 2> $out/r05_bench.err ) 2> $out/r05_bench.time; tail -3 $out/r05_bench.time
     bench_line $out/r05_bench.json "driver command:"
     ;;
-  final2)  # records: rocprofv3 kernel tables of the three precisions, PMC passes of the fast one, BASELINE configs[4], the CLI path in the fp16 precision
+  final2)  # the driver command once more on the final tree (bench.py gained the tolerance mode's evidence fields after final1), then the records: rocprofv3 kernel tables of the three precisions, PMC passes of the fast one, BASELINE configs[4], the CLI path in the fp16 precision
+    ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/r05_bench.json 2> $out/r05_bench.err ) 2> $out/r05_bench.time; tail -3 $out/r05_bench.time
+    bench_line $out/r05_bench.json "driver command:"
     bash tools/profile_bench.sh r05 fast > $out/r05_profile.log 2>&1; tail -14 $out/r05_profile.log | cut -c1-220
     bash tools/profile_bench.sh r05_fp16 fp16 stats > $out/r05_profile_fp16.log 2>&1; tail -12 $out/r05_profile_fp16.log | cut -c1-200
     bash tools/profile_bench.sh r05_parity parity stats > $out/r05_profile_parity.log 2>&1; tail -8 $out/r05_profile_parity.log | cut -c1-200
