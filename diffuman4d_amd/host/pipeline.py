@@ -16,7 +16,7 @@ from __future__ import annotations
 
 import json
 from pathlib import Path
-from typing import Callable, Dict, NamedTuple, Optional
+from typing import Callable, Dict, List, NamedTuple, Optional
 
 import numpy as np
 import torch
@@ -316,20 +316,34 @@ class Diffuman4DPipeline:
         window call split over them by frames with K/V all-gathers in the 3-D attention layers -- every rank
         passes the same arguments and gets the same result; `noise_seed`: the random draws come from a device generator seeded
         with it instead of the global one, so that the ranks of a shard group draw the same numbers."""
+        self._check_sweep_call(decode)
+        plan, tensors = self._prepare_sweep(pixel_values, plucker_embeds, skeletons, cond_masks, latents, domain, timestep_indices,
+                                            window_size, sliding_stride, sliding_shift, bidirectional, num_denoising_steps,
+                                            alternation_rounds, noise, cache_keys, cameras, noise_seed)
+        lat = tensors[4]
+        self.denoise_latents(*tensors, plan, domain, guidance_scale, tqdm, shard=shard)
+        return self._finish_sweep(lat, plan, decode)
+
+    def _check_sweep_call(self, decode: str) -> None:
         if decode not in ("all", "denoised", "none"):
             raise ValueError("decode must be 'all', 'denoised' or 'none'")
         if self.vae is None:
             raise RuntimeError("this pipeline was built without a VAE; use denoise_latents()")
         torch.cuda.set_device(self._device)  # worker threads inherit device 0 (sampling_runner.py:36)
+
+    def _prepare_sweep(self, pixel_values, plucker_embeds, skeletons, cond_masks, latents, domain, timestep_indices, window_size,
+                       sliding_stride, sliding_shift, bidirectional, num_denoising_steps, alternation_rounds, noise, cache_keys,
+                       cameras, noise_seed):
+        """Window plan + the task's device tensors (pipeline_diffuman4d.py:466-519): (plan, (pv, pl, sk, cm, lat))."""
         cond_flags = (cond_masks[:, 0, 0, 0] == 0.0).cpu().numpy()
         plan = plan_sweep(cond_flags, torch.as_tensor(timestep_indices).cpu().numpy(), domain, window_size,
                           sliding_stride, sliding_shift, bidirectional, num_denoising_steps, alternation_rounds)
         if noise_seed is not None and noise is None:
             noise = self.seeded_noise(int(noise_seed), pixel_values.shape[0], pixel_values.shape[-2] // self.vae_scale_factor,
                                       pixel_values.shape[-1] // self.vae_scale_factor, need_latents=latents is None)
-        pv_lat, pl_lat, sk_lat, cm_lat, lat = self.prepare_all_latents(pixel_values, plucker_embeds, skeletons,
-                                                                       cond_masks, latents, noise, cache_keys, cameras)
-        self.denoise_latents(pv_lat, pl_lat, sk_lat, cm_lat, lat, plan, domain, guidance_scale, tqdm, shard=shard)
+        return plan, self.prepare_all_latents(pixel_values, plucker_embeds, skeletons, cond_masks, latents, noise, cache_keys, cameras)
+
+    def _finish_sweep(self, lat, plan: SweepPlan, decode: str) -> dict:
         tidx = torch.from_numpy(plan.final_timestep_indices)
         rows = (tidx == plan.num_inference_steps) if decode == "denoised" else (torch.zeros_like(tidx, dtype=torch.bool) if decode == "none" else None)
         images = self.vae.decode_to_images(lat, rows=rows)  # [N,3,H,W] in [0,1]
@@ -339,3 +353,61 @@ class Diffuman4DPipeline:
             "timestep_indices": tidx,
             "fully_denoised": tidx == plan.num_inference_steps,
         }
+
+    @staticmethod
+    def same_plan(a: SweepPlan, b: SweepPlan) -> bool:
+        """Two tasks can share their window calls exactly when their plans agree call by call."""
+        def eq(x, y):
+            return len(x) == len(y) and all(np.array_equal(u, v) for u, v in zip(x, y))
+        return (a.num_inference_steps == b.num_inference_steps and eq(a.windows, b.windows) and eq(a.is_cond, b.is_cond)
+                and eq(a.timestep_index, b.timestep_index) and np.array_equal(a.final_timestep_indices, b.final_timestep_indices))
+
+    @torch.no_grad()
+    def sliding_iterative_denoise_stack(self, tasks: List[Dict], domain: str = "spatial", window_size: int = 12, sliding_stride: int = 1,
+                                        sliding_shift: int = 0, bidirectional: bool = True, num_denoising_steps: int = 1,
+                                        alternation_rounds: int = 3, guidance_scale: float = 2.0, tqdm: Callable = _identity_tqdm,
+                                        decode: str = "all") -> List[Dict]:
+        """Extension (runner.task_batch): several tasks of ONE alternation round through SHARED window calls.  The reference runs one
+        task per pipeline call (sliding_iterative_sampler.py:201-204); tasks of a round have the same geometry and the same timestep
+        indices, hence the same window plan, so their tensors can be stacked along the frame axis: every call then carries
+        len(tasks) x F frames, the 3-D attention still folds F frames per task, and each task's arithmetic is what it is alone
+        (per-row GEMMs, per-sample GroupNorm, per-(task, head) attention) -- the results equal, bit for bit, those of
+        `sliding_iterative_denoise` called once per task in list order (random draws included: the tasks are prepared in that
+        order).  `tasks[k]`: the per-task arguments of `sliding_iterative_denoise` (pixel_values, plucker_embeds, skeletons, cond_masks,
+        latents, timestep_indices and, optionally, noise, cache_keys, cameras, noise_seed).  Raises ValueError when the plans differ."""
+        self._check_sweep_call(decode)
+        if not tasks:
+            return []
+        per_task = ("pixel_values", "plucker_embeds", "skeletons", "cond_masks", "latents", "timestep_indices", "noise", "cache_keys",
+                    "cameras", "noise_seed")
+        preps = []
+        for t in tasks:
+            unknown = set(t) - set(per_task)
+            if unknown:
+                raise TypeError(f"unexpected per-task arguments: {sorted(unknown)}")
+            a = {k: t.get(k) for k in per_task}
+            preps.append(self._prepare_sweep(a["pixel_values"], a["plucker_embeds"], a["skeletons"], a["cond_masks"], a["latents"], domain,
+                                             a["timestep_indices"], window_size, sliding_stride, sliding_shift, bidirectional,
+                                             num_denoising_steps, alternation_rounds, a["noise"], a["cache_keys"], a["cameras"],
+                                             a["noise_seed"]))
+        plan = preps[0][0]
+        n = preps[0][1][4].shape[0]
+        for other, tens in preps[1:]:
+            if tens[4].shape != preps[0][1][4].shape or not self.same_plan(plan, other):
+                raise ValueError("tasks of a stack need identical window plans (same rows, conditioning flags and timestep indices)")
+        if len(preps) == 1:
+            stacked = preps[0][1]
+        else:
+            cols = list(zip(*[tens for _, tens in preps]))
+            sk = cols[2]
+            if isinstance(sk[0], PoseFeatures):
+                sk = PoseFeatures(torch.cat([f.feat for f in sk]), sk[0].neg)
+            elif sk[0] is not None:
+                sk = torch.cat(sk)
+            else:
+                sk = None
+            stacked = (torch.cat(cols[0]), torch.cat(cols[1]), sk, torch.cat(cols[3]), torch.cat(cols[4]))
+        tables = self.upload_plan(plan, guidance_scale, copies=len(preps), rows_per_task=n) if len(preps) > 1 else None
+        self.denoise_latents(*stacked, plan, domain, guidance_scale, tqdm, tables=tables)
+        lat = stacked[4]
+        return [self._finish_sweep(lat[k * n:(k + 1) * n], plan, decode) for k in range(len(preps))]

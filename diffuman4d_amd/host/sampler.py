@@ -190,23 +190,71 @@ class SlidingIterativeSampler:
         sample["timestep_indices"] = cell_indices
         return sample
 
-    @torch.no_grad()
-    def denoise(self, sample: dict, pipe_idx: int = 0) -> dict:
-        pipe = self.pipelines[pipe_idx]
+    def _wait_for_cells(self, sample: dict, pipe) -> bool:
         on_gpu = torch.cuda.is_available() and getattr(pipe.device, "type", "cpu") == "cuda"
         ready = sample.pop("_latents_ready", None)
         if on_gpu and ready is not None:  # the grid cells were gathered on another stream (load_sample)
             cur = torch.cuda.current_stream(pipe.device)
             cur.wait_event(ready)
             sample["latents"].record_stream(cur)  # allocated in the loader stream's pool, consumed here
-        axis = "spa" if sample["domain"] == "temporal" else "tem"  # the label names the FIXED axis of the task
-        bar = partial(_tqdm, desc=f"Denoising alt{sample['alt']}_{axis}{sample['domain_label']} on {pipe.device}")
+        return on_gpu
+
+    def _task_tensors(self, sample: dict) -> dict:
         tensors = {k: sample[k] for k in ("pixel_values", "plucker_embeds", "skeletons", "cond_masks", "latents",
                                           "timestep_indices")}
         if self.plucker_on_device:
             tensors["plucker_embeds"] = None
-        result = pipe.sliding_iterative_denoise(domain=sample["domain"], tqdm=bar, **tensors, **asdict(self.sweep),
-                                                **self._pipeline_extensions(sample))
+        return tensors
+
+    @staticmethod
+    def _bar(sample: dict, pipe, more: int = 0):
+        axis = "spa" if sample["domain"] == "temporal" else "tem"  # the label names the FIXED axis of the task
+        also = f" (+{more})" if more else ""
+        return partial(_tqdm, desc=f"Denoising alt{sample['alt']}_{axis}{sample['domain_label']}{also} on {pipe.device}")
+
+    @torch.no_grad()
+    def denoise(self, sample: dict, pipe_idx: int = 0) -> dict:
+        pipe = self.pipelines[pipe_idx]
+        on_gpu = self._wait_for_cells(sample, pipe)
+        result = pipe.sliding_iterative_denoise(domain=sample["domain"], tqdm=self._bar(sample, pipe), **self._task_tensors(sample),
+                                                **asdict(self.sweep), **self._pipeline_extensions(sample))
+        return self._take_result(sample, result, pipe, on_gpu)
+
+    def stackable(self, samples: List[dict]) -> bool:
+        """Tasks that can share their window calls (pipeline.sliding_iterative_denoise_stack): one domain, the same rows conditioned,
+        the same timestep indices, the same tensor shapes -- what the tasks of one alternation round have -- and no frame sharding."""
+        if len(samples) < 2 or self.frame_shard is not None or getattr(self, "shard_follower", False):
+            return False
+        if not hasattr(self.pipelines[0], "sliding_iterative_denoise_stack"):
+            return False
+        a = samples[0]
+        for b in samples[1:]:
+            if b["domain"] != a["domain"] or b["pixel_values"].shape != a["pixel_values"].shape \
+                    or (a["latents"] is None) != (b["latents"] is None) \
+                    or not torch.equal(b["cond_masks"][:, 0, 0, 0] == 0.0, a["cond_masks"][:, 0, 0, 0] == 0.0) \
+                    or not torch.equal(torch.as_tensor(b["timestep_indices"]), torch.as_tensor(a["timestep_indices"])):
+                return False
+        return True
+
+    @torch.no_grad()
+    def denoise_stack(self, samples: List[dict], pipe_idx: int = 0) -> List[dict]:
+        """Extension (runner.task_batch): the samples' tasks through shared window calls; every sample ends up exactly as `denoise`
+        leaves it (results are bitwise those of one `denoise` per sample in list order).  Samples that are not `stackable` run
+        one by one."""
+        if not self.stackable(samples):
+            return [self.denoise(s, pipe_idx=pipe_idx) for s in samples]
+        pipe = self.pipelines[pipe_idx]
+        on_gpu = [self._wait_for_cells(s, pipe) for s in samples][0]
+        ext = [self._pipeline_extensions(s) for s in samples]
+        decode = ext[0].pop("decode", "all")
+        for e in ext[1:]:
+            e.pop("decode", None)
+        tasks = [dict(self._task_tensors(s), **e) for s, e in zip(samples, ext)]
+        results = pipe.sliding_iterative_denoise_stack(tasks, domain=samples[0]["domain"], tqdm=self._bar(samples[0], pipe, len(samples) - 1),
+                                                       decode=decode, **asdict(self.sweep))
+        return [self._take_result(s, r, pipe, on_gpu) for s, r in zip(samples, results)]
+
+    def _take_result(self, sample: dict, result: dict, pipe, on_gpu: bool) -> dict:
         sample["timestep_indices"] = result["timestep_indices"].cpu()
         sample["fully_denoised"] = result["fully_denoised"].cpu()
         if self.device_results and on_gpu and self.result_writer is not None:  # (device_results is off for caller-supplied writers)

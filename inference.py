@@ -39,10 +39,12 @@ def inference(cfg: dict):
     sampler = cfglib.instantiate(cfg["sampler"], dataset=dataset, pipelines=pipelines)
     # runner.gpu_streams=N (default 3): tasks of a round in flight per GPU, one HIP stream each; 1 = the reference's
     # one-task-at-a-time order
+    # runner.task_batch=K (default 1): K consecutive tasks of a round share their window calls (tensors stacked along the frame axis;
+    # every task's result is bitwise what it is alone)
     # runner.writer_processes=N (default 0): with sampler.device_results=true the JPEG / WebP encoding of every task's uint8
     # package runs in N writer processes (host/imgwrite.py) instead of the writer threads
     rk = {k: int(v) for k, v in (cfg.get("runner") or {}).items()
-          if k in ("prefetch_depth", "writers", "gpu_streams", "writer_processes")}
+          if k in ("prefetch_depth", "writers", "gpu_streams", "writer_processes", "task_batch")}
     # runner.host_threads=N: torch's intra-op CPU threads for the host-side stages (loader, writer).  The 256-thread GPU hosts
     # default to 128-256 threads per op, and several loader / writer threads each fanning small tensor ops out over all of
     # them is what made the host stages the bottleneck (profiles/r02_e2e_demo.log)

@@ -690,10 +690,8 @@ def case_pipeline_plucker_on_device(seed=51):
     return (err if exact else 1.0), 0.0
 
 
-def case_golden_pipeline(name, precision="fast"):
-    """HIP sliding_iterative_denoise vs the output of the REFERENCE's own pipeline code (committed
-    fixture tests/golden/pipeline_sliding.pt, fp32): same seeded weights, task tensors and noise."""
-    from diffuman4d_amd.host.pipeline import Diffuman4DPipeline
+def _golden_setup(name):
+    """(fixture, host scheduler, oracle scheduler factory) of one golden-pipeline case."""
     gdir = Path(__file__).resolve().parent / "golden"
     dpm = name.startswith("dpm_")  # fixture of the reference pipeline run with one stateful DPM-Solver++ object per latent
     multistep = name.startswith(("unipc", "deis"))  # ... with one stateful UniPC / DEIS object per latent (make_golden.py multistep)
@@ -715,6 +713,67 @@ def case_golden_pipeline(name, precision="fast"):
         g = torch.load(gdir / "pose_encoder.pt")["pipeline"] if name == "pose_encoder" else torch.load(gdir / "pipeline_sliding.pt")[name]
         host_sched = HS(HC(prediction_type=g["case"]["pred"]))
         oracle_sched = lambda: DDIMScheduler(DDIMConfig(prediction_type=g["case"]["pred"]))  # noqa: E731
+    return g, host_sched, oracle_sched
+
+
+def case_task_stack(name="spatial", precision="fast", copies=3, global_rng=False):
+    """runner.task_batch: `sliding_iterative_denoise_stack` (several tasks of a round through shared window calls, VAE encode and decode
+    included) returns, task by task, what `sliding_iterative_denoise` returns for each task alone -- bit for bit on the GPU.  Task 0 is
+    the golden fixture's task (so the stack is also held to the reference pipeline's output), the others differ in images, cameras and
+    noise.  global_rng: no injected noise, the draws come from the device's global generator, reseeded before the serial and before the
+    stacked pass (the stack prepares its tasks in list order, so the draw sequence is that of the serial order)."""
+    from diffuman4d_amd.host.pipeline import Diffuman4DPipeline
+    g, host_sched, _ = _golden_setup(name)
+    c, seeds = g["case"], g["seeds"]
+    cfg_u, ou = make_unet(seeds["unet"], **g.get("cfg_kw", {}))
+    cfg_v, ov = make_vae(seeds["vae"])
+    hp = Diffuman4DPipeline(hip_vae(cfg_v, ov, precision), hip_unet(cfg_u, ou, precision), host_sched, "cuda")
+    dev = hp.device
+    common = dict(domain=c["domain"], **c["kw"])
+    tasks = []
+    for k in range(copies):
+        pv, pl, sk, cm = synthetic_task(c["n"], 64, 64, c["inputs"], seeds["task"] + 17 * k)
+        if k == 0:
+            noise = {q: v.to(hp.dtype) for q, v in g["noise"].items()}
+            lat_in = g["latents_in"].to(hp.dtype) if g["latents_in"] is not None else None
+        else:
+            gen = torch.Generator().manual_seed(seeds["task"] + 1000 + k)
+            noise = {q: torch.randn(v.shape, generator=gen).to(BF).to(hp.dtype) for q, v in g["noise"].items()}
+            lat_in = None if g["latents_in"] is None else torch.randn(g["latents_in"].shape, generator=gen).to(BF).to(hp.dtype)
+        t = dict(pixel_values=pv, plucker_embeds=pl, skeletons=sk, cond_masks=cm, latents=lat_in, timestep_indices=g["timestep_indices_in"])
+        if not global_rng:
+            t["noise"] = noise
+        tasks.append(t)
+
+    def seed():
+        torch.manual_seed(4321)
+        if dev.type == "cuda":
+            torch.cuda.manual_seed_all(4321)
+
+    seed()
+    alone = [hp.sliding_iterative_denoise(**t, **common) for t in tasks]
+    seed()
+    stacked = hp.sliding_iterative_denoise_stack(tasks, **common)
+    worst = 0.0
+    for a, b in zip(alone, stacked):
+        assert torch.equal(a["timestep_indices"], b["timestep_indices"]) and torch.equal(a["fully_denoised"], b["fully_denoised"])
+        assert bool(torch.isfinite(b["latents"].float()).all()) and bool(torch.isfinite(b["images"].float()).all())
+        for q in ("latents", "images"):
+            worst = max(worst, float((a[q].float() - b[q].float()).abs().max()) / max(float(a[q].float().abs().max()), 1e-30))
+    assert not torch.equal(stacked[0]["latents"], stacked[1]["latents"])  # the tasks are different tasks
+    if not global_rng:  # task 0 of the stack against the reference pipeline's own output
+        e_lat = rel_l2(stacked[0]["latents"], g["latents"])
+        print(f"    [task stack {name} {precision} x{copies}] worst |stack - alone| / max = {worst:.3e}; task 0 vs the reference fixture: latents rel_l2 {e_lat:.3e}", flush=True)
+        bound = {"fast": 0.1, "fp16": FP16_BOUNDS["latents"], "parity": 1e-4}[precision]
+        assert e_lat <= bound, (e_lat, bound)
+    return worst, 0.0
+
+
+def case_golden_pipeline(name, precision="fast"):
+    """HIP sliding_iterative_denoise vs the output of the REFERENCE's own pipeline code (committed
+    fixture tests/golden/pipeline_sliding.pt, fp32): same seeded weights, task tensors and noise."""
+    from diffuman4d_amd.host.pipeline import Diffuman4DPipeline
+    g, host_sched, oracle_sched = _golden_setup(name)
     c, seeds = g["case"], g["seeds"]
     cfg_u, ou = make_unet(seeds["unet"], **g.get("cfg_kw", {}))
     cfg_v, ov = make_vae(seeds["vae"])
@@ -908,6 +967,16 @@ CASES = {
     "task_batching_spatial": (case_task_batching, dict(domain="spatial")),
     "task_batching_temporal_x3": (case_task_batching, dict(domain="temporal", copies=3)),
     "task_batching_dpm": (case_task_batching, dict(domain="spatial", sched="dpm")),
+    # runner.task_batch: whole tasks (VAE encode, window calls, decode) through pipeline.sliding_iterative_denoise_stack
+    "task_stack_spatial": (case_task_stack, dict(name="spatial")),
+    "task_stack_temporal_v_x2": (case_task_stack, dict(name="temporal_v", copies=2)),
+    "task_stack_round2_shift": (case_task_stack, dict(name="round2_shift")),
+    "task_stack_pose_encoder": (case_task_stack, dict(name="pose_encoder", copies=2)),
+    "task_stack_dpm_heun_round2": (case_task_stack, dict(name="dpm_temporal_v_heun_round2")),
+    "task_stack_unipc_round2": (case_task_stack, dict(name="unipc_temporal_v_bh1_round2", copies=2)),
+    "task_stack_global_rng": (case_task_stack, dict(name="spatial", global_rng=True)),
+    "fp16_task_stack_spatial": (case_task_stack, dict(name="spatial", precision="fp16")),
+    "par_task_stack_temporal_v": (case_task_stack, dict(name="temporal_v", precision="parity", copies=2)),
     "unet_pose_encoder": (case_unet, dict(num_frames=4, cfg_batch=2, pose=True)),
     "pipeline_pose_encoder": (case_pipeline, dict(domain="spatial", pose=True)),
     "pipeline_cache_lazy_decode": (case_pipeline_cache_lazy, dict()),
@@ -1050,6 +1119,7 @@ TOL = {"task_batching_spatial": 0.0, "task_batching_temporal_x3": 0.0, "task_bat
        "par_pipeline_prune_cond_rows": 1e-4, "fp16_pipeline_prune_cond_rows": 1e-3,
        "pipeline_cache_lazy_decode": 0.0, "pipeline_prune_cond_rows": 5e-3, "pipeline_prune_cond_rows_temporal": 5e-3,
        "pipeline_plucker_on_device": 5e-3, "resize": 4e-3}
+TOL.update({n: 0.0 for n in CASES if "task_stack_" in n})  # bit for bit the tasks run alone
 # Tighter fixed bounds of individual par_* cases, ~8x above what MI355X measured (every quantity below 1.6e-5 where
 # the fixture is fp32 / 16-bit fixed point).  Cases whose fixture stores the decoded RGB in fp16 (floor 1.7-1.8e-4) keep 5e-4.
 PARITY_TOLS: dict = {n: 1e-4 for n in CASES if n.startswith("par_") and not n.startswith(("par_golden", "par_vae_sd"))}

@@ -32,6 +32,19 @@ class StubPipeline:
                 "fully_denoised": tidx == plan.num_inference_steps}
 
 
+class StackStubPipeline(StubPipeline):
+    """StubPipeline that also takes the runner's task stacks (runner.task_batch): every task of a stack gets what it gets alone, and the
+    stack sizes are recorded."""
+
+    def __init__(self, h=2, w=2):
+        super().__init__(h, w)
+        self.stacks = []
+
+    def sliding_iterative_denoise_stack(self, tasks, domain, tqdm=None, decode="all", **sweep):
+        self.stacks.append(len(tasks))
+        return [self.sliding_iterative_denoise(domain=domain, tqdm=tqdm, **t, **sweep) for t in tasks]
+
+
 class ShardStubPipeline(StubPipeline):
     """StubPipeline that also takes the runner's frame-shard extensions: with `shard` (parallel.FrameShard) every rank of the
     group updates ITS frames of each window and the rows are all-gathered (a real collective of the test's backend), as

@@ -20,8 +20,15 @@ class FakeDevicePipeline:
     """What LatentGridPipeline needs of Diffuman4DPipeline: .device, upload_plan, window_call (adds 1 to the window's targets)."""
     device = torch.device("cpu")
 
-    def upload_plan(self, plan, guidance_scale, shard=None):
-        return dict(win=[torch.from_numpy(w) for w in plan.windows], cond=[torch.from_numpy(c) for c in plan.is_cond],
+    def __init__(self):
+        self.copies_seen = []
+
+    def upload_plan(self, plan, guidance_scale, shard=None, copies=1, rows_per_task=0):
+        assert copies == 1 or rows_per_task > 0
+        self.copies_seen.append(copies)
+        win = [np.concatenate([w + k * rows_per_task for k in range(copies)]) for w in plan.windows]  # stacked tasks: rows k * n ...
+        cond = [np.concatenate([c] * copies) for c in plan.is_cond]
+        return dict(win=[torch.from_numpy(w) for w in win], cond=[torch.from_numpy(c) for c in cond],
                     calls=len(plan.windows), cfg=2 if guidance_scale > 1 else 1)
 
     def window_call(self, lat3, pv3, pl3, sk3, cm3, tb, i, h, w, domains, gs, use_cfg, vpred, shard=None):
@@ -47,6 +54,29 @@ def test_grid_depth_keeps_the_call_mix():
 def test_grid_pass_single_process(small_latents):
     calls = bench.run_grid_pass(FakeDevicePipeline(), {"spatial": 2, "temporal": 5}, 12, 1, 0, 2)
     assert calls == (12 + 12) * 2 + 44 * 5
+
+
+def test_grid_pass_in_task_stacks(small_latents):
+    """runner.task_batch through the adapter: the tasks of a round in stacks of at most three sharing their window calls; the count is in
+    task-calls (a stacked call counts once per task), so it equals the unstacked pass's."""
+    fake = FakeDevicePipeline()
+    calls = bench.run_grid_pass(fake, {"spatial": 2, "temporal": 5}, 12, 1, 0, 2, task_batch=3)
+    assert calls == (12 + 12) * 2 + 44 * 5
+    assert sorted(set(fake.copies_seen)) == [2, 3] and fake.copies_seen.count(3) == 4 + 14 + 4 and fake.copies_seen.count(2) == 1
+
+
+def test_deal_units():
+    assert bench.deal_units(20, 2, 2) == [[2] * 5, [2] * 5]
+    assert bench.deal_units(20, 2, 3) == [[3, 3, 2, 2], [3, 3, 2, 2]]
+    assert bench.deal_units(20, 3, 1) == [[1] * 7, [1] * 7, [1] * 6]
+    assert bench.deal_units(5, 2, 2) == [[2, 1], [2]]
+    assert bench.deal_units(1, 3, 4) == [[1], [], []]
+    assert bench.deal_units(0, 2, 2) == [[], []]
+    for count in range(0, 40):
+        for streams in (1, 2, 3):
+            for batch in (1, 2, 3, 4):
+                d = bench.deal_units(count, streams, batch)
+                assert sum(map(sum, d)) == count and all(0 < z <= batch for st in d for z in st)
 
 
 def _worker(rank, world, port, outdir):

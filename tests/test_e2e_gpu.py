@@ -83,6 +83,51 @@ def test_cli_path_in_the_wide_precisions(tmp_path):
     assert 1e-6 < dh < 0.2 * d, (dh, d)
 
 
+@pytest.mark.parametrize("fast", [False, True])
+def test_task_stacks_through_the_runner_equal_the_task_by_task_job(tmp_path, fast):
+    """runner.task_batch through the CLI path (config -> pipelines -> sampler -> SamplingRunner): a job whose rounds run as stacks of
+    three tasks sharing their window calls (one stream, so that the random draws come in task order in both jobs) leaves BITWISE the grid
+    of the job run task by task and writes byte-identical files -- with the reference's protocol (strict) and with the extensions on."""
+    import filecmp
+    import os
+    from glob import glob
+    from diffuman4d_amd.host import config as cfglib
+    from diffuman4d_amd.host.runner import SamplingRunner
+    from diffuman4d_amd.host.weights import write_synthetic_checkpoint
+    ucfg, vcfg = _tiny_cfgs()
+    ckpt = write_synthetic_checkpoint(tmp_path / "ckpt", ucfg, vcfg, seed=3)
+    grids, dirs, stacks = {}, {}, []
+    for batch in (1, 3):
+        ov = ["exp=demo_4d_tiny", "model=diffuman4d_mi355x", "data=synthetic", f"model.model_dir={ckpt}", "model.gpu_ids=[0]",
+              "data.height=64", "data.width=64", "data.num_cameras=8", f"result_dir={tmp_path / f'b{batch}'}",
+              "sampler.spa_label_range=[0,8,1]", "sampler.tem_label_range=[0,4,1]", "sampler.input_spa_labels=[1,5]",
+              "sampler.window_size=4", "sampler.sliding_stride=2"]
+        if fast:
+            ov += ["sampler.vae_cache=true", "sampler.decode_policy=denoised", "sampler.plucker_on_device=true", "data.plucker=cameras",
+                   "sampler.device_results=true"]
+        cfg = cfglib.compose(ov)
+        pipelines = cfglib.instantiate(cfg["model"])
+        sampler = cfglib.instantiate(cfg["sampler"], dataset=cfglib.instantiate(cfg["data"]), pipelines=pipelines)
+        if batch > 1:
+            real = pipelines[0].sliding_iterative_denoise_stack
+
+            def counted(tasks, **kw):
+                stacks.append(len(tasks))
+                return real(tasks, **kw)
+            pipelines[0].sliding_iterative_denoise_stack = counted
+        torch.manual_seed(1234)
+        SamplingRunner(sampler, prefetch_depth=1, writers=1, gpu_streams=1, task_batch=batch).inference()
+        grids[batch] = torch.stack([sampler.latents[c][f].float().cpu() for c in sampler.target_spa_labels for f in sampler.tem_labels])
+        dirs[batch] = sampler.output_dir
+    assert stacks == [2, 2, 3, 3, 2, 2]  # 4 frames, 6 target cameras, 4 frames: stacks of at most three, as even as the round allows
+    assert bool(torch.isfinite(grids[3]).all()) and torch.equal(grids[1], grids[3])
+    fa = sorted(os.path.relpath(f, dirs[1]) for f in glob(dirs[1] + "/**/*.*", recursive=True))
+    fb = sorted(os.path.relpath(f, dirs[3]) for f in glob(dirs[3] + "/**/*.*", recursive=True))
+    assert fa == fb and len(fa) > 8 * 4
+    for f in fa:
+        assert filecmp.cmp(os.path.join(dirs[1], f), os.path.join(dirs[3], f), shallow=False), f
+
+
 @pytest.mark.parametrize("domain,n", [("spatial", 8), ("temporal", 12)])
 def test_device_results_match_the_host_writer(tmp_path, domain, n):
     """results.pack_results_on_device on the GPU + imgwrite.write_package vs save_sampling_results on the host copy of the

@@ -63,6 +63,16 @@ def test_fast_precision_host_wiring_stays_inside_the_bf16_yardstick(cpu_standin,
         assert err[q] <= mc.YARD_FACTOR * yard[q], (q, err[q], yard[q])
 
 
+@pytest.mark.parametrize("name,precision,kw", [("spatial", "parity", {}), ("pose_encoder", "parity", dict(copies=2)),
+                                               ("dpm_temporal_v_heun_round2", "fp16", dict(copies=2)), ("spatial", "parity", dict(global_rng=True))])
+def test_task_stack_host_wiring_returns_what_each_task_returns_alone(cpu_standin, name, precision, kw):
+    """runner.task_batch, host side (stacked tensors, copies of the plan tables, frames per attention group, per-task decode, the order
+    of the random draws): `sliding_iterative_denoise_stack` against one `sliding_iterative_denoise` per task.  On the GPU the equality is
+    bitwise (modelcheck task_stack_*); the CPU stand-in's fp32 matmuls block differently for a taller matrix, hence a bound here."""
+    worst, _ = cpu_standin.case_task_stack(name, precision=precision, **kw)
+    assert worst <= (2e-5 if precision == "parity" else 2e-3), worst
+
+
 def test_the_standin_is_removed_again():
     """After the fixture the real wrappers are back: they refuse CPU tensors (no CPU compute path in the product)."""
     import torch

@@ -8,7 +8,7 @@ import pytest
 from diffuman4d_amd.host.dataset import SyntheticSpaTemDataset
 from diffuman4d_amd.host.runner import SamplingRunner, run_round_pipelined
 from diffuman4d_amd.host.sampler import SlidingIterativeSampler
-from stubs import StubPipeline
+from stubs import StackStubPipeline, StubPipeline
 
 
 def make(writer, **kw):
@@ -19,7 +19,7 @@ def make(writer, **kw):
     return SlidingIterativeSampler(ds, [StubPipeline()], "/tmp/unused", **args)
 
 
-def run(depth, writers=1, gpu_streams=1):
+def run(depth, writers=1, gpu_streams=1, task_batch=1, pipe=None):
     written, threads = [], set()
 
     def writer(sample, output_dir=None):
@@ -27,8 +27,10 @@ def run(depth, writers=1, gpu_streams=1):
         written.append((sample["alt"], sample["domain"], sample["domain_label"], sample["timestep_indices"].tolist()))
 
     s = make(writer)
+    if pipe is not None:
+        s.pipelines[0] = pipe
     for tasks in s.all_tasks:
-        run_round_pipelined(s, tasks, 0, depth, writers, gpu_streams)
+        run_round_pipelined(s, tasks, 0, depth, writers, gpu_streams, task_batch=task_batch)
     grid = {c: {f: (s.timestep_indices[c][f], float(s.latents[c][f].flatten()[0])) for f in s.tem_labels} for c in s.spa_labels}
     return grid, s.pipelines[0].calls, written, threads
 
@@ -55,6 +57,31 @@ def test_concurrent_gpu_streams_leave_the_same_grid(streams, depth):
     assert g1 == g0
     assert sorted(map(repr, calls1)) == sorted(map(repr, calls0))  # same calls; their start order is not defined
     assert w1 == w0  # results are still collected and written in task order
+
+
+@pytest.mark.parametrize("batch,streams,depth", [(3, 1, 0), (3, 2, 1), (2, 3, 2), (5, 1, 1), (64, 2, 0)])
+def test_task_stacks_leave_the_same_grid(batch, streams, depth):
+    """runner.task_batch: consecutive tasks of a round handed to the pipeline as one stack (shared window calls) -- same grid, same
+    per-task pipeline calls, every sample written in task order; stacks are as even as the round allows (12 spatial tasks by 5 -> 4 + 4 + 4,
+    18 temporal tasks by 5 -> 5 + 5 + 4 + 4) and never cross a round."""
+    g0, calls0, w0, _ = run(0)
+    pipe = StackStubPipeline()
+    g1, calls1, w1, _ = run(depth, 1, streams, batch, pipe)
+    assert g1 == g0 and w1 == w0
+    assert sorted(map(repr, calls1)) == sorted(map(repr, calls0))
+    per_round = [12, 18, 12]  # frames, target cameras, frames
+    want = []
+    for n in per_round:
+        k = -(-n // batch)
+        want += sorted([n // k + (1 if i < n % k else 0) for i in range(k)])
+    got = pipe.stacks + [1] * (sum(per_round) - sum(pipe.stacks))  # a stack of one goes through the plain call
+    assert sorted(got) == sorted(want), (pipe.stacks, want)
+
+
+def test_a_pipeline_without_the_stack_entry_runs_its_tasks_one_by_one():
+    g0, calls0, w0, _ = run(0)
+    g1, calls1, w1, _ = run(1, 1, 2, 3)  # StubPipeline has no sliding_iterative_denoise_stack
+    assert g1 == g0 and w1 == w0 and sorted(map(repr, calls1)) == sorted(map(repr, calls0))
 
 
 def test_runner_uses_the_pipeline_and_checks_nothing_without_a_writer():

@@ -131,5 +131,35 @@ PY
         sampler.plucker_on_device=true data.plucker=cameras model.precision=fp16 > $out/r05_e2e_demo4d_fp16.json 2> $out/r05_e2e_demo4d_fp16.err
     cat $out/r05_e2e_demo4d_fp16.json | cut -c1-600; tail -2 $out/r05_e2e_demo4d_fp16.err | cut -c1-300
     ;;
+  batch)  # tasks of a round stacked along M (bench.py --task-batch k: upload_plan(copies=k), bit-identical latents) against task streams of single tasks
+    ab="--steps 12 --warmup 6 --no-cpu-baseline --no-grid-secondary --no-vae --no-parity-precision --no-tolerance-mode --no-latent128"
+    for rep in 1 2; do
+      for cfg in "1 3" "2 1" "2 2" "3 1" "3 2" "6 1"; do set -- $cfg
+        timeout 300 python bench.py $ab --task-batch $1 --task-streams $2 > $out/r05_batch_b$1_s$2_$rep.json 2>/dev/null; bench_line $out/r05_batch_b$1_s$2_$rep.json "task-batch $1 x streams $2 rep $rep:"
+      done
+    done
+    ;;
+  w4)  # A/B: strip-convolution tiles on FOUR waves with twice the wave tile (variants built with tools/dev/build_variant.sh w4a gemm -DSTRIP_160_W4:
+       # 256 x 160 on 4 waves of 64 x 160 instead of 8 of 32 x 160 at level 0; w4b gemm -DSTRIP_128_W4: 256 x 128 on 4 waves of 128 x 64 instead of 8 of 64 x 64)
+    ab="--steps 9 --warmup 3 --no-cpu-baseline --no-grid-secondary --no-vae --no-parity-precision --no-tolerance-mode --no-latent128"
+    cp diffuman4d_amd/libdm4d.so /tmp/cur.so
+    for v in w4a w4b; do
+      cp tools/dev/libdm4d_$v.so diffuman4d_amd/libdm4d.so
+      timeout 600 python tests/opcheck.py conv_ > $out/r05_${v}_opcheck_conv.log 2>&1; tail -1 $out/r05_${v}_opcheck_conv.log
+    done
+    for rep in 1 2; do for v in cur w4a w4b; do
+      if [ $v = cur ]; then cp /tmp/cur.so diffuman4d_amd/libdm4d.so; else cp tools/dev/libdm4d_$v.so diffuman4d_amd/libdm4d.so; fi
+      timeout 300 python bench.py $ab > $out/r05_w4_${v}_$rep.json 2>/dev/null; bench_line $out/r05_w4_${v}_$rep.json "A/B $v rep $rep:"
+      python - $out/r05_w4_${v}_$rep.json <<'PY'
+import json, sys
+try:
+    k = json.load(open(sys.argv[1]))["kernel_breakdown_one_step"]
+    print("     conv levels:", {x: k[x]["ms"] for x in k if x.startswith("conv3x3.L")})
+except Exception as e:
+    print("     unreadable", e)
+PY
+    done; done
+    cp /tmp/cur.so diffuman4d_amd/libdm4d.so
+    ;;
   *) echo "unknown stage $stage"; exit 2;;
 esac

@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--depth", type=int, default=2)
     ap.add_argument("--writers", type=int, default=8)
     ap.add_argument("--gpu-streams", type=int, default=3, help="tasks of a round in flight on the GPU (runner.gpu_streams)")
+    ap.add_argument("--task-batch", type=int, default=1, help="tasks of a round per stack of shared window calls (runner.task_batch)")
     ap.add_argument("--fast-vae", action="store_true",
                     help="sampler.vae_cache=true sampler.decode_policy=denoised (encoder moments cached per grid cell, "
                          "decode only the rows that are saved)")
@@ -106,13 +107,14 @@ def main():
         sampler._scatter_cells = timed("d.scatter", sampler._scatter_cells)
     sampler.load_sample = timed("load_sample", sampler.load_sample)
     sampler.denoise = timed("denoise", sampler.denoise)
+    sampler.denoise_stack = timed("denoise", sampler.denoise_stack)
     if sampler.result_writer is not None:
         sampler.result_writer = timed("save", sampler.result_writer)
 
     n_tasks = sum(len(t) for t in sampler.all_tasks)
     t0 = time.perf_counter()
     SamplingRunner(sampler, prefetch_depth=a.depth, writers=a.writers, gpu_streams=a.gpu_streams,
-                   writer_processes=a.writer_processes).inference()
+                   writer_processes=a.writer_processes, task_batch=a.task_batch).inference()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     # GPU-stage occupancy: fraction of the wall time during which at least one / every denoise worker was inside `denoise`
@@ -131,7 +133,7 @@ def main():
     done = sum(sampler.timestep_indices[c][f] > 0 for c in sampler.target_spa_labels for f in sampler.tem_labels)
     n_img = len(list(Path(sampler.output_dir).rglob("*.jpg")))
     print(json.dumps({
-        "exp": a.exp, "image_size": [H, W], "prefetch_depth": a.depth, "writers": a.writers, "gpu_streams": a.gpu_streams, "fast_vae": a.fast_vae, "prune_cond_rows": a.prune, "tasks": n_tasks,
+        "exp": a.exp, "image_size": [H, W], "prefetch_depth": a.depth, "writers": a.writers, "gpu_streams": a.gpu_streams, "task_batch": a.task_batch, "fast_vae": a.fast_vae, "prune_cond_rows": a.prune, "tasks": n_tasks,
         "target_latents": n_lat, "denoised": int(done), "images_written": n_img, "wall_s": round(wall, 3),
         "latents_per_s_end_to_end": round(n_lat / wall, 3),
         "stage_seconds": {k: round(v, 3) for k, v in acc.items()},
