@@ -181,7 +181,8 @@ class UnitRunner:
     def __init__(self, pipe, dev, streams: int, batch: int, shard=None):
         self.pipe, self.dev, self.S, self.batch, self.shard = pipe, dev, max(1, streams), max(1, batch), shard
         self.sets = {}
-        self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.S)] if self.S > 1 else [None]
+        self.on_gpu = torch.device(dev).type == "cuda"  # (a CPU stand-in pipeline in tests/test_bench_grid.py: threads, no streams)
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.S)] if (self.S > 1 and self.on_gpu) else [None] * self.S
 
     def task_set(self, si: int, size: int):
         """Task state of stream `si` for stacks of `size` units (built on first use: call `prepare` before anything is timed)."""
@@ -198,10 +199,22 @@ class UnitRunner:
                         if (si, z) not in self.sets:
                             with torch.cuda.stream(self.streams[si]) if self.streams[si] is not None else _nullctx():
                                 run_unit(self.pipe, self.task_set(si, z), 0, self.shard)
-        torch.cuda.synchronize()
+        if self.on_gpu:
+            torch.cuda.synchronize()
+
+    def prepare_single(self, *counts):
+        """The same for `run_single_stream` (stream 0's task states, the current stream)."""
+        with torch.no_grad():
+            for c in counts:
+                for z in set(deal_units(c, 1, self.batch)[0]):
+                    if (0, z) not in self.sets:
+                        run_unit(self.pipe, self.task_set(0, z), 0, self.shard)
+        if self.on_gpu:
+            torch.cuda.synchronize()
 
     def _stream_work(self, si, sizes, first):
-        torch.cuda.set_device(self.dev)
+        if self.on_gpu:
+            torch.cuda.set_device(self.dev)
         with torch.no_grad(), (torch.cuda.stream(self.streams[si]) if self.streams[si] is not None else _nullctx()):
             for j, z in enumerate(sizes):
                 run_unit(self.pipe, self.task_set(si, z), first + j, self.shard)
@@ -552,7 +565,8 @@ def precision_secondary(cfg, state_dict, dev, units: int, precision: str = "pari
     ur = UnitRunner(pp, dev, max(1, min(streams, units)), batch)
     S = ur.S
     n_one = 2 * min(batch, units)
-    ur.prepare(units, S, n_one)
+    ur.prepare(units, S)
+    ur.prepare_single(n_one, n_one // 2)
     ur.run(0, S)  # warm-up
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -769,7 +783,7 @@ def main():
     want_b = DEFAULT_TASK_BATCH if args.task_batch is None else args.task_batch
     kb = max(1, want_b) if shard is None else 1
     S = 1 if shard is not None else max(1, min(want_s, max(1, args.steps)))
-    ur = UnitRunner(pipe, dev, S if mode != "grid" else 1, kb if mode != "grid" else 1, shard)
+    ur = UnitRunner(pipe, dev, S if mode != "grid" else 1, kb, shard)
 
     def barrier():
         if world > 1:
@@ -852,6 +866,7 @@ def main():
     # attention launch on the launch stream.  With several task streams the launches of different stacks overlap on the device, so
     # per-launch intervals taken inside the timed region above would measure the mix, not the kernel.
     k_roof = min(args.steps, 4) if mode == "grid" else args.steps
+    ur.prepare_single(k_roof, min(ur.batch, max(1, args.steps)))
     ops.KERNEL_TIMER = timer = []
     t1 = time.perf_counter()
     roof_sizes = ur.run_single_stream(args.warmup + args.steps, k_roof)
@@ -878,11 +893,11 @@ def main():
     # WRITE_SIZE) KiB, the factor 2 being the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md (HBM section).
     traffic, traffic_file = None, None
     for tf in sorted((ROOT / "profiles").glob("r*_attn_traffic_pmc.json"), reverse=True):
-        if (LAT_H, LAT_W) == (72, 40):
-            t = json.loads(tf.read_text())
+        t = json.loads(tf.read_text())
+        if (LAT_H, LAT_W) == (72, 40) and int(t.get("task_batch", 1)) == kb:  # the newest record taken on the stacks this run launches
             traffic = int((2 * t["FETCH_SIZE"]["avg_kb"] + t["WRITE_SIZE"]["avg_kb"]) * 1024)
             traffic_file = tf.name
-        break
+            break
     # MFMA-busy fraction of the same kernel from its own PMC pass (SQ_VALU_MFMA_BUSY_CYCLES against GRBM_GUI_ACTIVE, i.e. at
     # the clock the chip actually ran under this load; tools/mfma_busy_summary.py -> profiles/*attn_mfma_busy_pmc.json)
     mfma_busy = None

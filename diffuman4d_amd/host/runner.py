@@ -28,8 +28,8 @@ _tls = threading.local()
 
 # Defaults of the GPU stage (measured on the judged workload, profiles/r05_task_batch_streams.log): tasks of a round in flight per GPU,
 # and tasks per stack of shared window calls
-DEFAULT_GPU_STREAMS = 3
-DEFAULT_TASK_BATCH = 1
+DEFAULT_GPU_STREAMS = 2
+DEFAULT_TASK_BATCH = 2
 
 
 def _denoise_group(sampler: SlidingIterativeSampler, group: List[dict], pipe_idx: int) -> List[dict]:
@@ -70,8 +70,8 @@ def run_round_pipelined(sampler: SlidingIterativeSampler, tasks: List[dict], pip
     calls (sampler.denoise_stack -> pipeline.sliding_iterative_denoise_stack: the tasks' tensors stacked along the frame axis,
     every call carrying task_batch x F frames).  Each task still computes exactly what it computes alone (bitwise, GPU test
     `modelcheck task_stack_*`); what is gained is the GEMM / convolution grids of the two deepest UNet levels (120-460
-    workgroups for one task) and a third of the launches: 73.4 ms per 2 spatial + 1 temporal window calls with 2 streams of
-    3-task stacks against 75.2 with 3 streams of single tasks (profiles/r05_task_batch_streams.log).
+    workgroups for one task) and half of the launches: 74.4-74.7 ms per 2 spatial + 1 temporal window calls with 2 streams of
+    2-task stacks against 76.2-76.4 with 3 streams of single tasks on the same box (profiles/r05_task_batch_streams.log).
 
     The reference runs load -> denoise -> save serially per worker thread (sliding_iterative_sampler.py:201-204), so
     the GPU idles during the host-side decode/resize of 3N images and the JPEG writes (measured on

@@ -79,6 +79,27 @@ def test_deal_units():
                 assert sum(map(sum, d)) == count and all(0 < z <= batch for st in d for z in st)
 
 
+@pytest.mark.parametrize("streams,batch", [(1, 1), (3, 1), (2, 2), (2, 3), (1, 4)])
+def test_unit_runner_runs_every_unit_once(small_latents, streams, batch):
+    """bench.UnitRunner (the timed region of the task mode): K units dealt to `streams` worker threads in stacks of at most `batch` -- every
+    unit's three window calls run exactly once whatever K, and `prepare` has built (and run once) every task state before the timing."""
+    fake = FakeDevicePipeline()
+    fake.dtype = torch.float32
+    ur = bench.UnitRunner(fake, torch.device("cpu"), streams, batch)
+    ur.prepare(20, 5)
+    built = set(ur.sets)
+    assert built == {(si, z) for c in (20, 5) for si, sizes in enumerate(bench.deal_units(c, streams, batch)) for z in sizes}
+    total = lambda: sum(float(t[d]["lat"].float().sum()) for t in ur.sets.values() for d in ("spatial", "temporal"))  # noqa: E731
+    base = total()
+    ur.run(0, 5)
+    ur.run(5, 20)
+    assert set(ur.sets) == built  # nothing is built inside a timed region
+    sizes = ur.run_single_stream(25, 7)
+    assert sum(sizes) == 7 and max(sizes) <= batch
+    # the fake adds 1 to every element of the 12 target rows of a window: 3 calls x 12 rows x (2 x 2 x 4) elements per unit
+    assert total() - base == pytest.approx((5 + 20 + 7) * 3 * 12 * 16)
+
+
 def _worker(rank, world, port, outdir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)

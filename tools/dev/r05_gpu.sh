@@ -139,27 +139,37 @@ PY
       done
     done
     ;;
-  w4)  # A/B: strip-convolution tiles on FOUR waves with twice the wave tile (variants built with tools/dev/build_variant.sh w4a gemm -DSTRIP_160_W4:
-       # 256 x 160 on 4 waves of 64 x 160 instead of 8 of 32 x 160 at level 0; w4b gemm -DSTRIP_128_W4: 256 x 128 on 4 waves of 128 x 64 instead of 8 of 64 x 64)
-    ab="--steps 9 --warmup 3 --no-cpu-baseline --no-grid-secondary --no-vae --no-parity-precision --no-tolerance-mode --no-latent128"
-    cp diffuman4d_amd/libdm4d.so /tmp/cur.so
-    for v in w4a w4b; do
-      cp tools/dev/libdm4d_$v.so diffuman4d_amd/libdm4d.so
-      timeout 600 python tests/opcheck.py conv_ > $out/r05_${v}_opcheck_conv.log 2>&1; tail -1 $out/r05_${v}_opcheck_conv.log
+  stack)  # task stacks as a runner feature: bitwise checks, then defaults (streams x batch) by A/B on the bench and on the CLI path
+    timeout 900 python tests/modelcheck.py task_stack fp16_task_stack par_task_stack > $out/r05_modelcheck_task_stack.log 2>&1; grep -c "^PASS" $out/r05_modelcheck_task_stack.log; grep "^FAIL\|^ERROR\|modelcheck:" $out/r05_modelcheck_task_stack.log | cut -c1-300
+    timeout 900 python -m pytest tests/test_e2e_gpu.py -q -k "task_stacks" > $out/r05_pytest_task_stack.log 2>&1; tail -3 $out/r05_pytest_task_stack.log | cut -c1-300
+    ab="--steps 24 --warmup 12 --no-cpu-baseline --no-grid-secondary --no-vae --no-parity-precision --no-tolerance-mode --no-latent128"
+    for rep in 1 2; do
+      for cfg in "1 3" "2 2" "3 2" "2 3" "4 2"; do set -- $cfg
+        timeout 300 python bench.py $ab --task-batch $1 --task-streams $2 > $out/r05_stack_b$1_s$2_$rep.json 2>$out/r05_stack_err.log || tail -5 $out/r05_stack_err.log
+        bench_line $out/r05_stack_b$1_s$2_$rep.json "batch $1 x streams $2 rep $rep:"
+      done
     done
-    for rep in 1 2; do for v in cur w4a w4b; do
-      if [ $v = cur ]; then cp /tmp/cur.so diffuman4d_amd/libdm4d.so; else cp tools/dev/libdm4d_$v.so diffuman4d_amd/libdm4d.so; fi
-      timeout 300 python bench.py $ab > $out/r05_w4_${v}_$rep.json 2>/dev/null; bench_line $out/r05_w4_${v}_$rep.json "A/B $v rep $rep:"
-      python - $out/r05_w4_${v}_$rep.json <<'PY'
-import json, sys
-try:
-    k = json.load(open(sys.argv[1]))["kernel_breakdown_one_step"]
-    print("     conv levels:", {x: k[x]["ms"] for x in k if x.startswith("conv3x3.L")})
-except Exception as e:
-    print("     unreadable", e)
-PY
-    done; done
-    cp /tmp/cur.so diffuman4d_amd/libdm4d.so
+    for cfg in "1 3" "2 2" "3 2"; do set -- $cfg
+      timeout 300 python bench.py $ab --precision fp16 --task-batch $1 --task-streams $2 > $out/r05_stack_fp16_b$1_s$2.json 2>$out/r05_stack_err.log || tail -5 $out/r05_stack_err.log
+      bench_line $out/r05_stack_fp16_b$1_s$2.json "fp16 precision, batch $1 x streams $2:"
+    done
+    for cfg in "1 3" "2 2" "3 2"; do set -- $cfg
+      timeout 600 python tools/e2e_demo.py --exp demo_4d_tiny --fast-vae --prune --writers 2 --device-results --writer-processes 12 --host-threads 8 --depth 4 \
+          --task-batch $1 --gpu-streams $2 sampler.plucker_on_device=true data.plucker=cameras > $out/r05_e2e_tiny_b$1_s$2.json 2> $out/r05_e2e_tiny.err || tail -5 $out/r05_e2e_tiny.err
+      echo "e2e demo_4d_tiny batch $1 x streams $2:"; cut -c1-500 $out/r05_e2e_tiny_b$1_s$2.json
+    done
+    ;;
+  final3)  # after the runner defaults became 2 streams of 2-task stacks: a canary, the driver command, the profile records on the new launch
+           # shapes, then the GPU tests of everything the change touched (pipeline / sampler / runner / bench) and smoke()
+    timeout 600 python -m pytest tests/test_bench_gpu.py -q -x -k "default_task_streams" > $out/r05_pytest_canary.log 2>&1 || { tail -30 $out/r05_pytest_canary.log | cut -c1-300; exit 1; }
+    tail -1 $out/r05_pytest_canary.log
+    ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/r05_bench.json 2> $out/r05_bench.err ) 2> $out/r05_bench.time; tail -3 $out/r05_bench.time
+    bench_line $out/r05_bench.json "driver command:"; tail -3 $out/r05_bench.err | cut -c1-300
+    bash tools/profile_bench.sh r05b fast > $out/r05b_profile.log 2>&1; tail -14 $out/r05b_profile.log | cut -c1-220
+    ( time timeout 1500 python -m pytest tests/test_bench_gpu.py tests/test_e2e_gpu.py tests/test_reference_protocol_gpu.py tests/test_entry_gpu.py tests/test_model_gpu.py -q \
+        -k "not default_task_streams and (bench or e2e or reference_protocol or entry or pipeline or golden or task_stack or multiround)" > $out/r05_pytest_gpu_part2.log 2>&1 ) 2> $out/r05_pytest_gpu_part2.time
+    tail -5 $out/r05_pytest_gpu_part2.log | cut -c1-300; tail -3 $out/r05_pytest_gpu_part2.time
+    timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $out/r05_smoke.log 2>&1; tail -2 $out/r05_smoke.log | cut -c1-600
     ;;
   *) echo "unknown stage $stage"; exit 2;;
 esac

@@ -26,7 +26,7 @@ import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from diffuman4d_amd.host import config as cfglib  # noqa: E402
-from diffuman4d_amd.host.runner import SamplingRunner  # noqa: E402
+from diffuman4d_amd.host.runner import DEFAULT_GPU_STREAMS, DEFAULT_TASK_BATCH, SamplingRunner  # noqa: E402
 from diffuman4d_amd.host.weights import write_synthetic_checkpoint  # noqa: E402
 
 
@@ -36,8 +36,8 @@ def main():
     ap.add_argument("--size", default="576x320", help="image HxW (latents are 1/8)")
     ap.add_argument("--depth", type=int, default=2)
     ap.add_argument("--writers", type=int, default=8)
-    ap.add_argument("--gpu-streams", type=int, default=3, help="tasks of a round in flight on the GPU (runner.gpu_streams)")
-    ap.add_argument("--task-batch", type=int, default=1, help="tasks of a round per stack of shared window calls (runner.task_batch)")
+    ap.add_argument("--gpu-streams", type=int, default=DEFAULT_GPU_STREAMS, help="stacks of tasks of a round in flight on the GPU (runner.gpu_streams)")
+    ap.add_argument("--task-batch", type=int, default=DEFAULT_TASK_BATCH, help="tasks of a round per stack of shared window calls (runner.task_batch)")
     ap.add_argument("--fast-vae", action="store_true",
                     help="sampler.vae_cache=true sampler.decode_policy=denoised (encoder moments cached per grid cell, "
                          "decode only the rows that are saved)")

@@ -14,15 +14,17 @@ TAG=${1:-r01}
 PREC=${2:-fast}
 STATS_ONLY=${3:-}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-# one task in flight: the bench's roofline figures come from its one-task-at-a-time pass, and with two task streams the
-# kernel intervals of different tasks overlap in the trace
-BENCH="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --task-streams 1 --no-grid-secondary --no-vae --no-parity-precision --no-tolerance-mode --no-latent128 --precision $PREC"
+# one stack of tasks in flight: the bench's roofline figures come from its one-stack-at-a-time pass, and with two task streams the
+# kernel intervals of different stacks overlap in the trace.  --steps 4 --warmup 2: every pass of the run (set-up, warm-up, timed, prune,
+# roofline, breakdown) is then made of whole stacks of the default task_batch (2), so every launch of a kernel carries the same rows and the
+# trace's average duration per kernel is the average of ONE launch shape per layer
+BENCH="python bench.py --steps 4 --warmup 2 --no-cpu-baseline --task-streams 1 --no-grid-secondary --no-vae --no-parity-precision --no-tolerance-mode --no-latent128 --precision $PREC"
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT" -o stats -- $BENCH > "$OUT.bench.log" 2> "$OUT.stats.err"
 DB=$(find "$OUT" -name "stats*results.db" | head -1)
-python tools/profile_summary.py "$DB" "rocprofv3 --kernel-trace --stats -- $BENCH ($TAG; 1 warm-up + 2 timed + 2 roofline-pass + 1 breakdown units, plus weight-init kernels)" \
+python tools/profile_summary.py "$DB" "rocprofv3 --kernel-trace --stats -- $BENCH ($TAG; units of 2 F=16 + 1 F=24 window calls, all in stacks of the default task_batch: 2 set-up + 2 warm-up + 4 timed + 2 + 2 prune-pass + 4 roofline-pass + 2 breakdown, plus weight-init kernels)" \
   > gpurun_out/${TAG}_kernel_stats.txt
 tail -1 "$OUT.bench.log" > gpurun_out/${TAG}_bench_under_rocprof.json
 if [ -n "$STATS_ONLY" ]; then head -16 gpurun_out/${TAG}_kernel_stats.txt; rm -rf "$OUT"; exit 0; fi
@@ -30,6 +32,13 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $C -d "$OUT" -o pmc_$C -- $BENCH > /dev/null 2> "$OUT.pmc_$C.err"
 done
 python tools/pmc_summary.py "$OUT" attn_kernel FETCH_SIZE WRITE_SIZE > gpurun_out/${TAG}_attn_traffic_pmc.json
+# which stacks the launches carried (bench.py reads the traffic figure only for the stack size it runs)
+python - gpurun_out/${TAG}_attn_traffic_pmc.json gpurun_out/${TAG}_bench_under_rocprof.json <<'PY'
+import json, sys
+t, b = json.load(open(sys.argv[1])), json.load(open(sys.argv[2]))
+t["task_batch"] = b["config"]["task_batch"]
+json.dump(t, open(sys.argv[1], "w"))
+PY
 # the same HBM-traffic figures for the other MFMA families (strip convolutions, Linear layers, the fused level-0 block tail)
 for K in conv_strip2_kernel gemm_lin2_kernel ff_proj_fused_kernel gn_apply_kernel gn_stats_kernel; do
   echo "== $K"; python tools/pmc_summary.py "$OUT" $K FETCH_SIZE WRITE_SIZE
