@@ -61,6 +61,7 @@ INPUT_CAMS = [1, 13, 25, 37]
 WINDOW, STRIDE, ROUNDS, GUIDANCE = 12, 2, 3, 2.0
 STEPS_PER_LATENT = WINDOW // STRIDE * ROUNDS  # 18
 LATENTS_PER_UNIT = 3 * WINDOW / STEPS_PER_LATENT  # 2.0
+PARITY_STATE_UNITS = 37  # units the task whose first window call is compared with the CPU oracle has been through (see main)
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 UNIT_TFLOP = {(72, 40): (20.13, 33.06), (128, 128): (261.9, 485.8)}  # F=16 / F=24 UNet calls
 
@@ -998,7 +999,14 @@ def main():
         if world == 1 and not args.no_vae and LAT_H * LAT_W <= 128 * 128:
             out["secondary"]["vae"] = vae_secondary(dev)
         if want_cpu:  # rank 0 at N = 1 only (the CPU sample would skew multi-rank timing)
-            one = build_tasks(pipe, dev)  # one unstacked task of each domain
+            # one unstacked task of each domain, its latents taken through PARITY_STATE_UNITS units first: the state rounds 3-4 compared
+            # on (their stream-0 task had run that many units when the CPU forward started), so that `parity` stays comparable across
+            # rounds -- the distance of a UNet call to the fp32 oracle depends on its input (tools/dev/parity_state_probe.py)
+            one = build_tasks(pipe, dev)
+            with torch.no_grad():
+                for u in range(min(PARITY_STATE_UNITS, args.warmup + 2 * args.steps + 3)):
+                    run_unit(pipe, one, u)
+            torch.cuda.synchronize()
             out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(pipe, state_dict, one["spatial"], args.cpu_frames,
                                                                          args.cpu_threads, not args.no_parity_bf16,
                                                                          one["temporal"], args.cpu_budget_s)

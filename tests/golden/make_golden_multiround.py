@@ -70,11 +70,24 @@ class SeededNoise:
     def __getattr__(self, name):  # everything else (prune_cond_rows, vae, ...) is the wrapped pipeline's
         return getattr(self.__dict__["pipe"], name)
 
-    def sliding_iterative_denoise(self, **kw):
-        n = kw["pixel_values"].shape[0]
+    def _draws(self, n):
         g = torch.Generator().manual_seed(NOISE_SEED + self.calls)
         self.calls += 1
-        noise = {k: torch.randn(n, 4, H // 8, W // 8, generator=g).to(BF) for k in ("pixel", "skeleton", "latents")}
+        return {k: torch.randn(n, 4, H // 8, W // 8, generator=g).to(BF) for k in ("pixel", "skeleton", "latents")}
+
+    def sliding_iterative_denoise_stack(self, tasks, **kw):
+        """The runner's task stacks (runner.task_batch; HIP pipeline only): every task of the stack gets the draws of ITS call number in
+        the task-by-task job, so the stacked job is held to the same fixture."""
+        assert not self.oracle
+        first = self.calls
+        outs = self.pipe.sliding_iterative_denoise_stack([dict(t, noise=self._draws(t["pixel_values"].shape[0])) for t in tasks], **kw)
+        for k, out in enumerate(outs):
+            if first + k in self.keep_images_of:
+                self.images[first + k] = out["images"].float().cpu()
+        return outs
+
+    def sliding_iterative_denoise(self, **kw):
+        noise = self._draws(kw["pixel_values"].shape[0])
         if not self.oracle:
             out = self.pipe.sliding_iterative_denoise(noise=noise, **kw)
             if self.calls - 1 in self.keep_images_of:

@@ -936,7 +936,9 @@ def case_multiround_sd21(precision="fast"):
         _check_fixture_inputs("multiround dataset " + k, f(first[key]), g["checksums"][k])
     own.result_writer = None  # nothing is written (and the runner's completeness check of the files is skipped)
     t0 = time.time()
-    SamplingRunner(own, prefetch_depth=0, writers=1, gpu_streams=1).inference()  # one task at a time: the draws come in the job's order
+    # one stream: the draws come in the job's order; the runner's default task_batch: the rounds run as stacks of two tasks sharing their
+    # window calls (4 spatial -> 2 + 2, 6 temporal -> 2 + 2 + 2), and the job is still held to the task-by-task fixture
+    SamplingRunner(own, prefetch_depth=0, writers=1, gpu_streams=1).inference()
     torch.cuda.synchronize()
     secs = time.time() - t0
     lat = torch.stack([torch.stack([own.latents[c][fr].float().cpu() for fr in own.tem_labels]) for c in own.spa_labels])

@@ -171,5 +171,11 @@ PY
     tail -5 $out/r05_pytest_gpu_part2.log | cut -c1-300; tail -3 $out/r05_pytest_gpu_part2.time
     timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $out/r05_smoke.log 2>&1; tail -2 $out/r05_smoke.log | cut -c1-600
     ;;
+  final4)  # the multi-round job in stacks against its task-by-task fixture, the UNet-call distance against the input state, the driver command
+    timeout 900 python tests/modelcheck.py multiround par_multiround fp16_multiround > $out/r05_modelcheck_multiround_stacks.log 2>&1; grep "^PASS\|^FAIL\|^ERROR\|multi-round" $out/r05_modelcheck_multiround_stacks.log | cut -c1-330
+    timeout 300 python tools/dev/parity_state_probe.py > $out/r05_parity_state_probe.log 2>&1; grep -v "^/opt\|warn" $out/r05_parity_state_probe.log | tail -12
+    ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/r05_bench.json 2> $out/r05_bench.err ) 2> $out/r05_bench.time; tail -3 $out/r05_bench.time
+    bench_line $out/r05_bench.json "driver command:"; tail -3 $out/r05_bench.err | cut -c1-300
+    ;;
   *) echo "unknown stage $stage"; exit 2;;
 esac
