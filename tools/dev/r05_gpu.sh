@@ -177,5 +177,15 @@ PY
     ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/r05_bench.json 2> $out/r05_bench.err ) 2> $out/r05_bench.time; tail -3 $out/r05_bench.time
     bench_line $out/r05_bench.json "driver command:"; tail -3 $out/r05_bench.err | cut -c1-300
     ;;
+  final5)  # the driver command with the stack-of-2 PMC records in profiles/ (roofline.traffic), then the CLI path on a 48 x 64 grid
+           # (64 + 44 + 64 tasks) with the new runner defaults and with round 4's (the new ones FIRST: whatever runs first meets the colder chip)
+    ( time timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/r05_bench.json 2> $out/r05_bench.err ) 2> $out/r05_bench.time; tail -3 $out/r05_bench.time
+    bench_line $out/r05_bench.json "driver command:"; tail -2 $out/r05_bench.err | cut -c1-300
+    for cfg in "2 2" "1 3"; do set -- $cfg
+      timeout 230 python tools/e2e_demo.py --exp demo_4d --fast-vae --prune --writers 2 --device-results --writer-processes 12 --host-threads 8 --depth 4 \
+          --task-batch $1 --gpu-streams $2 sampler.plucker_on_device=true data.plucker=cameras "sampler.tem_label_range=[0,64,1]" > $out/r05_e2e_64fr_b$1_s$2.json 2> $out/r05_e2e_64fr.err || tail -3 $out/r05_e2e_64fr.err | cut -c1-300
+      echo "e2e 48 x 64 grid, batch $1 x streams $2:"; cut -c1-520 $out/r05_e2e_64fr_b$1_s$2.json
+    done
+    ;;
   *) echo "unknown stage $stage"; exit 2;;
 esac
