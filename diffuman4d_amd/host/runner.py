@@ -26,9 +26,11 @@ from .sampler import SlidingIterativeSampler
 _tls = threading.local()
 
 
-# Defaults of the GPU stage (measured on the judged workload, profiles/r05_task_batch_streams.log): tasks of a round in flight per GPU,
-# and tasks per stack of shared window calls
-DEFAULT_GPU_STREAMS = 2
+# Defaults of the GPU stage (profiles/r05_task_batch_streams.log): stacks of tasks of a round in flight per GPU, and tasks per stack of
+# shared window calls.  Two streams of 2-task stacks are the fastest resident steady state (+2.4 % over three single tasks, three streams
+# of stacks +1.9 %), but end to end two streams leave the GPU to ONE stack whenever the other is in a host-side phase (image upload,
+# result packing): 23.8 against 24.5 latents/s on a 48 x 64 grid.  Three streams of stacks keep both.
+DEFAULT_GPU_STREAMS = 3
 DEFAULT_TASK_BATCH = 2
 
 

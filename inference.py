@@ -37,7 +37,7 @@ def inference(cfg: dict):
     pipelines = cfglib.instantiate(cfg["model"])
     log.info("Instantiating sampler <%s>", cfg["sampler"]["_target_"])
     sampler = cfglib.instantiate(cfg["sampler"], dataset=dataset, pipelines=pipelines)
-    # runner.gpu_streams=N (default 2): stacks of tasks of a round in flight per GPU, one HIP stream each
+    # runner.gpu_streams=N (default 3): stacks of tasks of a round in flight per GPU, one HIP stream each
     # runner.task_batch=K (default 2): K consecutive tasks of a round share their window calls (tensors stacked along the frame axis;
     # every task's result is bitwise what it is alone); gpu_streams=1 task_batch=1 = the reference's one-task-at-a-time order
     # runner.writer_processes=N (default 0): with sampler.device_results=true the JPEG / WebP encoding of every task's uint8

@@ -187,5 +187,10 @@ PY
       echo "e2e 48 x 64 grid, batch $1 x streams $2:"; cut -c1-520 $out/r05_e2e_64fr_b$1_s$2.json
     done
     ;;
+  final6)  # the driver command's GPU part with the final runner defaults (3 streams of 2-task stacks); the CPU baseline / parity objects of the
+           # full command do not depend on the defaults (final5's record has them) and the round's GPU budget ends here
+    timeout 100 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-parity-precision --no-latent128 > $out/r05_bench_default_3x2.json 2> $out/r05_bench_default_3x2.err
+    bench_line $out/r05_bench_default_3x2.json "default (3 streams x 2-task stacks), no CPU legs:"; tail -2 $out/r05_bench_default_3x2.err | cut -c1-300
+    ;;
   *) echo "unknown stage $stage"; exit 2;;
 esac
