@@ -100,21 +100,24 @@ def test_unit_runner_runs_every_unit_once(small_latents, streams, batch):
     assert total() - base == pytest.approx((5 + 20 + 7) * 3 * 12 * 16)
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, task_batch=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         bench.LAT_H, bench.LAT_W = 2, 2
-        calls = bench.run_grid_pass(FakeDevicePipeline(), {"spatial": 1, "temporal": 3}, 12, world, rank, 2)
+        fake = FakeDevicePipeline()
+        calls = bench.run_grid_pass(fake, {"spatial": 1, "temporal": 3}, 12, world, rank, 2, task_batch=task_batch)
+        assert task_batch == 1 or max(fake.copies_seen) == task_batch
         torch.save(calls, f"{outdir}/r{rank}.pt")
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
-def test_grid_pass_two_ranks_gloo():
+@pytest.mark.parametrize("task_batch", [1, 2])
+def test_grid_pass_two_ranks_gloo(task_batch):
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(2, 29400 + os.getpid() % 500, d), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, 29400 + os.getpid() % 500 + task_batch, d, task_batch), nprocs=2, join=True)
         per_rank = [torch.load(f"{d}/r{r}.pt") for r in range(2)]
     # every window call of the job ran exactly once; an even split unless the runner measured different task rates on a
     # loaded test machine and re-dealt a round (DistributedSamplingRunner.balance)

@@ -11,7 +11,7 @@ import torch.multiprocessing as mp
 from diffuman4d_amd.host.dataset import SyntheticSpaTemDataset
 from diffuman4d_amd.host.runner import DistributedSamplingRunner
 from diffuman4d_amd.host.sampler import SlidingIterativeSampler
-from stubs import ShardStubPipeline, StubPipeline
+from stubs import ShardStubPipeline, StackStubPipeline, StubPipeline
 
 KW = dict(spa_label_range=[0, 20, 1], tem_label_range=[0, 12, 1], input_spa_labels=[1, 9], window_size=6,
           sliding_stride=2, alternation_rounds=3, bidirectional=False)
@@ -39,11 +39,11 @@ def grid_state(s, cells=None):
     return out
 
 
-def _worker(rank, world, port, outdir, kw=None, slow_rank=None, slow_delay=0.18, mode="task"):
+def _worker(rank, world, port, outdir, kw=None, slow_rank=None, slow_delay=0.18, mode="task", task_batch=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        s = make_sampler(kw, ShardStubPipeline if mode != "task" else StubPipeline)
+        s = make_sampler(kw, ShardStubPipeline if mode != "task" else (StackStubPipeline if task_batch > 1 else StubPipeline))
         if slow_rank is not None:  # one GPU three times slower than the others
             import time
             pipe, delay = s.pipelines[0], (slow_delay if rank == slow_rank else 0.06)
@@ -53,12 +53,13 @@ def _worker(rank, world, port, outdir, kw=None, slow_rank=None, slow_delay=0.18,
                 time.sleep(delay)
                 return inner(**kwargs)
             pipe.sliding_iterative_denoise = slowed
-        runner = DistributedSamplingRunner(s, gpu_streams=1, prefetch_depth=1, mode=mode)
+        runner = DistributedSamplingRunner(s, gpu_streams=1 if task_batch == 1 else 2, prefetch_depth=1, mode=mode, task_batch=task_batch)
         runner.inference()
         last = len(s.all_tasks) - 1
         owned = set(runner._owned_after(last, rank))
         torch.save({"state": grid_state(s, owned), "n_calls": len(s.pipelines[0].calls),
                     "sharded": [(c["domain"], c["sharded"], c["noise_seed"]) for c in s.pipelines[0].calls if c.get("sharded")],
+                    "stacks": list(getattr(s.pipelines[0], "stacks", [])),
                     "tails": [[(t["domain_label"], ranks) for t, ranks in runner.tail_of(ri)] for ri in range(len(s.all_tasks))],
                     "deal": [[len(runner.tasks_of(ri, q)) for q in range(world)] for ri in range(len(s.all_tasks))]},
                    f"{outdir}/rank{rank}.pt")
@@ -93,6 +94,35 @@ def test_ranks_match_single_process(world, kw, steps):
         ridx, rlat = ref_state[cell]
         assert idx == ridx == steps
         assert torch.equal(lat, rlat)
+
+
+@pytest.mark.timeout(300)
+def test_ranks_running_task_stacks_match_single_process():
+    """runner.task_batch across processes: every rank runs ITS tasks of a round in stacks of at most three sharing their window calls (two
+    stacks in flight), the exchange at the round boundaries ships the same cells, and the merged grid equals the single-process task-by-task
+    run cell for cell.  World 2 on the 12-frame x 18-target-camera grid: 6 + 9 + 6 tasks per rank = stacks 3 3 | 3 3 3 | 3 3."""
+    ref = make_sampler(KW)
+    for tasks in ref.all_tasks:
+        for t in tasks:
+            ref.execute_one_task(t)
+    ref_state = grid_state(ref)
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        port = 29500 + (os.getpid() % 2000) + 11
+        mp.spawn(_worker, args=(world, port, d, KW, None, 0.18, "task", 3), nprocs=world, join=True)
+        blobs = [torch.load(f"{d}/rank{r}.pt") for r in range(world)]
+    assert sum(b["n_calls"] for b in blobs) == sum(len(t) for t in ref.all_tasks)
+    for b in blobs:  # stacks never exceed task_batch, never cross a round, and cover all of the rank's tasks
+        assert b["stacks"] and max(b["stacks"]) <= 3 and sum(b["stacks"]) == b["n_calls"], b["stacks"]
+    merged = {}
+    for b in blobs:
+        for k, v in b["state"].items():
+            assert k not in merged
+            merged[k] = v
+    cells = {(c, f) for c in ref.target_spa_labels for f in ref.tem_labels}
+    assert cells == set(merged)
+    for cell in cells:
+        assert merged[cell][0] == ref_state[cell][0] == 9 and torch.equal(merged[cell][1], ref_state[cell][1])
 
 
 @pytest.mark.timeout(300)
