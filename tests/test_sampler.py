@@ -119,3 +119,35 @@ def test_task_noise_seeds_do_not_collide():
         load_pipelines(gpu_ids=[], precision="fp8")
     for prec in load_pipelines_precisions:  # no GPU ids: nothing is loaded, the argument checks run
         assert load_pipelines(model_dir="/nonexistent-but-unused", gpu_ids=[], precision=prec) == []
+
+
+def test_only_tasks_with_one_window_plan_are_stacked():
+    """sampler.stackable / denoise_stack (runner.task_batch): tasks of one round share their plan and go to the pipeline as ONE stack; tasks
+    whose plans differ (another domain, targets at another timestep index), a frame-sharded sampler, or a pipeline without the stack entry
+    run one by one -- and every sample ends up exactly as `denoise` leaves it."""
+    from stubs import StackStubPipeline
+    s = make(window_size=6, spa_label_range=[0, 20, 1], tem_label_range=[0, 12, 1], input_spa_labels=[1, 9])
+    s.pipelines[0] = pipe = StackStubPipeline()
+    a, b = (s.load_sample(**t) for t in s.all_tasks[0][:2])
+    assert s.stackable([a, b]) and not s.stackable([a])
+    out = s.denoise_stack([a, b])
+    assert pipe.stacks == [2] and [o["domain_label"] for o in out] == ["000000", "000001"]
+    assert all(int(o["timestep_indices"][o["target_indices"][0]]) == 3 for o in out)  # window 6, stride 2: 3 steps per round
+    # a spatial task of round 1 that has not run next to one that has: targets at different timestep indices
+    c = s.load_sample(**s.all_tasks[0][2])
+    a2 = s.load_sample(**s.all_tasks[0][0])  # frame 0 again: its cells now sit at index 3 and carry latents
+    assert not s.stackable([c, a2])
+    # another domain (a round never mixes them; the check is by the samples, not by where they came from)
+    assert not s.stackable([c, dict(c, domain="temporal")])
+    # fall-back: one plain call per sample, in order
+    before = len(pipe.calls)
+    s.denoise_stack([c, a2])
+    assert pipe.stacks == [2] and len(pipe.calls) == before + 2
+    # a frame-sharded sampler never stacks (collectives are issued task by task); neither does a pipeline without the entry
+    d, e = (s.load_sample(**t_) for t_ in s.all_tasks[0][3:5])
+    s.frame_shard = object()
+    assert not s.stackable([d, e])
+    s.frame_shard = None
+    assert s.stackable([d, e])
+    s.pipelines[0] = StubPipeline()
+    assert not s.stackable([d, e])
