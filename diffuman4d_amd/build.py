@@ -34,7 +34,7 @@ def source_hash() -> str:
     """sha256 over every source, header and compile flag that goes into libdm4d.so."""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted([CSRC / s for s in SOURCES] + list(CSRC.glob("*.h")) + list(INCLUDE.glob("*.h"))):  # EXTRA_DEPS are SOURCES too
+    for f in sorted([CSRC / s for s in SOURCES] + list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc")) + list(INCLUDE.glob("*.h"))):  # EXTRA_DEPS are SOURCES too
         h.update(f.name.encode() + b"\0" + f.read_bytes() + b"\0")
     h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
@@ -72,7 +72,7 @@ def build(force: bool = False, verbose: bool = True, defines=()) -> Path:
     from concurrent.futures import ThreadPoolExecutor
     objdir = ROOT / "build"
     objdir.mkdir(exist_ok=True)
-    headers = list(CSRC.glob("*.h")) + list(INCLUDE.glob("*.h"))
+    headers = list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc")) + list(INCLUDE.glob("*.h"))  # attn64_asm.inc: tools/attn64/gen.py --write
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}"] + [f"-D{d}" for d in defines]
     hipcc = _hipcc()
     jobs = []

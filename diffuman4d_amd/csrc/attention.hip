@@ -27,6 +27,7 @@
 #include "common.h"
 #include "dm4d.h"
 #include "errors.h"
+#include "attn64_asm.inc"
 #include <stdlib.h>
 
 namespace {
@@ -98,6 +99,10 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
 // (a sum below 2^16 has no term above it; the first tile alone puts l >= 2^-H16_OFF).  The exact loop keeps every probability below
 // 2^RESCALE_THR = 256 already.
 constexpr float H16_OFF = 8.0f;
+// fp32 row sums are taken before (8-wave kernel) or after (attn64: on the matrix pipe) the fp16 rounding of the probabilities; a term in
+// [65520, 65536) rounds to +inf while its fp32 sum can still sit below 2^16, so the bound that sends a workgroup to the exact loop is
+// 2^15: a row sum below it has no term above 32768, which fp16 holds.
+constexpr float H16_L_MAX = 0x1p15f;
 template <bool H16>
 __device__ __forceinline__ uint32_t cvt_pk(float lo, float hi) {
   if constexpr (H16) return pack_h2(lo, hi);
@@ -461,7 +466,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnParams p) {  // tw
     l_tot = l_run + __shfl_xor(l_run, 32);
   }
   // out of range (a later tile outgrew the first tile's max by more than 2^60) or NaN: redo with the exact loop
-  if (__syncthreads_or(!(l_tot < (H16 ? 0x1p16f : 0x1p60f)) || !(l_tot > 0x1p-100f))) {
+  if (__syncthreads_or(!(l_tot < (H16 ? H16_L_MAX : 0x1p60f)) || !(l_tot > 0x1p-100f))) {
     m_run = -1e30f;
     l_run = 0.f;
 #pragma unroll
@@ -498,7 +503,159 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnParams p) {  // tw
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// attn64_kernel: the hand-placed form.  4 waves = 256 query rows per workgroup, ONE wave per SIMD, 64 query rows and the whole
+// 512-register file per wave; the main loop is a single asm statement with its own register allocation (tools/attn64/gen.py writes
+// attn64_asm.inc: register map, schedule, counted waits, static hazard check; tools/attn64/sim.py executes the stream on a numpy model of
+// the workgroup -- tests/test_attn64_sim.py).  What the C++ side does: the lane-constant addresses the stream takes as operands, the
+// epilogue (accumulator file -> normalise -> wave-private LDS tile -> whole 128-byte rows), and the exact running-max loop as the
+// in-kernel fallback of the optimistic soft-max, run per 32-row block with the 8-wave kernel's kv_loop<SAFE>.
+// Pre-scaled Q only (FOLD); Lk must be a multiple of 64 and at least three tiles (attention_launch falls back to attn_kernel otherwise).
+// Row sums come from the matrix pipe: v_mfma_f32_16x16x32 of a constant ones pattern (lanes 0 / 32: row 0, lanes 17 / 49: row 1) against
+// the PACKED probabilities, so the normaliser is the sum of exactly the values the PV product used.
+// ------------------------------------------------------------------------------------------------
+template <int BASE>
+__device__ __forceinline__ void acc_read16(f32x16_t& x) {
+  float t[16];
+#define ATTN64_RD(i) asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(t[i]) : "n"(BASE + i));
+  ATTN64_RD(0) ATTN64_RD(1) ATTN64_RD(2) ATTN64_RD(3) ATTN64_RD(4) ATTN64_RD(5) ATTN64_RD(6) ATTN64_RD(7)
+  ATTN64_RD(8) ATTN64_RD(9) ATTN64_RD(10) ATTN64_RD(11) ATTN64_RD(12) ATTN64_RD(13) ATTN64_RD(14) ATTN64_RD(15)
+#undef ATTN64_RD
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = t[i];
+}
+template <int BASE>
+__device__ __forceinline__ float acc_read1() {
+  float t;
+  asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(t) : "n"(BASE));
+  return t;
+}
 
+// 32 rows of O^T (two d-blocks of one row block) * inv -> wave-private LDS tile -> 4 row-wide stores
+template <bool H16>
+__device__ __forceinline__ void store_rows32(const f32x16_t (&o)[2], float inv, u16* Os, u16* Ob, int64_t ldo, int q_first, int L, int lane,
+                                             int l31, int lh) {
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      uint2 w;
+      w.x = cvt_pk<H16>(o[db][4 * g + 0] * inv, o[db][4 * g + 1] * inv);
+      w.y = cvt_pk<H16>(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+      *reinterpret_cast<uint2*>(Os + l31 * LDS_LDO + db * 32 + 8 * g + 4 * lh) = w;
+    }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int row = 8 * k + (lane >> 3), ch = lane & 7;
+    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(Os + row * LDS_LDO + ch * 8);
+    const int q = q_first + row;
+    if (q < L) *reinterpret_cast<u32x4_t*>(Ob + (int64_t)q * ldo + ch * 8) = v;
+  }
+}
+
+template <bool H16>
+__global__ __launch_bounds__(256, 1) void attn64_kernel(AttnParams p) {
+  constexpr int SMEM_EXACT = 2 * KV * LDS_LD + 2 * KV * LDS_LDV, SMEM_RINGS = 2 * RING * TILE;  // u16 elements; >= 4 * 32 * LDS_LDO
+  __shared__ __attribute__((aligned(16))) u16 smem[SMEM_EXACT > SMEM_RINGS ? SMEM_EXACT : SMEM_RINGS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int L = p.L, Lk = p.Lk;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int qt = lid % p.nqt, bh = lid / p.nqt;
+  const int head = bh % p.heads, batch = bh / p.heads;
+  const int q_tile0 = qt * 256 + wave * 64;
+  const u16* Qb = p.Q + (int64_t)batch * L * p.ldq + head * 64;
+  const u16* Kb = p.K + (int64_t)batch * Lk * p.ldk + head * 64;
+  const u16* Vb = p.V + (int64_t)batch * Lk * p.ldv + head * 64;
+  u16* Ob = p.O + (int64_t)batch * L * p.ldo + head * 64;
+  u16* Ks = smem;
+  u16* Vs = smem + RING * TILE;
+  {
+    // operands of the stream (tools/attn64/sim.py::wave_inputs restates these): fragment byte addresses inside stage 0 of each ring,
+    // DMA source offsets of this lane's two pieces per operand, the first-row pointers of the two row blocks, the ones pattern
+    uint32_t kfa[4], vfa[2], dk[2], dv[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kfa[j] = lds_addr(Ks) + 2u * (uint32_t)(l31 * 64 + (((2 * j + lh) ^ ((l31 >> 1) & 7)) * 8));
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+      vfa[db] = lds_addr(Vs) + 2u * (uint32_t)((4 * lh + ((lane & 15) >> 2)) * 64 +
+                                                ((4 * (db ^ ((lane >> 3) & 1)) + 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1)) * 8) + 4 * (lane & 1));
+    const int d_row = wave * 8 + (lane >> 3), d_slot = lane & 7;
+    const int k_chunk = d_slot ^ ((d_row >> 1) & 7), v_chunk = d_slot ^ (((d_row >> 1) & 1) << 2);
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc) {
+      dk[pc] = 2u * ((uint32_t)(d_row + 32 * pc) * (uint32_t)p.ldk + (uint32_t)k_chunk * 8u);
+      dv[pc] = 2u * ((uint32_t)(d_row + 32 * pc) * (uint32_t)p.ldv + (uint32_t)v_chunk * 8u);
+    }
+    const u16* qa[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      int q = q_tile0 + qb * 32 + l31;
+      q = q > L - 1 ? L - 1 : q;
+      qa[qb] = Qb + (int64_t)q * p.ldq + lh * 8;
+    }
+    const uint32_t ones = (lane == 0 || lane == 32 || lane == 17 || lane == 49) ? (H16 ? 0x3C003C00u : 0x3F803F80u) : 0u;
+    const uint32_t kstride = 128u * (uint32_t)p.ldk, vstride = 128u * (uint32_t)p.ldv;
+    const uint32_t nt = (uint32_t)(Lk / KV);
+    const uint32_t m0k = lds_addr(Ks) + wave * 1024, m0v = lds_addr(Vs) + wave * 1024;
+#define ATTN64_OPERANDS                                                                                                                        \
+  [kfa0] "v"(kfa[0]), [kfa1] "v"(kfa[1]), [kfa2] "v"(kfa[2]), [kfa3] "v"(kfa[3]), [vfa0] "v"(vfa[0]), [vfa1] "v"(vfa[1]), [dk0] "v"(dk[0]),    \
+      [dk1] "v"(dk[1]), [dv0] "v"(dv[0]), [dv1] "v"(dv[1]), [qa0] "v"(qa[0]), [qa1] "v"(qa[1]), [ones] "v"(ones), [kbase] "s"(Kb),             \
+      [vbase] "s"(Vb), [kstride] "s"(kstride), [vstride] "s"(vstride), [nt] "s"(nt), [m0k] "s"(m0k), [m0v] "s"(m0v)
+    if constexpr (H16) asm volatile(ATTN64_ASM_F16 : : ATTN64_OPERANDS : ATTN64_CLOBBERS);
+    else asm volatile(ATTN64_ASM_BF16 : : ATTN64_OPERANDS : ATTN64_CLOBBERS);
+#undef ATTN64_OPERANDS
+  }
+  // the stream ends behind a workgroup barrier with every DMA landed: the rings are free.  O^T (db, qb) = a[16 (2 db + qb) ..],
+  // row sums of block qb = a[64 + 4 qb] (rows 0..15, lanes 0..15) and a[65 + 4 qb] (rows 16..31)
+  f32x16_t o[2][2];  // [qb][db]
+  acc_read16<0>(o[0][0]);
+  acc_read16<16>(o[1][0]);
+  acc_read16<32>(o[0][1]);
+  acc_read16<48>(o[1][1]);
+  float l_tot[2];
+  {
+    const float a0 = __shfl(acc_read1<64>(), l31 & 15), a1 = __shfl(acc_read1<65>(), l31 & 15);
+    const float b0 = __shfl(acc_read1<68>(), l31 & 15), b1 = __shfl(acc_read1<69>(), l31 & 15);
+    l_tot[0] = l31 < 16 ? a0 : a1;
+    l_tot[1] = l31 < 16 ? b0 : b1;
+  }
+  const float l_max = H16 ? H16_L_MAX : 0x1p60f;
+  const bool bad = !(l_tot[0] < l_max) || !(l_tot[0] > 0x1p-100f) || !(l_tot[1] < l_max) || !(l_tot[1] > 0x1p-100f);
+  u16* Os = smem + wave * (32 * LDS_LDO);
+  if (!__syncthreads_or(bad)) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) store_rows32<H16>(o[qb], 1.0f / l_tot[qb], Os, Ob, p.ldo, q_tile0 + qb * 32, L, lane, l31, lh);
+    return;
+  }
+  // out of range (a later tile outgrew the first tile's maximum by more than the operand type holds) or NaN: both row blocks again
+  // with the exact running-max loop
+  u16* Vx = smem + 2 * KV * LDS_LD;
+  const u16* v_lane = Vx + (4 * (lane >> 5) + ((lane & 15) >> 2)) * LDS_LDV + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+#pragma unroll 1
+  for (int qb = 0; qb < 2; ++qb) {
+    bf16x8_t qf[4];
+    int q = q_tile0 + qb * 32 + l31;
+    q = q > L - 1 ? L - 1 : q;
+    const u16* qp = Qb + (int64_t)q * p.ldq + lh * 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      U4 v = ldg16(qp + j * 16);
+      qf[j] = *reinterpret_cast<bf16x8_t*>(&v);
+    }
+    f32x16_t ox[2];
+    float m_run = -1e30f, l_run = 0.f;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ox[db][r] = 0.f;
+    kv_loop<true, true, 4, H16>(p, Kb, Vb, smem, Vx, v_lane, qf, ox, m_run, l_run, tid, l31, lh);  // ends with a workgroup barrier
+    const float lt = l_run + __shfl_xor(l_run, 32);
+    store_rows32<H16>(ox, 1.0f / lt, Os, Ob, p.ldo, q_tile0 + qb * 32, L, lane, l31, lh);
+    __syncthreads();  // the staging tiles alias the exact loop's K stage
+  }
+}
 
 }  // namespace
 
@@ -518,6 +675,17 @@ static int attention_launch(void* stream, const void* Q, const void* K, const vo
                scale * 1.4426950408889634f, exact};
   // 8 waves per workgroup.  The kernels are written for NW = 4 as well (two independent 128-row workgroups per CU);
   // measured in one call: +1..3 % on the 2-D L0 shapes, -3..-5 % on the 3-D ones (profiles/r01_attn_nw4_ab.log)
+  // the hand-placed 4 x 64 form: pre-scaled Q, whole key tiles, at least three of them (DM4D_ATTN64=0: tuning aid, the 8-wave kernel)
+  static const int use64 = [] { const char* e = getenv("DM4D_ATTN64"); return e ? atoi(e) : 1; }();
+  if (use64 && q_scaled && !exact && (Lk % KV) == 0 && Lk >= 3 * KV) {
+    p.nqt = (Lq + 255) / 256;
+    const long nwg64 = (long)p.nqt * heads * batch;
+    if (nwg64 > 0x7fffffffL) return dm4d_set_error(DM4D_ERR_ARG, "attention: grid too large");
+    const dim3 grid64((unsigned)nwg64), block64(256);
+    if (h16) hipLaunchKernelGGL((attn64_kernel<true>), grid64, block64, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((attn64_kernel<false>), grid64, block64, 0, (hipStream_t)stream, p);
+    return dm4d_check_launch("attn64_kernel");
+  }
   constexpr int nw = 8;
   const int rows = nw * 32;  // 32 query rows per wave (64 rows per wave measured slower)
   p.nqt = (Lq + rows - 1) / rows;

@@ -1163,6 +1163,14 @@ CASES = {
     "attn_qs_spike": (case_attention, dict(batch=1, heads=2, L=1000, spike=True, q_scaled=True)),
     "attn_qs_ramp_fallback": (case_attention, dict(batch=2, heads=2, L=1500, ramp=True, q_scaled=True)),
     "attn_qs_kv_split": (case_attention_kv_split, dict(batch=2, heads=2, L=16 * 180, parts=8, q_scaled=True)),
+    # whole-tile key counts = the hand-placed 4 x 64 kernel (attn64_kernel): its minimum of three tiles, a query tail inside the last
+    # workgroup, the optimistic soft-max under a late spike, and the in-kernel exact-loop fallback
+    "attn_qs_L192": (case_attention, dict(batch=2, heads=1, L=192, q_scaled=True)),
+    "attn_qs_L256": (case_attention, dict(batch=1, heads=2, L=256, q_scaled=True)),
+    "attn_qs_L320": (case_attention, dict(batch=3, heads=1, L=320, q_scaled=True, seed=3)),
+    "attn_qs_spike1024": (case_attention, dict(batch=1, heads=2, L=1024, spike=True, q_scaled=True)),
+    "attn_qs_ramp_fallback1536": (case_attention, dict(batch=2, heads=2, L=1536, ramp=True, q_scaled=True)),
+    "attn_qs_kv_split_f24": (case_attention_kv_split, dict(batch=2, heads=1, L=24 * 720, parts=8, q_scaled=True)),
     # the shapes the bench TIMES (72x40 latents, SD-2.1 heads; 3-D = CFG batch 2 over F*HW tokens, 2-D = CFG*F frames) ...
     "attn_qs_judged_3d_l1_f16": (case_attention, dict(batch=2, heads=10, L=16 * 720, q_scaled=True, threads=32)),
     "attn_qs_judged_3d_l1_f24": (case_attention, dict(batch=2, heads=10, L=24 * 720, q_scaled=True, threads=32)),
@@ -1312,6 +1320,10 @@ CASES = {
     "h16_attn_ramp_fallback": (case_h16_attention, dict(batch=2, heads=2, L=1500, ramp=True)),
     "h16_attn_flat_rows": (case_h16_attention, dict(batch=1, heads=1, L=24 * 720, flat=True, threads=32)),
     "h16_attn_kv_split": (case_h16_attention, dict(batch=2, heads=2, L=16 * 180, parts=8)),
+    "h16_attn_L192": (case_h16_attention, dict(batch=2, heads=1, L=192)),
+    "h16_attn_L320": (case_h16_attention, dict(batch=3, heads=1, L=320, seed=3)),
+    "h16_attn_spike1024": (case_h16_attention, dict(batch=1, heads=2, L=1024, spike=True)),
+    "h16_attn_ramp_fallback1536": (case_h16_attention, dict(batch=2, heads=2, L=1536, ramp=True)),
     "h16_attn_judged_3d_l1_f16": (case_h16_attention, dict(batch=2, heads=10, L=16 * 720, threads=32)),
     "h16_attn_judged_3d_l1_f24": (case_h16_attention, dict(batch=2, heads=10, L=24 * 720, threads=32)),
     "h16_attn_judged_2d_l0": (case_h16_attention, dict(batch=32, heads=5, L=2880, threads=32)),
@@ -1326,7 +1338,7 @@ CASES = {
     "resize_aa_mixed": (case_resize_aa, dict(N=2, C=1, H=50, W=30, h=17, w=45)),
 }
 
-TOLS = {"multistep_step_3slots": 1e-6, "multistep_step_2slots": 1e-6, "resize_aa_spatial_mosaic": 5e-5, "resize_aa_temporal_mosaic": 5e-5, "resize_aa_mixed": 5e-5, "plucker_576x320": 2e-3, "plucker_odd_ratio": 2e-3, "plucker_identity_size": 2e-3, "layout": 0.0, "temb": 6e-3, "attn_kv_split": 0.0, "attn_kv_split3": 0.0, "attn_qs_kv_split": 0.0,
+TOLS = {"multistep_step_3slots": 1e-6, "multistep_step_2slots": 1e-6, "resize_aa_spatial_mosaic": 5e-5, "resize_aa_temporal_mosaic": 5e-5, "resize_aa_mixed": 5e-5, "plucker_576x320": 2e-3, "plucker_odd_ratio": 2e-3, "plucker_identity_size": 2e-3, "layout": 0.0, "temb": 6e-3, "attn_kv_split": 0.0, "attn_kv_split3": 0.0, "attn_qs_kv_split": 0.0, "attn_qs_kv_split_f24": 0.0,
         "conv_batch_invariance_l3": 0.0, "conv_batch_invariance_l2": 0.0}
 
 
