@@ -27,7 +27,10 @@
 #include "common.h"
 #include "dm4d.h"
 #include "errors.h"
-#include "attn64_asm.inc"
+#ifndef ATTN64_INC  // tuning builds (tools/attn64/ab.py) compile other schedules of the same stream
+#define ATTN64_INC "attn64_asm.inc"
+#endif
+#include ATTN64_INC
 #include <stdlib.h>
 
 namespace {
@@ -39,7 +42,14 @@ struct AttnParams {
   int L, Lk, heads, nqt;  // L = queries per (batch, head), Lk = keys (== L for plain self-attention)
   float c;         // scale * log2(e)   (unused when Q is pre-scaled)
   int exact_only;  // tuning / debugging: skip the optimistic pass (DM4D_ATTN_EXACT=1)
+#ifdef ATTN64_TIMING  // tuning builds only: s_memtime stamps of attn64_kernel's stream (start, loop entry, end) per wave
+  unsigned long long* dbg;
+#endif
 };
+#ifdef ATTN64_TIMING
+static unsigned long long* g_attn64_dbg = nullptr;
+extern "C" void dm4d_attn64_set_debug(void* ptr) { g_attn64_dbg = (unsigned long long*)ptr; }
+#endif
 
 constexpr int KV = 64;       // keys per staged tile
 constexpr int LDS_LD = 72;   // exact loop, K rows: 64 + 8 pad bf16 = 144 B  (conflict-free ds_read_b128 fragments)
@@ -603,8 +613,21 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(AttnParams p) {
   [kfa0] "v"(kfa[0]), [kfa1] "v"(kfa[1]), [kfa2] "v"(kfa[2]), [kfa3] "v"(kfa[3]), [vfa0] "v"(vfa[0]), [vfa1] "v"(vfa[1]), [dk0] "v"(dk[0]),    \
       [dk1] "v"(dk[1]), [dv0] "v"(dv[0]), [dv1] "v"(dv[1]), [qa0] "v"(qa[0]), [qa1] "v"(qa[1]), [ones] "v"(ones), [kbase] "s"(Kb),             \
       [vbase] "s"(Vb), [kstride] "s"(kstride), [vstride] "s"(vstride), [nt] "s"(nt), [m0k] "s"(m0k), [m0v] "s"(m0v)
+#ifdef ATTN64_TIMING
+    uint32_t ts[6];
+#define ATTN64_STAMPS [ts0] "=s"(ts[0]), [ts1] "=s"(ts[1]), [ts2] "=s"(ts[2]), [ts3] "=s"(ts[3]), [ts4] "=s"(ts[4]), [ts5] "=s"(ts[5])
+    if constexpr (H16) asm volatile(ATTN64_ASM_F16 : ATTN64_STAMPS : ATTN64_OPERANDS : ATTN64_CLOBBERS);
+    else asm volatile(ATTN64_ASM_BF16 : ATTN64_STAMPS : ATTN64_OPERANDS : ATTN64_CLOBBERS);
+    if (p.dbg && lane == 0) {
+      unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 4 + wave) * 3;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) d[i] = ((unsigned long long)ts[2 * i + 1] << 32) | ts[2 * i];
+    }
+#undef ATTN64_STAMPS
+#else
     if constexpr (H16) asm volatile(ATTN64_ASM_F16 : : ATTN64_OPERANDS : ATTN64_CLOBBERS);
     else asm volatile(ATTN64_ASM_BF16 : : ATTN64_OPERANDS : ATTN64_CLOBBERS);
+#endif
 #undef ATTN64_OPERANDS
   }
   // the stream ends behind a workgroup barrier with every DMA landed: the rings are free.  O^T (db, qb) = a[16 (2 db + qb) ..],
@@ -615,7 +638,11 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(AttnParams p) {
   acc_read16<32>(o[0][1]);
   acc_read16<48>(o[1][1]);
   float l_tot[2];
-  {
+  if constexpr (ATTN64_ROWSUM_VALU) {  // a schedule with VALU row sums (tools/attn64/gen.py rowsum = pk | add): each lane's half of its row
+    const float a = acc_read1<64>(), b = acc_read1<68>();
+    l_tot[0] = a + __shfl_xor(a, 32);
+    l_tot[1] = b + __shfl_xor(b, 32);
+  } else {
     const float a0 = __shfl(acc_read1<64>(), l31 & 15), a1 = __shfl(acc_read1<65>(), l31 & 15);
     const float b0 = __shfl(acc_read1<68>(), l31 & 15), b1 = __shfl(acc_read1<69>(), l31 & 15);
     l_tot[0] = l31 < 16 ? a0 : a1;
@@ -673,6 +700,9 @@ static int attention_launch(void* stream, const void* Q, const void* K, const vo
   static const int exact = [] { const char* e = getenv("DM4D_ATTN_EXACT"); return e ? atoi(e) : 0; }();  // tuning aid
   AttnParams p{(const u16*)Q, (const u16*)K, (const u16*)V, (u16*)O, ldq, ldk, ldv, ldo, Lq, Lk, heads, 0,
                scale * 1.4426950408889634f, exact};
+#ifdef ATTN64_TIMING
+  p.dbg = g_attn64_dbg;
+#endif
   // 8 waves per workgroup.  The kernels are written for NW = 4 as well (two independent 128-row workgroups per CU);
   // measured in one call: +1..3 % on the 2-D L0 shapes, -3..-5 % on the 3-D ones (profiles/r01_attn_nw4_ab.log)
   // the hand-placed 4 x 64 form: pre-scaled Q, whole key tiles, at least three of them (DM4D_ATTN64=0: tuning aid, the 8-wave kernel)

@@ -42,9 +42,10 @@ Reg = Tuple[str, int]  # ("v", n) | ("a", n) | ("s", n)
 # ---- register map -------------------------------------------------------------------------------------------------
 S_BASE, NEGM_BASE, P_BASE, TMP_BASE = 0, 128, 160, 192
 O_BASE, L_BASE, Q_BASE, KF_BASE, VF_BASE, ONES_BASE = 0, 64, 72, 104, 136, 168
-N_VGPR_CLOBBER, N_AGPR_CLOBBER = 200, 172
+LV_BASE = 200            # row-sum accumulators of the VALU row-sum forms: 4 per row block
+N_VGPR_CLOBBER, N_AGPR_CLOBBER = 208, 172
 SG = dict(kptr=40, vptr=42, kstride=44, vstride=45, rem=46, remk=47, remv=48, inc=49, mk=50, mv=54, t0=58, t1=59)
-SGPR_CLOBBER = list(range(40, 62))
+SGPR_CLOBBER = list(range(40, 68))  # s[62:67]: s_memtime stamps of the timing build (tools/attn64/ab.py)
 KV_STAGE = 8192          # bytes of one [64 keys][64 d] stage
 HALF_TILE = 4096         # 32 key rows
 
@@ -101,7 +102,7 @@ class Ins:
     def size(self):  # wait states this instruction provides to hazards that follow it
         if self.kind == "nop":
             return self.sim[1] + 1
-        return 0 if self.kind == "label" else 1
+        return 0 if self.kind in ("label", "touch") else 1
 
 
 class Variant:
@@ -174,11 +175,15 @@ def set_m0(sgpr):
 
 # ---- the stream of one step ------------------------------------------------------------------------------------------
 class Program:
-    def __init__(self, var: Variant, gap_big=5.0, gap_small=2.2, defer_valu=True, bare_head=0):
+    def __init__(self, var: Variant, gap_big=5.0, gap_small=2.2, defer_valu=False, bare_head=0, timing=False, dma_round=None, order="pqpqL", ablate=(), rowsum="mfma", merge_waits=True):
         self.var = var
         self.ins: List[Ins] = []
         self.gap_big, self.gap_small = gap_big, gap_small
-        self.defer_valu, self.bare_head = defer_valu, bare_head
+        self.defer_valu, self.bare_head, self.timing, self.dma_round, self.order = defer_valu, bare_head, timing, dma_round, order
+        self.rowsum, self.merge_waits = rowsum, merge_waits  # rowsum: mfma | pk (v_pk_add_f32) | add (v_add_f32)
+        if rowsum != "mfma":
+            self.order = self.order.replace("L", "")
+        self.ablate = set(ablate)  # timing experiments only (wrong results): kinds of loop instructions left out of the stream
 
     def emit(self, *ins):
         self.ins.extend(ins)
@@ -220,13 +225,36 @@ class Program:
             out.append(m)
             if q == 0:
                 out.append(mfma(var, "a", O(1, qb), "a", VF(g, 1), "v", P(p), "a", O(1, qb)))
-        out.append(mfma_rowsum(var, qb, p))
-        return out  # PV db0, QK qb0, PV db1, QK qb1, rowsum
+        out.append(mfma_rowsum(var, qb, p))  # PV db0, QK qb0, PV db1, QK qb1, rowsum
+        pick = {"p": [out[0], out[2]], "q": [out[1], out[3]], "L": [out[4]]}
+        res = [pick[c].pop(0) for c in self.order]
+        if self.merge_waits:  # one counted wait in front of the round instead of one per fragment
+            res.insert(0, Ins("", "touch", reads=sorted({r for m in res for r in m.reads if r[0] == "a" and r[1] >= KF_BASE and r[1] < ONES_BASE})))
+        return res
+
+    def rowsum_fillers(self, set_, p):
+        """VALU row sums (rowsum = pk | add): the exponentials of probability group p, still in place in S set `set_`, into the four
+        accumulators of its row block.  Issued in the round that CONSUMES the group, so a tile past the end is never summed."""
+        if self.rowsum == "mfma":
+            return []
+        g, qb = p >> 1, p & 1
+        kb, jj = g >> 1, g & 1
+        s0 = S(set_, kb, qb) + 8 * jj
+        lv = LV_BASE + 4 * qb
+        if self.rowsum == "pk":
+            return [Ins(f"v_pk_add_f32 v[{lv + 2 * (i & 1)}:{lv + 2 * (i & 1) + 1}], v[{lv + 2 * (i & 1)}:{lv + 2 * (i & 1) + 1}], v[{s0 + 2 * i}:{s0 + 2 * i + 1}]", "valu",
+                        reads=regs("v", lv + 2 * (i & 1), 2) + regs("v", s0 + 2 * i, 2), writes=regs("v", lv + 2 * (i & 1), 2),
+                        sim=("pkadd", lv + 2 * (i & 1), s0 + 2 * i)) for i in range(4)]
+        return [Ins(f"v_add_f32 v{lv + (i & 3)}, v{lv + (i & 3)}, v{s0 + i}", "valu", reads=[("v", lv + (i & 3)), ("v", s0 + i)], writes=[("v", lv + (i & 3))],
+                    sim=("add", lv + (i & 3), lv + (i & 3), s0 + i)) for i in range(8)]
 
     def place(self, anchors: Sequence[Ins], fillers: Sequence[Ins], lead: Sequence[Ins] = (), bare=0):
         """MFMA anchors in order, fillers spread behind them by issue-slot budget (big gap / small gap); `lead` goes first.
         `bare` = number of leading anchors that get no filler (MFMA-only head after a barrier)."""
         self.emit(*lead)
+        anchors = list(anchors)
+        while anchors and anchors[0].kind == "touch":
+            self.emit(anchors.pop(0))
         fillers = list(fillers)
         total = sum(f.cost for f in fillers)
         caps = [(self.gap_small if a.kind == "mfma16" else self.gap_big) if i >= bare else 0.0 for i, a in enumerate(anchors)]
@@ -280,7 +308,8 @@ class Program:
         old = 1 - par
         self.emit(Ins("s_waitcnt vmcnt(0) lgkmcnt(0)", "wait", sim=("wait", 0, 0)), Ins("s_barrier", "barrier", sim=("barrier",)))
         lead = self.head_reads(par)
-        defer_fill = self.dma_issue(par) + (self.softmax_fillers(par, 1) if self.defer_valu else [])
+        defer_fill = ([] if self.dma_round is not None else self.dma_issue(par)) + (self.softmax_fillers(par, 1) if self.defer_valu else []) + \
+            self.rowsum_fillers(old, 7)
         self.place(self.round_mfmas(old, 7), defer_fill, lead=lead, bare=self.bare_head)
         if entry_label:
             self.emit(label(entry_label))
@@ -297,12 +326,34 @@ class Program:
                 fill += lds + self.softmax_fillers(cur, r + 2)
             else:
                 fill += self.softmax_fillers(nxt, 0)
+            fill += self.rowsum_fillers(cur, r)
+            if self.dma_round == r:
+                fill = self.dma_issue(par) + fill
             self.place(self.round_mfmas(par, r), fill)
 
     # -- whole program -----------------------------------------------------------------------------------------------
+    def rowsum_handover(self):
+        """VALU row sums: the four accumulators of a row block -> one value per lane (its half of the row's keys) in a[64] / a[68]."""
+        if self.rowsum == "mfma":
+            return []
+        out = []
+        for qb in range(2):
+            lv = LV_BASE + 4 * qb
+            add = lambda d, a, b: Ins(f"v_add_f32 v{d}, v{a}, v{b}", "valu", reads=[("v", a), ("v", b)], writes=[("v", d)], sim=("add", d, a, b))  # noqa: E731
+            out += [add(lv, lv, lv + 1), add(lv + 2, lv + 2, lv + 3), s_nop(0), add(lv, lv, lv + 2), s_nop(1),
+                    Ins(f"v_accvgpr_write_b32 a{L(qb)}, v{lv}", "valu", reads=[("v", lv)], writes=[("a", L(qb))], sim=("acc_from_v", L(qb), lv))]
+        return out
+
+    @staticmethod
+    def stamp(sg):
+        """s_memtime into s[sg:sg+1] (an SMEM load: lgkmcnt(0) behind it; the stream has no LDS read in flight where stamps sit)."""
+        return [Ins(f"s_memtime s[{sg}:{sg + 1}]", "nop", sim=("nop", 0)), Ins("s_waitcnt lgkmcnt(0)", "nop", sim=("nop", 0))]
+
     def prologue(self):
         var, s = self.var, SG
         e = self.emit
+        if self.timing:
+            e(*self.stamp(62))
         # loop state into the fixed SGPRs (M0 belongs to the compiler: saved here, restored behind the loop)
         e(salu(f"s_mov_b32 s{s['t0']}, m0", ("s_save_m0", s["t0"]), writes=[s["t0"]]),
           salu(f"s_mov_b64 s[{s['kptr']}:{s['kptr'] + 1}], %[kbase]", ("s_mov64_in", s["kptr"], "kbase"), writes=[s["kptr"], s["kptr"] + 1]),
@@ -332,6 +383,9 @@ class Program:
         # accumulators and the ones pattern while the loads fly
         for r in range(72):
             e(Ins(f"v_accvgpr_write_b32 a{O_BASE + r}, 0", "valu", writes=[("a", O_BASE + r)], sim=("acc_zero", O_BASE + r)))
+        if self.rowsum != "mfma":
+            for r in range(8):
+                e(Ins(f"v_mov_b32 v{LV_BASE + r}, 0", "valu", writes=[("v", LV_BASE + r)], sim=("movc", LV_BASE + r, 0.0)))
         for r in range(4):
             e(Ins(f"v_accvgpr_write_b32 a{ONES_BASE + r}, %[ones]", "valu", writes=[("a", ONES_BASE + r)], sim=("acc_in", ONES_BASE + r, "ones")))
         e(Ins("s_waitcnt vmcnt(0)", "wait", sim=("wait", 0, None)), Ins("s_barrier", "barrier", sim=("barrier",)))
@@ -371,12 +425,15 @@ class Program:
         # everybody has read K stage 0: the first head may overwrite it
         e(Ins("s_waitcnt lgkmcnt(0)", "wait", sim=("wait", None, 0)), Ins("s_barrier", "barrier", sim=("barrier",)))
         e(*self.head_reads(0))
-        e(*[x for x in self.dma_issue(0)])
-        e(*self.softmax_fillers(0, 0), *self.softmax_fillers(0, 1), s_nop(1))
+        if self.dma_round is None:  # else the first step issues its own
+            e(*self.dma_issue(0))
+        e(*self.softmax_fillers(0, 0), *(self.softmax_fillers(0, 1) if self.defer_valu else []), s_nop(1))
 
     def build(self):
         s = SG
         self.prologue()
+        if self.timing:
+            self.emit(*self.stamp(64))
         self.emit(branch("s_branch", "ENTRY0"))
         self.emit(label("LOOP"))
         self.step(0, entry_label="ENTRY0")
@@ -388,16 +445,20 @@ class Program:
                   salu(f"s_cmp_lg_u32 s{s['rem']}, 0", ("s_cmp_lg", s["rem"], 0), reads=[s["rem"]]),
                   branch("s_cbranch_scc1", "LOOP"))
         # the last step's deferred round (old parity 1 after falling out of step(1), old parity 0 at EXIT0)
-        self.emit(Ins("s_waitcnt lgkmcnt(0)", "wait", sim=("wait", None, 0)), *self.round_mfmas(1, 7), branch("s_branch", "DONE"))
-        self.emit(label("EXIT0"), Ins("s_waitcnt lgkmcnt(0)", "wait", sim=("wait", None, 0)), *self.round_mfmas(0, 7))
+        self.emit(Ins("s_waitcnt lgkmcnt(0)", "wait", sim=("wait", None, 0)), *self.round_mfmas(1, 7), *self.rowsum_fillers(1, 7), branch("s_branch", "DONE"))
+        self.emit(label("EXIT0"), Ins("s_waitcnt lgkmcnt(0)", "wait", sim=("wait", None, 0)), *self.round_mfmas(0, 7), *self.rowsum_fillers(0, 7))
         self.emit(label("DONE"), Ins("s_waitcnt vmcnt(0) lgkmcnt(0)", "wait", sim=("wait", 0, 0)), Ins("s_barrier", "barrier", sim=("barrier",)),
-                  salu(f"s_mov_b32 m0, s{s['t0']}", ("s_mov_m0", s["t0"]), reads=[s["t0"]]), s_nop(15))
-        insert_lgkm_waits(self.ins)
+                  salu(f"s_mov_b32 m0, s{s['t0']}", ("s_mov_m0", s["t0"]), reads=[s["t0"]]), *self.rowsum_handover(), *(self.stamp(66) + [Ins(f"s_mov_b32 %[ts{i}], s{62 + i}", "salu", sim=("nop", 0)) for i in range(6)] if self.timing else []), s_nop(15))
+        if self.ablate:
+            lo = next(i for i, x in enumerate(self.ins) if x.kind == "label" and x.sim[1] == "LOOP")
+            hi = next(i for i, x in enumerate(self.ins) if x.kind == "label" and x.sim[1] == "EXIT0")
+            self.ins = [x for i, x in enumerate(self.ins) if not (lo < i < hi and x.kind in self.ablate)]
+        insert_lgkm_waits(self.ins, strict=not self.ablate)
         return self
 
 
 # ---- counted LDS waits -----------------------------------------------------------------------------------------------------
-def insert_lgkm_waits(ins: List[Ins]):
+def insert_lgkm_waits(ins: List[Ins], strict=True):
     """ds_read results return in order: in front of the first consumer of a fragment put s_waitcnt lgkmcnt(N), N = number of LDS
     reads issued behind the youngest one the consumer needs.  Linear scan; at a label the two ways in must agree on the reads in
     flight (or the label is followed by a full wait): the queue recorded at the branch is compared with the fall-through's."""
@@ -415,7 +476,7 @@ def insert_lgkm_waits(ins: List[Ins]):
             snap = at_branch.get(x.sim[1])
             if dead:
                 queue = [list(w) for w in (snap or [])]
-            elif snap is not None and not full:
+            elif snap is not None and not full and strict:
                 assert snap == queue, f"reads in flight differ at {x.text}: {snap} vs {queue}"
             dead = False
         elif x.kind == "wait" and x.sim[2] is not None:
@@ -446,8 +507,10 @@ def check_hazards(ins: List[Ins]):
     last_valu_w, last_trans_w, last_mfma_w, last_m0 = {}, {}, {}, None
     pos = 0
     for x in ins:
-        if x.kind == "label":
+        if x.kind in ("label", "touch"):
             continue
+        if x.kind == "branch" and x.sim[1] == "s_branch":  # what follows is reached from elsewhere (behind its own waits)
+            last_valu_w, last_trans_w, last_mfma_w, last_m0 = {}, {}, {}, None
         if x.kind in ("mfma", "mfma16"):
             for r in x.reads:
                 if r in last_valu_w and pos - last_valu_w[r] - 1 < 2:
@@ -487,11 +550,11 @@ def check_hazards(ins: List[Ins]):
 
 # ---- output ----------------------------------------------------------------------------------------------------------------------
 def render(prog: Program) -> str:
-    return " \\\n".join(f'  "{x.text}\\n\\t"' for x in prog.ins)
+    return " \\\n".join(f'  "{x.text}\\n\\t"' for x in prog.ins if x.kind != "touch")
 
 
 def emit_file(opts=None) -> str:
-    opts = opts or {}
+    opts = dict(opts or {})
     parts = ["// GENERATED by tools/attn64/gen.py -- do not edit; `python tools/attn64/gen.py --write` after changing the generator.\n",
              "// The hand-placed main loop of attention.hip::attn64_kernel (register map and schedule: tools/attn64/gen.py header).\n",
              "#pragma once\n"]
@@ -501,6 +564,7 @@ def emit_file(opts=None) -> str:
         if errs:
             raise SystemExit("hazards:\n" + "\n".join(errs[:40]))
         parts.append(f"#define ATTN64_ASM_{prog.var.name} \\\n" + render(prog) + "\n\n")
+    parts.append(f"#define ATTN64_ROWSUM_VALU {int(prog.rowsum != 'mfma')}  // 1: a[64] / a[68] hold each lane's half of its row's sum\n")
     clob = ", ".join([f'"v{i}"' for i in range(N_VGPR_CLOBBER)] + [f'"a{i}"' for i in range(N_AGPR_CLOBBER)] + [f'"s{i}"' for i in SGPR_CLOBBER] + ['"scc"', '"memory"'])
     parts.append(f"#define ATTN64_CLOBBERS {clob}\n")
     return "".join(parts)

@@ -132,7 +132,7 @@ class Workgroup:
             w.pc += 1
             k = x.kind
             self.count[k] = self.count.get(k, 0) + 1
-            if k == "label" or k == "nop":
+            if k in ("label", "nop", "touch"):
                 continue
             op = x.sim
             if k == "barrier":
@@ -243,6 +243,19 @@ class Workgroup:
 
     def op_sub(self, w, d, a, b):
         w.v[d] = u32(f32(w.v[a]) - f32(w.v[b]))
+
+    def op_pkadd(self, w, d, a):
+        for i in range(2):
+            w.v[d + i] = u32(f32(w.v[d + i]) + f32(w.v[a + i]))
+
+    def op_add(self, w, d, a, b):
+        w.v[d] = u32(f32(w.v[a]) + f32(w.v[b]))
+
+    def op_movc(self, w, d, c):
+        w.v[d] = u32(np.full(64, c, np.float32))
+
+    def op_acc_from_v(self, w, d, a):
+        w.a[d] = w.v[a].copy()
 
     def op_acc_zero(self, w, r):
         w.a[r] = 0
@@ -373,9 +386,12 @@ def read_result(wg: Workgroup, wave: int):
         for db in range(2):
             m = wg.acc32(w, "a", O(db, qb))  # [d within block][q within block]
             out[32 * qb:32 * qb + 32, 32 * db:32 * db + 32] = m.T
-        lr = f32(w.a[L(qb):L(qb) + 2])        # lanes 0..15: reg 0 = rows 0..15, reg 1 = rows 16..31
-        lsum[32 * qb:32 * qb + 16] = lr[0, :16]
-        lsum[32 * qb + 16:32 * qb + 32] = lr[1, :16]
+        lr = f32(w.a[L(qb):L(qb) + 2])
+        if wg.prog.rowsum != "mfma":             # each lane's half of its row's keys
+            lsum[32 * qb:32 * qb + 32] = lr[0, :32] + lr[0, 32:]
+        else:                                    # lanes 0..15: reg 0 = rows 0..15, reg 1 = rows 16..31
+            lsum[32 * qb:32 * qb + 16] = lr[0, :16]
+            lsum[32 * qb + 16:32 * qb + 32] = lr[1, :16]
     return out, lsum
 
 
