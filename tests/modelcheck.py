@@ -460,6 +460,53 @@ def case_demo3d_sd21(precision="fast", matched=False):
     return e, y
 
 
+def case_demo4dtiny_temporal(precision="fast"):
+    """BASELINE.json configs[1], ONE WHOLE TEMPORAL TASK on the judged geometry: `demo_4d_tiny` (configs/exp/demo_4d_tiny.yaml:6-9 +
+    sampler/sliding_fast.yaml: 16 frames, window 12, stride 2, 3 alternation rounds), the middle round: one target camera = 32 rows
+    (sliding_iterative_sampler.py:112-118: 16 input frames + 16 target frames), targets entering at timestep index 6 with the grid's
+    latents, 8 window calls of F = 24 frames = CFG batch 48 (pipeline_diffuman4d.py:504-518), 2 x 32 VAE encodes, decode of the four
+    target rows the fixture keeps.  Compared with the fp32 CPU oracle's latents (all 32 rows), its decoded RGB (16-bit fixed point) and
+    -- bit for bit -- its timestep bookkeeping (tests/golden/demo4dtiny_temporal_sd21_72x40.pt, made by
+    tests/golden/make_golden_demo4d_tiny_temporal.py together with the bf16-oracle yardsticks).  Temporal tasks are one third of the
+    judged job's window calls and F = 24 is where the fp16 precision is weakest on a single call."""
+    from diffuman4d_amd.host.pipeline import Diffuman4DPipeline
+    from diffuman4d_amd.host.scheduler import DDIMConfig as HC, DDIMScheduler as HS
+    from diffuman4d_amd.host.unet import UNetConfig, UNetMultiviewConditionModel
+    from diffuman4d_amd.host.vae import AutoencoderKL, VAEConfig
+    sys.path.insert(0, str(GOLDEN))
+    import make_golden_demo4d_tiny_temporal as mk
+    g = torch.load(GOLDEN / "demo4dtiny_temporal_sd21_72x40.pt")
+    usd, vsd = sd_weights("unet", mk.UNET_SEED), sd_weights("vae", mk.VAE_SEED)
+    pv, pl, sk, cm = mk.task_inputs()
+    noise, lat = mk.task_noise(), mk.grid_latents()
+    got, want = mk.checksums(pv, pl, sk, cm, noise, lat, usd, vsd), g["checksums"]
+    for k in ("pixel_values", "plucker", "skeletons", "cond_masks", "latents_in", "unet_weights", "vae_weights"):
+        _check_fixture_inputs("demo4dtiny temporal " + k, got[k], want[k])
+    for k in noise:
+        _check_fixture_inputs("demo4dtiny temporal noise " + k, got["noise"][k], want["noise"][k])
+    hp = Diffuman4DPipeline(AutoencoderKL(VAEConfig(), vsd, "cuda", precision), UNetMultiviewConditionModel(UNetConfig(), usd, "cuda", precision),
+                            HS(HC()), "cuda")
+    del usd, vsd
+    t0 = time.time()
+    out = hp.sliding_iterative_denoise(pixel_values=pv, plucker_embeds=pl, skeletons=sk, cond_masks=cm, latents=lat, domain="temporal",
+                                       timestep_indices=mk.start_indices(), noise=noise, **g["kw"])
+    torch.cuda.synchronize()
+    secs = time.time() - t0
+    exact = torch.equal(out["timestep_indices"].cpu(), g["timestep_indices"]) and torch.equal(out["fully_denoised"].cpu(), g["fully_denoised"])
+    ref_img = g["images_u16"].to(torch.int32).float() / 65535.0
+    e = {"latents": rel_l2(out["latents"], g["latents"]), "images": rel_l2(out["images"][g["image_rows"]], ref_img)}
+    e_t = rel_l2(out["latents"].cpu()[mk.T:], g["latents"][mk.T:])
+    y = {"latents": g["yard_latents"], "images": g["yard_images"]}
+    print(f"    [demo_4d_tiny temporal task {precision}, SD-2.1 + SD VAE, 72x40, 8 calls of F = 24, {secs:.1f}s] latents rel_l2={e['latents']:.3e} (targets only "
+          f"{e_t:.3e}; oracle-bf16 {y['latents']:.3e}) images rel_l2={e['images']:.3e} (oracle-bf16 {y['images']:.3e}; north_star {NORTH_STAR:.0e}: "
+          f"{'met' if e['images'] <= NORTH_STAR else 'NOT met'}) bookkeeping_exact={exact}", flush=True)
+    del hp
+    torch.cuda.empty_cache()
+    if not exact:
+        return {"bookkeeping": 1.0}, {"bookkeeping": 0.0}
+    return e, y
+
+
 def case_vae_1024(name="vae_1024"):
     """AutoencoderKL at the SD geometry on ONE 1024 x 1024 image -- the reference's native image size (spatem_dataset.py:27-28 ->
     pipeline_diffuman4d.py:47-72, 553): mid-block attention over L = 16 384 tokens at d = 512, 1024^2 x 128-channel activations.
@@ -1114,6 +1161,11 @@ if (GOLDEN / "demo3d_sd21_72x40.pt").exists():
     CASES["fp16_demo3d_sd21_72x40"] = (case_demo3d_sd21, dict(**FP16))  # the same bar at one MFMA per product
     if "matched_latents" in torch.load(GOLDEN / "demo3d_sd21_72x40.pt"):  # make_golden_demo3d.py matched
         CASES["demo3d_sd21_72x40_matched"] = (case_demo3d_sd21, dict(matched=True))
+# BASELINE.json configs[1]: one whole temporal task of demo_4d_tiny (8 calls of F = 24) at the judged geometry, all three precisions
+if (GOLDEN / "demo4dtiny_temporal_sd21_72x40.pt").exists():
+    CASES["demo4dtiny_temporal_sd21_72x40"] = (case_demo4dtiny_temporal, dict())
+    CASES["par_demo4dtiny_temporal_sd21_72x40"] = (case_demo4dtiny_temporal, dict(**PAR))    # fixed bound 1e-4
+    CASES["fp16_demo4dtiny_temporal_sd21_72x40"] = (case_demo4dtiny_temporal, dict(**FP16))  # fixed bound: decoded RGB <= 1e-3
 # Cases with a fixed bound of their own: bitwise equalities (0.0), extension-vs-strict comparisons, exact resampling.
 # Every other case is judged against its bf16-oracle yardstick (YARD_FACTOR, see the module docstring).
 TOL = {"task_batching_spatial": 0.0, "task_batching_temporal_x3": 0.0, "task_batching_dpm": 0.0, "pipeline_shard_rccl_world1": 0.0, "unet_frame_shard_p4": 0.0, "unet_frame_shard_p8": 0.0,
