@@ -173,6 +173,9 @@ __global__ void cfg_linear_step_kernel(T* latents, T* x0_prev, const T* np, int6
 //   m = guided model output;  conv = k0 x + k1 m;  xc = k2 x + k3 s3 + k4 s1 + k5 s2 + k6 conv;  x' = k7 xc + k8 conv + k9 s1 + k10 s2
 //   s3' = xc, s2' = s1, s1' = conv.   s2 / s3 may be NULL (order-1 / DEIS schedulers keep fewer tensors).  The stored tensors start a
 // call as ZEROS (the host allocates them so): a latent's first steps meet zero coefficients on them.
+// Two more fields serve PNDM's linear multistep form (PLMS, four model outputs deep): k11 = weight of s3 in x', and k12 = what the stored
+// tensors become -- 0: as above;  1: kept as they are (the repeated second step of PLMS re-does the first from the stored sample and must
+// not enter the history);  2: shifted as a history, s3' = s2, s2' = s1, s1' = conv.
 template <typename T>
 __global__ void cfg_multistep_kernel(T* latents, T* s1, T* s2, T* s3, const T* np, int64_t ldn, const float* coef, const int32_t* is_cond,
                                      const int32_t* frame_idx, int F, int HW, int use_cfg, float gs) {
@@ -196,8 +199,10 @@ __global__ void cfg_multistep_kernel(T* latents, T* s1, T* s2, T* s3, const T* n
     const float p1 = ldv(s1 + i * 4 + ch), p2 = s2 ? ldv(s2 + i * 4 + ch) : 0.f, p3 = s3 ? ldv(s3 + i * 4 + ch) : 0.f;
     const float conv = k[0] * x + k[1] * m;
     const float xc = k[2] * x + k[3] * p3 + k[4] * p1 + k[5] * p2 + k[6] * conv;
-    stv(latents + i * 4 + ch, k[7] * xc + k[8] * conv + k[9] * p1 + k[10] * p2);
-    if (s3) stv(s3 + i * 4 + ch, xc);
+    stv(latents + i * 4 + ch, k[7] * xc + k[8] * conv + k[9] * p1 + k[10] * p2 + k[11] * p3);
+    const int keep = (int)k[12];
+    if (keep == 1) continue;
+    if (s3) stv(s3 + i * 4 + ch, keep == 2 ? p2 : xc);
     if (s2) stv(s2 + i * 4 + ch, p1);
     stv(s1 + i * 4 + ch, conv);
   }

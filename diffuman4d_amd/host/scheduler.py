@@ -3,7 +3,7 @@
 The reference takes whatever scheduler the checkpoint's ``scheduler/scheduler_config.json`` names
 (pipeline_diffuman4d.py:28,134,265-271) and deep-copies it per latent because some Karras-family
 schedulers are stateful.  Its loop calls ``scale_model_input`` with a VECTOR of per-frame timesteps (:376), which only
-identity implementations survive, so the class has to be one of DDIM / DDPM / PNDM / DPM-Solver / UniPC / DEIS.  Built here:
+identity implementations survive, so the class has to be one of DDIM / DDPM / PNDM / DPM-Solver / UniPC / DEIS.  Built here (all but DDPM):
 
 * ``DDIMScheduler`` (eta = 0): stateless; one table serves every latent and the per-latent ``.step()`` Python loop
   (:413-422) becomes one batched device kernel fed with the coefficient rows computed here.
@@ -16,8 +16,10 @@ identity implementations survive, so the class has to be one of DDIM / DDPM / PN
   ``x' = a x + b m + c p,  p' = d x + e m`` (p = the latent's stored x0 prediction) consumed by
   ``dm4d_cfg_linear_step_bf16``; the only state is one bf16 tensor the shape of the task's latents.
 
-Anything else raises in ``load_scheduler`` instead of guessing (stochastic samplers need the reference's RNG stream, PNDM
-evaluates the model twice on its first step).
+* ``PNDMScheduler`` with ``skip_prk_steps`` (PLMS, the Stable Diffusion family's stock scheduler): Adams-Bashforth combinations of up to
+  four model outputs and the repeated second step, as rows of the same kernel (see the class).
+
+Anything else raises in ``load_scheduler`` instead of guessing (stochastic samplers need the reference's RNG stream).
 """
 from __future__ import annotations
 
@@ -537,6 +539,116 @@ class DEISMultistepScheduler(_MultistepRows):
         return np.nan_to_num(rows, nan=0.0, posinf=0.0, neginf=0.0).astype(np.float32)
 
 
+@dataclass
+class PNDMConfig:
+    num_train_timesteps: int = 1000
+    beta_start: float = 0.0001
+    beta_end: float = 0.02
+    beta_schedule: str = "linear"
+    trained_betas: object = None
+    skip_prk_steps: bool = False
+    set_alpha_to_one: bool = False
+    prediction_type: str = "epsilon"
+    timestep_spacing: str = "leading"
+    steps_offset: int = 0
+
+    @classmethod
+    def from_dict(cls, d: Dict) -> "PNDMConfig":
+        names = {f.name for f in fields(cls)}
+        return cls(**{k: v for k, v in d.items() if k in names})
+
+
+class PNDMScheduler(_MultistepRows):
+    """PNDM with ``skip_prk_steps`` (= PLMS, the stock scheduler of the Stable Diffusion family) as coefficient rows.
+
+    The linear multistep part of Liu et al., "Pseudo Numerical Methods for Diffusion Models on Manifolds": the noise estimate that
+    enters the transfer formula is an Adams-Bashforth combination of up to four model outputs,
+        1: e0;   2: (3 e0 - e1) / 2;   3: (23 e0 - 16 e1 + 5 e2) / 12;   4+: (55 e0 - 59 e1 + 37 e2 - 9 e3) / 24,
+    with one warm-up twist in diffusers 0.33.1's ``step_plms``: the scheduler object's SECOND call does not advance -- it re-does the
+    first step from the stored sample with the average of the two outputs (improved Euler), and its output does not enter the history.
+    ``set_timesteps`` repeats the second timestep for that purpose, so the table has n + 1 entries.  The reference makes fresh scheduler
+    copies per ``sliding_iterative_denoise`` call and indexes the table with its own per-latent indices (pipeline_diffuman4d.py:265-271,
+    413-422, 500-501): every latent therefore spends the second step of EVERY call on the repetition, wherever its index stands, and the
+    object's counter -- not the timestep value -- decides.  Reproduced as planned rows of the general multistep kernel
+    (dm4d_cfg_multistep_step_*: k11 = weight of the third stored output, k12 = keep / shift the history); stored tensors:
+    s1, s2, s3 = the last three model outputs, s3 doubling as the stored sample between a call's first and second step.
+    oracle/multistep.py::PNDMScheduler is the stateful form the tests compare against (unpinned like every diffusers internal)."""
+    state_slots = 3
+
+    def __init__(self, config: PNDMConfig = PNDMConfig()):
+        self.config = c = config
+        if not c.skip_prk_steps:
+            raise NotImplementedError("PNDMScheduler: skip_prk_steps=false runs four Runge-Kutta model evaluations per step for the first "
+                                      "three steps, which the reference's one-evaluation-per-step loop (pipeline_diffuman4d.py:398-422) cannot "
+                                      "drive either; the Stable Diffusion family ships skip_prk_steps=true")
+        if c.trained_betas is not None or c.prediction_type not in ("epsilon", "v_prediction"):
+            raise NotImplementedError(f"PNDMScheduler: trained_betas / prediction_type {c.prediction_type!r} are not implemented")
+        self.alphas_cumprod = _alphas_cumprod(c)
+        self.final_alpha_cumprod = np.float32(1.0) if c.set_alpha_to_one else self.alphas_cumprod[0]
+        self.num_inference_steps = self.timesteps = None
+
+    def set_timesteps(self, num_inference_steps: int) -> np.ndarray:
+        c, n = self.config, num_inference_steps
+        last = c.num_train_timesteps
+        if n > last:
+            raise ValueError("num_inference_steps > num_train_timesteps")
+        if c.timestep_spacing == "linspace":
+            base = np.linspace(0, last - 1, n).round().astype(np.int64)
+        elif c.timestep_spacing == "leading":
+            base = (np.arange(0, n) * (last // n)).round().astype(np.int64) + c.steps_offset
+        elif c.timestep_spacing == "trailing":
+            base = np.round(np.arange(last, 0, -last / n))[::-1].astype(np.int64) - 1
+        else:
+            raise NotImplementedError(f"timestep_spacing {c.timestep_spacing}")
+        # the second step of the schedule is repeated: n + 1 entries (the reference's indices stop at n - 1: its last latents end one
+        # transfer short of the clean image, as they do under the reference)
+        self.timesteps = np.concatenate([base[:-1], base[-2:-1], base[-1:]])[::-1].copy().astype(np.int64)
+        self.num_inference_steps = n
+        return self.timesteps
+
+    def step_rows(self, step_index: np.ndarray, n_prev: np.ndarray) -> np.ndarray:
+        """[..., 16] fp32 rows for latents whose table index is `step_index` and that have taken `n_prev` steps in this call."""
+        c, n = self.config, self.num_inference_steps
+        idx = np.asarray(step_index, dtype=np.int64)
+        cnt = np.asarray(n_prev, dtype=np.int64)
+        ratio = c.num_train_timesteps // n
+        t_given = self.timesteps[np.clip(idx, 0, len(self.timesteps) - 1)]
+        redo = cnt == 1                                    # the object's second call: from t + ratio back to t, on the stored sample
+        t = np.where(redo, t_given + ratio, t_given)
+        prev = np.where(redo, t_given, t_given - ratio)
+        ac = self.alphas_cumprod.astype(np.float64)
+        a_t = ac[np.clip(t, 0, len(ac) - 1)]
+        a_p = np.where(prev >= 0, ac[np.clip(prev, 0, len(ac) - 1)], np.float64(self.final_alpha_cumprod))
+        b_t, b_p = 1.0 - a_t, 1.0 - a_p
+        sample_coeff = np.sqrt(a_p / a_t)
+        g = (a_p - a_t) / (a_t * np.sqrt(b_p) + np.sqrt(a_t * b_t * a_p))     # x' = sample_coeff xs - g eps
+        if c.prediction_type == "v_prediction":                              # eps = sqrt(a_t) M + sqrt(b_t) xs
+            k_x, k_m = sample_coeff - g * np.sqrt(b_t), -g * np.sqrt(a_t)
+        else:
+            k_x, k_m = sample_coeff, -g
+        # Adams-Bashforth weights on (this output, s1, s2, s3) by the number of outputs in the history AFTER this step's append:
+        # cnt 0 -> 1 (plain);  cnt 1 -> the repetition: (m + s1) / 2, nothing appended;  cnt 2 -> 2;  cnt 3 -> 3;  cnt >= 4 -> 4
+        w = np.zeros(idx.shape + (4,), dtype=np.float64)
+        w[cnt == 0] = (1.0, 0.0, 0.0, 0.0)
+        w[cnt == 1] = (0.5, 0.5, 0.0, 0.0)
+        w[cnt == 2] = (1.5, -0.5, 0.0, 0.0)
+        w[cnt == 3] = (23.0 / 12.0, -16.0 / 12.0, 5.0 / 12.0, 0.0)
+        w[cnt >= 4] = (55.0 / 24.0, -59.0 / 24.0, 37.0 / 24.0, -9.0 / 24.0)
+        rows = np.zeros(idx.shape + (self.ROW,), dtype=np.float64)
+        rows[..., 1] = 1.0                                  # conv = the raw model output (what the history stores)
+        rows[..., 2] = np.where(redo, 0.0, 1.0)             # xc = x ...
+        rows[..., 3] = np.where(redo, 1.0, 0.0)             # ... or the stored sample (s3 after a call's first step)
+        rows[..., 7] = k_x
+        rows[..., 8] = k_m * w[..., 0]
+        rows[..., 9] = k_m * w[..., 1]
+        rows[..., 10] = k_m * w[..., 2]
+        rows[..., 11] = k_m * w[..., 3]
+        # stored tensors: first step (s1, s2, s3) <- (m, -, x);  repetition: kept;  afterwards a history shift.  After the repetition
+        # s1 still holds the first output, so the second-order weights above read the right tensor
+        rows[..., 12] = np.where(cnt == 0, 0.0, np.where(redo, 1.0, 2.0))
+        return rows.astype(np.float32)
+
+
 def load_scheduler(path):
     """`scheduler/scheduler_config.json` of a diffusers checkpoint -> the scheduler object of this package."""
     cfg = json.loads((Path(path) / "scheduler_config.json").read_text())
@@ -549,9 +661,10 @@ def load_scheduler(path):
         return UniPCMultistepScheduler(UniPCConfig.from_dict(cfg))
     if name == "DEISMultistepScheduler":
         return DEISMultistepScheduler(DEISConfig.from_dict(cfg))
+    if name == "PNDMScheduler":
+        return PNDMScheduler(PNDMConfig.from_dict(cfg))
     raise NotImplementedError(
-        f"scheduler {name}: DDIMScheduler, DPMSolverMultistepScheduler (dpmsolver++), UniPCMultistepScheduler and DEISMultistepScheduler "
-        f"are implemented.  The reference's loop "
+        f"scheduler {name}: DDIMScheduler, PNDMScheduler (skip_prk_steps), DPMSolverMultistepScheduler (dpmsolver++), UniPCMultistepScheduler "
+        f"and DEISMultistepScheduler are implemented.  The reference's loop "
         f"passes a vector of per-frame timesteps to scale_model_input (pipeline_diffuman4d.py:376), so Euler / Heun / LMS cannot "
-        f"be what a working checkpoint names; DDPM and the ancestral / SDE samplers draw noise from the reference's RNG stream; "
-        f"PNDM evaluates the model twice on its first step (SURVEY.md D7)")
+        f"be what a working checkpoint names; DDPM and the ancestral / SDE samplers draw noise from the reference's RNG stream")

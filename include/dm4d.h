@@ -191,8 +191,10 @@ int dm4d_cfg_linear_step_bf16(void* stream, void* latents, void* x0_prev, const 
 /* CFG combine + per-latent GENERAL linear multistep step with up to three stored tensors per latent: UniPC (with its corrector) and DEIS,
  * where the reference keeps one stateful scheduler object per latent (pipeline_diffuman4d.py:265-271, 420, 500-501).  coef [F,16] fp32 rows
  * (k0..k10, host/scheduler.py::step_rows):   m = u + s (c - u);   conv = k0 x + k1 m;   xc = k2 x + k3 s3 + k4 s1 + k5 s2 + k6 conv;
- * x <- k7 xc + k8 conv + k9 s1 + k10 s2;   s3 <- xc, s2 <- s1, s1 <- conv   for non-cond rows.  s1 / s2 / s3: same shape and indexing as
- * latents, ZERO at the start of a sliding_iterative_denoise call (s2, s3 may be NULL).                                                   */
+ * x <- k7 xc + k8 conv + k9 s1 + k10 s2 + k11 s3;   s3 <- xc, s2 <- s1, s1 <- conv   for non-cond rows.  s1 / s2 / s3: same shape and
+ * indexing as latents, ZERO at the start of a sliding_iterative_denoise call (s2, s3 may be NULL).  k12 selects what the stored tensors
+ * become: 0 as written, 1 kept unchanged, 2 shifted as a history (s3 <- s2, s2 <- s1, s1 <- conv): PNDM's linear multistep form (PLMS),
+ * whose repeated second step re-does the first from the stored sample (host/scheduler.py::PNDMScheduler).                                 */
 int dm4d_cfg_multistep_step_bf16(void* stream, void* latents, void* s1, void* s2, void* s3, const void* noise_pred, int64_t ldn,
                                  const float* coef, const int32_t* is_cond, const int32_t* frame_idx, int F, int HW, int use_cfg,
                                  float guidance_scale);

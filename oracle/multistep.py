@@ -262,3 +262,88 @@ class DEISMultistepScheduler(_Base):
             self.lower_order_nums += 1
         self._step_index += 1
         return prev.to(model_output.dtype)
+
+
+# ---- PNDM with skip_prk_steps (PLMS): diffusers 0.33.1 ``PNDMScheduler.step_plms`` / ``_get_prev_sample`` / ``set_timesteps`` -------------
+@dataclass
+class PNDMConfig:
+    num_train_timesteps: int = 1000
+    beta_start: float = 0.0001
+    beta_end: float = 0.02
+    beta_schedule: str = "linear"
+    skip_prk_steps: bool = True
+    set_alpha_to_one: bool = False
+    prediction_type: str = "epsilon"
+    timestep_spacing: str = "leading"
+    steps_offset: int = 0
+
+
+class PNDMScheduler:
+    """Stateful PLMS as the reference's per-latent copies run it: a counter, the last four model outputs, the stored first sample.
+    The object's second ``step`` re-does the first transfer with the averaged output (``counter == 1``); which timestep VALUE it is
+    handed does not matter to that decision (the reference hands it whatever its own index table says)."""
+    init_noise_sigma = 1.0
+
+    def __init__(self, cfg: PNDMConfig = PNDMConfig()):
+        assert cfg.skip_prk_steps, "the Runge-Kutta warm-up needs four model evaluations per step"
+        self.cfg = cfg
+        self.alphas_cumprod = torch.cumprod(1.0 - _betas(cfg), dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if cfg.set_alpha_to_one else self.alphas_cumprod[0]
+        self.timesteps = None
+        self.ets: List[torch.Tensor] = []
+        self.counter = 0
+        self.cur_sample = None
+
+    def set_timesteps(self, n):
+        c, last = self.cfg, self.cfg.num_train_timesteps
+        self.num_inference_steps = n
+        if c.timestep_spacing == "linspace":
+            base = np.linspace(0, last - 1, n).round().astype(np.int64)
+        elif c.timestep_spacing == "leading":
+            base = (np.arange(0, n) * (last // n)).round().astype(np.int64) + c.steps_offset
+        elif c.timestep_spacing == "trailing":
+            base = np.round(np.arange(last, 0, -last / n))[::-1].astype(np.int64) - 1
+        else:
+            raise NotImplementedError(c.timestep_spacing)
+        plms = np.concatenate([base[:-1], base[-2:-1], base[-1:]])[::-1].copy()
+        self.timesteps = torch.from_numpy(plms.astype(np.int64))
+        self.ets, self.counter, self.cur_sample = [], 0, None
+        return self.timesteps
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def _prev_sample(self, sample, timestep, prev_timestep, model_output):
+        a_t = self.alphas_cumprod[timestep]
+        a_p = self.alphas_cumprod[prev_timestep] if prev_timestep >= 0 else self.final_alpha_cumprod
+        b_t, b_p = 1 - a_t, 1 - a_p
+        if self.cfg.prediction_type == "v_prediction":
+            model_output = (a_t**0.5) * model_output + (b_t**0.5) * sample
+        sample_coeff = (a_p / a_t) ** 0.5
+        denom = a_t * b_p ** 0.5 + (a_t * b_t * a_p) ** 0.5
+        return sample_coeff * sample - (a_p - a_t) * model_output / denom
+
+    def step(self, model_output: torch.Tensor, t: int, sample: torch.Tensor) -> torch.Tensor:
+        ratio = self.cfg.num_train_timesteps // self.num_inference_steps
+        timestep, prev_timestep = int(t), int(t) - ratio
+        if self.counter != 1:
+            self.ets = self.ets[-3:]
+            self.ets.append(model_output)
+        else:
+            prev_timestep = timestep
+            timestep = timestep + ratio
+        if len(self.ets) == 1 and self.counter == 0:
+            self.cur_sample = sample
+        elif len(self.ets) == 1 and self.counter == 1:
+            model_output = (model_output + self.ets[-1]) / 2
+            sample = self.cur_sample
+            self.cur_sample = None
+        elif len(self.ets) == 2:
+            model_output = (3 * self.ets[-1] - self.ets[-2]) / 2
+        elif len(self.ets) == 3:
+            model_output = (23 * self.ets[-1] - 16 * self.ets[-2] + 5 * self.ets[-3]) / 12
+        else:
+            model_output = (1 / 24) * (55 * self.ets[-1] - 59 * self.ets[-2] + 37 * self.ets[-3] - 9 * self.ets[-4])
+        out = self._prev_sample(sample, timestep, prev_timestep, model_output)
+        self.counter += 1
+        return out

@@ -262,21 +262,23 @@ def cfg_multistep_step(latents, states, noise_pred, coef, is_cond, use_cfg, guid
     Fn = is_cond.shape[0]
     npd = noise_pred.double()[..., :4]
     m = npd[:Fn] + guidance_scale * (npd[Fn:] - npd[:Fn]) if use_cfg else npd
-    k = [coef[:, i].double()[:, None, None] for i in range(11)]
+    k = [coef[:, i].double()[:, None, None] for i in range(13)]
     z = torch.zeros_like(latents[rows].double())
     x = latents[rows].double()
     s1, s2, s3 = (states[j][rows].double() if j < len(states) else z for j in range(3))
     conv = k[0] * x + k[1] * m
     xc = k[2] * x + k[3] * s3 + k[4] * s1 + k[5] * s2 + k[6] * conv
-    xn = k[7] * xc + k[8] * conv + k[9] * s1 + k[10] * s2
+    xn = k[7] * xc + k[8] * conv + k[9] * s1 + k[10] * s2 + k[11] * s3
     keep = ~is_cond.bool()
     dt = latents.dtype
     latents[rows[keep]] = xn.to(dt)[keep]
+    mode = coef[:, 12].long()  # 0: (conv, s1, xc);  1: stored tensors kept;  2: shifted (conv, s1, s2)
+    upd = keep & (mode != 1)
     if len(states) >= 3:
-        states[2][rows[keep]] = xc.to(dt)[keep]
+        states[2][rows[upd]] = torch.where((mode == 2)[:, None, None], s2, xc).to(dt)[upd]
     if len(states) >= 2:
-        states[1][rows[keep]] = s1.to(dt)[keep]
-    states[0][rows[keep]] = conv.to(dt)[keep]
+        states[1][rows[upd]] = s1.to(dt)[upd]
+    states[0][rows[upd]] = conv.to(dt)[upd]
     return latents
 
 

@@ -188,11 +188,26 @@ MULTISTEP_CASES = {
                                                beta_schedule="scaled_linear", beta_start=0.00085, beta_end=0.012),
                                     kw=dict(window_size=4, sliding_stride=1, sliding_shift=0, bidirectional=False, num_denoising_steps=1,
                                             alternation_rounds=3, guidance_scale=2.0)),
+    # PNDM with skip_prk_steps (PLMS), the Stable Diffusion family's stock scheduler_config.json: 8 steps per latent in the call = first
+    # step, the repeated second step, second / third / fourth-order Adams-Bashforth updates (round 6)
+    "pndm_spatial_bidir": dict(kind="pndm", domain="spatial", n=8, inputs=[1, 5],
+                               sched=dict(prediction_type="epsilon", skip_prk_steps=True, timestep_spacing="leading", steps_offset=1,
+                                          set_alpha_to_one=False, beta_schedule="scaled_linear", beta_start=0.00085, beta_end=0.012),
+                               kw=dict(window_size=4, sliding_stride=2, sliding_shift=0, bidirectional=True, num_denoising_steps=2,
+                                       alternation_rounds=1, guidance_scale=2.0)),
+    # ... v-prediction, a second-round call: the latents come back at step index 4 and every object starts its history again
+    "pndm_temporal_v_round2": dict(kind="pndm", domain="temporal", n=8, inputs=[0, 1, 2, 3], start_idx=4,
+                                   sched=dict(prediction_type="v_prediction", skip_prk_steps=True, timestep_spacing="leading", steps_offset=1,
+                                              set_alpha_to_one=False, beta_schedule="scaled_linear", beta_start=0.00085, beta_end=0.012),
+                                   kw=dict(window_size=4, sliding_stride=1, sliding_shift=0, bidirectional=False, num_denoising_steps=1,
+                                           alternation_rounds=3, guidance_scale=2.0)),
 }
 
 
 def oracle_multistep(kind, sched):
     from oracle import multistep as ms
+    if kind == "pndm":
+        return ms.PNDMScheduler(ms.PNDMConfig(**sched))
     return ms.UniPCMultistepScheduler(ms.UniPCConfig(**sched)) if kind == "unipc" else ms.DEISMultistepScheduler(ms.DEISConfig(**sched))
 
 
@@ -200,8 +215,10 @@ def golden_pipeline_multistep():
     """The reference's own pipeline with STATEFUL UniPC / DEIS scheduler objects (oracle/multistep.py behind the diffusers API), one deep
     copy per latent made afresh per call (pipeline_diffuman4d.py:265-271, 500-501, 535): pins what the product's planned 16-float rows
     assume about the reference's control flow (which steps a latent has taken in a call, where the corrector applies)."""
-    out = {}
+    out = torch.load(OUT / "pipeline_multistep.pt") if (OUT / "pipeline_multistep.pt").exists() and "--all" not in sys.argv else {}
     for name, c in MULTISTEP_CASES.items():
+        if name in out:  # cases of earlier rounds stay as committed (`--all` regenerates every case)
+            continue
         cfg_u, ou = mc.make_unet(11)
         cfg_v, ov = mc.make_vae(12)
         pipe = RefPipeline(vae=refshim.AutoencoderKL(ov), unet=ref_unet_from(cfg_u, ou),
@@ -306,7 +323,7 @@ def golden_sampler():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    only = sys.argv[1:]  # e.g. `make_golden.py pose` regenerates one fixture file
+    only = [a for a in sys.argv[1:] if not a.startswith("--")]  # e.g. `make_golden.py pose` regenerates one fixture file
     for name, fn in (("unet", golden_unet), ("pipeline", golden_pipeline), ("sampler", golden_sampler),
                      ("pose", golden_pose), ("dpm", golden_pipeline_dpm), ("multistep", golden_pipeline_multistep)):
         if not only or name in only:

@@ -741,14 +741,17 @@ def _golden_setup(name):
     """(fixture, host scheduler, oracle scheduler factory) of one golden-pipeline case."""
     gdir = Path(__file__).resolve().parent / "golden"
     dpm = name.startswith("dpm_")  # fixture of the reference pipeline run with one stateful DPM-Solver++ object per latent
-    multistep = name.startswith(("unipc", "deis"))  # ... with one stateful UniPC / DEIS object per latent (make_golden.py multistep)
+    multistep = name.startswith(("unipc", "deis", "pndm"))  # ... with one stateful UniPC / DEIS / PNDM object per latent (make_golden.py multistep)
     if multistep:
         from diffuman4d_amd.host import scheduler as hs
         from oracle import multistep as ms
         g = torch.load(gdir / "pipeline_multistep.pt")[name]
         sc, kind = g["case"]["sched"], g["case"]["kind"]
-        host_sched = (hs.UniPCMultistepScheduler(hs.UniPCConfig.from_dict(sc)) if kind == "unipc" else hs.DEISMultistepScheduler(hs.DEISConfig.from_dict(sc)))
-        oracle_sched = (lambda: ms.UniPCMultistepScheduler(ms.UniPCConfig(**sc))) if kind == "unipc" else (lambda: ms.DEISMultistepScheduler(ms.DEISConfig(**sc)))
+        if kind == "pndm":
+            host_sched, oracle_sched = hs.PNDMScheduler(hs.PNDMConfig.from_dict(sc)), (lambda: ms.PNDMScheduler(ms.PNDMConfig(**sc)))
+        else:
+            host_sched = (hs.UniPCMultistepScheduler(hs.UniPCConfig.from_dict(sc)) if kind == "unipc" else hs.DEISMultistepScheduler(hs.DEISConfig.from_dict(sc)))
+            oracle_sched = (lambda: ms.UniPCMultistepScheduler(ms.UniPCConfig(**sc))) if kind == "unipc" else (lambda: ms.DEISMultistepScheduler(ms.DEISConfig(**sc)))
     elif dpm:
         from diffuman4d_amd.host.scheduler import DPMSolverConfig as HC, DPMSolverMultistepScheduler as HS
         from oracle.dpmsolver import DPMSolverConfig as OC_, DPMSolverMultistepScheduler as OS_
@@ -1057,6 +1060,8 @@ CASES = {
     "golden_unipc_temporal_v_bh1_round2": (case_golden_pipeline, dict(name="unipc_temporal_v_bh1_round2")),
     "golden_deis3_spatial_bidir": (case_golden_pipeline, dict(name="deis3_spatial_bidir")),
     "golden_deis2_temporal_v_round2": (case_golden_pipeline, dict(name="deis2_temporal_v_round2")),
+    "golden_pndm_spatial_bidir": (case_golden_pipeline, dict(name="pndm_spatial_bidir")),
+    "golden_pndm_temporal_v_round2": (case_golden_pipeline, dict(name="pndm_temporal_v_round2")),
     # the judged configuration (BASELINE.json configs[1..2]): SD-2.1 geometry at 72x40, vs tests/golden/sd21_72x40.pt
     "unet_sd21_72x40_f16": (case_unet_sd21, dict(name="unet_f16_spatial")),
     "unet_sd21_72x40_f24": (case_unet_sd21, dict(name="unet_f24_temporal")),
@@ -1083,6 +1088,8 @@ CASES.update({
     "par_golden_unipc_temporal_v_bh1_round2": (case_golden_pipeline, dict(name="unipc_temporal_v_bh1_round2", **PAR)),
     "par_golden_unipc_spatial_bidir": (case_golden_pipeline, dict(name="unipc_spatial_bidir", **PAR)),
     "par_golden_deis3_spatial_bidir": (case_golden_pipeline, dict(name="deis3_spatial_bidir", **PAR)),
+    "par_golden_pndm_spatial_bidir": (case_golden_pipeline, dict(name="pndm_spatial_bidir", **PAR)),
+    "par_golden_pndm_temporal_v_round2": (case_golden_pipeline, dict(name="pndm_temporal_v_round2", **PAR)),
     # ... and on the judged geometry, against the committed fp32 fixtures
     "par_unet_sd21_72x40_f16": (case_unet_sd21, dict(name="unet_f16_spatial", **PAR)),
     "par_vae_sd_576x320": (case_vae_sd, dict(**PAR)),
@@ -1115,6 +1122,8 @@ CASES.update({
     "fp16_golden_dpm_temporal_v_heun_round2": (case_golden_pipeline, dict(name="dpm_temporal_v_heun_round2", **FP16)),
     "fp16_golden_unipc_temporal_v_bh1_round2": (case_golden_pipeline, dict(name="unipc_temporal_v_bh1_round2", **FP16)),
     "fp16_golden_deis3_spatial_bidir": (case_golden_pipeline, dict(name="deis3_spatial_bidir", **FP16)),
+    "fp16_golden_pndm_spatial_bidir": (case_golden_pipeline, dict(name="pndm_spatial_bidir", **FP16)),
+    "fp16_golden_pndm_temporal_v_round2": (case_golden_pipeline, dict(name="pndm_temporal_v_round2", **FP16)),
     "fp16_unet_sd21_72x40_f16": (case_unet_sd21, dict(name="unet_f16_spatial", **FP16)),
     "fp16_unet_sd21_72x40_f24": (case_unet_sd21, dict(name="unet_f24_temporal", **FP16)),
     "fp16_vae_sd_576x320": (case_vae_sd, dict(**FP16)),

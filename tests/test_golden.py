@@ -191,7 +191,8 @@ def test_planned_rows_reproduce_the_reference_pipeline_with_a_stateful_scheduler
 
 
 # ---- UniPC / DEIS: fixture = the REFERENCE's pipeline run with one stateful scheduler object per latent (make_golden.py multistep) ----
-MULTISTEP_CASES = ["unipc_spatial_bidir", "unipc_temporal_v_bh1_round2", "deis3_spatial_bidir", "deis2_temporal_v_round2"]
+MULTISTEP_CASES = ["unipc_spatial_bidir", "unipc_temporal_v_bh1_round2", "deis3_spatial_bidir", "deis2_temporal_v_round2",
+                   "pndm_spatial_bidir", "pndm_temporal_v_round2"]  # PNDM with skip_prk_steps (PLMS): round 6
 
 
 def _multistep_task(name):
@@ -204,11 +205,15 @@ def _multistep_task(name):
 
 def _oracle_multistep(c):
     from oracle import multistep as ms
+    if c["kind"] == "pndm":
+        return ms.PNDMScheduler(ms.PNDMConfig(**c["sched"]))
     return ms.UniPCMultistepScheduler(ms.UniPCConfig(**c["sched"])) if c["kind"] == "unipc" else ms.DEISMultistepScheduler(ms.DEISConfig(**c["sched"]))
 
 
 def _host_multistep(c):
     from diffuman4d_amd.host import scheduler as hs
+    if c["kind"] == "pndm":
+        return hs.PNDMScheduler(hs.PNDMConfig.from_dict(c["sched"]))
     return (hs.UniPCMultistepScheduler(hs.UniPCConfig.from_dict(c["sched"])) if c["kind"] == "unipc"
             else hs.DEISMultistepScheduler(hs.DEISConfig.from_dict(c["sched"])))
 
@@ -250,8 +255,10 @@ class _PlannedRows16:
         s1, s2, s3 = self.s if self.s is not None else (torch.zeros_like(sample),) * 3
         conv = r[0] * sample + r[1] * model_output
         xc = r[2] * sample + r[3] * s3 + r[4] * s1 + r[5] * s2 + r[6] * conv
-        self.s, self.k = (conv, s1, xc), self.k + 1
-        return r[7] * xc + r[8] * conv + r[9] * s1 + r[10] * s2
+        out = r[7] * xc + r[8] * conv + r[9] * s1 + r[10] * s2 + r[11] * s3
+        self.s = {0: (conv, s1, xc), 1: (s1, s2, s3), 2: (conv, s1, s2)}[int(r[12])]  # k12: as planned / kept / shifted (PLMS)
+        self.k += 1
+        return out
 
 
 @pytest.mark.parametrize("name", MULTISTEP_CASES)

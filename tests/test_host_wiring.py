@@ -32,7 +32,8 @@ def cpu_standin(monkeypatch):
         fake_ops.uninstall()
 
 
-FIXTURES = ["spatial", "temporal_v", "round2_shift", "pose_encoder", "dpm_temporal_v_heun_round2", "unipc_temporal_v_bh1_round2", "deis3_spatial_bidir"]
+FIXTURES = ["spatial", "temporal_v", "round2_shift", "pose_encoder", "dpm_temporal_v_heun_round2", "unipc_temporal_v_bh1_round2", "deis3_spatial_bidir", "pndm_spatial_bidir",
+            "pndm_temporal_v_round2"]
 
 
 @pytest.mark.parametrize("name", FIXTURES)

@@ -56,7 +56,9 @@ def _run_general_rows(host, stateful, n_list=(6, 18, 36)):
                 r = host.step_rows(np.array([i]), np.array([k]))[0].astype(np.float64)
                 conv = r[0] * x + r[1] * m.double()
                 xc = r[2] * x + r[3] * s3 + r[4] * s1 + r[5] * s2 + r[6] * conv
-                x, s3, s2, s1 = r[7] * xc + r[8] * conv + r[9] * s1 + r[10] * s2, xc, s1, conv
+                xn = r[7] * xc + r[8] * conv + r[9] * s1 + r[10] * s2 + r[11] * s3
+                s1, s2, s3 = {0: (conv, s1, xc), 1: (s1, s2, s3), 2: (conv, s1, s2)}[int(r[12])]  # k12: as planned / kept / shifted (PLMS)
+                x = xn
                 xo = oc.step(m, int(to[i]), xo)
                 err = (x - xo.double()).abs().max().item() / max(1.0, xo.abs().max().item())
                 assert err <= 5e-5, (n, start, i, err)
@@ -85,6 +87,25 @@ def test_deis_rows_reproduce_the_stateful_scheduler(order, pred, spacing, lof):
     kw = dict(solver_order=order, prediction_type=pred, timestep_spacing=spacing, lower_order_final=lof, **SD_BETAS)
     torch.manual_seed(0)
     _run_general_rows(DEISMultistepScheduler(DEISConfig(**kw)), OS_(OC_(**kw)))
+
+
+@pytest.mark.parametrize("pred,spacing,off,alpha_one", list(itertools.product(("epsilon", "v_prediction"), ("leading", "linspace", "trailing"), (0, 1),
+                                                                              (False, True))))
+def test_pndm_rows_reproduce_the_stateful_scheduler(pred, spacing, off, alpha_one):
+    """PLMS as planned rows: the first step, the repeated second step on the stored sample (wherever in the table the latent stands when a
+    call starts), Adams-Bashforth orders 2-4 on a shifted history -- against the stateful object the reference deep-copies per latent."""
+    from diffuman4d_amd.host.scheduler import PNDMConfig, PNDMScheduler
+    from oracle.multistep import PNDMConfig as OC_, PNDMScheduler as OS_
+    kw = dict(skip_prk_steps=True, prediction_type=pred, timestep_spacing=spacing, steps_offset=off, set_alpha_to_one=alpha_one, **SD_BETAS)
+    h = PNDMScheduler(PNDMConfig(**kw))
+    assert len(h.set_timesteps(18)) == 19 and h.timesteps[1] == h.timesteps[2]  # the repeated second step of the table
+    _run_general_rows(h, OS_(OC_(**kw)))
+
+
+def test_pndm_without_skip_prk_steps_is_refused():
+    from diffuman4d_amd.host.scheduler import PNDMConfig, PNDMScheduler
+    with pytest.raises(NotImplementedError, match="skip_prk_steps"):
+        PNDMScheduler(PNDMConfig(skip_prk_steps=False))
 
 
 def test_oracle_multistep_schedulers_converge_on_a_solvable_ode():
@@ -146,6 +167,14 @@ def test_factory_dispatch(tmp_path):
     assert isinstance(u, UniPCMultistepScheduler) and u.general_rows and u.state_slots == 3 and u.config.disable_corrector == (0,)
     (tmp_path / "scheduler_config.json").write_text(json.dumps({"_class_name": "DEISMultistepScheduler", "solver_order": 3}))
     assert isinstance(load_scheduler(tmp_path), DEISMultistepScheduler)
+    from diffuman4d_amd.host.scheduler import PNDMScheduler
+    # the Stable Diffusion family's stock scheduler/scheduler_config.json
+    (tmp_path / "scheduler_config.json").write_text(json.dumps({"_class_name": "PNDMScheduler", "_diffusers_version": "0.8.0", "beta_end": 0.012,
+                                                                "beta_schedule": "scaled_linear", "beta_start": 0.00085, "num_train_timesteps": 1000,
+                                                                "set_alpha_to_one": False, "skip_prk_steps": True, "steps_offset": 1,
+                                                                "trained_betas": None, "clip_sample": False}))
+    pn = load_scheduler(tmp_path)
+    assert isinstance(pn, PNDMScheduler) and pn.general_rows and pn.state_slots == 3 and pn.config.steps_offset == 1
     for bad in ({"_class_name": "UniPCMultistepScheduler", "solver_order": 3}, {"_class_name": "UniPCMultistepScheduler", "predict_x0": False},
                 {"_class_name": "DEISMultistepScheduler", "use_karras_sigmas": True}):
         (tmp_path / "scheduler_config.json").write_text(json.dumps(bad))

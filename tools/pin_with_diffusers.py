@@ -13,7 +13,7 @@ feeds both the same seeded input and requires the outputs to agree to fp32 round
 Blocks: ResnetBlock2D (with / without shortcut, output_scale_factor), Downsample2D, Upsample2D, Timesteps + TimestepEmbedding,
 Attention (AttnProcessor2_0), FeedForward(GEGLU), BasicTransformerBlock wiring (norm1 / attn1 / norm3 / ff as the reference's
 MultiviewTransformerBlock inherits it), AutoencoderKL (moments, decode), DDIMScheduler, DPMSolverMultistepScheduler,
-UniPCMultistepScheduler and DEISMultistepScheduler steps (oracle/ddim.py, dpmsolver.py, multistep.py).
+UniPCMultistepScheduler, DEISMultistepScheduler and PNDMScheduler (skip_prk_steps) steps (oracle/ddim.py, dpmsolver.py, multistep.py).
 
     python tools/pin_with_diffusers.py --self-test    # no diffusers needed: the scheduler comparison loop run oracle-against-oracle, so that
                                                       # the code of the check itself is exercised where the package is absent
@@ -172,9 +172,9 @@ def check_schedulers():
 
 def _walk(make_o, make_u, n=12):
     """Both schedulers over the same n steps from the same start and the same model outputs: worst relative deviation of the sample."""
-    x0, eps = torch.randn(1, 4, 8, 8, generator=_gen(15)), [torch.randn(1, 4, 8, 8, generator=_gen(20 + i)) for i in range(n)]
+    x0, eps = torch.randn(1, 4, 8, 8, generator=_gen(15)), [torch.randn(1, 4, 8, 8, generator=_gen(20 + i)) for i in range(n + 1)]
     o, u = make_o(), make_u()
-    ts = o.set_timesteps(n)
+    ts = o.set_timesteps(n)  # n entries; n + 1 for PNDM (its second step is repeated)
     u.set_timesteps(n)
     assert [int(t) for t in u.timesteps] == [int(t) for t in ts], "timestep tables differ"
     xo = xu = x0
@@ -194,6 +194,9 @@ MULTISTEP_GRID = (
     ("deis", dict()),
     ("deis", dict(solver_order=3, prediction_type="v_prediction", timestep_spacing="trailing")),
     ("deis", dict(solver_order=1, timestep_spacing="leading", steps_offset=1)),
+    # PNDM with skip_prk_steps (PLMS): the table repeats its second step, the object's second call re-does the first transfer (round 6)
+    ("pndm", dict(skip_prk_steps=True, beta_schedule="scaled_linear", beta_start=0.00085, beta_end=0.012, steps_offset=1)),
+    ("pndm", dict(skip_prk_steps=True, prediction_type="v_prediction", timestep_spacing="trailing", set_alpha_to_one=True)),
 )
 
 
@@ -203,12 +206,14 @@ def check_multistep(upstream=True):
     from dataclasses import asdict
     from oracle import multistep as ms
     if upstream:
-        from diffusers import DEISMultistepScheduler as UDe, UniPCMultistepScheduler as UUn
+        from diffusers import DEISMultistepScheduler as UDe, PNDMScheduler as UPn, UniPCMultistepScheduler as UUn
     worst = 0.0
+    cfgs = {"unipc": ms.UniPCConfig, "deis": ms.DEISConfig, "pndm": ms.PNDMConfig}
+    ours = {"unipc": ms.UniPCMultistepScheduler, "deis": ms.DEISMultistepScheduler, "pndm": ms.PNDMScheduler}
     for kind, kw in MULTISTEP_GRID:
-        cfg = (ms.UniPCConfig if kind == "unipc" else ms.DEISConfig)(**kw)
-        make_o = (lambda c=cfg, k=kind: (ms.UniPCMultistepScheduler if k == "unipc" else ms.DEISMultistepScheduler)(c))
-        make_u = (lambda c=cfg, k=kind: (UUn if k == "unipc" else UDe)(**asdict(c))) if upstream else make_o
+        cfg = cfgs[kind](**kw)
+        make_o = (lambda c=cfg, k=kind: ours[k](c))
+        make_u = (lambda c=cfg, k=kind: {"unipc": UUn, "deis": UDe, "pndm": UPn}[k](**asdict(c))) if upstream else make_o
         worst = max(worst, _walk(make_o, make_u))
     return worst
 
@@ -216,7 +221,7 @@ def check_multistep(upstream=True):
 CHECKS = [("ResnetBlock2D", check_resnet), ("Downsample2D / Upsample2D", check_samplers),
           ("Timesteps + TimestepEmbedding", check_time_embedding), ("Attention / FeedForward / BasicTransformerBlock", check_attention_ff_block),
           ("AutoencoderKL", check_vae), ("DDIMScheduler / DPMSolverMultistepScheduler", check_schedulers),
-          ("UniPCMultistepScheduler / DEISMultistepScheduler", check_multistep)]
+          ("UniPCMultistepScheduler / DEISMultistepScheduler / PNDMScheduler", check_multistep)]
 
 
 def main() -> int:
