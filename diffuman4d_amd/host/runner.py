@@ -258,7 +258,8 @@ class DistributedSamplingRunner:
       * ``frame-shard``: every task runs on ALL ranks together -- each window call split over them by frames, K/V all-gathered inside
         the 3-D attention layers (parallel.FrameShard; BASELINE.json configs[3]).  The grid stays replicated, the
         exchange has nothing to send.  The latency mode: one task finishes world times sooner, throughput is lower.
-      * ``hybrid``: full waves of a round run task-parallel; when the LAST wave would leave at least half of the ranks idle
+      * ``hybrid``: full waves of a round run task-parallel (a sub-group's tail starts when ITS ranks are done with their main
+        waves: the sub-groups exist before the first round); when the LAST wave would leave at least half of the ranks idle
         (r = tasks mod world, 0 < r <= world / 2 -- the 44-camera temporal round on 8 GPUs: 5 waves + 4 tasks) those r tasks run
         frame-sharded on r sub-groups of P = world / r ranks (P a power of two dividing the window's frame count) instead of on r
         single ranks beside world - r idle ones.  Also what a round with fewer tasks than ranks gets.
@@ -515,16 +516,24 @@ class DistributedSamplingRunner:
         s = self.sampler
         import time
         pool = _make_writer_pool(s, self.writer_processes)
+        # The sub-groups of every tail width the job will need are made HERE, by all ranks together (new_group is collective over the
+        # default group): inside a round nothing then makes a rank wait for ranks outside its own sub-group, so the tail of a sub-group
+        # starts as soon as ITS members have finished their main waves -- not when the slowest rank of the world has
+        for width in sorted({self._split_round(ri)[2] for ri in range(len(s.all_tasks)) if self._split_round(ri)[1]}):
+            self._subgroup(self._group_ranks(width, 0))
+        self.timeline: List[Tuple[int, str, float]] = []  # (round, "main_end" | "tail_start" | "tail_end", time.time()) of this rank
         try:
             for ri in range(len(s.all_tasks)):
                 mine = self.tasks_of(ri, self.rank)
                 t0 = time.perf_counter()
                 run_round_pipelined(s, mine, 0, self.prefetch_depth, self.writers, self.gpu_streams, pool, self.task_batch)
                 dt = time.perf_counter() - t0
+                self.timeline.append((ri, "main_end", time.time()))
                 for task, ranks in self.tail_of(ri):  # the round's tail: tasks a group of ranks runs together, frame-sharded
-                    grp = self._subgroup(ranks)       # (collective over all ranks the first time a width is used)
-                    if self.rank in ranks:
-                        self._run_sharded(task, ranks, grp)
+                    if self.rank in ranks:            # (the group's own collectives are what its members meet at)
+                        self.timeline.append((ri, "tail_start", time.time()))
+                        self._run_sharded(task, ranks, self._subgroup(ranks))
+                        self.timeline.append((ri, "tail_end", time.time()))
                 self._plan_next_round(ri, dt, len(mine))  # before the exchange: it ships what the NEXT deal reads
                 self.dist.barrier(self.group)
                 self.exchange(ri)

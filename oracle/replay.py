@@ -158,9 +158,12 @@ def replay_layernorm(inp: Dict, out: torch.Tensor) -> float:
 
 def replay_attention(inp: Dict, out: torch.Tensor, first_tile: int = 64) -> float:
     """csrc/attention.hip: S in fp32, P = exp2(S' - m) with m the row maximum over the FIRST 64 keys (S' = S scale log2 e, already in
-    the Q rows when q_scaled), row sums of the unrounded P, P rounded to bf16 for P V, O / l rounded."""
+    the Q rows when q_scaled), P rounded to bf16 for P V, O / l rounded.  Row sums: of the unrounded P in attn_kernel; of the ROUNDED P in
+    the hand-placed attn64_kernel (the sums run on the matrix pipe against the packed probabilities), which takes the launches with a
+    pre-scaled Q and a whole number (>= 3) of 64-key tiles (attention_launch)."""
     batch, heads, seq, kv = inp["batch"], inp["heads"], inp["seq"], inp["kv_seq"]
     c = 1.0 if inp["q_scaled"] else (0.125 if inp["scale"] is None else inp["scale"]) * 1.4426950408889634
+    hand_placed = bool(inp["q_scaled"]) and kv % 64 == 0 and kv >= 192
     qs = torch.linspace(0, seq - 1, min(seq, MAX_QUERIES)).long().unique()
     bs = range(batch) if batch <= 4 else (0, batch - 1)  # 2-D attention folds nothing: 32 - 48 sequences, two of them are recomputed
     want, have = [], []
@@ -172,7 +175,8 @@ def replay_attention(inp: Dict, out: torch.Tensor, first_tile: int = 64) -> floa
             qq, kk, vv = q[:, cols].double(), k[:, cols].double(), v[:, cols].double()
             s = (qq @ kk.t()) * c
             p = torch.exp2(s - s[:, :first_tile].amax(dim=-1, keepdim=True))
-            want.append((p.to(BF).double() @ vv) / p.sum(dim=-1, keepdim=True))
+            pr = p.to(BF).double()
+            want.append((pr @ vv) / (pr if hand_placed else p).sum(dim=-1, keepdim=True))
             have.append(got[:, cols])
     want, have = torch.cat(want), torch.cat(have)
     return rel_l2(have, _r(want, have))

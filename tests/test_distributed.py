@@ -57,7 +57,7 @@ def _worker(rank, world, port, outdir, kw=None, slow_rank=None, slow_delay=0.18,
         runner.inference()
         last = len(s.all_tasks) - 1
         owned = set(runner._owned_after(last, rank))
-        torch.save({"state": grid_state(s, owned), "n_calls": len(s.pipelines[0].calls),
+        torch.save({"state": grid_state(s, owned), "n_calls": len(s.pipelines[0].calls), "timeline": list(getattr(runner, "timeline", [])),
                     "sharded": [(c["domain"], c["sharded"], c["noise_seed"]) for c in s.pipelines[0].calls if c.get("sharded")],
                     "stacks": list(getattr(s.pipelines[0], "stacks", [])),
                     "tails": [[(t["domain_label"], ranks) for t, ranks in runner.tail_of(ri)] for ri in range(len(s.all_tasks))],
@@ -240,6 +240,35 @@ def test_hybrid_mode_shards_the_tail_wave_and_matches_single_process():
         seeds = [blobs[r]["sharded"] for r in grp]
         assert seeds[0] == seeds[1] and len(seeds[0]) == 1 and seeds[0][0][:2] == ("temporal", 2)
     assert blobs[0]["sharded"] != blobs[2]["sharded"]            # different tasks, different seeds
+
+
+@pytest.mark.timeout(300)
+def test_hybrid_tail_of_a_subgroup_starts_before_the_slowest_rank_of_the_world_is_done():
+    """4 ranks, rank 3 three times slower: in the temporal round (one wave + 2 tail tasks on the sub-groups [0, 1] and [2, 3]) the sub-group
+    [0, 1] runs its frame-sharded tail task while rank 3 is still inside its main wave -- the sub-groups were made before the first
+    round, so nothing in a round makes a rank wait for ranks outside its own sub-group until the round's exchange.  Same grid as ever."""
+    kw = KW_HYBRID
+    with tempfile.TemporaryDirectory() as d:
+        port = 29500 + (os.getpid() % 2000) + 27
+        mp.spawn(_worker, args=(4, port, d, kw, 3, 0.6, "hybrid"), nprocs=4, join=True)
+        blobs = [torch.load(f"{d}/rank{r}.pt") for r in range(4)]
+    assert [ranks for _, ranks in blobs[0]["tails"][1]] == [[0, 1], [2, 3]]
+    when = lambda r, ri, what: [t for (i, w, t) in blobs[r]["timeline"] if i == ri and w == what]  # noqa: E731
+    slow_main_end = when(3, 1, "main_end")[0]
+    for r in (0, 1):
+        assert when(r, 1, "tail_start")[0] < slow_main_end, "sub-group [0, 1] waited for the world's slowest rank before its tail"
+        assert when(r, 1, "tail_end")[0] < slow_main_end + 0.6
+    assert when(2, 1, "tail_start")[0] < slow_main_end  # rank 2 is ready early; its tail's first collective is where it meets rank 3
+    ref = make_sampler(kw)
+    for tasks in ref.all_tasks:
+        for t in tasks:
+            ref.execute_one_task(t)
+    merged = {}
+    for b in blobs:
+        merged.update(b["state"])
+    ref_state = grid_state(ref)
+    for cell in {(c, f) for c in ref.target_spa_labels for f in ref.tem_labels}:
+        assert merged[cell][0] == ref_state[cell][0] and torch.equal(merged[cell][1], ref_state[cell][1]), cell
 
 
 @pytest.mark.timeout(300)
