@@ -79,6 +79,21 @@ __device__ __forceinline__ U4 pack8h(const float* f) {
   return v;
 }
 
+// Saturating forms for the HBM-bound kernels that turn UN-NORMALISED fp32 activations into fp16 operands (dm4d_to_f16_f32, the norm
+// kernels' outputs and GroupNorm's raw plane, the parity-file conversions): |x| > 65504 becomes +-65504 instead of +-inf, which the next
+// MFMA would turn into NaN.  One v_med3_f32 per value, free beside the memory traffic there; the GEMM / convolution epilogues and the
+// attention probabilities keep the plain conversion (issue-bound loops; the probabilities have their own range guard).
+__device__ __forceinline__ float sat_h(float x) { return __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f); }
+__device__ __forceinline__ u16 f2h_sat(float f) { return f2h(sat_h(f)); }
+__device__ __forceinline__ U4 pack8h_sat(const float* f) {
+  U4 v;
+  v.x = pack_h2(sat_h(f[0]), sat_h(f[1]));
+  v.y = pack_h2(sat_h(f[2]), sat_h(f[3]));
+  v.z = pack_h2(sat_h(f[4]), sat_h(f[5]));
+  v.w = pack_h2(sat_h(f[6]), sat_h(f[7]));
+  return v;
+}
+
 __device__ __forceinline__ U4 ldg16(const void* p) { return *reinterpret_cast<const U4*>(p); }
 __device__ __forceinline__ void stg16(void* p, const U4& v) { *reinterpret_cast<U4*>(p) = v; }
 

@@ -55,7 +55,7 @@ __global__ void silu_kernel(const u16* X, u16* Y, int64_t n) {
 template <int OUT>
 __device__ __forceinline__ void put_in(u16* row, int c, int cpad, float v) {  // bf16 values survive the float round trip bit for bit
   if constexpr (OUT == 2) {
-    row[c] = f2h(v);
+    row[c] = f2h_sat(v);
   } else {
     const u16 hi = f2bf(v);
     row[c] = hi;

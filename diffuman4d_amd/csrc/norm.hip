@@ -51,7 +51,7 @@ struct NormIO<2> {
     v[4] = r.b[0]; v[5] = r.b[1]; v[6] = r.b[2]; v[7] = r.b[3];
   }
   static __device__ __forceinline__ float ld1(const float* p) { return *p; }
-  static __device__ __forceinline__ void st8(u16* p, const float* v) { stg16(p, pack8h(v)); }
+  static __device__ __forceinline__ void st8(u16* p, const float* v) { stg16(p, pack8h_sat(v)); }
   static __device__ __forceinline__ void par8(const u16* p, float* v) { unpack8h(ldg16(p), v); }
 };
 

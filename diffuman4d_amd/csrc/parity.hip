@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void split_kernel(SplitParams p) {
   x *= p.scale;
   u16* y = p.Y + m * p.ldy + c;
   if (p.pattern == 3) {
-    y[0] = f2h(x);
+    y[0] = f2h_sat(x);
     return;
   }
   u16 hi, lo;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn32_apply_kernel(GN32Params p) {
       float y = (src[(int64_t)px * ld] - mu) * a + bt;
       if (p.silu) y = silu_f(y);
       if constexpr (H16) {
-        dst[(int64_t)px * C] = f2h(y);
+        dst[(int64_t)px * C] = f2h_sat(y);
       } else {
         u16 hi, lo;
         split2(y, hi, lo);
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn32_apply4_kernel(GN32Params p) {
           if (p.silu) y[e] = silu_f(y[e]);
         }
         uint2 ph;
-        ph.x = pack_h2(y[0], y[1]), ph.y = pack_h2(y[2], y[3]);
+        ph.x = pack_h2(sat_h(y[0]), sat_h(y[1])), ph.y = pack_h2(sat_h(y[2]), sat_h(y[3]));
         *reinterpret_cast<uint2*>(dst + (int64_t)px * C) = ph;
         continue;
       }
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void ln32_kernel(const float* X, int64_t ldx, 
   u16* y = Y + (int64_t)row * ldy;
   for (int c = lane; c < C; c += 64) {
     if constexpr (H16) {
-      y[c] = f2h((x[c] - mu) * rs * h2f(gamma[c]) + h2f(beta[c]));
+      y[c] = f2h_sat((x[c] - mu) * rs * h2f(gamma[c]) + h2f(beta[c]));
     } else {
       const float v = (x[c] - mu) * rs * bf2f(gamma[c]) + bf2f(beta[c]);
       u16 hi, lo;

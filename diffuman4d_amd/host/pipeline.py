@@ -344,6 +344,12 @@ class Diffuman4DPipeline:
         return plan, self.prepare_all_latents(pixel_values, plucker_embeds, skeletons, cond_masks, latents, noise, cache_keys, cameras)
 
     def _finish_sweep(self, lat, plan: SweepPlan, decode: str) -> dict:
+        if self.h16 and not bool(torch.isfinite(lat).all()):
+            # fp16 operands stop at 65504: the norm / conversion kernels saturate, the GEMM and convolution epilogues do not, and an inf
+            # operand turns the next product into NaN.  Seeded synthetic weights never get there; a checkpoint whose activations do
+            # must be told so instead of being handed a NaN image (one 0.5 MB reduction per task, next to the decode)
+            raise FloatingPointError("precision 'fp16': the denoised latents are not finite -- an activation left the fp16 range (|x| > 65504) "
+                                     "on its way to a matrix product; run this checkpoint with precision 'fast' (bf16 range) or 'parity'")
         tidx = torch.from_numpy(plan.final_timestep_indices)
         rows = (tidx == plan.num_inference_steps) if decode == "denoised" else (torch.zeros_like(tidx, dtype=torch.bool) if decode == "none" else None)
         images = self.vae.decode_to_images(lat, rows=rows)  # [N,3,H,W] in [0,1]

@@ -220,12 +220,12 @@ class SlidingIterativeSampler:
                                                 **asdict(self.sweep), **self._pipeline_extensions(sample))
         return self._take_result(sample, result, pipe, on_gpu)
 
-    def stackable(self, samples: List[dict]) -> bool:
+    def stackable(self, samples: List[dict], pipe_idx: int = 0) -> bool:
         """Tasks that can share their window calls (pipeline.sliding_iterative_denoise_stack): one domain, the same rows conditioned,
         the same timestep indices, the same tensor shapes -- what the tasks of one alternation round have -- and no frame sharding."""
         if len(samples) < 2 or self.frame_shard is not None or getattr(self, "shard_follower", False):
             return False
-        if not hasattr(self.pipelines[0], "sliding_iterative_denoise_stack"):
+        if not hasattr(self.pipelines[pipe_idx], "sliding_iterative_denoise_stack"):
             return False
         a = samples[0]
         for b in samples[1:]:
@@ -241,7 +241,7 @@ class SlidingIterativeSampler:
         """Extension (runner.task_batch): the samples' tasks through shared window calls; every sample ends up exactly as `denoise`
         leaves it (results are bitwise those of one `denoise` per sample in list order).  Samples that are not `stackable` run
         one by one."""
-        if not self.stackable(samples):
+        if not self.stackable(samples, pipe_idx):
             return [self.denoise(s, pipe_idx=pipe_idx) for s in samples]
         pipe = self.pipelines[pipe_idx]
         on_gpu = [self._wait_for_cells(s, pipe) for s in samples][0]
@@ -299,7 +299,9 @@ class SlidingIterativeSampler:
         with (round 2, frame x) and spatial frame 50021 + c with temporal camera c -- tasks that would then draw identical noise."""
         import hashlib
         key = f"{int(self.noise_base_seed)}/{int(alt)}/{domain}/{domain_label}".encode()
-        return int.from_bytes(hashlib.sha256(key).digest()[:4], "little") & 0x7FFFFFFF
+        # 63 bits of the digest (torch.Generator.manual_seed takes 64-bit seeds): a 48 x 150 job has ~7 000 tasks, for which 31 bits
+        # would leave a ~1 % chance of two tasks sharing a seed
+        return int.from_bytes(hashlib.sha256(key).digest()[:8], "little") & 0x7FFFFFFFFFFFFFFF
 
     def execute_one_task(self, task: dict, pipe_idx: int = 0) -> dict:
         sample = self.denoise(self.load_sample(**task), pipe_idx=pipe_idx)

@@ -351,7 +351,9 @@ int dm4d_to_f16_f32(void* stream, const float* X1, int64_t row_stride1, int64_t 
                     int64_t row_stride2, int C2, void* Y, int64_t ldy, int64_t M, int Cp, int act_silu, float scale);
 
 /* GroupNorm (+SiLU) / LayerNorm / row softmax with fp32 input and ONE fp16 plane out (gamma, beta fp16): Y [B*HW, C1 + C2] /
- *   Y [M, ldy >= C] / P [M, ldp >= Np] (columns N .. Np-1 zero).  GroupNorm statistics in fp64, ws as dm4d_groupnorm_f32_ws_bytes. */
+ *   Y [M, ldy >= C] / P [M, ldp >= Np] (columns N .. Np-1 zero).  GroupNorm statistics: fp32 shifted sums (the fast precision's) on the
+ *   vectorised path (channel counts that are multiples of 8; ws = float[B][chunks][groups][2]), fp64 only in the `_general` fall-back kernels;
+ *   dm4d_groupnorm_f32_ws_bytes is an upper bound for both.  fp16 outputs saturate at +-65504 (they never become inf).              */
 int dm4d_groupnorm_nhwc_f32_f16(void* stream, const float* X1, int C1, const float* X2, int C2, int B, int HW, int groups, float eps,
                                 const void* gamma, const void* beta, void* Y, int apply_silu, void* ws);
 /* ... and the same GroupNorm with a SECOND output Yraw [B*HW, C1 + C2] = fp16 of the un-normalised input (the channel concat of X1 | X2):

@@ -112,7 +112,7 @@ def test_task_noise_seeds_do_not_collide():
     seeds = {s.task_noise_seed(alt, dom, lab) for alt in (1, 2, 3, 4, 5) for dom, labs in
              (("spatial", [f"{f:06d}" for f in range(0, 3000, 7)]), ("temporal", [f"{c:02d}" for c in range(48)])) for lab in labs}
     assert len(seeds) == 5 * (len(range(0, 3000, 7)) + 48)
-    assert all(0 <= v < 2 ** 31 for v in seeds) and s.task_noise_seed(1, "spatial", "000003") == s.task_noise_seed(1, "spatial", "000003")
+    assert all(0 <= v < 2 ** 63 for v in seeds) and any(v >= 2 ** 31 for v in seeds) and s.task_noise_seed(1, "spatial", "000003") == s.task_noise_seed(1, "spatial", "000003")
     load_pipelines_precisions = ("auto", "fast", "parity", "fp16")
     from diffuman4d_amd.host.loader import load_pipelines
     with pytest.raises(ValueError, match="Unsupported precision"):
