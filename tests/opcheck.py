@@ -951,20 +951,24 @@ def case_multistep_step(f32=False, slots=3, seed=0):
     for step in range(2):
         eps = torch.randn(2 * F_, HW, 4, generator=g).to(dt)
         k = (torch.rand(F_, 16, generator=g) - 0.3).float()
+        # k12 = what the stored tensors become (0: conv / s1 / xc; 1: kept; 2: shifted history -- PLMS rows): every mode over the two steps
+        k[:, 12] = torch.tensor([0.0, 1.0, 2.0, 0.0] if step == 0 else [2.0, 0.0, 1.0, 2.0])
         ops.cfg_multistep_step(d_lat, d_st, eps.cuda(), k.cuda(), cond.cuda(), True, 2.0, frame_idx=widx.cuda())
         m = eps[:F_].double() + 2.0 * (eps[F_:].double() - eps[:F_].double())
-        kk = [k[:, j].double()[:, None, None] for j in range(11)]
+        kk = [k[:, j].double()[:, None, None] for j in range(12)]
         xr, s1, s2, s3 = x[rows], st[0][rows], st[1][rows], st[2][rows]
         conv = kk[0] * xr + kk[1] * m
         xc = kk[2] * xr + kk[3] * s3 + kk[4] * s1 + kk[5] * s2 + kk[6] * conv
-        xn = kk[7] * xc + kk[8] * conv + kk[9] * s1 + kk[10] * s2
+        xn = kk[7] * xc + kk[8] * conv + kk[9] * s1 + kk[10] * s2 + kk[11] * s3
         rnd = (lambda t: t.to(dt).double())
         x[rows[keep]] = rnd(xn)[keep]
+        mode = k[:, 12].long()
+        upd = keep & (mode != 1)
         if slots >= 3:
-            st[2][rows[keep]] = rnd(xc)[keep]
+            st[2][rows[upd]] = torch.where((mode == 2)[:, None, None], s2, rnd(xc))[upd]
         if slots >= 2:
-            st[1][rows[keep]] = s1[keep]
-        st[0][rows[keep]] = rnd(conv)[keep]
+            st[1][rows[upd]] = s1[upd]
+        st[0][rows[upd]] = rnd(conv)[upd]
         worst = max(worst, rel_l2(d_lat, x), *(rel_l2(d_st[j], st[j]) for j in range(slots)))
     return worst, 0.0
 
