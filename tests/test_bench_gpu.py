@@ -125,15 +125,15 @@ def test_bench_self_launches_grid_mode_for_two_ranks():
 
 @pytest.mark.gpu
 def test_bench_hybrid_mode_runs_a_frame_sharded_tail_wave():
-    """`bench.py --gpus 4 --mode hybrid` on a 48 x 6 grid: the spatial rounds have 6 tasks = one full wave of 4 (task-parallel) and a
+    """`bench.py --gpus 4 --mode hybrid` on a 48 x 14 grid: the spatial rounds have 14 tasks = three full waves of 4 (task-parallel) and a
     tail wave of 2 <= world / 2, which the product runner (DistributedSamplingRunner(mode="hybrid")) runs frame-sharded on the sub-groups
-    [0, 1] and [2, 3]; the 44 temporal tasks are 11 full waves.  (Frame counts are even under sliding_fast, so two ranks never leave a
-    tail: four is the smallest world that does.)  All ranks share GPU 0 over gloo (testing only): what is checked is that the HIP
+    [0, 1] and [2, 3]; the 44 temporal tasks are 11 full waves.  (Frame counts are even under sliding_fast and at least the window, 12: two ranks never
+    leave a tail, and 14 frames on four ranks is the smallest grid that does.)  All ranks share GPU 0 over gloo (testing only): what is checked is that the HIP
     pipeline, the sub-group collectives and the cell exchange of the tail tasks work together and every target cell of the grid reaches
     the final timestep index (bench raises otherwise)."""
     import os
     env = dict(os.environ, DM4D_BENCH_SHARED_GPU="1")
-    r = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--mode", "hybrid", "--steps", "1", "--warmup", "1", "--grid-frames", "6"],
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--mode", "hybrid", "--steps", "1", "--warmup", "0", "--grid-frames", "14"],
                        cwd=ROOT, capture_output=True, text=True, timeout=2400, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
@@ -141,5 +141,5 @@ def test_bench_hybrid_mode_runs_a_frame_sharded_tail_wave():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 4 and d["config"]["mode"].startswith("grid") and "hybrid" in d["config"]["parallelism"] and d["config"]["finite_outputs"] is True
     g = d["config"]["grid"]
-    # 6 spatial tasks x 1 call per spatial round (4 whole + 2 sharded over 2 ranks each, counted 0.5 per rank), 44 temporal tasks x 3 calls
-    assert abs(sum(g["calls_per_rank"]) - (6 + 44 * 3 + 6)) < 0.05, g
+    # 14 spatial tasks x 1 call per spatial round (12 whole + 2 sharded over 2 ranks each, counted 0.5 per rank), 44 temporal tasks x 3 calls
+    assert abs(sum(g["calls_per_rank"]) - (14 + 44 * 3 + 14)) < 0.05, g

@@ -31,7 +31,7 @@ if [ -n "$STATS_ONLY" ]; then head -16 gpurun_out/${TAG}_kernel_stats.txt; rm -r
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $C -d "$OUT" -o pmc_$C -- $BENCH > /dev/null 2> "$OUT.pmc_$C.err"
 done
-python tools/pmc_summary.py "$OUT" attn_kernel FETCH_SIZE WRITE_SIZE > gpurun_out/${TAG}_attn_traffic_pmc.json
+python tools/pmc_summary.py "$OUT" attn64_kernel FETCH_SIZE WRITE_SIZE > gpurun_out/${TAG}_attn_traffic_pmc.json
 # which stacks the launches carried (bench.py reads the traffic figure only for the stack size it runs)
 python - gpurun_out/${TAG}_attn_traffic_pmc.json gpurun_out/${TAG}_bench_under_rocprof.json <<'PY'
 import json, sys
@@ -46,7 +46,7 @@ done > gpurun_out/${TAG}_other_traffic_pmc.txt 2>&1
 # 3. MFMA-busy cycles of the attention kernel against the cycles the chip actually clocked (its own pass, kernel trace only)
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT" -o pmc_MFMA -- $BENCH > /dev/null 2> "$OUT.pmc_MFMA.err"
 DBM=$(find "$OUT" -name "pmc_MFMA*results.db" | head -1)
-python tools/mfma_busy_summary.py "$DBM" attn_kernel > gpurun_out/${TAG}_attn_mfma_busy_pmc.json
+python tools/mfma_busy_summary.py "$DBM" attn64_kernel > gpurun_out/${TAG}_attn_mfma_busy_pmc.json
 for K in conv_strip2_kernel gemm_lin2_kernel ff_proj_fused_kernel; do python tools/mfma_busy_summary.py "$DBM" $K; done > gpurun_out/${TAG}_other_mfma_busy_pmc.txt
 head -12 gpurun_out/${TAG}_kernel_stats.txt
 cat gpurun_out/${TAG}_attn_traffic_pmc.json gpurun_out/${TAG}_attn_mfma_busy_pmc.json gpurun_out/${TAG}_other_mfma_busy_pmc.txt
