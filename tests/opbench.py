@@ -165,6 +165,20 @@ def main():
         bench_conv(B, 18, 10, 1280, 1280, tag=" L2")
         bench_conv(B, 9, 5, 1280, 1280, tag=" L3")
         return
+    if only == "conv":  # the stride-1 3x3 convolutions of a UNet call: one task (CFG batch 32 / 48) and a stack of two; the VAE's
+        for B in (32, 64, 96):
+            bench_conv(B, 72, 40, 320, 320, tag=f" L0 B{B}")
+            bench_conv(B, 72, 40, 960, 320, tag=f" L0up B{B}")
+            bench_conv(B, 72, 40, 640, 320, tag=f" L0u2 B{B}")
+            bench_conv(B, 36, 20, 640, 640, tag=f" L1 B{B}")
+            bench_conv(B, 36, 20, 1920, 640, tag=f" L1up B{B}")
+            bench_conv(B, 36, 20, 320, 640, tag=f" L1in B{B}")
+            bench_conv(B, 18, 10, 1280, 1280, tag=f" L2 B{B}")
+            bench_conv(B, 18, 10, 2560, 1280, tag=f" L2up B{B}")
+        bench_conv(8, 576, 320, 128, 128, tag=" vae128")
+        bench_conv(8, 288, 160, 256, 256, tag=" vae256")
+        bench_conv(8, 144, 80, 512, 512, tag=" vae512")
+        return
     if only == "ff":
         bench_ff(32 * 2880, tag=" L0 F16")
         bench_ff(48 * 2880, tag=" L0 F24")
