@@ -992,7 +992,9 @@ def main():
                 "extensions": (["prune_cond_rows"] if args.prune_cond_rows else []),
             },
             "roofline": {
-                "kernel": "attn_kernel (2-D + 3-D view/time attention, all 48 launches of a stack's 3 window calls" +
+                "kernel": "attn64_kernel (the hand-placed 4 x 64-row form: 2-D + 3-D view/time attention, all 48 launches of a stack's 3 window "
+                          "calls; the launches whose key count is not a whole number of 64-key tiles -- the 9x5 level and the F = 24 call of the "
+                          "18x10 level, 2 % of the attention FLOPs -- run the 8-wave attn_kernel and are counted here too" +
                           (f"; a stack = {kb} tasks sharing their calls, so a launch carries {kb} x the rows of one task)" if kb > 1 else ")"),
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
