@@ -116,10 +116,11 @@ __device__ __forceinline__ void rows_fragments(const char* tile, int wm, int lan
 // the Linear kernels above, and the same gelu: results are BIT-IDENTICAL to gemm(GEGLU) followed by gemm(residual)
 // (tests/opcheck.py ff_fused_*).
 // ------------------------------------------------------------------------------------------------
-template <int CK, bool PROJ>
+template <int CK, bool PROJ, int PAR = 0>
 __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs& ln, const ProjArgs& proj, const u16* __restrict__ W1p,
                                               const u16* __restrict__ b1p, const u16* __restrict__ W2p, int nsteps) {
   static_assert(CK % 64 == 0 && (CK / 2) % 32 == 0, "channel count");
+  static_assert(PAR == 0 || (PAR == 2 && PROJ), "precision \"fp16\" is built for the whole block tail only");
   constexpr int NSLAB = CK / 64, KS1 = CK / 16, NJ = CK / 2 / 32;  // 64-wide K slabs of y / W1, k steps of product 1, column blocks per wave
   constexpr int W1_BYTES = 64 * CK * 2, W2_BYTES = CK * FF_STEP * 2, WBUF = W1_BYTES + W2_BYTES;
   constexpr int H_LD = 80, H_OFF = 2 * WBUF, H_BYTES = FF_BM * H_LD;  // H rows: 32 units = 64 B + 16 B pad (conflict-free b128 reads); 2 tiles
@@ -163,6 +164,7 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs&
   };
 
   bf16x8_t xf[KS1];
+  f32x16_t acc[1][NJ];
   if constexpr (PROJ) {
     // ---- projection prologue: h = A0 Wo^T + bo + X for this workgroup's 128 rows, into the LDS tile at Y_OFF (and, from
     // rows_layernorm, out to p.C: the epilogue's residual).  The products and their order are those of gemm(A0, Wo, bias, residual):
@@ -189,7 +191,7 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs&
     {
       GemmParams pb = p;
       pb.bias = proj.bo;
-      acc_init<1, NJ, CK / 2>(pb, hacc, 0, wn, lane, false);
+      acc_init<1, NJ, CK / 2, PAR>(pb, hacc, 0, wn, lane, false);
     }
     const int wo_rd = (wn * (CK / 2) + l31) * 128, wo_sw = (l31 >> 1) & 7;
 #pragma unroll
@@ -201,7 +203,7 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs&
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(wb + wo_rd + j * (32 * 128) + (((ks * 2 + lh) ^ wo_sw) * 16));
-          hacc[0][j] = mfma_t(xf[4 * t + ks], wf, hacc[0][j]);
+          hacc[0][j] = mfma_t<PAR>(xf[4 * t + ks], wf, hacc[0][j]);
         }
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -209,7 +211,85 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs&
     }
     // residual in the accumulators' own layout (lane: row l31 of its 32, runs of four columns): 8-byte loads, all issued first
     issue_w1(0, 0);  // buffer 0 (Wo slab NSLAB - 1 was its last reader, behind the barrier above); lands while h is formed
-    {
+    if constexpr (PAR == 2) {
+      // Precision "fp16": the residual stream is fp32 and h = A0 Wo^T + bo + X is never rounded -- and never stored.  It stays in
+      // the accumulators it was formed in: norm3 is taken from them (row sums over the lane pair l, l ^ 32 and, through 2 KB of LDS,
+      // over the two waves that share a row: two-pass mean / variance in fp32 like ln_row_stats, y rounded once to fp16 with the
+      // saturating conversion of ln_kernel<., 2>), the fp16 y rows go to the LDS tile the fragments are read from, and the very same
+      // registers then become the accumulators of the second product: O = h + b2 + W2 H.  Against the separate launches of this
+      // precision (gemm -> fp32 h, layernorm, gemm GEGLU, gemm + fp32 residual) the 118 MB of h per launch are neither written nor
+      // read twice; the sums differ from theirs only in the order of fp32 additions (h enters the output sum first instead of last,
+      // the row statistics are added up in a different order): tests/opcheck.py h16_ff_proj_fused_*.
+      const int r = wm * 32 + l31;
+      {
+        int m = m0 + r;
+        if (m > p.M - 1) m = p.M - 1;
+        const float* xr = reinterpret_cast<const float*>(proj.X) + (int64_t)m * proj.ldx + wn * (CK / 2) + 4 * lh;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          f32x4_t rx[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) rx[q] = *reinterpret_cast<const f32x4_t*>(xr + 32 * j + 8 * q);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hacc[0][j][4 * q + e] += rx[q][e];
+        }
+      }
+      float* st = reinterpret_cast<float*>(smem + W1_BYTES);  // [pass][wn][FF_BM]: buffer 0's W2 area, first written in body 0
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sum += hacc[0][j][e];
+      sum += __shfl_xor(sum, 32);
+      if (lh == 0) st[wn * FF_BM + r] = sum;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const float mu = (st[r] + st[FF_BM + r]) / (float)CK;
+      float sq = 0.f;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float d = hacc[0][j][e] - mu;
+          sq += d * d;
+        }
+      sq += __shfl_xor(sq, 32);
+      if (lh == 0) st[(2 + wn) * FF_BM + r] = sq;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const float rs = rsqrtf((st[2 * FF_BM + r] + st[3 * FF_BM + r]) / (float)CK + ln.eps);
+      const u16* gp = ln.gamma + wn * (CK / 2) + 4 * lh;
+      const u16* bp = ln.beta + wn * (CK / 2) + 4 * lh;
+      const int key = (r >> 1) & 7;
+      char* trow = smem + Y_OFF + r * 128 + 8 * lh;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint2 g2 = *reinterpret_cast<const uint2*>(gp + 32 * j + 8 * q), b2 = *reinterpret_cast<const uint2*>(bp + 32 * j + 8 * q);
+          const float g[4] = {h2f((u16)(g2.x & 0xffffu)), h2f((u16)(g2.x >> 16)), h2f((u16)(g2.y & 0xffffu)), h2f((u16)(g2.y >> 16))};
+          const float bt[4] = {h2f((u16)(b2.x & 0xffffu)), h2f((u16)(b2.x >> 16)), h2f((u16)(b2.y & 0xffffu)), h2f((u16)(b2.y >> 16))};
+          float y[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[e] = sat_h((hacc[0][j][4 * q + e] - mu) * rs * g[e] + bt[e]);
+          uint2 pk;
+          pk.x = pack_h2(y[0], y[1]);
+          pk.y = pack_h2(y[2], y[3]);
+          const int n = wn * (CK / 2) + 32 * j + 8 * q;  // first of the four columns, before the + 4 lh
+          *reinterpret_cast<uint2*>(trow + (n >> 6) * (FF_BM * 128) + ((((n & 63) >> 3) ^ key) << 4)) = pk;
+        }
+      // b2 as one more k step on top of h: the accumulators of the second product
+      const bf16x8_t one_h = k0_fragment(0x3c00, lh);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const u16 bits = p.bias ? p.bias[wn * (CK / 2) + j * 32 + l31] : (u16)0;
+        acc[0][j] = mfma_t<PAR>(one_h, k0_fragment(bits, lh), hacc[0][j]);
+      }
+    } else {
       int m = m0 + wm * 32 + l31;
       if (m > p.M - 1) m = p.M - 1;
       const u16* xr = proj.X + (int64_t)m * proj.ldx + wn * (CK / 2) + 4 * lh;
@@ -246,7 +326,7 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs&
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }
-  if (ln.gamma) {  // norm3 folded in: the tile holds x, not LayerNorm(x) (bit-identical to the stand-alone launch, rows_layernorm)
+  if (PAR != 2 && ln.gamma) {  // norm3 folded in: the tile holds x, not LayerNorm(x) (bit-identical to the stand-alone launch, rows_layernorm)
     if constexpr (PROJ) {
       rows_layernorm<CK, true>(smem + Y_OFF, ln, wave, lane, p.C + (int64_t)m0 * p.ldc, p.ldc, p.M - m0);
     } else {
@@ -265,12 +345,11 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs&
   __builtin_amdgcn_s_barrier();  // every wave has its y rows: buffer 1 and the H tile may be written
   asm volatile("" ::: "memory");
 
-  f32x16_t acc[1][NJ];
-  acc_init<1, NJ, CK / 2>(p, acc, 0, wn, lane, false);  // b2 as the first k step of product 2
+  if constexpr (PAR != 2) acc_init<1, NJ, CK / 2>(p, acc, 0, wn, lane, false);  // b2 as the first k step of product 2
   f32x16_t zero;
 #pragma unroll
   for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-  const bf16x8_t one0 = k0_fragment(0x3f80, lh);
+  const bf16x8_t one0 = k0_fragment(PAR == 2 ? 0x3c00 : 0x3f80, lh);
 
   // fragment read addresses (bytes from a buffer's start)
   const int w1_rd = (wn * 32 + l31) * 128, w1_sw = (l31 >> 1) & 7;
@@ -290,13 +369,13 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs&
   //    section 4, issue probe): vector work hides only behind a wave's OWN MFMAs, which is what A + B in one block provide.
   auto product1 = [&](int s, u16 bias_bits) {
     const char* wb = smem + (s & 1) * WBUF;
-    f32x16_t sa = mfma_t(one0, k0_fragment(bias_bits, lh), zero);
+    f32x16_t sa = mfma_t<PAR>(one0, k0_fragment(bias_bits, lh), zero);
 #pragma unroll
     for (int t = 0; t < NSLAB; ++t)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(wb + t * 8192 + w1_rd + (((ks * 2 + lh) ^ w1_sw) * 16));
-        sa = mfma_t(xf[4 * t + ks], wf, sa);
+        sa = mfma_t<PAR>(xf[4 * t + ks], wf, sa);
       }
     return sa;
   };
@@ -309,10 +388,17 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs&
 #pragma unroll
     for (int e = 0; e < 8; ++e) hv[e] = sa[e] * gelu_erf_f(sa[e + 8]);
     HPack h;
-    h.lo.x = pack_bf2(hv[0], hv[1]);
-    h.lo.y = pack_bf2(hv[2], hv[3]);
-    h.hi.x = pack_bf2(hv[4], hv[5]);
-    h.hi.y = pack_bf2(hv[6], hv[7]);
+    if constexpr (PAR == 2) {
+      h.lo.x = pack_h2(hv[0], hv[1]);
+      h.lo.y = pack_h2(hv[2], hv[3]);
+      h.hi.x = pack_h2(hv[4], hv[5]);
+      h.hi.y = pack_h2(hv[6], hv[7]);
+    } else {
+      h.lo.x = pack_bf2(hv[0], hv[1]);
+      h.lo.y = pack_bf2(hv[2], hv[3]);
+      h.hi.x = pack_bf2(hv[4], hv[5]);
+      h.hi.y = pack_bf2(hv[6], hv[7]);
+    }
     return h;
   };
   auto h_store = [&](int s, const HPack& h) {
@@ -329,7 +415,7 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs&
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(wb + w2_rd + j * (32 * 64) + (((ks * 2 + lh) ^ w2_sw) * 16));
-        acc[0][j] = mfma_t(hf, wf, acc[0][j]);
+        acc[0][j] = mfma_t<PAR>(hf, wf, acc[0][j]);
       }
     }
   };
@@ -395,7 +481,7 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs&
     close_interval();
   }
   // everybody's fragment reads are behind a barrier: the epilogue may stage through the same LDS
-  gemm_epilogue<1, NJ, 32, CK / 2, false>(p, acc, reinterpret_cast<float*>(smem), m0, 0, wm, wn, wave, lane);
+  gemm_epilogue<1, NJ, 32, CK / 2, false, PAR>(p, acc, reinterpret_cast<float*>(smem), m0, 0, wm, wn, wave, lane);
 }
 
 // (the body is a device function: the host pass instantiates only the stub of a __global__ template, and the register
@@ -413,6 +499,14 @@ template <int CK>
 __global__ __launch_bounds__(512) void ff_proj_fused_kernel(GemmParams p, LnArgs ln, ProjArgs proj, const u16* __restrict__ W1p,
                                                             const u16* __restrict__ b1p, const u16* __restrict__ W2p, int nsteps) {
   ff_fused_body<CK, true>(p, ln, proj, W1p, b1p, W2p, nsteps);
+}
+
+// The same tail in precision "fp16" (PAR = 2): fp16 attention rows, weights and vectors, the fp32 residual stream X; the result is
+// h + ff(norm3(h)) as an fp32 tensor or (the block hands the transformer's proj_out its operand) rounded once to fp16.
+template <int CK>
+__global__ __launch_bounds__(512) void ff_proj_fused_h16_kernel(GemmParams p, LnArgs ln, ProjArgs proj, const u16* __restrict__ W1p,
+                                                                const u16* __restrict__ b1p, const u16* __restrict__ W2p, int nsteps) {
+  ff_fused_body<CK, true, 2>(p, ln, proj, W1p, b1p, W2p, nsteps);
 }
 
 // Per-step packed copies of the feed-forward weights for ff_fused_kernel (once per layer, at load time):
@@ -456,6 +550,13 @@ int ff_launch_proj_fused(hipStream_t st, const GemmParams& p, const LnArgs& ln, 
   hipLaunchKernelGGL((ff_proj_fused_kernel<320>), dim3((unsigned)((p.M + FF_BM - 1) / FF_BM)), dim3(512), 0, st, p, ln, proj, W1p, b1p,
                      W2p, nsteps);
   return dm4d_check_launch("ff_proj_fused_kernel");
+}
+
+int ff_launch_proj_fused_h16(hipStream_t st, const GemmParams& p, const LnArgs& ln, const ProjArgs& proj, const u16* W1p, const u16* b1p,
+                             const u16* W2p, int nsteps) {
+  hipLaunchKernelGGL((ff_proj_fused_h16_kernel<320>), dim3((unsigned)((p.M + FF_BM - 1) / FF_BM)), dim3(512), 0, st, p, ln, proj, W1p,
+                     b1p, W2p, nsteps);
+  return dm4d_check_launch("ff_proj_fused_h16_kernel");
 }
 
 }  // namespace
@@ -511,4 +612,30 @@ extern "C" int dm4d_attn_out_ff_geglu_fused_bf16(void* stream, const void* A0, i
   const LnArgs ln{(const u16*)ln_gamma, (const u16*)ln_beta, ln_eps};
   const ProjArgs proj{(const u16*)A0, lda0, (const u16*)Wo, (const u16*)bo, (const u16*)X, ldx};
   return ff_launch_proj_fused((hipStream_t)stream, p, ln, proj, (const u16*)W1p, (const u16*)b1p, (const u16*)W2p, hidden / FF_STEP);
+}
+
+// precision "fp16": see ff_proj_fused_h16_kernel.  W1p / b1p / W2p come from dm4d_ff_geglu_prepare_bf16 (a permutation of 16-bit words,
+// whatever they encode).
+extern "C" int dm4d_attn_out_ff_geglu_fused_f16(void* stream, const void* A0, int64_t lda0, const void* Wo, const void* bo, const float* X,
+                                                int64_t ldx, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* W1p,
+                                                const void* b1p, const void* W2p, const void* b2, void* Out, int64_t ldo, int out_f32,
+                                                int M, int C, int hidden) {
+  if (!A0 || !Wo || !X || !ln_gamma || !ln_beta || !W1p || !b1p || !W2p || !Out || M <= 0)
+    return dm4d_set_error(DM4D_ERR_ARG, "attn_out_ff_geglu_fused_f16: null pointer or empty shape");
+  if (!dm4d_ff_geglu_supported(C, hidden))
+    return dm4d_set_error(DM4D_ERR_ARG, "attn_out_ff_geglu_fused_f16: built for C = 320 and a hidden size that is a multiple of 32");
+  if ((lda0 & 7) || (ldx & 3) || (ldo & 7) || ldx < C || ldo < C || ldo >= (1 << 23) ||
+      ((((uintptr_t)A0) | ((uintptr_t)Wo) | ((uintptr_t)X) | ((uintptr_t)Out) | ((uintptr_t)W1p) | ((uintptr_t)W2p) | ((uintptr_t)ln_gamma) |
+        ((uintptr_t)ln_beta)) & 15))
+    return dm4d_set_error(DM4D_ERR_ARG, "attn_out_ff_geglu_fused_f16: row strides must be multiples of 8 elements (4 for X), pointers 16-byte aligned");
+  if ((uint64_t)M * (uint64_t)lda0 * 2u >= (1ull << 32))
+    return dm4d_set_error(DM4D_ERR_ARG, "attn_out_ff_geglu_fused_f16: input of 4 GiB or more (split the rows)");
+  if (Out == A0 || Out == (const void*)X) return dm4d_set_error(DM4D_ERR_ARG, "attn_out_ff_geglu_fused_f16: the output may not alias an input");
+  GemmParams p{};
+  p.A = (const u16*)A0; p.lda = lda0; p.C = (u16*)Out; p.ldc = ldo; p.M = M; p.N = C; p.K = hidden;
+  p.bias = (const u16*)b2; p.res = nullptr; p.ld_res = 0; p.flags = out_f32 ? DM4D_EPI_F32OUT : 0u; p.out_scale = 1.0f; p.splits = 1;
+  p.rows_per_rb = 1; p.tiles_n = 1;
+  const LnArgs ln{(const u16*)ln_gamma, (const u16*)ln_beta, ln_eps};
+  const ProjArgs proj{(const u16*)A0, lda0, (const u16*)Wo, (const u16*)bo, (const u16*)X, ldx};
+  return ff_launch_proj_fused_h16((hipStream_t)stream, p, ln, proj, (const u16*)W1p, (const u16*)b1p, (const u16*)W2p, hidden / FF_STEP);
 }

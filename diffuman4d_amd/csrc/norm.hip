@@ -21,6 +21,7 @@ __host__ __device__ inline int gn_nchunk(int B, int HW) {
 // IO (template parameter of the GroupNorm / LayerNorm kernels): what a tensor element is on the way in and out.
 //   0  bf16 in, bf16 out, bf16 gamma / beta                    (fast precision)
 //   2  fp32 in, ONE fp16 plane out, fp16 gamma / beta          (precision "fp16": dm4d_groupnorm_nhwc_f32_f16 / dm4d_layernorm_f32_f16)
+//   3  fp16 in, ONE fp16 plane out, fp16 gamma / beta          (precision "fp16": dm4d_groupnorm_nhwc_f16_f16, GroupNorm only)
 // A "vector" is eight channels either way: 16 bytes of bf16, or 32 bytes of fp32 in and 16 bytes of fp16 out.
 template <int IO>
 struct NormIO;
@@ -51,6 +52,18 @@ struct NormIO<2> {
     v[4] = r.b[0]; v[5] = r.b[1]; v[6] = r.b[2]; v[7] = r.b[3];
   }
   static __device__ __forceinline__ float ld1(const float* p) { return *p; }
+  static __device__ __forceinline__ void st8(u16* p, const float* v) { stg16(p, pack8h_sat(v)); }
+  static __device__ __forceinline__ void par8(const u16* p, float* v) { unpack8h(ldg16(p), v); }
+};
+
+// IO = 3: fp16 in (an activation a convolution left in fp16: conv1 of a resnet, whose only reader is norm2), ONE fp16 plane out
+template <>
+struct NormIO<3> {
+  typedef u16 in_t;
+  typedef U4 raw_t;
+  static __device__ __forceinline__ raw_t ldraw(const u16* p) { return ldg16(p); }
+  static __device__ __forceinline__ void unpack(const raw_t& r, float* v) { unpack8h(r, v); }
+  static __device__ __forceinline__ float ld1(const u16* p) { return h2f(*p); }
   static __device__ __forceinline__ void st8(u16* p, const float* v) { stg16(p, pack8h_sat(v)); }
   static __device__ __forceinline__ void par8(const u16* p, float* v) { unpack8h(ldg16(p), v); }
 };
@@ -606,6 +619,16 @@ extern "C" int dm4d_groupnorm_nhwc_f32_f16(void* stream, const float* X1, int C1
   if ((C1 & 7) || (C2 & 7) || (((uintptr_t)X1) & 15) || (X2 && (((uintptr_t)X2) & 15)) || (((uintptr_t)Y) & 15))
     return dm4d_groupnorm_f32_f16_general(stream, X1, C1, X2, C2, B, HW, groups, eps, gamma, beta, Y, apply_silu, ws);
   return groupnorm_impl<2>(stream, X1, C1, X2, C2, B, HW, groups, eps, gamma, beta, Y, apply_silu, ws);
+}
+
+// precision "fp16", fp16 in: the input is an activation its producer already rounded to fp16 (same statistics, same output rounding;
+// half the bytes of the fp32 form on the way in).  Channel counts must be multiples of 8, tensors 16-byte aligned.
+extern "C" int dm4d_groupnorm_nhwc_f16_f16(void* stream, const void* X1, int C1, const void* X2, int C2, int B, int HW, int groups,
+                                           float eps, const void* gamma, const void* beta, void* Y, int apply_silu, void* ws) {
+  if (!X2) C2 = 0;
+  if ((C1 & 7) || (C2 & 7) || (((uintptr_t)X1) & 15) || (X2 && (((uintptr_t)X2) & 15)) || (((uintptr_t)Y) & 15))
+    return dm4d_set_error(DM4D_ERR_ARG, "groupnorm_f16_f16: channel counts must be multiples of 8, tensors 16-byte aligned");
+  return groupnorm_impl<3>(stream, X1, C1, X2, C2, B, HW, groups, eps, gamma, beta, Y, apply_silu, ws);
 }
 
 extern "C" int dm4d_groupnorm_nhwc_f32_f16_raw(void* stream, const float* X1, int C1, const float* X2, int C2, int B, int HW, int groups,

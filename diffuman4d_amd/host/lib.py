@@ -80,12 +80,15 @@ SIGNATURES = {
     "dm4d_conv_up2x_nhwc_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _u]),
     "dm4d_to_f16_f32": (_i, [_vp, _vp, _i64, _i64, _i, _vp, _i64, _i, _vp, _i64, _i64, _i, _i, _f]),
     "dm4d_groupnorm_nhwc_f32_f16": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp]),
+    "dm4d_groupnorm_nhwc_f16_f16": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp]),
     "dm4d_groupnorm_nhwc_f32_f16_raw": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _vp]),
     "dm4d_layernorm_f32_f16": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _f]),
     "dm4d_groupnorm_f32_f16_general": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp]),
     "dm4d_layernorm_f32_f16_general": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _f]),
     "dm4d_softmax_rows_f32_f16": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _f]),
     "dm4d_attention_qscaled_kv_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i]),
+    "dm4d_attn_out_ff_geglu_fused_f16": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i,
+                                               _i]),
     "dm4d_pack_model_input_f32_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     "dm4d_tune_set_gemm_config": (_i, [_i]),
     "dm4d_tune_set_groupnorm_resident": (_i, [_i]),

@@ -198,7 +198,8 @@ def conv3x3(x: torch.Tensor, wt: torch.Tensor, *, bias=None, rowbias=None, resid
 
 
 def _conv3x3_f16(x, wt, bias, rowbias, residual, stride, pad, pad_hi, upsample, out_scale, out_f32) -> torch.Tensor:
-    """precision "fp16": x / wt / bias fp16; fp32 result with fp32 rowbias / residual (out_f32), else fp16 everywhere."""
+    """precision "fp16": x / wt / bias fp16; rowbias / residual fp32 (always with an fp32 result) or fp16; fp32 (out_f32) or fp16 result
+    (an fp16 result with an fp32 row bias: conv1 of a resnet, whose fp32 sum is rounded once for norm2)."""
     lib = _l.load()
     _req(x, "x", F16), _req(wt, "wt", F16)
     assert x.is_contiguous() and wt.is_contiguous()
@@ -207,7 +208,8 @@ def _conv3x3_f16(x, wt, bias, rowbias, residual, stride, pad, pad_hi, upsample, 
     assert wt.shape[1] == 9 * Cin, (wt.shape, Cin)
     Ho, Wo = conv_out_hw(H, W, stride, pad, upsample, pad_hi)
     y = torch.empty((B, Ho, Wo, Cout), dtype=F32 if out_f32 else F16, device=x.device)
-    side = F32 if out_f32 else F16
+    sides = [t for t in (rowbias, residual) if t is not None]
+    side = F32 if (out_f32 or (sides and sides[0].dtype == F32)) else F16
     if bias is not None:
         _req(bias, "bias", F16)
     if residual is not None:
@@ -223,7 +225,7 @@ def _conv3x3_f16(x, wt, bias, rowbias, residual, stride, pad, pad_hi, upsample, 
                                        1 if upsample else 0, _p(bias), _p(rowbias),
                                        rowbias.stride(0) if rowbias is not None else 0, _p(residual),
                                        Cout if residual is not None else 0, out_scale,
-                                       (_l.EPI_F32OUT | _l.EPI_F32SIDE) if out_f32 else 0, _p(ws), ws_bytes)
+                                       (_l.EPI_F32OUT if out_f32 else 0) | (_l.EPI_F32SIDE if side == F32 else 0), _p(ws), ws_bytes)
     _l.check(rc, "dm4d_conv3x3_nhwc_f16")
     return y
 
@@ -295,9 +297,9 @@ class FeedForward:
         self.packed = None
         if w1.is_cuda and _l.load().dm4d_ff_geglu_supported(self.C, self.hidden):
             lib = _l.load()
-            _req(w1, "w1"), _req(w2, "w2")
+            _req(w1, "w1", w1.dtype), _req(w2, "w2", w1.dtype)  # bf16, or fp16 (precision "fp16": the packing permutes 16-bit words)
             with torch.cuda.device(w1.device):
-                w1p, b1p, w2p = torch.empty_like(w1), torch.empty(2 * self.hidden, dtype=BF16, device=w1.device), torch.empty_like(w2)
+                w1p, b1p, w2p = torch.empty_like(w1), torch.empty(2 * self.hidden, dtype=w1.dtype, device=w1.device), torch.empty_like(w2)
                 _l.check(lib.dm4d_ff_geglu_prepare_bf16(_stream(), _p(w1.contiguous()), _p(b1), _p(w2.contiguous()), _p(w1p), _p(b1p),
                                                         _p(w2p), self.C, self.hidden), "dm4d_ff_geglu_prepare_bf16")
                 torch.cuda.current_stream(w1.device).synchronize()
@@ -352,6 +354,28 @@ class FeedForward:
                                                        out.stride(0), M, self.C, self.hidden)
         _l.check(rc, "dm4d_attn_out_ff_geglu_fused_bf16")
         _trace("attn_out_ff_fused", out, a=a, wo=wo, bo=bo, x=x, ln=ln, w1=self.w1, b1=self.b1, w2=self.w2, b2=self.b2)
+        return out
+
+    def after_attention_f16(self, a: torch.Tensor, wo: torch.Tensor, bo: Optional[torch.Tensor], x: torch.Tensor, ln, out_f32: bool) -> torch.Tensor:
+        """The same tail in precision "fp16": a fp16 [M, C], x the fp32 residual stream; the result is fp32 (out_f32) or the fp16 operand
+        of the next contraction.  One launch (dm4d_attn_out_ff_geglu_fused_f16: h stays in the accumulators, never stored) where the kernel
+        is built for the shape, otherwise gemm -> fp32 h, layernorm, gemm(GEGLU), gemm(+ h); the two forms agree to fp32 rounding."""
+        aligned = (all(t.data_ptr() % 16 == 0 for t in (a, x, wo, ln[0], ln[1])) and a.stride(0) % 8 == 0 and x.stride(0) % 4 == 0)
+        if (self.packed is None or not FF_FUSED or not FF_PROJ_FUSED or not aligned or a.shape[0] * a.stride(0) * 2 >= (1 << 32)
+                or wo.shape != (self.C, self.C) or not wo.is_contiguous()):
+            h = gemm(a, wo, bias=bo, residual=x, out_f32=True)
+            f = gemm(layernorm(h, ln[0], ln[1], ln[2]), self.w1, bias=self.b1, geglu=True)
+            return gemm(f, self.w2, bias=self.b2, residual=h, out_f32=out_f32)
+        lib = _l.load()
+        _req(a, "a", F16), _req(wo, "wo", F16), _req(x, "x", F32), _req(ln[0], "gamma", F16), _req(ln[1], "beta", F16)
+        M = a.shape[0]
+        out = torch.empty((M, self.C), dtype=F32 if out_f32 else F16, device=a.device)
+        w1p, b1p, w2p = self.packed
+        with _Prof("linear", 2.0 * M * (3 * self.hidden + self.C) * self.C, "flop", M):
+            rc = lib.dm4d_attn_out_ff_geglu_fused_f16(_stream(), _p(a), a.stride(0), _p(wo), _p(bo), _p(x), x.stride(0), _p(ln[0]),
+                                                      _p(ln[1]), float(ln[2]), _p(w1p), _p(b1p), _p(w2p), _p(self.b2), _p(out),
+                                                      out.stride(0), 1 if out_f32 else 0, M, self.C, self.hidden)
+        _l.check(rc, "dm4d_attn_out_ff_geglu_fused_f16")
         return out
 
 
@@ -464,6 +488,8 @@ def groupnorm(x1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups:
     if isinstance(x1, torch.Tensor) and x1.dtype == F32:
         return _groupnorm_f32(x1, gamma, beta, groups, eps, x2, silu, raw_out)
     assert not raw_out
+    if isinstance(x1, torch.Tensor) and x1.dtype == F16:
+        return _groupnorm_f16(x1, gamma, beta, groups, eps, x2, silu)
     _req(x1, "x1"), _req(gamma, "gamma"), _req(beta, "beta")
     assert x1.is_contiguous()
     B, C1 = x1.shape[0], x1.shape[-1]
@@ -518,6 +544,27 @@ def _groupnorm_f32(x1, gamma, beta, groups, eps, x2, silu, raw_out=False):
         fn = lib.dm4d_groupnorm_nhwc_f32_f16 if h16 else lib.dm4d_groupnorm_nhwc_f32_split
         rc = fn(_stream(), _p(x1), C1, _p(x2), C2, B, HW, groups, eps, _p(gamma), _p(beta), _p(y), 1 if silu else 0, _p(ws))
     _l.check(rc, "dm4d_groupnorm_nhwc_f32_split")
+    return y
+
+
+def _groupnorm_f16(x1, gamma, beta, groups, eps, x2, silu):
+    """precision "fp16", fp16 input (an activation its producer left in fp16: conv1's output in front of norm2) -> one fp16 plane."""
+    lib = _l.load()
+    _req(x1, "x1", F16), _req(gamma, "gamma", F16), _req(beta, "beta", F16)
+    assert x1.is_contiguous()
+    B, C1 = x1.shape[0], x1.shape[-1]
+    HW = x1.numel() // (B * C1)
+    C2 = 0
+    if x2 is not None:
+        _req(x2, "x2", F16)
+        assert x2.is_contiguous() and x2.shape[0] == B
+        C2 = x2.shape[-1]
+    y = torch.empty(x1.shape[:-1] + (C1 + C2,), dtype=F16, device=x1.device)
+    ws = torch.empty(lib.dm4d_groupnorm_ws_bytes(B, HW, groups) // 4, dtype=torch.float32, device=x1.device)
+    with _Prof("groupnorm", 2.0 * y.numel() * 2, "byte", B * HW):
+        rc = lib.dm4d_groupnorm_nhwc_f16_f16(_stream(), _p(x1), C1, _p(x2), C2, B, HW, groups, eps, _p(gamma), _p(beta), _p(y),
+                                             1 if silu else 0, _p(ws))
+    _l.check(rc, "dm4d_groupnorm_nhwc_f16_f16")
     return y
 
 

@@ -13,6 +13,8 @@ consumers (two-source GroupNorm / split-K shortcut GEMM).
 """
 from __future__ import annotations
 
+import os
+
 import json
 from dataclasses import dataclass, fields
 from pathlib import Path
@@ -25,6 +27,7 @@ from . import ops
 BF16 = torch.bfloat16
 F16 = torch.float16
 PRECISIONS = ("fast", "parity", "fp16")
+H16_CONV1_F16 = os.environ.get("DM4D_H16_CONV1_F16", "1") != "0"  # fp16 precision: conv1 -> fp16 -> norm2 (off: fp32 in between; A/B, tests)
 
 
 def check_precision(precision: str) -> None:
@@ -191,7 +194,11 @@ class _Resnet:
             h, raw = ops.groupnorm(x, self.n1w, self.n1b, self.groups, self.eps, x2=skip, silu=True, raw_out=True)
         else:
             h = ops.groupnorm(x, self.n1w, self.n1b, self.groups, self.eps, x2=skip, silu=True)
-        h = ops.conv3x3(h, self.c1w, bias=self.c1b, rowbias=tproj[:, self.t_off:self.t_off + self.cout], out_f32=P)
+        # fp16 precision: conv1's fp32 sum (+ the fp32 time-embedding row) has ONE reader, norm2, whose output is rounded to fp16 anyway:
+        # it is rounded to fp16 once in the epilogue and norm2 reads two bytes per element (H16_CONV1_F16; measured on the whole-task
+        # cases)
+        h = ops.conv3x3(h, self.c1w, bias=self.c1b, rowbias=tproj[:, self.t_off:self.t_off + self.cout],
+                        out_f32=P and not (self.h16 and H16_CONV1_F16))
         h = ops.groupnorm(h, self.n2w, self.n2b, self.groups, self.eps, silu=True)
         if self.has_sc:
             M = B * H * Wd
@@ -226,7 +233,7 @@ class _TransformerBlock:
         self.n3w, self.n3b = W.vec(pfx + "norm3.weight"), W.vec(pfx + "norm3.bias")
         w1, b1 = W.linear(pfx + "ff.net.0.proj.weight"), W.vec(pfx + "ff.net.0.proj.bias")
         w2, b2 = W.linear(pfx + "ff.net.2.weight"), W.vec(pfx + "ff.net.2.bias")
-        self.ff = (w1, b1, w2, b2) if W.wide else ops.FeedForward(w1, b1, w2, b2)
+        self.ff = (w1, b1, w2, b2) if (W.wide and not W.h16) else ops.FeedForward(w1, b1, w2, b2)
         if (pfx + "attn2.to_q.weight") in W.sd:
             raise NotImplementedError(f"unet checkpoint holds '{pfx}attn2.*' (a cross-attention block, i.e. unet/config.json: "
                                       "cross_attention_dim is not null): not supported -- the reference never passes encoder_hidden_states "
@@ -259,7 +266,6 @@ class _TransformerBlock:
         output projection + fp32 residual; LayerNorm; GEGLU -> operand; projection + residual.  Parity precision: two-term operands,
         three MFMA terms per attention product.  fp16 precision: one fp16 plane each, Q pre-scaled in the projection's epilogue, the
         fast precision's attention loop on fp16 operands.  With `shard` the K | V planes are all-gathered as in the fast precision."""
-        w1, b1, w2, b2 = self.ff
         C = h.shape[1]
         n = ops.layernorm(h, self.n1w, self.n1b, 1e-5)
         if self.h16:
@@ -282,6 +288,9 @@ class _TransformerBlock:
             q = ops.gemm(n, self.qkv[:C], split_out=True)  # [M, 2C] = [q_hi | q_lo]
             kvg = shard.gather_kv_finish(pending).view(batch * shard.world * seq, 4 * C)
             a = ops.attention_split(None, batch, self.heads, seq, self.scale, q=q, kv=kvg, kv_seq=shard.world * seq)
+        if self.h16:  # the block's tail: one launch at C = 320 (level 0), four elsewhere (ops.FeedForward.after_attention_f16)
+            return self.ff.after_attention_f16(a, self.ow, self.ob, h, (self.n3w, self.n3b, 1e-5), out_f32=not operand_out)
+        w1, b1, w2, b2 = self.ff
         h = ops.gemm(a, self.ow, bias=self.ob, residual=h, out_f32=True)
         f = ops.gemm(ops.layernorm(h, self.n3w, self.n3b, 1e-5), w1, bias=b1, geglu=True, split_out=True)
         return ops.gemm(f, w2, bias=b2, residual=h, out_f32=not operand_out, split_out=operand_out)

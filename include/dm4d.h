@@ -361,6 +361,10 @@ int dm4d_groupnorm_nhwc_f32_f16(void* stream, const float* X1, int C1, const flo
  *   ResnetBlock2D.conv_shortcut), without a pass of its own over the fp32 tensor.  C1, C2 multiples of 8, 16-byte aligned tensors.  */
 int dm4d_groupnorm_nhwc_f32_f16_raw(void* stream, const float* X1, int C1, const float* X2, int C2, int B, int HW, int groups, float eps,
                                     const void* gamma, const void* beta, void* Y, void* Yraw, int apply_silu, void* ws);
+/* ... and with an fp16 INPUT (one or two sources): the activation a convolution already left in fp16 -- conv1 of a resnet, whose only
+ *   reader is norm2 (resnet.py ResnetBlock2D.forward: conv1 -> + temb -> norm2) -- read at two bytes per element.  ws as above.    */
+int dm4d_groupnorm_nhwc_f16_f16(void* stream, const void* X1, int C1, const void* X2, int C2, int B, int HW, int groups, float eps,
+                                const void* gamma, const void* beta, void* Y, int apply_silu, void* ws);
 int dm4d_layernorm_f32_f16(void* stream, const float* X, int64_t ldx, const void* gamma, const void* beta, void* Y, int64_t ldy, int M,
                            int C, float eps);
 int dm4d_softmax_rows_f32_f16(void* stream, const float* S, int64_t lds, void* P, int64_t ldp, int M, int N, int Np, float scale);
@@ -376,6 +380,21 @@ int dm4d_layernorm_f32_f16_general(void* stream, const float* X, int64_t ldx, co
  *   at 2^16 (attention.hip, "H16").  replaces F.scaled_dot_product_attention via attention.py:73-78.                                */
 int dm4d_attention_qscaled_kv_f16(void* stream, const void* Q, const void* K, const void* V, void* O, int64_t ldq, int64_t ldk,
                                   int64_t ldv, int64_t ldo, int batch, int heads, int Lq, int Lk);
+
+/* The tail of a transformer block in one launch, precision "fp16" (dm4d_attn_out_ff_geglu_fused_bf16 above; attention.py:88-90 and
+ *   :129-149): A0 [M, C] fp16 attention output, Wo / bo / LayerNorm vectors / b2 fp16, W1p / b1p / W2p = dm4d_ff_geglu_prepare_bf16 of
+ *   the fp16 matrices (a permutation of 16-bit words), X [M, C] the fp32 residual stream (ldx in floats, a multiple of 4):
+ *       h = A0 Wo^T + bo + X  (fp32, never rounded and never stored: it stays in the accumulators it was formed in),
+ *       Out = h + W2 (u * gelu(g)) + b2,  [u | g] = W1 fp16(LayerNorm(h)) + b1,
+ *   Out fp32 (out_f32 = 1) or rounded once to fp16 (out_f32 = 0: the operand of the transformer's proj_out).  Same products and
+ *   rounding points as dm4d_gemm_f16 (fp32 out + residual), dm4d_layernorm_f32_f16, dm4d_gemm_f16 (GEGLU), dm4d_gemm_f16 (+ fp32
+ *   residual); only the ORDER of fp32 additions differs (h enters the output sum first, the LayerNorm row sums are added up in another
+ *   order), so the two forms agree to fp32 rounding, not bit for bit (tests/opcheck.py h16_ff_proj_fused_*).  C = 320 only
+ *   (dm4d_ff_geglu_supported).  Out may not alias A0 or X.                                                                           */
+int dm4d_attn_out_ff_geglu_fused_f16(void* stream, const void* A0, int64_t lda0, const void* Wo, const void* bo, const float* X,
+                                     int64_t ldx, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* W1p,
+                                     const void* b1p, const void* W2p, const void* b2, void* Out, int64_t ldo, int out_f32, int M, int C,
+                                     int hidden);
 
 /* dm4d_pack_model_input_f32_split with ONE fp16 plane out: rows of cpad fp16 channels (the operand of conv_in).                    */
 int dm4d_pack_model_input_f32_f16(void* stream, float* latents, const float* pv_lat, const float* plucker, const float* skel,

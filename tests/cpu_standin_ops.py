@@ -87,7 +87,8 @@ def conv3x3(x, wt, *, bias=None, rowbias=None, residual=None, stride=1, pad=1, p
         xi = F.interpolate(xi, scale_factor=2, mode="nearest")
     ph = pad if pad_hi is None else pad_hi
     v = F.conv2d(F.pad(xi, (pad, ph, pad, ph)), w4, bias.double() if bias is not None else None, stride=stride)
-    side = F32 if out_f32 else wt.dtype
+    sides = [t for t in (rowbias, residual) if t is not None]
+    side = F32 if (out_f32 or (h16 and sides and sides[0].dtype == F32)) else wt.dtype
     if rowbias is not None:
         assert rowbias.dtype == side
         v = v + rowbias.double()[:, :, None, None]
@@ -144,7 +145,10 @@ def groupnorm(x1, gamma, beta, groups, eps, *, x2=None, silu=False, raw_out=Fals
     if silu:
         v = F.silu(v)
     v = v.reshape(x.shape).float().contiguous()
-    assert gamma.dtype == beta.dtype and (gamma.dtype == BF or f32)
+    assert gamma.dtype == beta.dtype and (gamma.dtype == BF or f32 or x1.dtype == F16)
+    if x1.dtype == F16:  # fp16 precision, fp16 in (conv1 -> norm2)
+        assert gamma.dtype == F16
+        return v.to(F16)
     return _out(v, split=True, h16=gamma.dtype == F16) if f32 else v.to(BF)
 
 
@@ -319,6 +323,11 @@ class FeedForward:
         h = gemm(a, wo, bias=bo, residual=x)
         f = gemm(layernorm(h, *ln), self.w1, bias=self.b1, geglu=True)
         return gemm(f, self.w2, bias=self.b2, residual=h)
+
+    def after_attention_f16(self, a, wo, bo, x, ln, out_f32):
+        h = gemm(a, wo, bias=bo, residual=x, out_f32=True)
+        f = gemm(layernorm(h, *ln), self.w1, bias=self.b1, geglu=True)
+        return gemm(f, self.w2, bias=self.b2, residual=h, out_f32=out_f32, split_out=not out_f32)
 
 
 class Upsampler:

@@ -1076,9 +1076,8 @@ CASES.update({
     "par_vae": (case_vae, dict(**PAR)),
     "par_vae_odd_latent_area": (case_vae, dict(h=264, w=328, **PAR)),
     "par_pipeline_spatial": (case_pipeline, dict(domain="spatial", **PAR)),
-    "par_pipeline_temporal_v": (case_pipeline, dict(domain="temporal", T=4, window=4, stride=1, pred="v_prediction", **PAR)),
-    "par_pipeline_bidir_nocfg": (case_pipeline, dict(domain="spatial", window=3, stride=3, bidir=True, gs=1.0, steps=2, **PAR)),
-    "par_pipeline_dpm_spatial": (case_pipeline, dict(domain="spatial", sched="dpm", steps=2, window=4, stride=2, bidir=True, **PAR)),
+    # (temporal / bidirectional / DPM configurations of this precision: the golden_* cases below, against the reference pipeline's own output;
+    #  their oracle-on-the-spot twins were dropped in round 6 to keep the GPU suite inside the driver's window)
     # parity precision against the fixtures made by the REFERENCE's own pipeline code (fp32): all three scheduler families, both domains
     "par_golden_spatial": (case_golden_pipeline, dict(name="spatial", **PAR)),
     "par_golden_temporal_v": (case_golden_pipeline, dict(name="temporal_v", **PAR)),
@@ -1112,9 +1111,6 @@ CASES.update({
     "fp16_vae": (case_vae, dict(**FP16)),
     "fp16_vae_odd_latent_area": (case_vae, dict(h=264, w=328, **FP16)),
     "fp16_pipeline_spatial": (case_pipeline, dict(domain="spatial", **FP16)),
-    "fp16_pipeline_temporal_v": (case_pipeline, dict(domain="temporal", T=4, window=4, stride=1, pred="v_prediction", **FP16)),
-    "fp16_pipeline_bidir_nocfg": (case_pipeline, dict(domain="spatial", window=3, stride=3, bidir=True, gs=1.0, steps=2, **FP16)),
-    "fp16_pipeline_dpm_spatial": (case_pipeline, dict(domain="spatial", sched="dpm", steps=2, window=4, stride=2, bidir=True, **FP16)),
     "fp16_golden_spatial": (case_golden_pipeline, dict(name="spatial", **FP16)),
     "fp16_golden_temporal_v": (case_golden_pipeline, dict(name="temporal_v", **FP16)),
     "fp16_golden_round2_shift": (case_golden_pipeline, dict(name="round2_shift", **FP16)),

@@ -765,8 +765,9 @@ def case_h16_gemm(M, N, K, bias=True, rowbias=False, residual=False, geglu=False
 
 
 def case_h16_conv(B, H, W, Cin, Cout, stride=1, pad=1, pad_hi=None, upsample=False, bias=True, rowbias=False, residual=False,
-                  scale=1.0, out_f32=True, seed=0):
-    """dm4d_conv3x3_nhwc_f16 (incl. the split over the kernel rows on small images with a deep K)."""
+                  scale=1.0, out_f32=True, seed=0, f32side=False):
+    """dm4d_conv3x3_nhwc_f16 (incl. the split over the kernel rows on small images with a deep K).
+    f32side with out_f32=False: fp32 row bias into an fp16 result (conv1 of a resnet in front of norm2)."""
     from diffuman4d_amd.host import ops
     g = torch.Generator().manual_seed(seed)
     x = _rndh((B, Cin, H, W), g)
@@ -776,7 +777,7 @@ def case_h16_conv(B, H, W, Cin, Cout, stride=1, pad=1, pad_hi=None, upsample=Fal
     ph = pad if pad_hi is None else pad_hi
     ref = F.conv2d(F.pad(xi, (pad, ph, pad, ph)), w.double(), b.double() if bias else None, stride=stride)
     Ho, Wo = ref.shape[-2:]
-    sdt = torch.float32 if out_f32 else F16
+    sdt = torch.float32 if (out_f32 or f32side) else F16
     rb = torch.randn(B, Cout, generator=g).to(sdt) if rowbias else None
     res = torch.randn(B, Ho, Wo, Cout, generator=g).to(sdt) if residual else None
     if rb is not None:
@@ -789,6 +790,7 @@ def case_h16_conv(B, H, W, Cin, Cout, stride=1, pad=1, pad_hi=None, upsample=Fal
     out = ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().to(d), wt, bias=b.to(d) if bias else None,
                       rowbias=rb.to(d) if rb is not None else None, residual=res.to(d) if res is not None else None, stride=stride,
                       pad=pad, pad_hi=pad_hi, upsample=upsample, out_scale=scale, out_f32=out_f32)
+    assert out.dtype == (torch.float32 if out_f32 else F16)
     got = out.double().cpu().permute(0, 3, 1, 2)
     return rel_l2(got, ref), float((got - ref).abs().max())
 
@@ -821,12 +823,15 @@ def case_h16_conv_up2x(B, H, W, Cin, Cout, bias=True, seed=0):
     return rel_l2(got, ref), float((got - ref).abs().max())
 
 
-def case_h16_groupnorm(B, HW, C1, C2=0, groups=32, silu=True, eps=1e-5, mean_shift=0.0, seed=0, raw=False):
-    """raw: the second output (fp16 of the un-normalised concat, the shortcut convolution's operand) must be bit for bit what ops.split makes."""
+def case_h16_groupnorm(B, HW, C1, C2=0, groups=32, silu=True, eps=1e-5, mean_shift=0.0, seed=0, raw=False, f16in=False):
+    """raw: the second output (fp16 of the un-normalised concat, the shortcut convolution's operand) must be bit for bit what ops.split makes.
+    f16in: the input is an fp16 tensor (dm4d_groupnorm_nhwc_f16_f16: conv1's output in front of norm2); reference on the same fp16 numbers."""
     from diffuman4d_amd.host import ops
     g = torch.Generator().manual_seed(seed)
     x1 = torch.randn(B, HW, C1, generator=g) * 2 + mean_shift
     x2 = torch.randn(B, HW, C2, generator=g) if C2 else None
+    if f16in:
+        x1, x2 = x1.to(F16), (x2.to(F16) if C2 else None)
     C = C1 + C2
     gam, bet = (1.0 + 0.1 * torch.randn(C, generator=g)).to(F16), (0.1 * torch.randn(C, generator=g)).to(F16)
     x = torch.cat([x1, x2], dim=-1) if C2 else x1
@@ -853,6 +858,51 @@ def case_h16_layernorm(M, C, seed=0):
     out = ops.layernorm(x.cuda(), gam.cuda(), bet.cuda(), 1e-5)
     assert out.dtype == F16 and out.shape == (M, C)
     got = out.double().cpu()
+    return rel_l2(got, ref), float((got - ref).abs().max())
+
+
+def case_h16_ff_proj_fused(M, C=320, hidden=1280, bias=True, out_f32=False, seed=0, strided=False):
+    """FeedForward.after_attention_f16 (dm4d_attn_out_ff_geglu_fused_f16): the tail of a transformer block of the fp16 precision in ONE
+    launch against (a) the four launches it replaces -- the same products and rounding points, fp32 sums in another order: agreement to
+    fp32 rounding (1e-6 on an fp32 result; an fp16 result may differ by one fp16 ulp where the fp32 sums straddle a rounding boundary)
+    -- and (b) the fp64 reference of attention.py:88-90 + :129-149 with the two fp16 roundings (norm3's output, the hidden tensor)."""
+    from diffuman4d_amd.host import ops
+    g = torch.Generator().manual_seed(seed)
+    a = _rndh((M, C), g)
+    x = torch.randn(M, C, generator=g) * 2
+    wo = _rndh((C, C), g, 1.0 / math.sqrt(C))
+    w1, w2 = _rndh((2 * hidden, C), g, 1.0 / math.sqrt(C)), _rndh((C, hidden), g, 1.0 / math.sqrt(hidden))
+    bo, b1, b2 = (_rndh((C,), g, 0.5), _rndh((2 * hidden,), g, 0.5), _rndh((C,), g, 0.5)) if bias else (None, None, None)
+    gam, bet = (1.0 + 0.1 * torch.randn(C, generator=g)).to(F16), (0.1 * torch.randn(C, generator=g)).to(F16)
+    h = a.double() @ wo.double().t() + (bo.double() if bias else 0.0) + x.double()
+    nn_ = F.layer_norm(h, (C,), gam.double(), bet.double(), 1e-5).to(F16).double()
+    pre = nn_ @ w1.double().t() + (b1.double() if bias else 0.0)
+    u, gate = pre.chunk(2, dim=-1)
+    hid = (u * F.gelu(gate)).to(F16).double()
+    ref = hid @ w2.double().t() + (b2.double() if bias else 0.0) + h
+    d = "cuda"
+    dev = lambda t: None if t is None else t.to(d)  # noqa: E731
+    ff = ops.FeedForward(dev(w1), dev(b1), dev(w2), dev(b2))
+    assert ff.packed is not None, "fused feed-forward not built for this shape"
+    ad, xd = dev(a), dev(x)
+    if strided:
+        ad = torch.cat([ad, ad], dim=1)[:, :C]
+        xd = torch.cat([xd, xd], dim=1)[:, C:]
+    lnp = (dev(gam), dev(bet), 1e-5)
+    old = ops.FF_PROJ_FUSED
+    try:
+        ops.FF_PROJ_FUSED = True
+        one = ff.after_attention_f16(ad, dev(wo), dev(bo), xd, lnp, out_f32)
+        ops.FF_PROJ_FUSED = False
+        four = ff.after_attention_f16(ad, dev(wo), dev(bo), xd, lnp, out_f32)
+    finally:
+        ops.FF_PROJ_FUSED = old
+    assert one.dtype == (torch.float32 if out_f32 else F16) and one.shape == (M, C)
+    between = rel_l2(one.double().cpu(), four.double().cpu())
+    # the hidden tensor's fp16 rounding can flip on an fp32-order difference of norm3's statistics: isolated elements, far below the
+    # distance either form has to the fp64 reference
+    assert between <= (2e-5 if out_f32 else 1e-4), f"one launch against four: rel-L2 {between:.3e}"
+    got = one.double().cpu()
     return rel_l2(got, ref), float((got - ref).abs().max())
 
 
@@ -1285,7 +1335,14 @@ CASES = {
     "h16_gemm_deep": (case_h16_gemm, dict(M=1440, N=1280, K=5120, residual=True)),
     "h16_gemm_wide_k640": (case_h16_gemm, dict(M=23040, N=1280, K=640, residual=False, out_f32=False)),
     "h16_gemm_two_sources": (case_h16_gemm, dict(M=2880, N=640, K=1920, a2=640)),
+    "h16_ff_proj_fused_128": (case_h16_ff_proj_fused, dict(M=128)),
+    "h16_ff_proj_fused_tail_f32out": (case_h16_ff_proj_fused, dict(M=300, out_f32=True, seed=1)),
+    "h16_ff_proj_fused_nobias_small_hidden": (case_h16_ff_proj_fused, dict(M=257, hidden=96, bias=False, seed=2)),
+    "h16_ff_proj_fused_strided": (case_h16_ff_proj_fused, dict(M=384, strided=True, seed=4)),
+    "h16_ff_proj_fused_judged": (case_h16_ff_proj_fused, dict(M=32 * 2880, seed=5)),
     "h16_conv_l0": (case_h16_conv, dict(B=2, H=72, W=40, Cin=320, Cout=320, rowbias=True)),
+    "h16_conv_l0_f32rowbias_h16out": (case_h16_conv, dict(B=2, H=72, W=40, Cin=320, Cout=320, rowbias=True, out_f32=False, f32side=True)),
+    "h16_conv_9x5_splitk_f32rowbias_h16out": (case_h16_conv, dict(B=4, H=9, W=5, Cin=1280, Cout=1280, rowbias=True, out_f32=False, f32side=True)),
     "h16_conv_l0_tall": (case_h16_conv, dict(B=24, H=72, W=40, Cin=320, Cout=320, rowbias=True, residual=True)),
     "h16_conv_resid_scale": (case_h16_conv, dict(B=2, H=36, W=20, Cin=640, Cout=640, residual=True, scale=0.5)),
     "h16_conv_l1_wide": (case_h16_conv, dict(B=32, H=36, W=20, Cin=640, Cout=640, rowbias=True)),
@@ -1309,6 +1366,10 @@ CASES = {
     "h16_gn_two_sources": (case_h16_groupnorm, dict(B=2, HW=180, C1=1280, C2=640)),
     "h16_gn_vae_128ch_eps6": (case_h16_groupnorm, dict(B=2, HW=4096, C1=128, eps=1e-6)),
     "h16_gn_mean_200sigma": (case_h16_groupnorm, dict(B=2, HW=512, C1=64, groups=8, silu=False, mean_shift=400.0)),
+    "h16_gn_f16in_l0_two_launch": (case_h16_groupnorm, dict(B=4, HW=2880, C1=320, f16in=True)),
+    "h16_gn_f16in_l2_resident": (case_h16_groupnorm, dict(B=3, HW=180, C1=1280, f16in=True, seed=1)),
+    "h16_gn_f16in_l3": (case_h16_groupnorm, dict(B=5, HW=45, C1=1280, f16in=True, seed=2)),
+    "h16_gn_f16in_mean_50sigma": (case_h16_groupnorm, dict(B=2, HW=512, C1=64, groups=8, silu=False, mean_shift=100.0, f16in=True)),
     "h16_gn_odd_channels": (case_h16_groupnorm, dict(B=2, HW=77, C1=66, groups=6, silu=True)),
     "h16_ln": (case_h16_layernorm, dict(M=1000, C=320)),
     "h16_ln_1280": (case_h16_layernorm, dict(M=333, C=1280)),
