@@ -367,6 +367,9 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs&
   //  * the two halves of the workgroup half a step apart, so that every SIMD pairs one wave in product 1 with one wave in GEGLU:
   //    305-336 us, SLOWER -- a wave that streams MFMAs starves the vector ALU of the wave it shares the SIMD with (DESIGN.md
   //    section 4, issue probe): vector work hides only behind a wave's OWN MFMAs, which is what A + B in one block provide.
+  // Round 6 (profiles/r06_ffp1.log): product 1's weight fragments read 3 / 4 / 6 k steps ahead of their MFMA with hand-counted waits
+  // (the compiler keeps one read in flight): bit-identical, +-1 % per launch, null over a bench step -- the partner wave already
+  // covers the LDS latency; removed.
   auto product1 = [&](int s, u16 bias_bits) {
     const char* wb = smem + (s & 1) * WBUF;
     f32x16_t sa = mfma_t<PAR>(one0, k0_fragment(bias_bits, lh), zero);
