@@ -10,6 +10,11 @@
 namespace {
 
 constexpr int FF_BM = 128, FF_STEP = 32;
+#ifdef FF_TILE_LN
+constexpr bool FF_REG_LN = false;  // round 3's form of the block tail: h through the LDS tile and the output buffer (A/B builds)
+#else
+constexpr bool FF_REG_LN = true;
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // A tile of FF_BM rows x CK channels: HBM -> LDS by DMA as CK / 64 slabs of [FF_BM rows][64 k] (128-byte row pieces, the 16-byte
@@ -211,7 +216,13 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs&
     }
     // residual in the accumulators' own layout (lane: row l31 of its 32, runs of four columns): 8-byte loads, all issued first
     issue_w1(0, 0);  // buffer 0 (Wo slab NSLAB - 1 was its last reader, behind the barrier above); lands while h is formed
-    if constexpr (PAR == 2) {
+    if constexpr (PAR == 2 || FF_REG_LN) {
+      // Round 6, fast precision too (FF_REG_LN; -DFF_TILE_LN restores round 3's form for the A/B): the same structure on bf16 tensors --
+      // v = A0 Wo^T + bo + X is rounded to bf16 IN THE REGISTERS (the rounding point of gemm(A0, Wo, bias, residual): h as the residual
+      // stream holds it), norm3 is taken from those values, and they start the accumulators of the second product, so h is neither stored
+      // nor re-read and the serial row-by-row LayerNorm over the LDS tile (36 us of a 348 us launch at M = 92 160, profiles/r06_ffabl2.log)
+      // is gone.  Same products and rounding points as the four launches; the ORDER of fp32 additions differs (row statistics, h first in
+      // the output sum), so the two forms agree except for isolated one-ulp differences of a bf16 rounding (tests/opcheck.py ff_proj_fused_*).
       // Precision "fp16": the residual stream is fp32 and h = A0 Wo^T + bo + X is never rounded -- and never stored.  It stays in
       // the accumulators it was formed in: norm3 is taken from them (row sums over the lane pair l, l ^ 32 and, through 2 KB of LDS,
       // over the two waves that share a row: two-pass mean / variance in fp32 like ln_row_stats, y rounded once to fp16 with the
@@ -220,20 +231,46 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs&
       // precision (gemm -> fp32 h, layernorm, gemm GEGLU, gemm + fp32 residual) the 118 MB of h per launch are neither written nor
       // read twice; the sums differ from theirs only in the order of fp32 additions (h enters the output sum first instead of last,
       // the row statistics are added up in a different order): tests/opcheck.py h16_ff_proj_fused_*.
+      // (lane-derived addresses of this block are formed HERE, from a copy of the lane id the compiler cannot see through: hoisted above
+      // the projection loop they would cost that loop -- hacc + xf = 160 registers -- its last free registers)
+      int lane_b = lane;
+      asm volatile("" : "+v"(lane_b));
+      const int l31 = lane_b & 31, lh = lane_b >> 5;
       const int r = wm * 32 + l31;
       {
         int m = m0 + r;
         if (m > p.M - 1) m = p.M - 1;
-        const float* xr = reinterpret_cast<const float*>(proj.X) + (int64_t)m * proj.ldx + wn * (CK / 2) + 4 * lh;
+        if constexpr (PAR == 2) {
+          const float* xr = reinterpret_cast<const float*>(proj.X) + (int64_t)m * proj.ldx + wn * (CK / 2) + 4 * lh;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          f32x4_t rx[4];
+          for (int j = 0; j < NJ; ++j) {
+            f32x4_t rx[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) rx[q] = *reinterpret_cast<const f32x4_t*>(xr + 32 * j + 8 * q);
+            for (int q = 0; q < 4; ++q) rx[q] = *reinterpret_cast<const f32x4_t*>(xr + 32 * j + 8 * q);
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) hacc[0][j][4 * q + e] += rx[q][e];
+              for (int e = 0; e < 4; ++e) hacc[0][j][4 * q + e] += rx[q][e];
+          }
+        } else {
+          const u16* xr = proj.X + (int64_t)m * proj.ldx + wn * (CK / 2) + 4 * lh;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            uint2 rx[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rx[q] = *reinterpret_cast<const uint2*>(xr + 32 * j + 8 * q);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float x4[4] = {bf2f((u16)(rx[q].x & 0xffffu)), bf2f((u16)(rx[q].x >> 16)), bf2f((u16)(rx[q].y & 0xffffu)), bf2f((u16)(rx[q].y >> 16))};
+              // h as the residual stream holds it: one rounding to bf16, kept as an fp32 value
+              const uint32_t p01 = pack_bf2(hacc[0][j][4 * q + 0] + x4[0], hacc[0][j][4 * q + 1] + x4[1]);
+              const uint32_t p23 = pack_bf2(hacc[0][j][4 * q + 2] + x4[2], hacc[0][j][4 * q + 3] + x4[3]);
+              hacc[0][j][4 * q + 0] = bf2f((u16)(p01 & 0xffffu));
+              hacc[0][j][4 * q + 1] = bf2f((u16)(p01 >> 16));
+              hacc[0][j][4 * q + 2] = bf2f((u16)(p23 & 0xffffu));
+              hacc[0][j][4 * q + 3] = bf2f((u16)(p23 >> 16));
+            }
+          }
         }
       }
       float* st = reinterpret_cast<float*>(smem + W1_BYTES);  // [pass][wn][FF_BM]: buffer 0's W2 area, first written in body 0
@@ -271,19 +308,28 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs&
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const uint2 g2 = *reinterpret_cast<const uint2*>(gp + 32 * j + 8 * q), b2 = *reinterpret_cast<const uint2*>(bp + 32 * j + 8 * q);
-          const float g[4] = {h2f((u16)(g2.x & 0xffffu)), h2f((u16)(g2.x >> 16)), h2f((u16)(g2.y & 0xffffu)), h2f((u16)(g2.y >> 16))};
-          const float bt[4] = {h2f((u16)(b2.x & 0xffffu)), h2f((u16)(b2.x >> 16)), h2f((u16)(b2.y & 0xffffu)), h2f((u16)(b2.y >> 16))};
+          auto par = [](u16 v) { return PAR == 2 ? h2f(v) : bf2f(v); };
+          const float g[4] = {par((u16)(g2.x & 0xffffu)), par((u16)(g2.x >> 16)), par((u16)(g2.y & 0xffffu)), par((u16)(g2.y >> 16))};
+          const float bt[4] = {par((u16)(b2.x & 0xffffu)), par((u16)(b2.x >> 16)), par((u16)(b2.y & 0xffffu)), par((u16)(b2.y >> 16))};
           float y[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) y[e] = sat_h((hacc[0][j][4 * q + e] - mu) * rs * g[e] + bt[e]);
+          for (int e = 0; e < 4; ++e) {
+            y[e] = (hacc[0][j][4 * q + e] - mu) * rs * g[e] + bt[e];
+            if constexpr (PAR == 2) y[e] = sat_h(y[e]);
+          }
           uint2 pk;
-          pk.x = pack_h2(y[0], y[1]);
-          pk.y = pack_h2(y[2], y[3]);
+          if constexpr (PAR == 2) {
+            pk.x = pack_h2(y[0], y[1]);
+            pk.y = pack_h2(y[2], y[3]);
+          } else {
+            pk.x = pack_bf2(y[0], y[1]);
+            pk.y = pack_bf2(y[2], y[3]);
+          }
           const int n = wn * (CK / 2) + 32 * j + 8 * q;  // first of the four columns, before the + 4 lh
           *reinterpret_cast<uint2*>(trow + (n >> 6) * (FF_BM * 128) + ((((n & 63) >> 3) ^ key) << 4)) = pk;
         }
       // b2 as one more k step on top of h: the accumulators of the second product
-      const bf16x8_t one_h = k0_fragment(0x3c00, lh);
+      const bf16x8_t one_h = k0_fragment(PAR == 2 ? 0x3c00 : 0x3f80, lh);
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const u16 bits = p.bias ? p.bias[wn * (CK / 2) + j * 32 + l31] : (u16)0;
@@ -326,7 +372,7 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs&
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }
-  if (PAR != 2 && ln.gamma) {  // norm3 folded in: the tile holds x, not LayerNorm(x) (bit-identical to the stand-alone launch, rows_layernorm)
+  if (!(PROJ && (PAR == 2 || FF_REG_LN)) && ln.gamma) {  // norm3 folded in: the tile holds x, not LayerNorm(x) (bit-identical to the stand-alone launch, rows_layernorm)
     if constexpr (PROJ) {
       rows_layernorm<CK, true>(smem + Y_OFF, ln, wave, lane, p.C + (int64_t)m0 * p.ldc, p.ldc, p.M - m0);
     } else {
@@ -345,7 +391,7 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs&
   __builtin_amdgcn_s_barrier();  // every wave has its y rows: buffer 1 and the H tile may be written
   asm volatile("" ::: "memory");
 
-  if constexpr (PAR != 2) acc_init<1, NJ, CK / 2>(p, acc, 0, wn, lane, false);  // b2 as the first k step of product 2
+  if constexpr (!(PROJ && (PAR == 2 || FF_REG_LN))) acc_init<1, NJ, CK / 2>(p, acc, 0, wn, lane, false);  // b2 as the first k step of product 2
   f32x16_t zero;
 #pragma unroll
   for (int r = 0; r < 16; ++r) zero[r] = 0.f;
@@ -369,7 +415,10 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs&
   //    section 4, issue probe): vector work hides only behind a wave's OWN MFMAs, which is what A + B in one block provide.
   // Round 6 (profiles/r06_ffp1.log): product 1's weight fragments read 3 / 4 / 6 k steps ahead of their MFMA with hand-counted waits
   // (the compiler keeps one read in flight): bit-identical, +-1 % per launch, null over a bench step -- the partner wave already
-  // covers the LDS latency; removed.
+  // covers the LDS latency; removed.  Timing-only ablations of the same round (profiles/r06_ffabl.log, r06_ffabl2.log; M = 92 160, 348 us):
+  // per step the kernel pays product 1 + product 2 + GEGLU + DMA issue + barrier IN SERIES (1690 + 835 + 780 + 500 + 335 cycles for 1984 cycles
+  // of matrix pipe per SIMD); the launch without the steady loop is 121 us, of which the row-by-row LayerNorm over the LDS tile was 36 us
+  // and the epilogue 20 us -- hence FF_REG_LN above.
   auto product1 = [&](int s, u16 bias_bits) {
     const char* wb = smem + (s & 1) * WBUF;
     f32x16_t sa = mfma_t<PAR>(one0, k0_fragment(bias_bits, lh), zero);
@@ -496,8 +545,9 @@ __global__ __launch_bounds__(512) void ff_fused_kernel(GemmParams p, LnArgs ln, 
 }
 
 // The tail of a transformer block in one launch: attention output projection + residual, norm3, feed-forward + residual
-// (attention.py:88-90 and :129-149).  p.res == p.C: the projection's result goes out once through rows_layernorm and comes back as
-// the epilogue's residual, element by element through the lane that overwrites it.
+// (attention.py:88-90 and :129-149).  Round 6 (FF_REG_LN): h stays in registers from the projection to the end of the launch.
+// (-DFF_TILE_LN, rounds 3-5: p.res == p.C, the projection's result goes out once through rows_layernorm and comes back as the
+// epilogue's residual, element by element through the lane that overwrites it.)
 template <int CK>
 __global__ __launch_bounds__(512) void ff_proj_fused_kernel(GemmParams p, LnArgs ln, ProjArgs proj, const u16* __restrict__ W1p,
                                                             const u16* __restrict__ b1p, const u16* __restrict__ W2p, int nsteps) {
@@ -610,7 +660,12 @@ extern "C" int dm4d_attn_out_ff_geglu_fused_bf16(void* stream, const void* A0, i
   if (Out == A0 || Out == X) return dm4d_set_error(DM4D_ERR_ARG, "attn_out_ff_geglu_fused: the output may not alias an input");
   GemmParams p{};
   p.A = (const u16*)A0; p.lda = lda0; p.C = (u16*)Out; p.ldc = ldo; p.M = M; p.N = C; p.K = hidden;
-  p.bias = (const u16*)b2; p.res = (const u16*)Out; p.ld_res = ldo; p.flags = 0; p.out_scale = 1.0f; p.splits = 1;
+  p.bias = (const u16*)b2; p.flags = 0; p.out_scale = 1.0f; p.splits = 1;
+  if (FF_REG_LN) {  // h starts the accumulators: the epilogue has no residual to add
+    p.res = nullptr; p.ld_res = 0;
+  } else {
+    p.res = (const u16*)Out; p.ld_res = ldo;
+  }
   p.rows_per_rb = 1; p.tiles_n = 1;
   const LnArgs ln{(const u16*)ln_gamma, (const u16*)ln_beta, ln_eps};
   const ProjArgs proj{(const u16*)A0, lda0, (const u16*)Wo, (const u16*)bo, (const u16*)X, ldx};

@@ -335,7 +335,9 @@ class FeedForward:
 
     def after_attention(self, a: torch.Tensor, wo: torch.Tensor, bo: Optional[torch.Tensor], x: torch.Tensor, ln) -> torch.Tensor:
         """The tail of a transformer block: h = a wo^T + bo + x (attention output projection + residual), then ff(LayerNorm(h)) + h.
-        One launch where the fused kernel is built for the shape (FF_PROJ_FUSED), gemm + __call__ otherwise; bit-identical."""
+        One launch where the fused kernel is built for the shape (FF_PROJ_FUSED), gemm + __call__ otherwise: the same products and bf16
+        rounding points either way (since round 6 the one-launch form adds its fp32 terms in another order: one-ulp differences on isolated
+        elements, tests/opcheck.py ff_proj_fused_*)."""
         # the one-launch form wants 16-byte aligned rows (row strides in multiples of 8 elements) and a contiguous square weight; a
         # column view of a wider tensor as `a` or `x` takes the separate launches, which accept any 8-element-aligned view
         aligned = all(t.data_ptr() % 16 == 0 and t.stride(0) % 8 == 0 for t in (a, x)) and wo.data_ptr() % 16 == 0

@@ -248,8 +248,11 @@ int dm4d_ff_geglu_fused_bf16(void* stream, const void* Y, int64_t ldy, const voi
  * (attention.py:88-90: attn1.to_out + residual; :129-149: ff(norm3(h)) + h):
  *     h = A0 Wo^T + bo + X          (A0 [M, C] = the attention output, Wo [C, C] row-major, bo [C] or NULL, X [M, C] = the block's input)
  *     Out = h + W2 (u * gelu(g)) + b2,   [u | g] = W1 LayerNorm(h) + b1
- * h is rounded to bf16 once, exactly as dm4d_gemm_bf16(A0, Wo, bias, residual) leaves it, and lives in Out between the two halves
- * of the launch: bit-identical to that GEMM followed by dm4d_ff_geglu_fused_bf16 with LayerNorm.  Out may not alias A0 or X.       */
+ * h is rounded to bf16 once, exactly as dm4d_gemm_bf16(A0, Wo, bias, residual) leaves it.  Since round 6 it never leaves the registers:
+ * LayerNorm is taken from the accumulators it was formed in, and its bf16 values start the accumulators of the second product
+ * (Out = (h + b2) + W2 (...)), so nothing of h is stored or re-read.  Same products and rounding points as that GEMM followed by
+ * dm4d_ff_geglu_fused_bf16 with LayerNorm; fp32 additions in another order (isolated one-ulp differences of a bf16 rounding; rounds
+ * 3-5 kept h in Out between the two halves of the launch and were bit-identical).  Out may not alias A0 or X.                      */
 int dm4d_attn_out_ff_geglu_fused_bf16(void* stream, const void* A0, int64_t lda0, const void* Wo, const void* bo, const void* X,
                                       int64_t ldx, const void* ln_gamma, const void* ln_beta, float ln_eps, const void* W1p,
                                       const void* b1p, const void* W2p, const void* b2, void* Out, int64_t ldo, int M, int C,

@@ -72,6 +72,23 @@ def bench_ff_proj(M, C=320, hidden=1280, tag=""):
     ops.FF_PROJ_FUSED = True
 
 
+def bench_ff_proj_h16(M, C=320, hidden=1280, tag=""):
+    """The same tail in the fp16 precision: one launch (fp32 h kept in the accumulators) vs the four launches it replaces."""
+    F16 = torch.float16
+    r16 = lambda *s, scale=1.0: (torch.randn(*s, device="cuda") * scale).to(F16)  # noqa: E731
+    a, x = r16(M, C), torch.randn(M, C, device="cuda")
+    wo, bo = r16(C, C, scale=1 / math.sqrt(C)), r16(C)
+    ff = ops.FeedForward(r16(2 * hidden, C, scale=1 / math.sqrt(C)), r16(2 * hidden), r16(C, hidden, scale=1 / math.sqrt(hidden)), r16(C))
+    fl = 2.0 * M * (3 * hidden + C) * C
+    lnp = (r16(C), r16(C), 1e-5)
+    for rep in range(2):
+        for fused in (True, False):
+            ops.FF_PROJ_FUSED = fused
+            t = timeit(lambda: ff.after_attention_f16(a, wo, bo, x, lnp, False))
+            print(f"ffproj16{tag:8s} M={M:6d} C={C} hidden={hidden} {'one launch      ' if fused else 'four launches   '} round {rep}  {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s", flush=True)
+    ops.FF_PROJ_FUSED = True
+
+
 def bench_conv(B, H, W, Cin, Cout, stride=1, upsample=False, tag=""):
     x = rnd(B, H, W, Cin)
     wt = rnd(Cout, 9 * Cin, scale=1 / math.sqrt(9 * Cin))
@@ -186,6 +203,10 @@ def main():
     if only == "ffproj":
         bench_ff_proj(32 * 2880, tag=" L0 F16")
         bench_ff_proj(48 * 2880, tag=" L0 F24")
+        return
+    if only == "ffproj16":
+        bench_ff_proj_h16(32 * 2880, tag=" L0 F16")
+        bench_ff_proj_h16(48 * 2880, tag=" L0 F24")
         return
     if only == "attn":
         print("attn q_scaled:", QS, flush=True)
