@@ -535,9 +535,9 @@ def cpu_baseline_and_parity(pipe, state_dict, task, frames: int, threads: int, b
         "modes": {k: {"rel_l2": float(f"{e:.3e}"), "rel_l2_fresh_latents": None if k not in fresh else float(f"{fresh[k]:.3e}"),
                       "meets_north_star": bool(max(e, fresh.get(k, 0.0)) <= 1e-3)}
                   for k, e in (("fast", err), ("fp16", errs["fp16"]), ("parity", errs["parity"]))},
-        "rel_l2": round(err, 6), "north_star_tolerance": 1e-3, "meets_north_star": bool(err <= 1e-3),
+        "rel_l2": float(f"{err:.3e}"), "north_star_tolerance": 1e-3, "meets_north_star": bool(float(f"{err:.3e}") <= 1e-3),  # the figure of modes.fast
         # the three distances between {HIP, oracle fp32, oracle bf16} on THIS input and THESE weights
-        "hip_vs_oracle_fp32": round(err, 6),
+        "hip_vs_oracle_fp32": float(f"{err:.3e}"),
         "hip_vs_oracle_bf16": None if err_vs_bf16 is None else round(err_vs_bf16, 6),
         "oracle_bf16_vs_oracle_fp32": None if yard_live is None else round(yard_live, 6),
         "oracle_bf16_seconds": None if dt_bf is None else round(dt_bf, 1),

@@ -75,6 +75,34 @@ __global__ __launch_bounds__(256) void split_kernel(SplitParams p) {
   }
 }
 
+// precision "fp16", the plain case (round 6): contiguous channels, every count a multiple of 8, 16-byte aligned rows -- eight channels per
+// thread, 2 x 16 bytes in, 16 bytes out (the per-element kernel above moved 1.6 TB/s on the 72 x 40 level's tensors; same values:
+// act, scale, one saturating rounding)
+__global__ __launch_bounds__(256) void to_f16_vec8_kernel(SplitParams p) {
+  const int CV = p.Cp >> 3;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.M * CV) return;
+  const int64_t m = i / CV;
+  const int c = (int)(i - m * CV) << 3;
+  float v[8];
+  if (c < p.C1 + p.C2) {
+    const float* src = c < p.C1 ? p.X1 + m * p.rs1 + c : p.X2 + m * p.rs2 + (c - p.C1);
+    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(src), b = *reinterpret_cast<const f32x4_t*>(src + 4);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+    v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float x = v[e];
+    if (p.act == 1) x = silu_f(x);
+    v[e] = x * p.scale;
+  }
+  stg16(p.Y + m * p.ldy + c, pack8h_sat(v));
+}
+
 // ------------------------------------------------------------------------------------------------
 // GroupNorm (+SiLU), fp32 NHWC in (two sources = channel concat), operand out.  Sums in fp64: no shift trick needed.
 // ------------------------------------------------------------------------------------------------
@@ -655,6 +683,12 @@ extern "C" int dm4d_to_f16_f32(void* stream, const float* X1, int64_t row_stride
   if (!X1 || !Y || M <= 0 || C1 <= 0 || C2 < 0 || (C2 > 0 && !X2) || Cp < C1 + C2 || ldy < Cp)
     return dm4d_set_error(DM4D_ERR_ARG, "to_f16_f32: bad arguments");
   SplitParams p{X1, row_stride1, col_stride1, X2, row_stride2, C1, C2, Cp, M, (u16*)Y, ldy, act_silu, scale, 3};
+  const bool vec8 = col_stride1 == 1 && ((C1 | C2 | Cp) & 7) == 0 && (row_stride1 & 3) == 0 && (C2 == 0 || (row_stride2 & 3) == 0) && (ldy & 7) == 0 &&
+                    (((uintptr_t)X1) & 15) == 0 && (C2 == 0 || (((uintptr_t)X2) & 15) == 0) && (((uintptr_t)Y) & 15) == 0;
+  if (vec8) {
+    hipLaunchKernelGGL(to_f16_vec8_kernel, grid1d(M * (Cp >> 3), 256), dim3(256), 0, (hipStream_t)stream, p);
+    return dm4d_check_launch("to_f16_vec8_kernel");
+  }
   hipLaunchKernelGGL(split_kernel, grid1d(M * Cp, 256), dim3(256), 0, (hipStream_t)stream, p);
   return dm4d_check_launch("split_kernel");
 }

@@ -1326,6 +1326,8 @@ CASES = {
     "h16_split": (case_h16_split, dict()),
     "h16_split_concat_pad_scale": (case_h16_split, dict(M=77, C1=4, C2=0, cpad=32, scale=1.0 / 0.18215)),
     "h16_split_two_sources": (case_h16_split, dict(M=333, C1=64, C2=32)),
+    "h16_split_two_sources_pad_vec8": (case_h16_split, dict(M=333, C1=64, C2=32, cpad=128, scale=0.5)),
+    "h16_split_l0_down": (case_h16_split, dict(M=2 * 2880, C1=320)),
     "h16_split_silu": (case_h16_split, dict(M=64, C1=320, silu=True)),
     "h16_split_transposed_pad": (case_h16_split, dict(M=64, C1=45, cpad=64, transposed=True)),
     "h16_gemm_resid": (case_h16_gemm, dict(M=1000, N=320, K=320, residual=True)),
