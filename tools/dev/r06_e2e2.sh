@@ -14,3 +14,9 @@ for prec in fast fp16; do
   timeout 1200 python tools/e2e_demo.py --exp demo_4d $C $P model.precision=$prec > gpurun_out/r06b_e2e_demo_4d_${prec}_strict.json 2> gpurun_out/r06b_e2e_${prec}_strict.err
   cut -c1-700 gpurun_out/r06b_e2e_demo_4d_${prec}_strict.json
 done
+# stacks of four (bench A/B of the same tree, profiles/r06_task_batch_streams.log: 3 x 4 +0.9 %, 2 x 4 +1.8 % over the default 3 x 2): end to end
+for cfg in "3 4" "2 4"; do
+  set -- $cfg
+  timeout 900 python tools/e2e_demo.py --exp demo_4d --fast-vae --prune $C --gpu-streams $1 --task-batch $2 $P model.precision=fast > gpurun_out/r06b_e2e_demo_4d_fast_s$1_b$2.json 2> gpurun_out/r06b_e2e_fast_s$1_b$2.err
+  cut -c1-700 gpurun_out/r06b_e2e_demo_4d_fast_s$1_b$2.json
+done

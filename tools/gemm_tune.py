@@ -54,7 +54,8 @@ def sweep(name, fn, flops):
 
 def main():
     tot_auto = tot_best = 0.0
-    for B in (32, 48):
+    batches = tuple(int(v) for v in sys.argv[1].split(",")) if len(sys.argv) > 1 else (32, 48)  # 64,96: the launches of a 2-task stack
+    for B in batches:
         print(f"===== B = {B} =====")
         for lvl, (h, w, c) in enumerate([(72, 40, 320), (36, 20, 640), (18, 10, 1280), (9, 5, 1280)]):
             M = B * h * w
