@@ -231,8 +231,9 @@ __device__ __forceinline__ void ff_fused_body(const GemmParams& p, const LnArgs&
       // precision (gemm -> fp32 h, layernorm, gemm GEGLU, gemm + fp32 residual) the 118 MB of h per launch are neither written nor
       // read twice; the sums differ from theirs only in the order of fp32 additions (h enters the output sum first instead of last,
       // the row statistics are added up in a different order): tests/opcheck.py h16_ff_proj_fused_*.
-      // (lane-derived addresses of this block are formed HERE, from a copy of the lane id the compiler cannot see through: hoisted above
-      // the projection loop they would cost that loop -- hacc + xf = 160 registers -- its last free registers)
+      // (lane-derived addresses of this block are formed HERE, from a copy of the lane id the compiler cannot see through, so that they do
+      // not live through the projection loop, whose hacc + xf hold 160 registers; the fast-precision kernel still spills 7 dwords of
+      // loop-invariant addresses around this block -- none inside the steady loop)
       int lane_b = lane;
       asm volatile("" : "+v"(lane_b));
       const int l31 = lane_b & 31, lh = lane_b >> 5;

@@ -1225,6 +1225,13 @@ int choose_cfg(const GemmParams& p) {
       if (lin2_ok(p)) return 69;
       if (p.K >= 1024) return 46;
     }
+#ifndef DM4D_NO_STACK_CFG  // (-DDM4D_NO_STACK_CFG: the table as tuned on single tasks, for the A/B)
+    // Round 6: the launches of a 2-task stack (CFG batch 64 / 96: 720 / 1080 row tiles of 256 at level 0) -- sweep of every id on those
+    // shapes, profiles/r06_gemm_tune_stacks.log: the level-0 QKV projection (N = 960, K = 320) on the 320-wide tile (three column tiles,
+    // no padded fourth: 209 -> 181 us, 301 -> 262 us), level 1's feed-forward output projection on the 160-wide one (197 -> 181, 288 -> 276)
+    if (!geglu && k64 && p.K == 320 && p.N == 960 && tm256 >= 700) return 46;
+    if (!geglu && p.N == 640 && p.K >= 2560 && tm256 >= 180 && lin2_ok(p)) return 69;
+#endif
     // deep-K layers (K >= 1280): the second form (gemm_lin2_kernel), bit-identical, -4..-17 % per launch
     // (profiles/r02_lin2_ab.log): 128x128 tiles with two workgroups per CU wherever they fill the chip, the 8-wave
     // 3-stage 128x128 tile for the few-row, very deep output projections of the deepest level, and the 256x128 K-slab-64
@@ -1274,6 +1281,12 @@ int choose_cfg(const GemmParams& p) {
         // 128 rows with two workgroups per CU (-6..-12 % per launch against ids 33 / 35 at CFG batch 32 and 48, cold-cache sweep
         // profiles/r03_strip_160_tiles.log); same K order as every strip kernel, so the choice never changes a result
         if (p.N == 320 && tm256 >= 256) {
+#ifndef DM4D_NO_STACK_CFG
+          // round 6, stacked launches (profiles/r06_gemm_tune_stacks.log): with 720 / 1080 row tiles the 320-wide tile -- the A strip staged
+          // once per kernel row for all of N -- is ahead of the 160-wide ones: 320 -> 320 292 -> 269 us, 960 -> 320 845 -> 758 / 1298 -> 1196,
+          // 640 -> 320 570 -> 510 / 874 -> 817 (at CFG batch 32 / 48 the 160-wide tiles stay: r03_strip_160_tiles.log)
+          if (tm256 >= 700) return 35;
+#endif
           const long t2 = tm256 * 2, last = t2 % 256;
           return (last == 0 || last >= 128) ? 37 : 36;
         }
