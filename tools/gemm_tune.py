@@ -22,7 +22,11 @@ def rnd(*s, scale=1.0):
     return (torch.randn(*s, device="cuda") * scale).to(BF)
 
 
-def timeit(f, it=6):
+IT = int(sys.argv[2]) if len(sys.argv) > 2 else 6  # launches per timing
+
+
+def timeit(f, it=None):
+    it = it or IT
     try:
         f()
     except L.Dm4dError:
