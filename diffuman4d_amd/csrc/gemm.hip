@@ -1249,6 +1249,9 @@ int choose_cfg(const GemmParams& p) {
         const long nw = geglu ? 2L * p.N : p.N, tn256 = (nw + 255) / 256, t = tm256 * tn256;
         const double fill = (double)t / (double)(((t + 255) / 256) * 256) * (double)nw / (double)(tn256 * 256);
         if (geglu && ((p.K >= 1280 && fill >= 0.85) || (p.K >= 640 && fill >= 0.95))) return 67;
+        // (round 6, second sweep of the stacked launches: id 67 for level 1's GEGLU projection at fill 0.94 and id 61 for level 2's K = 5120
+        // output projection were 6-8 % ahead per launch in the timing loop and 0.15 ms BEHIND over the Linear family of a bench step:
+        // profiles/r06_stackcfg2.log; not taken)
         if (!geglu && p.K >= 640 && p.N >= 1280 && fill >= 0.85) return 67;
         // one partial round (160-256 tiles) of the N = 1280 projections of level 2 at CFG batch 48: 42 vs 45 us, 122 vs 135 us
         if (!geglu && p.K >= 1280 && p.N == 1280 && t >= 160 && t <= 256) return 67;
@@ -1293,6 +1296,10 @@ int choose_cfg(const GemmParams& p) {
         if (tm128 * ((p.N + 63) / 64) >= 256) return 33;
       } else {
         const long t = tm256 * tn;
+        // (round 6, second sweep of the stacked launches, two passes of 12 launches, profiles/r06_gemm_tune_stacks_p1.log / _p2.log: the
+        // 160-wide tiles for level 1 (N = 640) and 256x128 for level 2 at CFG batch 96 are 4-7 % ahead per launch and take 0.7 ms off the
+        // convolution family of a one-stack-at-a-time pass -- and ADD 0.2-0.3 ms to the bench step with three stacks in flight
+        // (profiles/r06_stackcfg3.log): not taken)
         // N = 640 (level 1) when two 320-wide column tiles make ONE nearly full round of 256 workgroups (CFG batch 32: 180): the A strip
         // is read twice instead of five times, -3..-9 % per launch in both cold sweeps (r02_strip_cold.log, r03_strip_160_tiles.log);
         // at batch 48 the same tile needs a second, nearly empty round and loses 20 %

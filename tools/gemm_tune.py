@@ -14,7 +14,8 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from diffuman4d_amd.host import lib as L, ops  # noqa: E402
 
-BF = torch.bfloat16
+H16 = len(sys.argv) > 3 and sys.argv[3] == "f16"  # the fp16 precision's launches: fp16 operands, fp32 residual / row bias, fp32 or fp16 result
+BF = torch.float16 if H16 else torch.bfloat16
 IDS = [1, 2, 3, 4, 13, 14, 20, 31, 32, 33, 34, 35, 36, 37, 46, 61, 63, 64, 65, 67, 69]  # every id launch_by_id knows (csrc/gemm.hip); unsupported shapes report n/a
 
 
@@ -67,9 +68,9 @@ def main():
                                           ("ff1", 4 * c, c, True, False), ("ff2", c, 4 * c, False, True)):
                 a, wt = rnd(M, K), rnd(2 * N if geglu else N, K, scale=1 / math.sqrt(K))
                 b = rnd(2 * N if geglu else N)
-                r = rnd(M, N) if res else None
+                r = (torch.randn(M, N, device="cuda") if H16 else rnd(M, N)) if res else None  # fp16 precision: the fp32 residual stream
                 cnt = {"proj/out": 3, "qkv": 1, "ff1": 1, "ff2": 1}[tag] * (5 if lvl < 3 else 1)
-                t0, t1 = sweep(f"gemm L{lvl} {tag} M{M} N{N} K{K}", lambda: ops.gemm(a, wt, bias=b, residual=r, geglu=geglu),
+                t0, t1 = sweep(f"gemm L{lvl} {tag} M{M} N{N} K{K}", lambda: ops.gemm(a, wt, bias=b, residual=r, geglu=geglu, out_f32=H16 and res),
                                2.0 * M * K * (2 * N if geglu else N))
                 tot_auto += cnt * t0
                 tot_best += cnt * t1
@@ -82,7 +83,7 @@ def main():
                  (9, 5, 2560, 1280, 1, False, 3), (9, 5, 1280, 1280, 1, True, 1)]
         for (h, w, ci, co, st, up, cnt) in convs:
             x, wt = rnd(B, h, w, ci), rnd(co, 9 * ci, scale=1 / math.sqrt(9 * ci))
-            b, rb = rnd(co), rnd(B, co)
+            b, rb = rnd(co), (torch.randn(B, co, device="cuda") if H16 else rnd(B, co))  # fp16 precision: conv1's fp32 time-embedding row, fp16 result
             ho, wo = ops.conv_out_hw(h, w, st, 1, up)
             t0, t1 = sweep(f"conv {h}x{w} {ci}->{co} s{st} up{int(up)}",
                            lambda: ops.conv3x3(x, wt, bias=b, rowbias=rb, stride=st, upsample=up),
