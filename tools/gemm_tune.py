@@ -23,7 +23,7 @@ def rnd(*s, scale=1.0):
     return (torch.randn(*s, device="cuda") * scale).to(BF)
 
 
-IT = int(sys.argv[2]) if len(sys.argv) > 2 else 6  # launches per timing
+IT = int(sys.argv[2]) if len(sys.argv) > 2 else 6  # launches per timing (`gemm_tune.py vae 12`: the VAE's convolutions)
 
 
 def timeit(f, it=None):
@@ -57,7 +57,21 @@ def sweep(name, fn, flops):
     return res[0], ok[best]
 
 
+def vae():
+    """The SD VAE's stride-1 3x3 convolutions on a micro-batch of 8 images of 576 x 320 (encoder: full / half / quarter / eighth
+    resolution; the decoder runs the same shapes plus the wide first layers)."""
+    B = 8
+    shapes = [(576, 320, 128, 128), (288, 160, 128, 256), (288, 160, 256, 256), (144, 80, 256, 512), (144, 80, 512, 512), (72, 40, 512, 512),
+              (576, 320, 256, 128), (288, 160, 512, 256)]
+    for (h, w, ci, co) in shapes:
+        x, wt = rnd(B, h, w, ci), rnd(co, 9 * ci, scale=1 / math.sqrt(9 * ci))
+        b = rnd(co)
+        sweep(f"vae conv {h}x{w} {ci}->{co}", lambda: ops.conv3x3(x, wt, bias=b), 2.0 * B * h * w * 9 * ci * co)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "vae":
+        return vae()
     tot_auto = tot_best = 0.0
     batches = tuple(int(v) for v in sys.argv[1].split(",")) if len(sys.argv) > 1 else (32, 48)  # 64,96: the launches of a 2-task stack
     for B in batches:

@@ -1,10 +1,13 @@
 #!/bin/bash
-# First contact with an 8-GPU MI355X node (none was available to rounds 1-4: RCCL has only ever run at world size 1 here).
+# First contact with an 8-GPU MI355X node (none was available to rounds 1-6: RCCL has only ever run at world size 1 here).
 # Runs, in order and each to its own log under gpurun_out/scale/:
 #   1. the driver's scaling lines        python bench.py --gpus N --steps 20 --warmup 5        N = 1, 2, 4, 8   (grid mode at N > 1)
 #   2. the same grid job, hybrid deal    python bench.py --gpus N --mode hybrid ...            N = 4, 8         (frame-sharded tail waves)
 #   3. the latency mode                  python bench.py --gpus N --mode frame-shard ...       N = 2, 4, 8      (BASELINE.json configs[3])
-#   4. the GPU tests that need > 1 rank  python -m pytest tests/test_bench_gpu.py -m gpu -q
+#   4. the grid job without task stacks  python bench.py --gpus N --task-batch 1 ...           N = 8            (every line above runs the runner's
+#                                        defaults, three streams of 2-task stacks per rank: at 8 ranks a round deals 19 / 6 tasks per rank,
+#                                        and whether stacks still pay at that depth is the first thing to read off)
+#   5. the GPU tests that need > 1 rank  python -m pytest tests/test_bench_gpu.py -m gpu -q
 # and prints one summary row per line: n_gpus, mode, latents/s (secondary.grid for the 1 -> N curve), ms_per_step.
 # Usage: bash tools/scale_first_contact.sh [steps] [warmup]        (HSA_ENABLE_IPC_MODE_LEGACY=0 is exported: dmabuf IPC for RCCL)
 set -u
@@ -29,4 +32,5 @@ PY
 for n in 1 2 4 8; do run $n "" grid_n$n; done
 for n in 4 8; do run $n "--mode hybrid" hybrid_n$n; done
 for n in 2 4 8; do run $n "--mode frame-shard" frameshard_n$n; done
+run 8 "--task-batch 1" grid_n8_single_tasks
 timeout 900 python -m pytest tests/test_bench_gpu.py -m gpu -q > $out/pytest_multi.log 2>&1; tail -3 $out/pytest_multi.log
