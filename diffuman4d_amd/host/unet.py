@@ -93,14 +93,26 @@ class _Weights:
         """fp32 / bf16 / fp16 host matrix [N, taps * C] -> device bf16 (duplicated along K in parity precision) or fp16 (h16)."""
         w = w.to(self.wdtype)
         if self.h16:
-            w = w.to(F16)
+            w = self._to_f16(w)
         elif self.parity:
             w = ops.dup_k(w, taps)
         return w.to(self.device).contiguous()
 
     def host_vec(self, v: torch.Tensor) -> torch.Tensor:
         """A bias / norm parameter assembled on the host -> the device vector the kernels of this precision read."""
-        return v.to(self.wdtype).to(F16 if self.h16 else BF16).to(self.device).contiguous()
+        v = v.to(self.wdtype)
+        return (self._to_f16(v) if self.h16 else v.to(BF16)).to(self.device).contiguous()
+
+    @staticmethod
+    def _to_f16(w: torch.Tensor) -> torch.Tensor:
+        """The checkpoint's values in fp16.  bf16 values are exact in fp16 from 2^-14 up (below that they keep fewer bits, with an absolute
+        error of at most 2^-25); a value beyond fp16's range cannot be held at all and is refused here, at load, by name of the condition
+        rather than as an inf in the first matrix product."""
+        h = w.to(F16)
+        if not bool(torch.isfinite(h).all()):
+            raise ValueError(f"precision 'fp16': a checkpoint tensor holds |w| = {float(w.float().abs().max()):.4g} > 65504, outside the fp16 "
+                             "range (use model.precision=fast or parity for this checkpoint)")
+        return h
 
     def get(self, key: str) -> torch.Tensor:
         if key not in self.sd:
