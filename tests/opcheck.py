@@ -1265,6 +1265,9 @@ CASES = {
     "ln_320": (case_layernorm, dict(M=1000, C=320)),
     "ln_1280": (case_layernorm, dict(M=77, C=1280)),
     "ln_64": (case_layernorm, dict(M=130, C=64)),
+    "ln_320_tall_odd_rows": (case_layernorm, dict(M=9001, C=320)),   # tall problems, odd row count (round 6 measured two / four rows per wave on these: null, profiles/r06_ln.log)
+    "ln_640_tall": (case_layernorm, dict(M=8200, C=640, seed=1)),
+    "ln_1280_tall": (case_layernorm, dict(M=8193, C=1280, seed=2)),
     "softmax": (case_softmax, dict(M=50, N=2880)),
     "logits_softmax_f32": (case_logits_softmax_f32, dict(M=320, N=2880, K=512)),
     "logits_softmax_f32_ragged": (case_logits_softmax_f32, dict(M=77, N=200, K=64)),
@@ -1379,6 +1382,8 @@ CASES = {
     "h16_gn_odd_channels": (case_h16_groupnorm, dict(B=2, HW=77, C1=66, groups=6, silu=True)),
     "h16_ln": (case_h16_layernorm, dict(M=1000, C=320)),
     "h16_ln_1280": (case_h16_layernorm, dict(M=333, C=1280)),
+    "h16_ln_320_tall_odd_rows": (case_h16_layernorm, dict(M=9001, C=320, seed=3)),
+    "h16_ln_640_tall": (case_h16_layernorm, dict(M=8200, C=640, seed=4)),
     "h16_softmax": (case_h16_softmax, dict(M=96, N=2880, Np=2880)),
     "h16_softmax_padded": (case_h16_softmax, dict(M=33, N=1353, Np=1376)),
     "h16_attn_small": (case_h16_attention, dict(batch=2, heads=2, L=128)),
